@@ -1,0 +1,588 @@
+"""`climsim_utils.data_utils`-compatible loader / normalisation / evaluation API.
+
+Drop-in for the reference class ``data_utils`` (``climsim_utils/data_utils.py:45-1761`` in
+leap-stc/ClimSim): same constructor keywords, attribute names, method names, on-disk formats and
+numerical results (pinned by ``tests/golden/data_utils_golden.npz``, which was produced by the
+reference itself - see ``tests/golden/make_golden.py``).  It is a re-design, not a copy: the
+reference repeats every statement once per data split and once per variable; here splits and
+variables are table-driven, TensorFlow is never imported, and xarray/netCDF4/h5py are only
+imported by the raw-file paths that need them.
+
+Differences that are deliberate and documented:
+  * ``ml_backend`` accepts "tensorflow" for signature compatibility but the generator always
+    yields numpy (or torch, for "pytorch") - there is no tf.data dependency.
+  * ``load_ncdata_with_generator`` returns a re-iterable dataset (the reference's torch dataset
+    wraps an already-started generator and is empty on the second epoch, ``:876-877``).
+  * ``reweight_samplepreds`` is not provided: the reference calls an undefined
+    ``output_weighting_CRPS`` (``:1418``).
+"""
+from __future__ import annotations
+
+import glob
+import os
+import pickle
+import re
+from typing import Dict, List, Sequence
+
+import numpy as np
+
+SPLITS = ("train", "val", "scoring", "test")
+_LEV = 60
+
+_PROFILE_IN = [
+    "state_t", "state_rh", "state_q0001", "state_q0002", "state_q0003", "state_qn", "liq_partition",
+    "state_u", "state_v", "state_t_dyn", "state_q0_dyn", "state_u_dyn", "state_v_dyn",
+    "state_t_prvphy", "state_q0001_prvphy", "state_q0002_prvphy", "state_q0003_prvphy",
+    "state_qn_prvphy", "state_u_prvphy", "tm_state_t_dyn", "tm_state_q0_dyn", "tm_state_u_dyn",
+    "tm_state_t_prvphy", "tm_state_q0001_prvphy", "tm_state_q0002_prvphy", "tm_state_q0003_prvphy",
+    "tm_state_qn_prvphy", "tm_state_u_prvphy", "pbuf_ozone", "pbuf_CH4", "pbuf_N2O"]
+_SCALAR_IN = [
+    "state_ps", "pbuf_SOLIN", "pbuf_LHFLX", "pbuf_SHFLX", "pbuf_TAUX", "pbuf_TAUY", "pbuf_COSZRS",
+    "tm_state_ps", "tm_pbuf_SOLIN", "tm_pbuf_LHFLX", "tm_pbuf_SHFLX", "tm_pbuf_COSZRS",
+    "cam_in_ALDIF", "cam_in_ALDIR", "cam_in_ASDIF", "cam_in_ASDIR", "cam_in_LWUP", "cam_in_ICEFRAC",
+    "cam_in_LANDFRAC", "cam_in_OCNFRAC", "cam_in_SNOWHICE", "cam_in_SNOWHLAND", "clat", "slat", "icol",
+    "pbuf_SOLIN_pm", "pbuf_COSZRS_pm"]
+_PROFILE_OUT = ["ptend_t", "ptend_q0001", "ptend_q0002", "ptend_q0003", "ptend_qn", "ptend_u", "ptend_v"]
+_SCALAR_OUT = ["cam_out_NETSW", "cam_out_FLWDS", "cam_out_PRECSC", "cam_out_PRECC",
+               "cam_out_SOLS", "cam_out_SOLL", "cam_out_SOLSD", "cam_out_SOLLD"]
+_SURFACE = ["state_ps", "pbuf_SOLIN", "pbuf_LHFLX", "pbuf_SHFLX", "pbuf_TAUX", "pbuf_TAUY", "pbuf_COSZRS",
+            "cam_in_ALDIF", "cam_in_ALDIR", "cam_in_ASDIF", "cam_in_ASDIR", "cam_in_LWUP", "cam_in_ICEFRAC",
+            "cam_in_LANDFRAC", "cam_in_OCNFRAC", "cam_in_SNOWHICE", "cam_in_SNOWHLAND"]
+_TRACE = ["pbuf_ozone", "pbuf_CH4", "pbuf_N2O"]
+_V4_TAIL = (_TRACE + _SURFACE + ["tm_state_ps", "tm_pbuf_SOLIN", "tm_pbuf_LHFLX", "tm_pbuf_SHFLX",
+                                 "tm_pbuf_COSZRS", "clat", "slat", "icol"])
+
+
+def eliq(T):
+    """Liquid saturation pressure [Pa] from T [K], 8th-order polynomial fit (data_utils.py:18-29)."""
+    coef = np.array([-0.976195544e-15, -0.952447341e-13, 0.640689451e-10, 0.206739458e-7,
+                     0.302950461e-5, 0.264847430e-3, 0.142986287e-1, 0.443987641, 6.11239921])
+    return 100 * np.polyval(coef, np.maximum(-80, T - 273.16))
+
+
+def eice(T):
+    """Ice saturation pressure [Pa] from T [K] (data_utils.py:31-43)."""
+    coef = np.array([0.252751365e-14, 0.146898966e-11, 0.385852041e-9, 0.602588177e-7,
+                     0.615021634e-5, 0.420895665e-3, 0.188439774e-1, 0.503160820, 6.11147274])
+    t_hi, t_lo, dt_min, c0, c1, c2 = 273.15, 185, -100, 0.00763685, 0.000151069, 7.48215e-07
+    dT = T - 273.16
+    cold = np.maximum(dt_min, dT)
+    return ((T > t_hi) * eliq(T) + (T <= t_hi) * (T > t_lo) * 100 * np.polyval(coef, dT)
+            + (T <= t_lo) * 100 * (c0 + cold * (c1 + cold * c2)))
+
+
+class _ColumnDataset:
+    """Re-iterable stream of per-timestep ``(ncol, n_in)``, ``(ncol, n_out)`` float64 pairs."""
+
+    def __init__(self, make_gen, n_in, n_out, torch=None):
+        self._make_gen, self._n_in, self._n_out, self._torch = make_gen, n_in, n_out, torch
+
+    def as_numpy_iterator(self):
+        for xi, yi in self._make_gen():
+            xi, yi = np.asarray(xi), np.asarray(yi)
+            assert xi.shape[-1] == self._n_in and yi.shape[-1] == self._n_out
+            yield xi, yi
+
+    def __iter__(self):
+        if self._torch is None:
+            yield from self.as_numpy_iterator()
+        else:
+            for xi, yi in self.as_numpy_iterator():
+                yield (self._torch.tensor(xi, dtype=self._torch.float64),
+                       self._torch.tensor(yi, dtype=self._torch.float64))
+
+
+class data_utils:  # noqa: N801  (name fixed by the reference API)
+    def __init__(self, grid_info, input_mean, input_max, input_min, output_scale,
+                 ml_backend="tensorflow", normalize=True, input_abbrev="mli", output_abbrev="mlo",
+                 save_h5=False, save_npy=True):
+        self.input_abbrev, self.output_abbrev = input_abbrev, output_abbrev
+        self.data_path = None
+        self.save_h5, self.save_npy = save_h5, save_npy
+        self.input_vars: List[str] = []
+        self.target_vars: List[str] = []
+        self.input_feature_len = self.target_feature_len = None
+        self.grid_info = grid_info
+        self.level_name, self.sample_name = "lev", "sample"
+        self.num_levels = len(grid_info["lev"])
+        self.num_latlon = len(grid_info["ncol"])
+        area = np.asarray(_values(grid_info["area"]), dtype=np.float64)
+        self.area_wgt = area / area.mean()
+        try:
+            self.grid_info["area_wgt"] = grid_info["area"] / grid_info["area"].mean(dim="ncol")
+        except Exception:  # plain dict of ndarrays
+            self.grid_info["area_wgt"] = self.area_wgt
+        self.input_mean, self.input_max, self.input_min = input_mean, input_max, input_min
+        self.output_scale = output_scale
+        self.normalize = normalize
+        lat, lon = _values(grid_info["lat"]), _values(grid_info["lon"])
+        self.lats, self.lats_indices = np.unique(lat, return_index=True)
+        self.lons, self.lons_indices = np.unique(lon, return_index=True)
+        self.sort_lat_key = np.argsort(lat[np.sort(self.lats_indices)])
+        self.sort_lon_key = np.argsort(lon[np.sort(self.lons_indices)])
+        self.indextolatlon = {i: (lat[i], lon[i]) for i in range(self.num_latlon)}
+        self.lat_indices_list = sorted(([i for i in range(self.num_latlon) if lat[i] == v] for v in self.lats),
+                                       key=lambda idx: idx[0])
+
+        if ml_backend not in ("tensorflow", "pytorch"):
+            raise ValueError("ml_backend must be 'tensorflow' or 'pytorch'")
+        self.ml_backend, self.tf, self.torch = ml_backend, None, None
+        self.successful_backend_import = True
+        if ml_backend == "pytorch":
+            import torch
+            self.torch = torch
+
+        self.hyam, self.hybm = _values(grid_info["hyam"]), _values(grid_info["hybm"])
+        self.p0 = 1e5
+        self.ps_index = None
+        self.full_vars = self.full_vars_v5 = False
+
+        # physical constants (E3SM shr_const_mod)
+        self.grav, self.cp, self.lv, self.lf = 9.80616, 1.00464e3, 2.501e6, 3.337e5
+        self.lsub = self.lv + self.lf
+        self.rho_air = 101325 / (6.02214e26 * 1.38065e-23 / 28.966) / 273.15
+        self.rho_h20 = 1.e3
+
+        # variable subsets ------------------------------------------------------------------
+        dyn = ["state_t_dyn", "state_q0_dyn", "state_u_dyn", "tm_state_t_dyn", "tm_state_q0_dyn", "tm_state_u_dyn"]
+        self.v1_inputs = ["state_t", "state_q0001", "state_ps", "pbuf_SOLIN", "pbuf_LHFLX", "pbuf_SHFLX"]
+        self.v1_outputs = ["ptend_t", "ptend_q0001"] + _SCALAR_OUT
+        self.v2_inputs = (["state_t", "state_q0001", "state_q0002", "state_q0003", "state_u", "state_v"]
+                          + _SURFACE + _TRACE)
+        self.v2_rh_inputs = (["state_t", "state_rh", "state_q0002", "state_q0003", "state_u", "state_v"]
+                             + _TRACE + _SURFACE)
+        self.v4_inputs = (["state_t", "state_rh", "state_q0002", "state_q0003", "state_u", "state_v"] + dyn
+                          + ["state_t_prvphy", "state_q0001_prvphy", "state_q0002_prvphy", "state_q0003_prvphy",
+                             "state_u_prvphy", "tm_state_t_prvphy", "tm_state_q0001_prvphy",
+                             "tm_state_q0002_prvphy", "tm_state_q0003_prvphy", "tm_state_u_prvphy"] + _V4_TAIL)
+        self.v5_inputs = (["state_t", "state_rh", "state_qn", "liq_partition", "state_u", "state_v"] + dyn
+                          + ["state_t_prvphy", "state_q0001_prvphy", "state_qn_prvphy", "state_u_prvphy",
+                             "tm_state_t_prvphy", "tm_state_q0001_prvphy", "tm_state_qn_prvphy",
+                             "tm_state_u_prvphy"] + _V4_TAIL)
+        self.v2_outputs = ["ptend_t", "ptend_q0001", "ptend_q0002", "ptend_q0003", "ptend_u", "ptend_v"] + _SCALAR_OUT
+        self.v4_outputs = list(self.v2_outputs)
+        self.v5_outputs = ["ptend_t", "ptend_q0001", "ptend_qn", "ptend_u", "ptend_v"] + _SCALAR_OUT
+        self.var_lens = {**{v: self.num_levels for v in _PROFILE_IN + _PROFILE_OUT},
+                         **{v: 1 for v in _SCALAR_IN + _SCALAR_OUT}}
+        self.var_short_names = {"ptend_t": "$dT/dt$", "ptend_q0001": "$dq/dt$",
+                                **{v: v.replace("cam_out_", "") for v in _SCALAR_OUT}}
+        precip = self.lv * self.rho_h20
+        self.target_energy_conv = {"ptend_t": self.cp, "ptend_q0001": self.lv, "ptend_q0002": self.lv,
+                                   "ptend_q0003": self.lv, "ptend_qn": self.lv, "ptend_wind": None,
+                                   **{v: 1. for v in _SCALAR_OUT},
+                                   "cam_out_PRECSC": precip, "cam_out_PRECC": precip}
+
+        # per-split state (same attribute names as the reference) -----------------------------
+        for sp in SPLITS:
+            for stem in ("input", "target", "preds", "samplepreds", "pressure_grid", "dp"):
+                setattr(self, f"{stem}_{sp}", None)
+            for stem in ("regexps", "stride_sample", "filelist"):
+                setattr(self, f"{sp}_{stem}", None)
+            for stem in ("target_weighted", "preds_weighted", "samplepreds_weighted", "metrics_idx", "metrics_var"):
+                setattr(self, f"{stem}_{sp}", {})
+            setattr(self, f"metrics_{sp}", [])
+        self.model_names: List[str] = []
+        self.metrics_names: List[str] = []
+        self.metrics_dict = {"MAE": self.calc_MAE, "RMSE": self.calc_RMSE, "R2": self.calc_R2,
+                             "CRPS": self.calc_CRPS, "bias": self.calc_bias}
+        self.num_CRPS = 32
+        self.linecolors = ["#0072B2", "#E69F00", "#882255", "#009E73", "#D55E00"]
+
+    # ------------------------------------------------------------------ variable subsets
+    def _set_vars(self, inputs, outputs, ps_index, full, full_v5=False):
+        self.input_vars, self.target_vars, self.ps_index = inputs, outputs, ps_index
+        self.input_feature_len = sum(self.var_lens[v] for v in inputs)
+        self.target_feature_len = sum(self.var_lens[v] for v in outputs)
+        self.full_vars, self.full_vars_v5 = full, full_v5
+
+    def set_to_v1_vars(self):
+        """124 -> 128, ps at 120 (data_utils.py:558-568)."""
+        self._set_vars(self.v1_inputs, self.v1_outputs, 120, False)
+
+    def set_to_v2_vars(self):
+        """557 -> 368, ps at 360 (data_utils.py:570-580)."""
+        self._set_vars(self.v2_inputs, self.v2_outputs, 360, True)
+
+    def set_to_v2_rh_vars(self):
+        self._set_vars(self.v2_rh_inputs, self.v2_outputs, 360, True)
+
+    def set_to_v4_vars(self):
+        self._set_vars(self.v4_inputs, self.v4_outputs, 1500, True)
+
+    def set_to_v5_vars(self):
+        self._set_vars(self.v5_inputs, self.v5_outputs, 1380, False, True)
+
+    # ------------------------------------------------------------------ split selection
+    @staticmethod
+    def _check_split(data_split):
+        assert data_split in SPLITS, ("Provided data_split is not valid. Available options are "
+                                      "train, val, scoring, and test.")
+
+    def set_regexps(self, data_split, regexps):
+        self._check_split(data_split)
+        setattr(self, f"{data_split}_regexps", regexps)
+
+    def set_stride_sample(self, data_split, stride_sample):
+        self._check_split(data_split)
+        setattr(self, f"{data_split}_stride_sample", stride_sample)
+
+    def set_filelist(self, data_split, start_idx=0, end_idx=-1):
+        """sorted(glob)[start:end:stride]; the default end_idx=-1 drops the last file exactly as the
+        reference does (data_utils.py:742-771) - the published split sizes depend on it."""
+        self._check_split(data_split)
+        regexps = getattr(self, f"{data_split}_regexps")
+        stride = getattr(self, f"{data_split}_stride_sample")
+        assert regexps is not None, f"regexps for {data_split} is not set."
+        assert stride is not None, f"stride_sample for {data_split} is not set."
+        files: List[str] = []
+        for rx in regexps:
+            files += glob.glob(self.data_path + "*/" + rx)
+        setattr(self, f"{data_split}_filelist", sorted(files)[start_idx:end_idx:stride])
+
+    def get_filelist(self, data_split):
+        self._check_split(data_split)
+        fl = getattr(self, f"{data_split}_filelist")
+        assert fl is not None, f"filelist for {data_split} is not set."
+        return fl
+
+    # ------------------------------------------------------------------ raw files -> columns
+    def _read_vars(self, file, wanted: Sequence[str] | None):
+        """{var: ndarray (lev, ncol) or (ncol,)} for one timestep file, plus derived inputs
+        (state_rh, icol, liq_partition, state_qn*) computed like data_utils.py:625-668."""
+        raw = _open_columns(file)
+        if wanted is None:
+            return raw
+        out = {}
+        T0, T00 = 273.16, 253.16
+        for v in wanted:
+            if v in raw:
+                out[v] = raw[v]
+            elif v == "state_rh":
+                t = raw["state_t"]
+                w = np.clip((t - T00) / (T0 - T00), 0, 1)
+                esat = w * eliq(t) + (1 - w) * eice(t)
+                out[v] = raw["state_q0001"] / ((287 * esat) / (461 * raw["state_pmid"]))
+            elif v == "icol":
+                out[v] = np.arange(1, self.num_latlon + 1, dtype=np.float64)
+            elif v == "liq_partition":
+                out[v] = np.clip((raw["state_t"] - T00) / (T0 - T00), 0, 1)
+            elif v in ("state_qn", "state_qn_prvphy", "tm_state_qn_prvphy"):
+                out[v] = raw[v.replace("qn", "q0002")] + raw[v.replace("qn", "q0003")]
+            else:
+                raise KeyError(f"{v} not in {file}")
+        return out
+
+    def get_input(self, input_file):
+        return self._read_vars(input_file, self.input_vars)
+
+    def get_target(self, input_file):
+        """Targets of one timestep; tendencies are (mlo - mli)/1200 s (data_utils.py:678-712)."""
+        mli = _open_columns(input_file)
+        mlo = _open_columns(input_file.replace(f".{self.input_abbrev}.", f".{self.output_abbrev}."))
+        tend = lambda v: (mlo[v] - mli[v]) / 1200  # noqa: E731
+        out = dict(mlo)
+        out["ptend_t"], out["ptend_q0001"] = tend("state_t"), tend("state_q0001")
+        if self.full_vars or self.full_vars_v5:
+            out["ptend_u"], out["ptend_v"] = tend("state_u"), tend("state_v")
+        if self.full_vars:
+            out["ptend_q0002"], out["ptend_q0003"] = tend("state_q0002"), tend("state_q0003")
+        elif self.full_vars_v5:
+            out["ptend_qn"] = (mlo["state_q0002"] - mli["state_q0002"] + mlo["state_q0003"] - mli["state_q0003"]) / 1200
+        return {v: out[v] for v in self.target_vars}
+
+    def _stack(self, fields: Dict[str, np.ndarray], order: Sequence[str]):
+        """(ncol, features): variables in list order, a profile's 60 levels contiguous
+        (the layout xarray's to_stacked_array produces at data_utils.py:815-820)."""
+        cols = [np.asarray(fields[v], dtype=np.float64).T if self.var_lens[v] > 1
+                else np.asarray(fields[v], dtype=np.float64)[:, None] for v in order]
+        return np.concatenate(cols, axis=1)
+
+    def load_ncdata_with_generator(self, data_split):
+        """Stream of normalised (384,124)/(384,128) float64 pairs, one per file
+        (data_utils.py:791-882).  x = (x-mean)/(max-min), y = y*scale when normalize."""
+        filelist = self.get_filelist(data_split)
+        if self.normalize:
+            with np.errstate(divide="ignore", invalid="ignore"):
+                sub, div, scale = self.save_norm()
+                rdiv = div
+
+        def gen():
+            for f in filelist:
+                xi = self._stack(self.get_input(f), self.input_vars)
+                yi = self._stack(self.get_target(f), self.target_vars)
+                if self.normalize:
+                    with np.errstate(divide="ignore", invalid="ignore"):
+                        xi = (xi - sub) / rdiv
+                    yi = yi * scale
+                yield xi, yi
+
+        return _ColumnDataset(gen, self.input_feature_len, self.target_feature_len, self.torch)
+
+    def save_as_npy(self, data_split, save_path="", save_latlontime_dict=False):
+        """Materialise a split as float32 `<split>_input.npy` / `_target.npy` (and optionally .h5
+        dataset 'data'); inf/nan -> 0 on normalised inputs (data_utils.py:884-944)."""
+        pairs = list(self.load_ncdata_with_generator(data_split).as_numpy_iterator())
+        npy_input = np.concatenate([p[0] for p in pairs])
+        if self.normalize:
+            npy_input[~np.isfinite(npy_input)] = 0
+        if not os.path.exists(save_path):
+            os.makedirs(save_path)
+        if save_path[-1] != "/":
+            save_path += "/"
+        n_rows = npy_input.shape[0]
+        self._save_array(np.float32(npy_input), save_path + data_split + "_input")
+        del npy_input
+        self._save_array(np.float32(np.concatenate([p[1] for p in pairs])), save_path + data_split + "_target")
+        if save_latlontime_dict:
+            files = self.get_filelist(data_split)
+            dates = [re.sub(r"\.nc$", "", re.sub(rf"^.*{self.input_abbrev}\.", "", f)) for f in files]
+            lat, lon = _values(self.grid_info["lat"]), _values(self.grid_info["lon"])
+            latlontime = {i: [(lat[i % self.num_latlon], lon[i % self.num_latlon]), dates[i // self.num_latlon]]
+                          for i in range(n_rows)}
+            with open(save_path + data_split + "_indextolatlontime.pkl", "wb") as f:
+                pickle.dump(latlontime, f)
+
+    def _save_array(self, arr, stem):
+        if self.save_npy:
+            with open(stem + ".npy", "wb") as f:
+                np.save(f, arr)
+        if self.save_h5:
+            import h5py
+            with h5py.File(stem + ".h5", "w") as hdf:
+                hdf.create_dataset("data", data=arr, dtype=arr.dtype)
+
+    def reshape_npy(self, var_arr, var_arr_dim):
+        return var_arr.reshape((int(var_arr.shape[0] / self.num_latlon), self.num_latlon, var_arr_dim))
+
+    def save_norm(self, save_path="", write=False):
+        """(input_sub, input_div, out_scale) feature vectors; optional `%.6e` comma-separated
+        one-line text files (data_utils.py:954-988)."""
+        def expand(ds, var):
+            return np.atleast_1d(np.asarray(_values(ds[var]), dtype=np.float64))
+        input_sub = np.concatenate([expand(self.input_mean, v) for v in self.input_vars])
+        input_div = np.concatenate([expand(self.input_max, v) - expand(self.input_min, v) for v in self.input_vars])
+        out_scale = np.concatenate([expand(self.output_scale, v) for v in self.target_vars])
+        if write:
+            for name, vec in (("inp_sub", input_sub), ("inp_div", input_div), ("out_scale", out_scale)):
+                np.savetxt(f"{save_path}/{name}.txt", vec.reshape(1, -1), fmt="%.6e", delimiter=",")
+        return input_sub, input_div, out_scale
+
+    @staticmethod
+    def ls(dir_path=""):
+        return sorted(os.listdir(dir_path or "."))
+
+    @staticmethod
+    def load_npy_file(load_path=""):
+        with open(load_path, "rb") as f:
+            return np.load(f)
+
+    @staticmethod
+    def load_h5_file(load_path=""):
+        import h5py
+        with h5py.File(load_path, "r") as hf:
+            return np.array(hf.get("pred"))
+
+    # ------------------------------------------------------------------ evaluation
+    def set_pressure_grid(self, data_split):
+        """p_int = P0*hyai + hybi*ps, dp = diff over levels -> (T, ncol, 60)
+        (data_utils.py:1037-1086)."""
+        self._check_split(data_split)
+        x = getattr(self, f"input_{data_split}")
+        assert x is not None
+        ps = x[:, self.ps_index]
+        if self.normalize:
+            ps = (ps * (_values(self.input_max["state_ps"]) - _values(self.input_min["state_ps"]))
+                  + _values(self.input_mean["state_ps"]))
+        ps = np.reshape(ps, (-1, self.num_latlon))
+        p1 = np.asarray(_values(self.grid_info["P0"]) * _values(self.grid_info["hyai"]))[:, None, None]
+        grid = p1 + _values(self.grid_info["hybi"])[:, None, None] * ps[None, :, :]
+        setattr(self, f"pressure_grid_{data_split}", grid)
+        setattr(self, f"dp_{data_split}", (grid[1:61] - grid[0:60]).transpose((1, 2, 0)))
+
+    def output_weighting(self, output, data_split, just_weights=False):
+        """unscale -> x dp/g (profiles) -> x area weight -> x energy-unit factor
+        (data_utils.py:1112-1362).  Returns {var: (T, ncol[, 60])} or the (N, F) weight matrix."""
+        self._check_split(data_split)
+        n = output.shape[0]
+        T = int(n / self.num_latlon)
+        dp = getattr(self, f"dp_{data_split}")
+        assert dp is not None
+        src = np.ones(output.shape) if just_weights else output
+        fields, off = {}, 0
+        for v in self.target_vars:
+            ln = self.var_lens[v]
+            fields[v] = (src[:, off:off + ln].reshape(T, self.num_latlon, ln) if ln > 1
+                         else src[:, off].reshape(T, self.num_latlon))
+            off += ln
+        wind = None
+        if self.full_vars:
+            ou, ov = self.target_vars.index("ptend_u"), self.target_vars.index("ptend_v")
+            o0 = sum(self.var_lens[v] for v in self.target_vars[:ou])
+            o1 = sum(self.var_lens[v] for v in self.target_vars[:ov])
+            u = output[:, o0:o0 + 60].reshape(T, self.num_latlon, 60)
+            w = output[:, o1:o1 + 60].reshape(T, self.num_latlon, 60)
+            wind = ((u ** 2) + (w ** 2)) ** .5
+            self.target_energy_conv["ptend_wind"] = wind
+        for v in self.target_vars:
+            f = fields[v]
+            prof = self.var_lens[v] > 1
+            if self.normalize:
+                sc = _values(self.output_scale[v])
+                f = f / (sc[None, None, :] if prof else sc)
+            if prof:
+                f = f * dp / self.grav
+            f = f * (self.area_wgt[None, :, None] if prof else self.area_wgt[None, :])
+            conv = wind if v in ("ptend_u", "ptend_v") else self.target_energy_conv[v]
+            fields[v] = f * conv
+        if just_weights:
+            return np.concatenate([fields[v].reshape(n, self.var_lens[v]) for v in self.target_vars], axis=1)
+        return fields
+
+    def reweight_target(self, data_split):
+        self._check_split(data_split)
+        tgt = getattr(self, f"target_{data_split}")
+        assert tgt is not None
+        setattr(self, f"target_weighted_{data_split}", self.output_weighting(tgt, data_split))
+
+    def reweight_preds(self, data_split):
+        self._check_split(data_split)
+        preds = getattr(self, f"preds_{data_split}")
+        assert self.model_names is not None and preds is not None
+        store = getattr(self, f"preds_weighted_{data_split}")
+        for m in self.model_names:
+            store[m] = self.output_weighting(preds[m], data_split)
+
+    def _check_pair(self, pred, target):
+        assert pred.shape[1] == self.num_latlon
+        assert pred.shape == target.shape
+
+    def calc_MAE(self, pred, target, avg_grid=True):  # noqa: N802
+        self._check_pair(pred, target)
+        m = np.abs(pred - target).mean(axis=0)
+        return m.mean(axis=0) if avg_grid else m
+
+    def calc_RMSE(self, pred, target, avg_grid=True):  # noqa: N802
+        self._check_pair(pred, target)
+        m = np.sqrt(((pred - target) ** 2).mean(axis=0))
+        return m.mean(axis=0) if avg_grid else m
+
+    def calc_R2(self, pred, target, avg_grid=True):  # noqa: N802
+        self._check_pair(pred, target)
+        ss_res = ((pred - target) ** 2).sum(axis=0)
+        ss_tot = ((target - target.mean(axis=0)[None, ...]) ** 2).sum(axis=0)
+        m = 1 - ss_res / ss_tot
+        return m.mean(axis=0) if avg_grid else m
+
+    def calc_bias(self, pred, target, avg_grid=True):
+        self._check_pair(pred, target)
+        m = pred.mean(axis=0) - target.mean(axis=0)
+        return m.mean(axis=0) if avg_grid else m
+
+    def calc_CRPS(self, samplepreds, target, avg_grid=True):  # noqa: N802
+        """E|X-y| - E|X-X'|/2 via the sorted-sample identity (data_utils.py:1499-1524)."""
+        assert samplepreds.shape[1] == self.num_latlon
+        assert samplepreds.ndim == target.ndim + 1 and samplepreds.ndim in (3, 4)
+        k = samplepreds.shape[-1]
+        mae = np.mean(np.abs(samplepreds - target[..., None]), axis=(0, -1))
+        gaps = np.diff(np.sort(samplepreds, axis=-1), axis=-1)
+        count = np.arange(1, k) * np.arange(k - 1, 0, -1)
+        spread = (gaps * count).sum(axis=-1).mean(axis=0)
+        m = mae - spread / (k * (k - 1))
+        return m.mean(axis=0) if avg_grid else m
+
+    def create_metrics_df(self, data_split):
+        """Per-variable and per-output-index metric tables for every model
+        (data_utils.py:1526-1607)."""
+        import pandas as pd
+        self._check_split(data_split)
+        assert len(self.model_names) != 0 and len(self.metrics_names) != 0
+        assert len(self.target_vars) != 0 and self.target_feature_len is not None
+        pw = getattr(self, f"preds_weighted_{data_split}")
+        tw = getattr(self, f"target_weighted_{data_split}")
+        assert len(pw) != 0 and len(tw) != 0
+        for m in self.model_names:
+            df_var = pd.DataFrame(columns=self.metrics_names, index=self.target_vars)
+            df_var.index.name = "variable"
+            df_idx = pd.DataFrame(columns=self.metrics_names, index=range(self.target_feature_len))
+            df_idx.index.name = "output_idx"
+            for name in self.metrics_names:
+                at = 0
+                for v in self.target_vars:
+                    val = self.metrics_dict[name](pw[m][v], tw[v])
+                    df_var.loc[v, name] = np.mean(val)
+                    df_idx.loc[at:at + self.var_lens[v] - 1, name] = np.atleast_1d(val)
+                    at += self.var_lens[v]
+            getattr(self, f"metrics_var_{data_split}")[m] = df_var
+            getattr(self, f"metrics_idx_{data_split}")[m] = df_idx
+
+    def reshape_daily(self, output):
+        """(N,128) -> two (lat, Nday, 60) arrays (ptend_t, ptend_q0001): daily mean over the 12
+        stride-6 samples of a day, then mean over the columns of each latitude
+        (data_utils.py:1609-1629)."""
+        T = int(output.shape[0] / self.num_latlon)
+        res = []
+        for lo in (0, 60):
+            prof = output[:, lo:lo + 60].reshape(T, self.num_latlon, 60)
+            daily = prof.reshape(T // 12, 12, self.num_latlon, 60).mean(axis=1)
+            res.append(np.array([daily[:, idx, :].mean(axis=1) for idx in self.lat_indices_list]))
+        return res[0], res[1]
+
+    # ------------------------------------------------------------------ CNN layouts
+    @staticmethod
+    def reshape_input_for_cnn(npy_input, save_path=""):
+        """(N,124) -> (N,60,6) channels-last; the 4 scalars are broadcast over the 60 levels
+        (data_utils.py:1692-1712)."""
+        out = _to_level_channels(npy_input, n_scalar=4)
+        if save_path != "":
+            np.save(save_path + "train_input_cnn.npy", np.float32(out))
+        return out
+
+    @staticmethod
+    def reshape_target_for_cnn(npy_target, save_path=""):
+        """(N,128) -> (N,60,10) (data_utils.py:1714-1738)."""
+        out = _to_level_channels(npy_target, n_scalar=8)
+        if save_path != "":
+            np.save(save_path + "train_target_cnn.npy", np.float32(out))
+        return out
+
+    @staticmethod
+    def reshape_target_from_cnn(npy_predict_cnn, save_path=""):
+        """(N,60,10) -> (N,128); scalar channels collapse by level-mean (data_utils.py:1740-1761)."""
+        p = npy_predict_cnn
+        out = np.concatenate([p[:, :, 0], p[:, :, 1], np.mean(p[:, :, 2:], axis=1)], axis=1)
+        if save_path != "":
+            np.save(save_path + "cnn_predict_reshaped.npy", np.float32(out))
+        return out
+
+
+def _to_level_channels(flat, n_scalar):
+    n = flat.shape[0]
+    out = np.empty((n, _LEV, 2 + n_scalar), dtype=flat.dtype)
+    out[:, :, 0] = flat[:, 0:_LEV]
+    out[:, :, 1] = flat[:, _LEV:2 * _LEV]
+    out[:, :, 2:] = flat[:, None, 2 * _LEV:2 * _LEV + n_scalar]
+    return out
+
+
+def _values(v):
+    """ndarray behind an xarray.DataArray / AssetVar / plain array."""
+    return np.asarray(getattr(v, "values", v))
+
+
+def _open_columns(path) -> Dict[str, np.ndarray]:
+    """All variables of one E3SM-MMF timestep file as ndarrays.  NetCDF-4/HDF5 files need
+    xarray or netCDF4 (lazy import); classic CDF-1/2/5 files are read natively."""
+    with open(path, "rb") as f:
+        magic = f.read(4)
+    if magic[:3] == b"CDF":
+        from .assets import read_cdf5
+        raw = read_cdf5(path)
+        raw.pop("__dims__", None)
+        return {k: np.asarray(v, dtype=np.float64) for k, v in raw.items()}
+    try:
+        import xarray as xr
+    except ImportError as e:  # pragma: no cover - depends on the user's environment
+        raise ImportError(f"{path} is NetCDF-4/HDF5; reading it needs xarray+netCDF4 (not a dependency "
+                          "of climsim_amd). Use the pre-materialised .npy splits instead.") from e
+    with xr.open_dataset(path, engine="netcdf4") as ds:
+        return {k: np.asarray(ds[k].values, dtype=np.float64) for k in ds.data_vars}
