@@ -549,7 +549,9 @@ class data_utils:  # noqa: N801  (name fixed by the reference API)
     def reshape_target_from_cnn(npy_predict_cnn, save_path=""):
         """(N,60,10) -> (N,128); scalar channels collapse by level-mean (data_utils.py:1740-1761)."""
         p = npy_predict_cnn
-        out = np.concatenate([p[:, :, 0], p[:, :, 1], np.mean(p[:, :, 2:], axis=1)], axis=1)
+        # per-channel 2-D means: same summation order (hence bits) as the reference
+        out = np.concatenate([p[:, :, 0], p[:, :, 1]]
+                             + [np.mean(p[:, :, c], axis=1)[:, None] for c in range(2, p.shape[2])], axis=1)
         if save_path != "":
             np.save(save_path + "cnn_predict_reshaped.npy", np.float32(out))
         return out
