@@ -1,0 +1,87 @@
+"""torch-CPU float32 port of the reference MLP train step -- TEST INFRASTRUCTURE / CPU BASELINE.
+
+Second, independent restatement of step2_retrain.py:95-162 (model, mse loss) that lets torch
+autograd derive the backward pass, with a hand-written Keras-2.11 Adam (epsilon OUTSIDE the bias
+correction, eps=1e-7; torch.optim.Adam differs).  Used (a) in tests/test_oracle.py to cross-check
+the hand-derived gradients of oracle/mlp_oracle.py, (b) by bench.py's `cpu_baseline` leg as the
+multi-threaded CPU "port" of the reference training path (TensorFlow/Keras are not installable
+here).  Never imported by climsim_amd/.
+"""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+import torch
+
+from .mlp_oracle import MLPConfig, fuse_heads
+
+
+class TorchMLP:
+    def __init__(self, ws, cfg: MLPConfig):
+        self.cfg = cfg
+        self.params = [torch.tensor(np.asarray(a), dtype=torch.float32, requires_grad=True)
+                       for pair in fuse_heads(ws) for a in pair]
+        self.m = [torch.zeros_like(p) for p in self.params]
+        self.v = [torch.zeros_like(p) for p in self.params]
+        self.it = 0
+
+    def forward(self, x):
+        cfg, h = self.cfg, x
+        n = len(self.params) // 2
+        for i in range(n):
+            z = torch.addmm(self.params[2 * i + 1], h, self.params[2 * i])
+            if i < n - 1:
+                if cfg.act == "relu":
+                    h = torch.relu(z)
+                elif cfg.act == "elu":
+                    h = torch.nn.functional.elu(z)
+                else:
+                    h = torch.nn.functional.leaky_relu(z, cfg.alpha)
+            else:
+                h = torch.cat([z[:, :cfg.n_out_lin], torch.relu(z[:, cfg.n_out_lin:])], dim=1)
+        return h
+
+    def loss_and_grads(self, x, y):
+        for p in self.params:
+            p.grad = None
+        loss = torch.mean((self.forward(x) - y) ** 2)
+        loss.backward()
+        return float(loss.detach()), [p.grad for p in self.params]
+
+    @torch.no_grad()
+    def adam(self, grads, lr, b1=0.9, b2=0.999, eps=1e-7):
+        self.it += 1
+        alpha = lr * (1 - b2 ** self.it) ** 0.5 / (1 - b1 ** self.it)
+        for p, g, m, v in zip(self.params, grads, self.m, self.v):
+            m.add_(g - m, alpha=1 - b1)
+            v.add_(g * g - v, alpha=1 - b2)
+            p.addcdiv_(m, v.sqrt().add_(eps), value=-alpha)
+
+    def train_step(self, x, y, lr):
+        loss, grads = self.loss_and_grads(x, y)
+        self.adam(grads, lr)
+        return loss
+
+
+def time_cpu_baseline(ws, cfg, x, y, batch=1024, budget_s=15.0, warmup=5, threads=None):
+    """Median columns/s of the CPU port over as many batch-`batch` steps as fit in `budget_s`."""
+    threads = threads or torch.get_num_threads()
+    torch.set_num_threads(threads)
+    model = TorchMLP(ws, cfg)
+    xt, yt = torch.from_numpy(np.ascontiguousarray(x)), torch.from_numpy(np.ascontiguousarray(y))
+    n = (xt.shape[0] // batch) * batch
+    times, i, t_start = [], 0, time.perf_counter()
+    while True:
+        lo = (i * batch) % n
+        t0 = time.perf_counter()
+        model.train_step(xt[lo:lo + batch], yt[lo:lo + batch], 1e-3)
+        dt = time.perf_counter() - t0
+        if i >= warmup:
+            times.append(dt)
+        i += 1
+        if time.perf_counter() - t_start > budget_s and len(times) >= 10:
+            break
+    med = float(np.median(times))
+    return {"value": batch / med, "unit": "columns/s", "cores": threads, "kind": "port",
+            "sample": f"{len(times)} steps of batch {batch}, fp32 torch-CPU (oneDNN), median step {med * 1e3:.2f} ms"}

@@ -1,0 +1,119 @@
+"""The CPU oracle against the known answers the reference holds and against an independent
+torch-autograd restatement (parity for the training arithmetic is otherwise unpinned)."""
+import numpy as np
+import pytest
+
+from oracle import mlp_oracle as O
+
+
+def test_known_answers_published_model():
+    # lot-147/trial_0027: step1_results.csv:170 (1,753,472 params), FLOP_calculation.ipynb nb:231
+    pub = O.MLPConfig(hidden=(768, 640, 512, 640, 640))
+    assert pub.n_params() == 1_753_472
+    assert pub.fwd_flops() == 3_503_488
+    assert pub.train_flops() == 10_309_632
+    cfg = O.MLPConfig()
+    assert cfg.n_params() == 1_196_800
+    assert cfg.train_flops() == 7_036_928
+    ws = O.glorot_init(cfg, 0)
+    assert sum(w.size for w in ws) == cfg.n_params()
+    assert [w.shape for w in ws[-4:]] == [(128, 120), (120,), (128, 8), (8,)]
+
+
+def test_bf16_round():
+    a = np.array([1.0, 1.00390625, 1.005859375, -3.1415927, 1e-40, np.inf, 0.0], dtype=np.float32)
+    r = O.bf16_round(a)
+    assert r[0] == 1.0
+    assert r[1] == 1.0            # tie (1 + 2^-8) rounds to even
+    assert r[2] == 1.0078125      # above the tie rounds up
+    assert np.isinf(r[5]) and r[6] == 0
+    assert np.all((r.view(np.uint32) & 0xFFFF) == 0)
+    import torch
+    t = torch.randn(4096, dtype=torch.float32)
+    np.testing.assert_array_equal(O.bf16_round(t.numpy()), t.to(torch.bfloat16).to(torch.float32).numpy())
+
+
+@pytest.mark.parametrize("act", ["relu", "elu", "leakyrelu"])
+def test_gradients_match_autograd(act):
+    from oracle.mlp_torch_cpu import TorchMLP
+    import torch
+    cfg = O.MLPConfig(hidden=(128, 256, 128), act=act)
+    ws = O.glorot_init(cfg, 3)
+    for i in range(1, len(ws), 2):
+        ws[i] = np.random.default_rng(i).normal(0, 0.05, ws[i].shape).astype(np.float32)
+    x, y = O.synth_columns(256, seed=5)
+    loss, mae, grads, yhat = O.loss_and_grads(ws, x, y, cfg)
+    tm = TorchMLP(ws, cfg)
+    tloss, tgrads = tm.loss_and_grads(torch.from_numpy(x), torch.from_numpy(y))
+    assert abs(loss - tloss) <= 1e-6 * abs(tloss)
+    fused = O.fuse_heads(grads)
+    for (gw, gb), tw, tb in zip(fused, tgrads[0::2], tgrads[1::2]):
+        np.testing.assert_allclose(gw, tw.numpy(), rtol=2e-4, atol=1e-8)
+        np.testing.assert_allclose(gb, tb.numpy(), rtol=2e-4, atol=1e-8)
+    assert np.all(yhat[:, 120:] >= 0)
+
+
+def test_adam_matches_port_and_differs_from_torch_adam():
+    from oracle.mlp_torch_cpu import TorchMLP
+    import torch
+    cfg = O.MLPConfig(hidden=(128, 128))
+    ws = O.glorot_init(cfg, 1)
+    x, y = O.synth_columns(512, seed=9)
+    opt = O.Optimizer("Adam")
+    tm = TorchMLP(ws, cfg)
+    w = ws
+    for it in range(5):
+        w, loss, _ = O.train_step(w, opt, x, y, cfg, 1e-3)
+        tloss = tm.train_step(torch.from_numpy(x), torch.from_numpy(y), 1e-3)
+        assert abs(loss - tloss) <= 1e-5 * abs(tloss)
+    for (a, b), tw, tb in zip(O.fuse_heads(w), tm.params[0::2], tm.params[1::2]):
+        np.testing.assert_allclose(a, tw.detach().numpy(), rtol=1e-3, atol=2e-6)
+        np.testing.assert_allclose(b, tb.detach().numpy(), rtol=1e-3, atol=2e-6)
+
+
+def test_optimizer_rules_scalar():
+    # one scalar parameter, hand-computed first steps
+    g = np.array([0.5], dtype=np.float32)
+    w0 = [np.array([1.0], dtype=np.float32)]
+    adam = O.Optimizer("Adam")
+    w = adam.apply(w0, [g], 0.1)
+    # t=1: m=0.05, v=2.5e-4, alpha=0.1*sqrt(1-.999)/(1-.9) -> step = alpha*m/(sqrt(v)+eps) ~ 0.1
+    assert abs(w[0][0] - (1.0 - 0.1 * 0.5 / (0.5 + 1e-7 / np.sqrt(0.001)))) < 1e-6
+    sgd = O.Optimizer("SGD")
+    assert abs(sgd.apply(w0, [g], 0.1)[0][0] - 0.95) < 1e-7
+    rms = O.Optimizer("RMSprop")
+    assert abs(rms.apply(w0, [g], 0.1)[0][0] - (1 - 0.1 * 0.5 / np.sqrt(0.025 + 1e-7))) < 1e-6
+    radam = O.Optimizer("RAdam")
+    w = radam.apply(w0, [g], 0.1)
+    assert abs(w[0][0] - 0.95) < 1e-6          # sma_1 < 5: un-rectified step lr*m_hat = 0.1*0.5
+    for _ in range(5):
+        w = radam.apply(w, [g], 0.1)
+    t = 6
+    sma_inf = 2 / (1 - 0.999) - 1
+    sma_t = sma_inf - 2 * t * 0.999 ** t / (1 - 0.999 ** t)
+    assert sma_t >= 5 and radam.it == 6
+
+
+def test_cyclical_lr_triangular2():
+    s = 16
+    assert O.cyclical_lr(0, step_size=s) == pytest.approx(2.5e-4)
+    assert O.cyclical_lr(s, step_size=s) == pytest.approx(2.5e-3)
+    assert O.cyclical_lr(2 * s, step_size=s) == pytest.approx(2.5e-4)
+    assert O.cyclical_lr(3 * s, step_size=s) == pytest.approx(2.5e-4 + (2.5e-3 - 2.5e-4) / 2)
+    assert O.cyclical_lr(5 * s, step_size=s) == pytest.approx(2.5e-4 + (2.5e-3 - 2.5e-4) / 4)
+
+
+def test_normalise_inf_nan_rule():
+    x = np.array([[1.0, 2.0, 3.0]], dtype=np.float32)
+    out = O.normalise(x, np.array([1, 2, 1], np.float32), np.array([2, 0, 0], np.float32))
+    np.testing.assert_array_equal(out, [[0.0, 0.0, 0.0]])   # 0/2, 0/0 -> nan -> 0, 2/0 -> inf -> 0
+
+
+def test_bf16_mode_close_to_fp32():
+    cfg = O.MLPConfig(hidden=(256, 256))
+    ws = O.glorot_init(cfg, 2)
+    x, y = O.synth_columns(512, seed=4)
+    l32, _, g32, y32 = O.loss_and_grads(ws, x, y, cfg)
+    l16, _, g16, y16 = O.loss_and_grads(ws, x, y, cfg, bf16=True)
+    assert abs(l16 - l32) < 0.02 * l32
+    assert np.max(np.abs(y16 - y32)) < 0.02 * np.max(np.abs(y32))
