@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""bench.py - training columns/sec of the low-res MLP (BASELINE.json metric) on N MI355X.
+
+A "step" is one optimiser step of the cfg-MLP (124 -> 5x512 -> 128 -> [120 || 8], LeakyReLU 0.15,
+Adam eps=1e-7, bf16 MFMA with fp32 accumulate / fp32 master weights) on one batch of synthetic
+low-res-shaped columns gathered by a random permutation from an HBM-resident split:
+gather+normalise-cast -> 7 Dense forward -> fused MSE/dz -> 7 wgrad + 6 dgrad -> (N>1: ONE RCCL
+all-reduce of the flat fp32 gradient) -> fused optimiser + bf16 re-cast.  Nothing is skipped.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch PER_GPU_BATCH]
+  (N>1: launched by torch.distributed.run, one rank per GPU; weak scaling: global batch = N*batch)
+
+Prints ONE JSON line on rank 0 (see DESIGN.md section "Measurement").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+UNITS = (512, 512, 512, 512, 512)
+FLOPS_PER_COL = {"gemm_fwd": 2 * 1_193_984, "gemm_dgrad": 2 * 1_130_496, "wgrad": 2 * 1_193_984}
+TRAIN_FLOPS_PER_COL = 7_036_928
+HBM_BYTES_PER_COL = 1008                    # 496 B x + 512 B y (fp32 storage), SURVEY 8(d)
+PEAK_BF16_TFLOPS = 2500.0                   # dense MFMA peak, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+def synth_on_device(torch, n, seed, device):
+    """Low-res-shaped synthetic columns (SURVEY.md 8d recipe), generated on the GPU."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    x = torch.empty((n, 124), dtype=torch.float32, device=device)
+    x[:, :120] = (torch.randn((n, 120), generator=g, device=device) * 0.15).clamp_(-1, 1)
+    x[:, 120:] = torch.rand((n, 4), generator=g, device=device) - 0.5
+    night = torch.rand(n, generator=g, device=device) < 0.5
+    x[night, 121] = 0
+    ga = torch.Generator(device=device)
+    ga.manual_seed(20230614)
+    a = torch.randn((124, 128), generator=ga, device=device) / (124 ** 0.5)
+    y = torch.tanh(x @ a) * 0.05 + torch.randn((n, 128), generator=g, device=device) * 0.01
+    y[:, 120:] = y[:, 120:].clamp_(min=0)
+    y[:, 60:72] = 0
+    return x.contiguous(), y.contiguous()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=8192, help="per-GPU batch (columns per rank per step)")
+    ap.add_argument("--rows", type=int, default=1 << 20, help="HBM-resident synthetic rows per GPU")
+    ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU-baseline timing (0 = skip)")
+    ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event pass")
+    args = ap.parse_args()
+
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback for the engine)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    from climsim_amd import build
+    if rank == 0:
+        build.build()
+    if dist:
+        dist.barrier()
+    from climsim_amd.mlp import MLPEmulator
+
+    B = args.batch
+    model = MLPEmulator(units=UNITS, activation="leakyrelu", optimizer="Adam", max_batch=B, seed=0, device=local_rank)
+    x, y = synth_on_device(torch, args.rows, 20230614 + rank, device)
+    xv, yv = synth_on_device(torch, 65536, 777, device)
+    grad = model.gradient_tensor()
+    loss = torch.zeros(2, dtype=torch.float32, device=device)
+    lr = 1e-3
+    scale = 1.0 / (128.0 * B * world)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(1234 + rank)
+    perm = torch.randperm(args.rows, device=device, generator=gen)
+    nb = args.rows // B
+
+    def step(i):
+        idx = perm[(i % nb) * B:(i % nb + 1) * B]
+        if world > 1:
+            model.loss_grads(x, y, row_idx=idx, loss=loss)
+            dist.all_reduce(grad)
+            model.apply_gradients(lr, scale)
+        else:
+            model.train_on_batch(x, y, lr, row_idx=idx, loss=loss)
+
+    for i in range(args.warmup):
+        step(i)
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = B * world * args.steps / elapsed
+
+    # ---- untimed: held-out error of the model that was just trained, per-kernel timing, CPU baseline
+    held = model.evaluate(xv, yv)
+    roofline, kernels = None, None
+    if not args.no_profile and rank == 0:
+        agg = {}
+        reps = 20
+        for r in range(reps):
+            idx = perm[(r % nb) * B:(r % nb + 1) * B]
+            for k, (ms, cnt) in model.profile_step(x, y, lr, row_idx=idx).items():
+                a = agg.setdefault(k, [0.0, 0])
+                a[0] += ms
+                a[1] += cnt
+        kernels = {k: {"ms_per_step": v[0] / reps, "launches_per_step": v[1] / reps,
+                       "avg_us_per_launch": (v[0] / max(v[1], 1)) * 1e3} for k, v in agg.items()}
+        dom = max(FLOPS_PER_COL, key=lambda k: kernels[k]["ms_per_step"])
+        for k, f in FLOPS_PER_COL.items():
+            kernels[k]["tflops"] = f * B / (kernels[k]["ms_per_step"] * 1e-3) / 1e12
+        achieved = kernels[dom]["tflops"]
+        roofline = {"kernel": {"gemm_fwd": "k_gemm_nt<EPI_HIDDEN|EPI_OUT>", "gemm_dgrad": "k_gemm_nt<EPI_DGRAD>",
+                               "wgrad": "k_wgrad"}[dom],
+                    "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
+                    "avg_us_per_launch": round(kernels[dom]["avg_us_per_launch"], 2),
+                    "launches_per_step": kernels[dom]["launches_per_step"],
+                    "flops_per_launch": FLOPS_PER_COL[dom] * B / kernels[dom]["launches_per_step"],
+                    "traffic": None,
+                    "whole_step": {"achieved": round(TRAIN_FLOPS_PER_COL * B / (ms_per_step * 1e-3) / 1e12, 2),
+                                   "frac": round(TRAIN_FLOPS_PER_COL * B / (ms_per_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                                   "hbm_algorithmic_GBs": round(HBM_BYTES_PER_COL * B / (ms_per_step * 1e-3) / 1e9, 1)}}
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_budget > 0:
+        from oracle.mlp_oracle import MLPConfig, glorot_init, synth_columns
+        from oracle.mlp_torch_cpu import time_cpu_baseline
+        cfg = MLPConfig(hidden=UNITS)
+        xc, yc = synth_columns(16384, seed=1)
+        cpu = time_cpu_baseline(glorot_init(cfg, 0), cfg, xc, yc, batch=1024, budget_s=args.cpu_budget)
+        cpu["value"] = round(cpu["value"], 1)
+
+    if rank == 0:
+        out = {"metric": "training columns/sec", "value": round(value, 1), "unit": "columns/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": "cfg-MLP 124->5x512->128->(120||8) LeakyReLU(0.15), Adam(eps=1e-7) lr=1e-3, "
+                                      "mse, synthetic low-res columns gathered from an HBM-resident split",
+                          "per_gpu_batch": B, "global_batch": B * world, "rows_resident_per_gpu": args.rows,
+                          "parallelism": f"dp{world}", "params": model.count_params()},
+               "heldout": {"mse": held["mse"], "mae": held["mae"], "rows": 65536},
+               "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu}
+        print(json.dumps(out), flush=True)
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,85 @@
+"""ctypes binding of include/climsim_hip.h.  There is NO CPU fallback: if the shared library is
+missing or a call fails, an exception is raised."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libclimsim_hip.so")
+CS_MAX_HIDDEN = 16
+CS_FLAG_NO_TR_READ = 1
+
+ACT = {"relu": 0, "elu": 1, "leakyrelu": 2}
+OPT = {"Adam": 0, "RAdam": 1, "RMSprop": 2, "SGD": 3}
+
+
+class CsMlpCfg(C.Structure):
+    _fields_ = [("n_in", C.c_int32), ("n_hidden", C.c_int32), ("hidden", C.c_int32 * CS_MAX_HIDDEN),
+                ("n_out_lin", C.c_int32), ("n_out_relu", C.c_int32), ("act", C.c_int32), ("alpha", C.c_float),
+                ("optimizer", C.c_int32), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("rho", C.c_float), ("max_batch", C.c_int32), ("device", C.c_int32), ("flags", C.c_int32)]
+
+
+CS_K_COUNT = 8
+KERNEL_KINDS = ["prepare_input", "gemm_fwd", "gemm_dgrad", "wgrad", "optimizer", "memset"]
+
+
+class CsKernelTimes(C.Structure):
+    _fields_ = [("ms", C.c_float * CS_K_COUNT), ("launches", C.c_int32 * CS_K_COUNT)]
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+_P, _I64, _I32, _F = C.c_void_p, C.c_int64, C.c_int32, C.c_float
+# name -> (restype, argtypes); must list every symbol include/climsim_hip.h declares
+SIGNATURES = {
+    "cs_mlp_create": (C.c_int, [C.POINTER(_P), C.POINTER(CsMlpCfg)]),
+    "cs_mlp_destroy": (None, [_P]),
+    "cs_mlp_num_params": (_I64, [_P]),
+    "cs_mlp_device_bytes": (_I64, [_P]),
+    "cs_mlp_set_norm": (C.c_int, [_P, _P, _P]),
+    "cs_mlp_set_weights": (C.c_int, [_P, _P, _I64, _P]),
+    "cs_mlp_get_weights": (C.c_int, [_P, _P, _I64, _P]),
+    "cs_mlp_get_opt_state": (C.c_int, [_P, _P, _P, _I64, C.POINTER(_I64), _P]),
+    "cs_mlp_set_opt_state": (C.c_int, [_P, _P, _P, _I64, _I64, _P]),
+    "cs_mlp_forward": (C.c_int, [_P, _P, _P, _I64, C.c_int, _P, _P, _P, C.c_int, _P]),
+    "cs_mlp_loss_grads": (C.c_int, [_P, _P, _P, _P, _I64, C.c_int, _P, C.c_int, _P]),
+    "cs_mlp_grad_buffer": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_I64)]),
+    "cs_mlp_set_grad_buffer": (C.c_int, [_P, _P]),
+    "cs_mlp_apply": (C.c_int, [_P, _F, _F, _P]),
+    "cs_mlp_train_step": (C.c_int, [_P, _P, _P, _P, _I64, C.c_int, _F, _P, _P]),
+    "cs_mlp_profile_step": (C.c_int, [_P, _P, _P, _P, _I64, C.c_int, _F, _P, _P, C.POINTER(CsKernelTimes)]),
+    "cs_normalise_rows": (C.c_int, [_P, _P, _I64, _I32, _P, _P, _P, _P]),
+    "cs_last_error": (C.c_char_p, []),
+    "cs_version": (C.c_char_p, []),
+}
+
+_lib = None
+
+
+def load():
+    """Load libclimsim_hip.so (after torch, so that both share one HIP runtime)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EngineError(f"{LIB_PATH} not found - build it with `python -m climsim_amd.build` "
+                          "(there is no CPU fallback for the engine)")
+    try:
+        import torch  # noqa: F401  (its bundled libamdhip64 must be the one already mapped)
+    except ImportError:
+        pass
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError if the symbol is missing
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(rc: int):
+    if rc != 0:
+        raise EngineError(f"climsim_hip error {rc}: {load().cs_last_error().decode()}")

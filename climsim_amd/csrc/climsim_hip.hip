@@ -1,0 +1,466 @@
+// C-ABI implementation (include/climsim_hip.h) of the MI355X MLP engine.
+// Host-side orchestration only: owns device buffers, launches the kernels of kernels.h on the
+// caller's stream.  No PyTorch types, no CPU fallback: every compute entry point runs HIP kernels.
+#include "../../include/climsim_hip.h"
+#include "kernels.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail(CS_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+inline int64_t round_up(int64_t v, int64_t q) { return (v + q - 1) / q * q; }
+
+// Optional per-launch HIP-event timing (cs_mlp_profile_step): events are recorded on the SAME
+// stream the kernels run on, immediately before and after each launch.
+struct Profiler {
+    struct Rec { int kind; hipEvent_t a, b; };
+    std::vector<Rec> recs;
+    hipStream_t st = nullptr;
+    hipEvent_t begin(int kind) {
+        Rec r{kind, nullptr, nullptr};
+        (void)hipEventCreate(&r.a);
+        (void)hipEventCreate(&r.b);
+        (void)hipEventRecord(r.a, st);
+        recs.push_back(r);
+        return r.b;
+    }
+};
+thread_local Profiler* g_prof = nullptr;
+
+struct ProfScope {
+    hipEvent_t stop = nullptr;
+    hipStream_t st;
+    ProfScope(int kind, hipStream_t s) : st(s) { if (g_prof) stop = g_prof->begin(kind); }
+    ~ProfScope() { if (stop) (void)hipEventRecord(stop, st); }
+};
+
+struct Layer {
+    int K, Kp, N;
+    int64_t w_off, b_off;      // offsets (floats) in the flat parameter buffer
+    u16 *Wt, *Wn;              // bf16 operand copies [N][Kp], [Kp][N]
+    u16 *H;                    // layer INPUT activations [m_pad_max][Kp]
+    u16 *dZ;                   // d loss / d pre-activation of this layer [m_pad_max][N]
+};
+
+}  // namespace
+
+struct cs_mlp {
+    cs_mlp_cfg cfg;
+    int L = 0;
+    std::vector<Layer> layers;
+    int64_t n_params = 0;
+    int64_t m_pad_max = 0;
+    float *P = nullptr, *M = nullptr, *V = nullptr, *G = nullptr;
+    bool own_G = true;
+    float *sub = nullptr, *div = nullptr;
+    bool have_norm = false;
+    Segment* seg_dev = nullptr;
+    int n_seg = 0;
+    int64_t iterations = 0;
+    int64_t bytes = 0;
+    std::vector<void*> allocs;
+};
+
+namespace {
+
+int dev_alloc(cs_mlp* h, void** p, size_t bytes, bool zero) {
+    if (hipMalloc(p, bytes) != hipSuccess) return fail(CS_ERR_NOMEM, "hipMalloc(%zu bytes) failed", bytes);
+    if (zero) HIP_TRY(hipMemset(*p, 0, bytes));
+    h->allocs.push_back(*p);
+    h->bytes += (int64_t)bytes;
+    return CS_OK;
+}
+
+// Keras order <-> internal order differ only in the last layer: heads [W_lin(128,120), b_lin,
+// W_relu(128,8), b_relu] are stored as one fused [128][128] matrix + one [128] bias.
+void keras_to_internal(const cs_mlp* h, const float* src, float* dst) {
+    const Layer& last = h->layers[h->L - 1];
+    const int64_t head = last.w_off;
+    memcpy(dst, src, sizeof(float) * head);
+    const int nl = h->cfg.n_out_lin, nr = h->cfg.n_out_relu, K = last.K, N = last.N;
+    const float* wl = src + head;
+    const float* bl = wl + (int64_t)K * nl;
+    const float* wr = bl + nl;
+    const float* br = wr + (int64_t)K * nr;
+    for (int k = 0; k < K; ++k) {
+        memcpy(dst + last.w_off + (int64_t)k * N, wl + (int64_t)k * nl, sizeof(float) * nl);
+        memcpy(dst + last.w_off + (int64_t)k * N + nl, wr + (int64_t)k * nr, sizeof(float) * nr);
+    }
+    memcpy(dst + last.b_off, bl, sizeof(float) * nl);
+    memcpy(dst + last.b_off + nl, br, sizeof(float) * nr);
+}
+
+void internal_to_keras(const cs_mlp* h, const float* src, float* dst) {
+    const Layer& last = h->layers[h->L - 1];
+    const int64_t head = last.w_off;
+    memcpy(dst, src, sizeof(float) * head);
+    const int nl = h->cfg.n_out_lin, nr = h->cfg.n_out_relu, K = last.K, N = last.N;
+    float* wl = dst + head;
+    float* bl = wl + (int64_t)K * nl;
+    float* wr = bl + nl;
+    float* br = wr + (int64_t)K * nr;
+    for (int k = 0; k < K; ++k) {
+        memcpy(wl + (int64_t)k * nl, src + last.w_off + (int64_t)k * N, sizeof(float) * nl);
+        memcpy(wr + (int64_t)k * nr, src + last.w_off + (int64_t)k * N + nl, sizeof(float) * nr);
+    }
+    memcpy(bl, src + last.b_off, sizeof(float) * nl);
+    memcpy(br, src + last.b_off + nl, sizeof(float) * nr);
+}
+
+int launch_optimizer(cs_mlp* h, float lr, float grad_scale, bool recast_only, hipStream_t st) {
+    OptArgs a{};
+    a.P = h->P; a.M = h->M; a.V = h->V; a.G = h->G;
+    a.n4 = h->n_params / 4;
+    a.n_seg = h->n_seg; a.seg = h->seg_dev;
+    a.kind = h->cfg.optimizer; a.lr = lr; a.grad_scale = grad_scale;
+    a.beta1 = h->cfg.beta1; a.beta2 = h->cfg.beta2; a.eps = h->cfg.eps; a.rho = h->cfg.rho;
+    a.recast_only = recast_only ? 1 : 0;
+    const double t = (double)(h->iterations + 1);
+    const double b1 = h->cfg.beta1, b2 = h->cfg.beta2;
+    const double bc1 = 1.0 - std::pow(b1, t), bc2 = 1.0 - std::pow(b2, t);
+    a.bc1 = (float)bc1; a.bc2 = (float)bc2;
+    const double sma_inf = 2.0 / (1.0 - b2) - 1.0;
+    const double sma_t = sma_inf - 2.0 * t * std::pow(b2, t) / bc2;
+    a.radam_rect = sma_t >= 5.0 ? 1 : 0;
+    a.radam_r = a.radam_rect
+        ? (float)std::sqrt((sma_t - 4.0) / (sma_inf - 4.0) * (sma_t - 2.0) / (sma_inf - 2.0) * sma_inf / sma_t) : 0.f;
+    const int threads = 256;
+    const int64_t blocks = (a.n4 + threads - 1) / threads;
+    {
+        ProfScope ps(CS_K_OPTIMIZER, st);
+        hipLaunchKernelGGL(k_optimizer, dim3((unsigned)blocks), dim3(threads), 0, st, a);
+    }
+    HIP_TRY(hipGetLastError());
+    return CS_OK;
+}
+
+int run_forward(cs_mlp* h, const float* x, const int64_t* row_idx, int64_t n, int normalise, float* yhat,
+                const float* y, float* loss, bool want_dz, hipStream_t st) {
+    const int64_t m_pad = round_up(n, 128);
+    const Layer& l0 = h->layers[0];
+    {
+        const int64_t total = m_pad * (l0.Kp / 4);
+        ProfScope ps(CS_K_PREPARE, st);
+        hipLaunchKernelGGL(k_prepare_input, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, row_idx, n,
+                           m_pad, h->cfg.n_in, l0.Kp, h->sub, h->div, normalise, l0.H);
+    }
+    for (int l = 0; l < h->L; ++l) {
+        const Layer& ly = h->layers[l];
+        GemmNT p{};
+        p.A = ly.H; p.lda = ly.Kp; p.B = ly.Wt; p.ldb = ly.Kp; p.K = ly.Kp; p.N = ly.N;
+        p.act = h->cfg.act; p.alpha = h->cfg.alpha;
+        p.bias = h->P + ly.b_off;
+        const dim3 grid((unsigned)(m_pad / 128), (unsigned)(ly.N / 128));
+        ProfScope ps(CS_K_GEMM_FWD, st);
+        if (l + 1 < h->L) {
+            p.out = h->layers[l + 1].H; p.ldo = h->layers[l + 1].Kp;
+            hipLaunchKernelGGL(k_gemm_nt<EPI_HIDDEN>, grid, dim3(256), 0, st, p);
+        } else {
+            p.n_lin = h->cfg.n_out_lin; p.yhat = yhat; p.y = y; p.row_idx = row_idx; p.n_rows = n; p.loss = loss;
+            p.out = want_dz ? ly.dZ : nullptr; p.ldo = ly.N;
+            hipLaunchKernelGGL(k_gemm_nt<EPI_OUT>, grid, dim3(256), 0, st, p);
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    return CS_OK;
+}
+
+int run_backward(cs_mlp* h, int64_t n, bool atomics_needed, hipStream_t st) {
+    const int64_t m_pad = round_up(n, 128);
+    const int steps = (int)(m_pad / 64);
+    const bool tr = !(h->cfg.flags & CS_FLAG_NO_TR_READ);
+    for (int l = h->L - 1; l >= 0; --l) {
+        const Layer& ly = h->layers[l];
+        WgradArgs w{};
+        w.H = ly.H; w.ldh = ly.Kp; w.Z = ly.dZ; w.ldz = ly.N; w.m_pad = m_pad;
+        w.dW = h->G + ly.w_off; w.N = ly.N; w.k_real = ly.K; w.db = h->G + ly.b_off;
+        const int tiles = (ly.Kp / 128) * (ly.N / 128);
+        int splitk = 256 / tiles;
+        if (splitk < 1) splitk = 1;
+        if (splitk > steps) splitk = steps;
+        w.use_atomics = (splitk > 1 || atomics_needed) ? 1 : 0;
+        const dim3 grid((unsigned)(ly.Kp / 128), (unsigned)(ly.N / 128), (unsigned)splitk);
+        {
+            ProfScope ps(CS_K_WGRAD, st);
+            if (tr) hipLaunchKernelGGL(k_wgrad<true>, grid, dim3(256), 0, st, w);
+            else hipLaunchKernelGGL(k_wgrad<false>, grid, dim3(256), 0, st, w);
+        }
+        if (l > 0) {
+            GemmNT p{};
+            p.A = ly.dZ; p.lda = ly.N; p.B = ly.Wn; p.ldb = ly.N; p.K = ly.N; p.N = ly.Kp;
+            p.act = h->cfg.act; p.alpha = h->cfg.alpha;
+            p.out = h->layers[l - 1].dZ; p.ldo = h->layers[l - 1].N;
+            p.hprev = ly.H; p.ldh = ly.Kp;
+            const dim3 g2((unsigned)(m_pad / 128), (unsigned)(ly.Kp / 128));
+            ProfScope ps(CS_K_GEMM_DGRAD, st);
+            hipLaunchKernelGGL(k_gemm_nt<EPI_DGRAD>, g2, dim3(256), 0, st, p);
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    return CS_OK;
+}
+
+int check_batch(const cs_mlp* h, int64_t n) {
+    if (!h) return fail(CS_ERR_INVALID, "null handle");
+    if (n <= 0 || n > h->cfg.max_batch) return fail(CS_ERR_INVALID, "n=%lld outside 1..max_batch=%d", (long long)n, h->cfg.max_batch);
+    return CS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* cs_last_error(void) { return g_err.c_str(); }
+const char* cs_version(void) { return "climsim_hip 0.1 (gfx950)"; }
+
+int cs_mlp_create(cs_mlp_t** out, const cs_mlp_cfg* cfg) {
+    if (!out || !cfg) return fail(CS_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (cfg->n_in <= 0 || cfg->n_in > 4096) return fail(CS_ERR_INVALID, "n_in=%d out of range", cfg->n_in);
+    if (cfg->n_hidden < 1 || cfg->n_hidden > CS_MAX_HIDDEN) return fail(CS_ERR_INVALID, "n_hidden=%d not in 1..%d", cfg->n_hidden, CS_MAX_HIDDEN);
+    for (int i = 0; i < cfg->n_hidden; ++i)
+        if (cfg->hidden[i] <= 0 || cfg->hidden[i] % 128) return fail(CS_ERR_INVALID, "hidden[%d]=%d must be a positive multiple of 128", i, cfg->hidden[i]);
+    if (cfg->n_out_lin + cfg->n_out_relu != 128 || cfg->n_out_lin % 4 || cfg->n_out_lin < 0 || cfg->n_out_relu < 0)
+        return fail(CS_ERR_INVALID, "heads must total 128 outputs with n_out_lin a multiple of 4 (got %d+%d)", cfg->n_out_lin, cfg->n_out_relu);
+    if (cfg->act < 0 || cfg->act > 2) return fail(CS_ERR_INVALID, "unknown activation %d", cfg->act);
+    if (cfg->optimizer < 0 || cfg->optimizer > 3) return fail(CS_ERR_INVALID, "unknown optimizer %d", cfg->optimizer);
+    if (cfg->max_batch <= 0) return fail(CS_ERR_INVALID, "max_batch must be positive");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(CS_ERR_INVALID, "device %d not in 0..%d", cfg->device, ndev - 1);
+    HIP_TRY(hipSetDevice(cfg->device));
+
+    cs_mlp* h = new cs_mlp();
+    h->cfg = *cfg;
+    h->L = cfg->n_hidden + 2;
+    h->m_pad_max = round_up(cfg->max_batch, 128);
+    std::vector<int> dims;
+    dims.push_back(cfg->n_in);
+    for (int i = 0; i < cfg->n_hidden; ++i) dims.push_back(cfg->hidden[i]);
+    dims.push_back(128);
+    dims.push_back(128);
+    int64_t off = 0;
+    h->layers.resize(h->L);
+    for (int l = 0; l < h->L; ++l) {
+        Layer& ly = h->layers[l];
+        ly.K = dims[l]; ly.N = dims[l + 1]; ly.Kp = (int)round_up(ly.K, 128);
+        ly.w_off = off; off += (int64_t)ly.K * ly.N;
+        ly.b_off = off; off += ly.N;
+    }
+    h->n_params = off;
+    int rc = CS_OK;
+    auto A = [&](void** p, size_t b, bool z) { if (rc == CS_OK) rc = dev_alloc(h, p, b, z); };
+    A((void**)&h->P, sizeof(float) * off, true);
+    A((void**)&h->M, sizeof(float) * off, true);
+    A((void**)&h->V, sizeof(float) * off, true);
+    A((void**)&h->G, sizeof(float) * off, true);
+    A((void**)&h->sub, sizeof(float) * cfg->n_in, true);
+    A((void**)&h->div, sizeof(float) * cfg->n_in, true);
+    std::vector<Segment> segs;
+    for (int l = 0; l < h->L && rc == CS_OK; ++l) {
+        Layer& ly = h->layers[l];
+        A((void**)&ly.Wt, sizeof(u16) * ly.N * ly.Kp, true);
+        A((void**)&ly.Wn, sizeof(u16) * ly.Kp * ly.N, true);
+        A((void**)&ly.H, sizeof(u16) * h->m_pad_max * ly.Kp, true);
+        A((void**)&ly.dZ, sizeof(u16) * h->m_pad_max * ly.N, true);
+        Segment sw{ly.w_off, (int64_t)ly.K * ly.N, ly.K, ly.N, ly.Kp, ly.Wt, ly.Wn};
+        Segment sb{ly.b_off, (int64_t)ly.N, 1, ly.N, 0, nullptr, nullptr};
+        segs.push_back(sw);
+        segs.push_back(sb);
+    }
+    h->n_seg = (int)segs.size();
+    A((void**)&h->seg_dev, sizeof(Segment) * segs.size(), false);
+    if (rc == CS_OK && hipMemcpy(h->seg_dev, segs.data(), sizeof(Segment) * segs.size(), hipMemcpyHostToDevice) != hipSuccess)
+        rc = fail(CS_ERR_HIP, "segment table upload failed");
+    if (rc != CS_OK) { cs_mlp_destroy(h); return rc; }
+    *out = h;
+    return CS_OK;
+}
+
+void cs_mlp_destroy(cs_mlp_t* h) {
+    if (!h) return;
+    for (void* p : h->allocs) (void)hipFree(p);
+    delete h;
+}
+
+int64_t cs_mlp_num_params(const cs_mlp_t* h) { return h ? h->n_params : 0; }
+int64_t cs_mlp_device_bytes(const cs_mlp_t* h) { return h ? h->bytes : 0; }
+
+int cs_mlp_set_norm(cs_mlp_t* h, const float* input_sub, const float* input_div) {
+    if (!h || !input_sub || !input_div) return fail(CS_ERR_INVALID, "null argument");
+    HIP_TRY(hipMemcpy(h->sub, input_sub, sizeof(float) * h->cfg.n_in, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->div, input_div, sizeof(float) * h->cfg.n_in, hipMemcpyHostToDevice));
+    h->have_norm = true;
+    return CS_OK;
+}
+
+int cs_mlp_set_weights(cs_mlp_t* h, const float* host, int64_t n, void* stream) {
+    if (!h || !host) return fail(CS_ERR_INVALID, "null argument");
+    if (n != h->n_params) return fail(CS_ERR_INVALID, "expected %lld floats, got %lld", (long long)h->n_params, (long long)n);
+    std::vector<float> tmp((size_t)n);
+    keras_to_internal(h, host, tmp.data());
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(h->P, tmp.data(), sizeof(float) * n, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return launch_optimizer(h, 0.f, 0.f, true, st);
+}
+
+int cs_mlp_get_weights(cs_mlp_t* h, float* host, int64_t n, void* stream) {
+    if (!h || !host) return fail(CS_ERR_INVALID, "null argument");
+    if (n != h->n_params) return fail(CS_ERR_INVALID, "expected %lld floats, got %lld", (long long)h->n_params, (long long)n);
+    std::vector<float> tmp((size_t)n);
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(tmp.data(), h->P, sizeof(float) * n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    internal_to_keras(h, tmp.data(), host);
+    return CS_OK;
+}
+
+int cs_mlp_get_opt_state(cs_mlp_t* h, float* host_m, float* host_v, int64_t n, int64_t* iterations, void* stream) {
+    if (!h || !host_m || !host_v) return fail(CS_ERR_INVALID, "null argument");
+    if (n != h->n_params) return fail(CS_ERR_INVALID, "expected %lld floats, got %lld", (long long)h->n_params, (long long)n);
+    std::vector<float> tmp((size_t)n);
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(tmp.data(), h->M, sizeof(float) * n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    internal_to_keras(h, tmp.data(), host_m);
+    HIP_TRY(hipMemcpyAsync(tmp.data(), h->V, sizeof(float) * n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    internal_to_keras(h, tmp.data(), host_v);
+    if (iterations) *iterations = h->iterations;
+    return CS_OK;
+}
+
+int cs_mlp_set_opt_state(cs_mlp_t* h, const float* host_m, const float* host_v, int64_t n, int64_t iterations, void* stream) {
+    if (!h || !host_m || !host_v) return fail(CS_ERR_INVALID, "null argument");
+    if (n != h->n_params) return fail(CS_ERR_INVALID, "expected %lld floats, got %lld", (long long)h->n_params, (long long)n);
+    if (iterations < 0) return fail(CS_ERR_INVALID, "negative iteration count");
+    std::vector<float> tmp((size_t)n);
+    hipStream_t st = (hipStream_t)stream;
+    keras_to_internal(h, host_m, tmp.data());
+    HIP_TRY(hipMemcpyAsync(h->M, tmp.data(), sizeof(float) * n, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    keras_to_internal(h, host_v, tmp.data());
+    HIP_TRY(hipMemcpyAsync(h->V, tmp.data(), sizeof(float) * n, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    h->iterations = iterations;
+    return CS_OK;
+}
+
+int cs_mlp_forward(cs_mlp_t* h, const float* x_dev, const int64_t* row_idx_dev, int64_t n, int normalise,
+                   float* yhat_dev, const float* y_dev, float* loss_dev, int accumulate, void* stream) {
+    int rc = check_batch(h, n);
+    if (rc) return rc;
+    if (!x_dev) return fail(CS_ERR_INVALID, "x_dev is null");
+    if (y_dev && !loss_dev) return fail(CS_ERR_INVALID, "targets given without loss_dev");
+    if (normalise && !h->have_norm) return fail(CS_ERR_STATE, "normalise requested before cs_mlp_set_norm");
+    hipStream_t st = (hipStream_t)stream;
+    if (y_dev && !accumulate) HIP_TRY(hipMemsetAsync(loss_dev, 0, 2 * sizeof(float), st));
+    return run_forward(h, x_dev, row_idx_dev, n, normalise, yhat_dev, y_dev, loss_dev, false, st);
+}
+
+int cs_mlp_loss_grads(cs_mlp_t* h, const float* x_dev, const float* y_dev, const int64_t* row_idx_dev, int64_t n,
+                      int normalise, float* loss_dev, int accumulate, void* stream) {
+    int rc = check_batch(h, n);
+    if (rc) return rc;
+    if (!x_dev || !y_dev || !loss_dev) return fail(CS_ERR_INVALID, "x_dev, y_dev and loss_dev are required");
+    if (normalise && !h->have_norm) return fail(CS_ERR_STATE, "normalise requested before cs_mlp_set_norm");
+    hipStream_t st = (hipStream_t)stream;
+    if (!accumulate) {
+        ProfScope ps(CS_K_MEMSET, st);
+        HIP_TRY(hipMemsetAsync(loss_dev, 0, 2 * sizeof(float), st));
+        HIP_TRY(hipMemsetAsync(h->G, 0, sizeof(float) * h->n_params, st));
+    }
+    rc = run_forward(h, x_dev, row_idx_dev, n, normalise, nullptr, y_dev, loss_dev, true, st);
+    if (rc) return rc;
+    return run_backward(h, n, accumulate != 0, st);
+}
+
+int cs_mlp_grad_buffer(cs_mlp_t* h, void** dev_ptr, int64_t* n_floats) {
+    if (!h || !dev_ptr || !n_floats) return fail(CS_ERR_INVALID, "null argument");
+    *dev_ptr = h->G;
+    *n_floats = h->n_params;
+    return CS_OK;
+}
+
+int cs_mlp_set_grad_buffer(cs_mlp_t* h, void* dev_ptr) {
+    if (!h || !dev_ptr) return fail(CS_ERR_INVALID, "null argument");
+    if (((uintptr_t)dev_ptr) & 15) return fail(CS_ERR_INVALID, "gradient buffer must be 16-byte aligned");
+    h->G = (float*)dev_ptr;
+    h->own_G = false;
+    return CS_OK;
+}
+
+int cs_mlp_apply(cs_mlp_t* h, float lr, float grad_scale, void* stream) {
+    if (!h) return fail(CS_ERR_INVALID, "null handle");
+    int rc = launch_optimizer(h, lr, grad_scale, false, (hipStream_t)stream);
+    if (rc == CS_OK) h->iterations += 1;
+    return rc;
+}
+
+int cs_mlp_train_step(cs_mlp_t* h, const float* x_dev, const float* y_dev, const int64_t* row_idx_dev, int64_t n,
+                      int normalise, float lr, float* loss_dev, void* stream) {
+    int rc = cs_mlp_loss_grads(h, x_dev, y_dev, row_idx_dev, n, normalise, loss_dev, 0, stream);
+    if (rc) return rc;
+    return cs_mlp_apply(h, lr, 1.0f / (128.0f * (float)n), stream);
+}
+
+int cs_mlp_profile_step(cs_mlp_t* h, const float* x_dev, const float* y_dev, const int64_t* row_idx_dev, int64_t n,
+                        int normalise, float lr, float* loss_dev, void* stream, cs_kernel_times* out) {
+    if (!out) return fail(CS_ERR_INVALID, "null argument");
+    memset(out, 0, sizeof(*out));
+    Profiler prof;
+    prof.st = (hipStream_t)stream;
+    g_prof = &prof;
+    int rc = cs_mlp_train_step(h, x_dev, y_dev, row_idx_dev, n, normalise, lr, loss_dev, stream);
+    g_prof = nullptr;
+    hipError_t e = hipStreamSynchronize(prof.st);
+    for (auto& r : prof.recs) {
+        float ms = 0.f;
+        if (e == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess && r.kind >= 0 && r.kind < CS_K_COUNT) {
+            out->ms[r.kind] += ms;
+            out->launches[r.kind] += 1;
+        }
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(CS_ERR_HIP, "stream synchronize failed: %s", hipGetErrorString(e));
+    return CS_OK;
+}
+
+int cs_normalise_rows(const float* x_dev, const int64_t* row_idx_dev, int64_t n, int32_t width, const float* sub_dev,
+                      const float* div_dev, float* out_dev, void* stream) {
+    if (!x_dev || !sub_dev || !div_dev || !out_dev) return fail(CS_ERR_INVALID, "null argument");
+    if (n <= 0 || width <= 0) return fail(CS_ERR_INVALID, "empty input");
+    const int64_t total = n * ((width + 3) / 4);
+    hipLaunchKernelGGL(k_normalise_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x_dev,
+                       row_idx_dev, n, width, sub_dev, div_dev, out_dev);
+    HIP_TRY(hipGetLastError());
+    return CS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,475 @@
+// Device kernels of the MLP engine (gfx950 / CDNA4 only).
+//
+// Contractions run on v_mfma_f32_32x32x16_bf16 (bf16 operands, fp32 accumulate); everything
+// else (normalisation, loss, optimiser) is fp32 VALU work.  No CUDA/other-arch paths.
+//
+//   k_prepare_input : gather + normalise + bf16 cast of the column batch        (HBM-bound)
+//   k_gemm_nt<EPI>  : C[M,N] = A[M,K] * B[N,K]^T, both operands K-contiguous     (MFMA-bound)
+//                     EPI_HIDDEN : + bias, activation, bf16 store       (Dense + act, forward)
+//                     EPI_OUT    : + bias, per-column head activation, yhat fp32, fused
+//                                  squared/absolute error sums and dz = 2(yhat-y)*mask
+//                     EPI_DGRAD  : * act'(h) -> bf16 dz of the previous layer   (backward data)
+//   k_wgrad<TR>     : dW[K,N] += H[M,K]^T dZ[M,N] (reduction over rows, split over the grid),
+//                     db[N] += column sums of dZ                                 (backward weights)
+//   k_optimizer     : Keras Adam / RMSprop / SGD, tfa RectifiedAdam + bf16 re-cast (HBM/L2-bound)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned short u16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+enum { EPI_HIDDEN = 0, EPI_OUT = 1, EPI_DGRAD = 2 };
+enum { ACT_RELU = 0, ACT_ELU = 1, ACT_LEAKY = 2 };
+
+// ---------------------------------------------------------------- small helpers
+__device__ __forceinline__ u16 f2bf(float f) {           // round-to-nearest-even, NaN kept quiet
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u16)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (u16)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(u16 h) { return __uint_as_float(((unsigned)h) << 16); }
+__device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) {
+    return make_uint2((unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16), (unsigned)f2bf(c) | ((unsigned)f2bf(d) << 16));
+}
+__device__ __forceinline__ float act_fwd(float z, int kind, float alpha) {
+    if (kind == ACT_RELU) return fmaxf(z, 0.f);
+    if (kind == ACT_LEAKY) return z > 0.f ? z : alpha * z;
+    return z > 0.f ? z : expm1f(z);
+}
+// d act/dz from the stored activation OUTPUT h (h>0 <=> z>0 for all three activations)
+__device__ __forceinline__ float act_bwd_from_h(float h, int kind, float alpha) {
+    if (kind == ACT_RELU) return h > 0.f ? 1.f : 0.f;
+    if (kind == ACT_LEAKY) return h > 0.f ? 1.f : alpha;
+    return h > 0.f ? 1.f : h + 1.f;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------- input staging
+// h0[m][0..127] = bf16( normalise ? (x-sub)/div with inf/nan->0 : x ), zero for cols >= n_in and
+// rows >= n (rows up to m_pad are written so that later tiles read finite data).
+// One thread = 4 consecutive features.  x rows are n_in floats (124 -> 496 B, 16-B aligned).
+__global__ __launch_bounds__(256) void k_prepare_input(const float* __restrict__ x, const int64_t* __restrict__ row_idx,
+                                                       int64_t n, int64_t m_pad, int n_in, int kp,
+                                                       const float* __restrict__ sub, const float* __restrict__ div,
+                                                       int normalise, u16* __restrict__ h0) {
+    const int groups = kp >> 2;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= m_pad * groups) return;
+    const int64_t m = gid / groups;
+    const int c = (int)(gid - m * groups) * 4;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (m < n && c < n_in) {
+        const int64_t src = row_idx ? row_idx[m] : m;
+        const float* xr = x + src * n_in + c;
+        if (c + 3 < n_in && (n_in & 3) == 0) {
+            const float4 t = *reinterpret_cast<const float4*>(xr);
+            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+        } else {
+            for (int j = 0; j < 4 && c + j < n_in; ++j) v[j] = xr[j];
+        }
+        if (normalise) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (c + j < n_in) {
+                    float t = (v[j] - sub[c + j]) / div[c + j];
+                    v[j] = (fabsf(t) <= 3.402823466e38f) ? t : 0.f;   // false for inf and nan
+                }
+        }
+    }
+    *reinterpret_cast<uint2*>(h0 + m * kp + c) = pack4(v[0], v[1], v[2], v[3]);
+}
+
+// float32 -> float32 loader-path normalisation (optionally gathered), 4 features per thread.
+__global__ __launch_bounds__(256) void k_normalise_rows(const float* __restrict__ x, const int64_t* __restrict__ row_idx,
+                                                        int64_t n, int width, const float* __restrict__ sub,
+                                                        const float* __restrict__ div, float* __restrict__ out) {
+    const int groups = (width + 3) >> 2;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n * groups) return;
+    const int64_t m = gid / groups;
+    const int c = (int)(gid - m * groups) * 4;
+    const int64_t src = row_idx ? row_idx[m] : m;
+    for (int j = 0; j < 4 && c + j < width; ++j) {
+        float t = (x[src * width + c + j] - sub[c + j]) / div[c + j];
+        out[m * width + c + j] = (fabsf(t) <= 3.402823466e38f) ? t : 0.f;
+    }
+}
+
+// ---------------------------------------------------------------- NT GEMM (forward, dgrad)
+struct GemmNT {
+    const u16* A;  int lda;      // [m_pad][lda]  activations / dz, K-contiguous
+    const u16* B;  int ldb;      // [N][ldb]      weights with the contraction index contiguous
+    int K;                       // contraction length, multiple of 64
+    int N;                       // output width, multiple of 128
+    int act; float alpha;
+    // EPI_HIDDEN / EPI_OUT
+    const float* bias;           // [N]
+    u16* out;  int ldo;          // bf16 output [m_pad][ldo] (hidden activation, or dz of the heads / prev layer)
+    // EPI_OUT
+    int n_lin;                   // columns < n_lin are linear, the rest relu
+    float* yhat;                 // [n][N] fp32 or null
+    const float* y;              // targets (row-gathered) or null
+    const int64_t* row_idx;
+    int64_t n_rows;              // valid rows
+    float* loss;                 // [2] sum sq err, sum abs err
+    // EPI_DGRAD
+    const u16* hprev; int ldh;   // activation output of the previous layer (same shape as out)
+};
+
+// LDS tile [128 rows][64 k] bf16, 16-B chunks XOR-swizzled with (row>>1)&7: the 16 lanes of every
+// ds_read_b128 service group then hit 16 distinct 16-B slots of the 256-B bank row (conflict-free),
+// and each ds_write_b128 group (8 lanes = one row) stays inside one 128-B row.
+__device__ __forceinline__ int swz_nt(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3); }
+
+template <int EPI>
+__global__ __launch_bounds__(256) void k_gemm_nt(const GemmNT p) {
+    __shared__ __attribute__((aligned(16))) u16 smem[2][2][128 * 64];   // [buffer][A|B] = 64 KiB
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;             // 2x2 waves, each a 64(m) x 64(n) sub-tile
+    const int64_t m0 = (int64_t)blockIdx.x * 128;
+    const int n0 = blockIdx.y * 128;
+    const int srow = tid >> 3, sch = tid & 7;          // staging: 4 rows (stride 32) x one 16-B chunk
+    const u16* Ag = p.A + (m0 + srow) * p.lda + sch * 8;
+    const u16* Bg = p.B + (int64_t)(n0 + srow) * p.ldb + sch * 8;
+    uint4 ra[4], rb[4];
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nt = p.K >> 6;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        ra[i] = *reinterpret_cast<const uint4*>(Ag + (int64_t)i * 32 * p.lda);
+        rb[i] = *reinterpret_cast<const uint4*>(Bg + (int64_t)i * 32 * p.ldb);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        *reinterpret_cast<uint4*>(&smem[0][0][swz_nt(srow + 32 * i, sch)]) = ra[i];
+        *reinterpret_cast<uint4*>(&smem[0][1][swz_nt(srow + 32 * i, sch)]) = rb[i];
+    }
+    __syncthreads();
+    const int frow = lane & 31, fch = lane >> 5;
+    for (int t = 0; t < nt; ++t) {
+        if (t + 1 < nt) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ra[i] = *reinterpret_cast<const uint4*>(Ag + (int64_t)i * 32 * p.lda + (t + 1) * 64);
+                rb[i] = *reinterpret_cast<const uint4*>(Bg + (int64_t)i * 32 * p.ldb + (t + 1) * 64);
+            }
+        }
+        const u16* As = smem[t & 1][0];
+        const u16* Bs = smem[t & 1][1];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            bf16x8_t fa[2], fb[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                fa[j] = *reinterpret_cast<const bf16x8_t*>(&As[swz_nt(wm * 64 + j * 32 + frow, kk * 2 + fch)]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                fb[i] = *reinterpret_cast<const bf16x8_t*>(&Bs[swz_nt(wn * 64 + i * 32 + frow, kk * 2 + fch)]);
+            // weights as the MFMA A operand (result rows = n), activations as B (result cols = m):
+            // every lane then owns 4 consecutive n of one row m -> 8-byte bf16 stores.
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[i], fa[j], acc[i][j], 0, 0, 0);
+        }
+        if (t + 1 < nt) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                *reinterpret_cast<uint4*>(&smem[(t + 1) & 1][0][swz_nt(srow + 32 * i, sch)]) = ra[i];
+                *reinterpret_cast<uint4*>(&smem[(t + 1) & 1][1][swz_nt(srow + 32 * i, sch)]) = rb[i];
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane owns row m = ..+(lane&31), columns n = ..+8q+4*(lane>>5)+{0..3}
+    float sq = 0.f, ab = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int n = n0 + wn * 64 + i * 32 + 8 * q + 4 * (lane >> 5);
+            float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (EPI != EPI_DGRAD) b4 = *reinterpret_cast<const float4*>(p.bias + n);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int64_t m = m0 + wm * 64 + j * 32 + (lane & 31);
+                float v[4] = {acc[i][j][4 * q + 0], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                if (EPI == EPI_HIDDEN) {
+                    v[0] = act_fwd(v[0] + b4.x, p.act, p.alpha); v[1] = act_fwd(v[1] + b4.y, p.act, p.alpha);
+                    v[2] = act_fwd(v[2] + b4.z, p.act, p.alpha); v[3] = act_fwd(v[3] + b4.w, p.act, p.alpha);
+                    *reinterpret_cast<uint2*>(p.out + m * p.ldo + n) = pack4(v[0], v[1], v[2], v[3]);
+                } else if (EPI == EPI_DGRAD) {
+                    const uint2 hh = *reinterpret_cast<const uint2*>(p.hprev + m * p.ldh + n);
+                    v[0] *= act_bwd_from_h(bf2f((u16)(hh.x & 0xffff)), p.act, p.alpha);
+                    v[1] *= act_bwd_from_h(bf2f((u16)(hh.x >> 16)), p.act, p.alpha);
+                    v[2] *= act_bwd_from_h(bf2f((u16)(hh.y & 0xffff)), p.act, p.alpha);
+                    v[3] *= act_bwd_from_h(bf2f((u16)(hh.y >> 16)), p.act, p.alpha);
+                    *reinterpret_cast<uint2*>(p.out + m * p.ldo + n) = pack4(v[0], v[1], v[2], v[3]);
+                } else {  // EPI_OUT
+                    v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+                    const bool valid = m < p.n_rows;
+                    float d[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (n >= p.n_lin) {  // relu head (n_lin is a multiple of 4)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    }
+                    if (valid && p.yhat)
+                        *reinterpret_cast<float4*>(p.yhat + m * p.N + n) = make_float4(v[0], v[1], v[2], v[3]);
+                    if (p.y && valid) {
+                        const int64_t src = p.row_idx ? p.row_idx[m] : m;
+                        const float4 t4 = *reinterpret_cast<const float4*>(p.y + src * p.N + n);
+                        const float e4[4] = {v[0] - t4.x, v[1] - t4.y, v[2] - t4.z, v[3] - t4.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            sq += e4[e] * e4[e];
+                            ab += fabsf(e4[e]);
+                            d[e] = 2.f * e4[e];
+                            if (n >= p.n_lin && !(v[e] > 0.f)) d[e] = 0.f;
+                        }
+                    }
+                    if (p.out) *reinterpret_cast<uint2*>(p.out + m * p.ldo + n) = pack4(d[0], d[1], d[2], d[3]);
+                }
+            }
+        }
+    }
+    if (EPI == EPI_OUT && p.y) {
+        sq = wave_sum(sq);
+        ab = wave_sum(ab);
+        if (lane == 0) { atomicAdd(p.loss, sq); atomicAdd(p.loss + 1, ab); }
+    }
+}
+
+// ---------------------------------------------------------------- TN GEMM (wgrad)
+struct WgradArgs {
+    const u16* H;  int ldh;      // [m_pad][ldh]  layer input activations (bf16)
+    const u16* Z;  int ldz;      // [m_pad][ldz]  dz of the layer (bf16)
+    int64_t m_pad;               // multiple of 128; rows >= n hold zeros in Z
+    float* dW;     int N;        // [K][N] fp32, Keras (in,out) layout
+    int k_real;                  // rows of dW that exist (124 for the first layer, else Kp)
+    float* db;                   // [N]
+    int use_atomics;             // gridDim.z > 1 or accumulate
+};
+
+// LDS tile [64 m][128 cols] bf16 (256-B rows).  The four 64-B units of a row are XOR-swizzled with
+// (m & 3): the 4 rows x 64 B touched by one half-wave of a ds_read_b64_tr_b16 then cover all 64 banks.
+__device__ __forceinline__ int swz_tn(int m, int col) {
+    const int c16 = col >> 3;
+    return m * 128 + (((((c16 >> 2) ^ (m & 3)) << 2) | (c16 & 3)) << 3) + (col & 7);
+}
+
+// Fragment of the 32x32x16 MFMA for an operand stored [contraction m][row index i] (i.e. transposed):
+// lane l needs X[mb + 8*(l>>5) + 0..7][cb + (l&31)].
+template <bool TR>
+__device__ __forceinline__ bf16x8_t load_frag_tn(const u16* tile, int mb, int cb, int lane) {
+    union { bf16x8_t v; s16x4_t h[2]; u16 s[8]; } u;
+    if (TR) {
+        // ds_read_b64_tr_b16: within a 16-lane group, lane t supplies the address of 4 consecutive
+        // columns (t&3)*4.. of row t>>2 and receives column t of that 4x16 block (4 rows).
+        const int col = cb + 16 * ((lane >> 4) & 1) + (lane & 3) * 4;
+        const int m = mb + 8 * (lane >> 5) + ((lane & 15) >> 2);
+        typedef s16x4_t __attribute__((address_space(3))) * lds_v4;
+        u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(tile + swz_tn(m, col)));
+        u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(tile + swz_tn(m + 4, col)));
+    } else {
+        const int col = cb + (lane & 31);
+        const int m = mb + 8 * (lane >> 5);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) u.s[j] = tile[swz_tn(m + j, col)];
+    }
+    return u.v;
+}
+
+template <bool TR>
+__global__ __launch_bounds__(256) void k_wgrad(const WgradArgs p) {
+    __shared__ __attribute__((aligned(16))) u16 smem[2][2][64 * 128];   // [buffer][H|Z] = 64 KiB
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wk = wid >> 1, wn = wid & 1;
+    const int k0 = blockIdx.x * 128, n0 = blockIdx.y * 128;
+    const int steps = (int)(p.m_pad >> 6);
+    const int s_begin = (int)((int64_t)steps * blockIdx.z / gridDim.z);
+    const int s_end = (int)((int64_t)steps * (blockIdx.z + 1) / gridDim.z);
+    const int srow = tid >> 4, sc = (tid & 15) * 8;     // staging: 4 rows (stride 16) x one 16-B chunk
+    const u16* Hg = p.H + (int64_t)srow * p.ldh + k0 + sc;
+    const u16* Zg = p.Z + (int64_t)srow * p.ldz + n0 + sc;
+    uint4 rh[4], rz[4];
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float bsum[2] = {0.f, 0.f};
+    const bool do_bias = (blockIdx.x == 0) && (wk == 0);
+
+    if (s_begin < s_end) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            rh[i] = *reinterpret_cast<const uint4*>(Hg + ((int64_t)s_begin * 64 + i * 16) * p.ldh);
+            rz[i] = *reinterpret_cast<const uint4*>(Zg + ((int64_t)s_begin * 64 + i * 16) * p.ldz);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<uint4*>(&smem[0][0][swz_tn(srow + 16 * i, sc)]) = rh[i];
+            *reinterpret_cast<uint4*>(&smem[0][1][swz_tn(srow + 16 * i, sc)]) = rz[i];
+        }
+    }
+    __syncthreads();
+    for (int s = s_begin; s < s_end; ++s) {
+        const int buf = (s - s_begin) & 1;
+        if (s + 1 < s_end) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                rh[i] = *reinterpret_cast<const uint4*>(Hg + ((int64_t)(s + 1) * 64 + i * 16) * p.ldh);
+                rz[i] = *reinterpret_cast<const uint4*>(Zg + ((int64_t)(s + 1) * 64 + i * 16) * p.ldz);
+            }
+        }
+        const u16* Hs = smem[buf][0];
+        const u16* Zs = smem[buf][1];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            bf16x8_t fh[2], fz[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fh[i] = load_frag_tn<TR>(Hs, kk * 16, wk * 64 + i * 32, lane);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fz[j] = load_frag_tn<TR>(Zs, kk * 16, wn * 64 + j * 32, lane);
+            if (do_bias) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    union { bf16x8_t v; u16 s[8]; } u;
+                    u.v = fz[j];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bsum[j] += bf2f(u.s[e]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[i], fz[j], acc[i][j], 0, 0, 0);
+        }
+        if (s + 1 < s_end) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                *reinterpret_cast<uint4*>(&smem[buf ^ 1][0][swz_tn(srow + 16 * i, sc)]) = rh[i];
+                *reinterpret_cast<uint4*>(&smem[buf ^ 1][1][swz_tn(srow + 16 * i, sc)]) = rz[i];
+            }
+        }
+        __syncthreads();
+    }
+    // D[i = k][j = n]: lane owns column n = ..+(lane&31), rows k = ..+(r&3)+8*(r>>2)+4*(lane>>5)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = k0 + wk * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (k < p.k_real) {
+                    float* dst = p.dW + (int64_t)k * p.N + n;
+                    if (p.use_atomics) atomicAdd(dst, acc[i][j][r]); else *dst = acc[i][j][r];
+                }
+            }
+        }
+    if (do_bias) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float v = bsum[j] + __shfl_xor(bsum[j], 32, 64);
+            if (lane < 32) {
+                float* dst = p.db + n0 + wn * 64 + j * 32 + lane;
+                if (p.use_atomics) atomicAdd(dst, v); else *dst = v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- optimiser
+struct Segment {          // one parameter tensor of the flat buffer
+    int64_t off;          // offset in floats (multiple of 4)
+    int64_t size;         // K*N (weights) or N (bias), multiple of 4
+    int K, N, Kp;         // Kp: padded contraction length of the bf16 copies (0 for a bias)
+    u16* Wt;              // [N][Kp]  (forward operand,  contraction k contiguous)
+    u16* Wn;              // [Kp][N]  (dgrad operand,    contraction n contiguous)
+};
+struct OptArgs {
+    float* P; float* M; float* V; const float* G;
+    int64_t n4;           // number of float4 groups
+    int n_seg; const Segment* seg;
+    int kind; float lr, grad_scale, beta1, beta2, eps, rho;
+    float bc1, bc2;       // 1-beta1^t, 1-beta2^t
+    float radam_r; int radam_rect;   // rectification term and whether sma_t >= threshold
+    int recast_only;      // set_weights: only refresh the bf16 copies
+};
+
+__global__ __launch_bounds__(256) void k_optimizer(const OptArgs a) {
+    const int64_t g4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g4 >= a.n4) return;
+    const int64_t i0 = g4 * 4;
+    float4 w = *reinterpret_cast<const float4*>(a.P + i0);
+    float wv[4] = {w.x, w.y, w.z, w.w};
+    if (!a.recast_only) {
+        const float4 g = *reinterpret_cast<const float4*>(a.G + i0);
+        const float gv[4] = {g.x * a.grad_scale, g.y * a.grad_scale, g.z * a.grad_scale, g.w * a.grad_scale};
+        if (a.kind == 3) {                       // SGD
+#pragma unroll
+            for (int e = 0; e < 4; ++e) wv[e] -= a.lr * gv[e];
+        } else if (a.kind == 2) {                // RMSprop: v = rho v + (1-rho) g^2 ; w -= lr g / sqrt(v + eps)
+            float4 v4 = *reinterpret_cast<const float4*>(a.V + i0);
+            float vv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                vv[e] = a.rho * vv[e] + (1.f - a.rho) * gv[e] * gv[e];
+                wv[e] -= a.lr * gv[e] / sqrtf(vv[e] + a.eps);
+            }
+            *reinterpret_cast<float4*>(a.V + i0) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        } else {                                 // Adam / RectifiedAdam
+            float4 m4 = *reinterpret_cast<const float4*>(a.M + i0);
+            float4 v4 = *reinterpret_cast<const float4*>(a.V + i0);
+            float mv[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
+            const float alpha = a.lr * sqrtf(a.bc2) / a.bc1;      // Keras Adam: eps outside the correction
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                mv[e] += (gv[e] - mv[e]) * (1.f - a.beta1);
+                vv[e] += (gv[e] * gv[e] - vv[e]) * (1.f - a.beta2);
+                if (a.kind == 0) {
+                    wv[e] -= (mv[e] * alpha) / (sqrtf(vv[e]) + a.eps);
+                } else {
+                    const float mhat = mv[e] * (1.f / a.bc1);
+                    if (a.radam_rect) wv[e] -= a.lr * a.radam_r * mhat / (sqrtf(vv[e] * (1.f / a.bc2)) + a.eps);
+                    else wv[e] -= a.lr * mhat;
+                }
+            }
+            *reinterpret_cast<float4*>(a.M + i0) = make_float4(mv[0], mv[1], mv[2], mv[3]);
+            *reinterpret_cast<float4*>(a.V + i0) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        }
+        *reinterpret_cast<float4*>(a.P + i0) = make_float4(wv[0], wv[1], wv[2], wv[3]);
+    }
+    // bf16 operand copies of weight tensors
+    int s = 0;
+    while (s + 1 < a.n_seg && i0 >= a.seg[s + 1].off) ++s;
+    const Segment sg = a.seg[s];
+    if (sg.Kp == 0) return;
+    const int64_t rel = i0 - sg.off;
+    const int k = (int)(rel / sg.N), n = (int)(rel - (int64_t)k * sg.N);
+    *reinterpret_cast<uint2*>(sg.Wn + (int64_t)k * sg.N + n) = pack4(wv[0], wv[1], wv[2], wv[3]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sg.Wt[(int64_t)(n + e) * sg.Kp + k] = f2bf(wv[e]);
+}

@@ -1,0 +1,134 @@
+/*
+ * climsim_hip.h - C ABI of the MI355X (gfx950) engine for ClimSim's baseline column emulators.
+ *
+ * The reference (leap-stc/ClimSim) has no FFI: its hot path is Keras `Model.fit` / `Model.predict`
+ * on a functional MLP.  Each entry point below names the reference interface it stands in for, so a
+ * maintainer can bind it from Python with ctypes (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - every function returns 0 (CS_OK) or a negative cs_status; nothing throws or aborts across the
+ *     ABI; cs_last_error() gives a thread-local message for the last failure.
+ *   - `*_dev` pointers are HIP device pointers owned by the CALLER (e.g. tensor.data_ptr()); the
+ *     library owns weights, optimiser state and workspace (sized by cfg.max_batch at create time).
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); all work is enqueued
+ *     asynchronously on it, nothing synchronises the device except get_weights/get_opt_state.
+ *   - a handle is not thread-safe; handles on distinct devices are independent.
+ *   - feature layout: x rows are 124 float32 (v1 inputs: state_t[60], state_q0001[60], state_ps,
+ *     pbuf_SOLIN, pbuf_LHFLX, pbuf_SHFLX), y rows 128 float32 (ptend_t[60], ptend_q0001[60], 8
+ *     scalars), both C-contiguous - the `.npy` layout of climsim_utils/data_utils.py:906-925.
+ */
+#ifndef CLIMSIM_HIP_H
+#define CLIMSIM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cs_mlp cs_mlp_t;
+
+typedef enum { CS_OK = 0, CS_ERR_INVALID = -1, CS_ERR_HIP = -2, CS_ERR_NOMEM = -3, CS_ERR_STATE = -4 } cs_status;
+
+/* keras.layers.ReLU / ELU / LeakyReLU(alpha) - step2_retrain.py:104-110 */
+typedef enum { CS_ACT_RELU = 0, CS_ACT_ELU = 1, CS_ACT_LEAKYRELU = 2 } cs_act;
+/* keras.optimizers.Adam / tfa RectifiedAdam / keras RMSprop / SGD - step2_retrain.py:150-157 */
+typedef enum { CS_OPT_ADAM = 0, CS_OPT_RADAM = 1, CS_OPT_RMSPROP = 2, CS_OPT_SGD = 3 } cs_opt;
+
+#define CS_MAX_HIDDEN 16
+
+/* Hyper-parameters of build_model() - step2_retrain.py:79-126 (hpo_baseline_v1.py:64-103). */
+typedef struct cs_mlp_cfg {
+    int32_t n_in;                 /* input_length = 124                                         */
+    int32_t n_hidden;             /* hp num_layers (2..12 in the HPO space)                      */
+    int32_t hidden[CS_MAX_HIDDEN];/* hp units_k, multiples of 128 (128..1024 in the HPO space)   */
+    int32_t n_out_lin;            /* output_length_lin  = 120 (linear head)                      */
+    int32_t n_out_relu;           /* output_length_relu = 8   (relu head); lin+relu must be 128  */
+    int32_t act;                  /* cs_act                                                       */
+    float   alpha;                /* LeakyReLU slope (0.15)                                       */
+    int32_t optimizer;            /* cs_opt                                                       */
+    float   beta1, beta2, eps;    /* 0.9, 0.999, 1e-7 (Keras defaults)                            */
+    float   rho;                  /* RMSprop rho 0.9                                              */
+    int32_t max_batch;            /* largest n accepted by forward / loss_grads                   */
+    int32_t device;               /* HIP device ordinal                                           */
+    int32_t flags;                /* CS_FLAG_*                                                    */
+} cs_mlp_cfg;
+
+#define CS_FLAG_NO_TR_READ 1      /* wgrad operands by 16-bit LDS gathers instead of ds_read_b64_tr_b16 */
+
+/* keras.Model(...) + compile(): allocates weights (zero), optimiser state, workspace. */
+int  cs_mlp_create(cs_mlp_t** out, const cs_mlp_cfg* cfg);
+void cs_mlp_destroy(cs_mlp_t* h);
+/* model.count_params() */
+int64_t cs_mlp_num_params(const cs_mlp_t* h);
+
+/* data_utils.save_norm() vectors (data_utils.py:954-988): x_hat = (x - sub)/div, inf/nan -> 0
+ * (data_utils.py:807-809, :894-897).  Host pointers, copied.  Only used when a call passes
+ * normalise != 0; the .npy splits of save_as_npy are already normalised. */
+int cs_mlp_set_norm(cs_mlp_t* h, const float* input_sub, const float* input_div);
+
+/* model.set_weights / model.get_weights: one flat float32 host buffer in Keras order
+ * [W0(in,out), b0, ..., W_up(.,128), b_up, W_lin(128,120), b_lin, W_relu(128,8), b_relu].
+ * set_weights also refreshes the bf16 operand copies.  get_* synchronise `stream`. */
+int cs_mlp_set_weights(cs_mlp_t* h, const float* host, int64_t n, void* stream);
+int cs_mlp_get_weights(cs_mlp_t* h, float* host, int64_t n, void* stream);
+/* optimizer.get_weights(): first/second moments (Keras order, like the weights) and iteration. */
+int cs_mlp_get_opt_state(cs_mlp_t* h, float* host_m, float* host_v, int64_t n, int64_t* iterations, void* stream);
+int cs_mlp_set_opt_state(cs_mlp_t* h, const float* host_m, const float* host_v, int64_t n, int64_t iterations, void* stream);
+
+/* model.predict / model.evaluate (step3_inference.ipynb cell 2; validation pass of model.fit):
+ *   x_dev      (rows, 124) float32; row i of the batch is x_dev[row_idx ? row_idx[i] : i]
+ *   yhat_dev   (n, 128) float32 output in scaled space, may be NULL
+ *   y_dev      targets (indexed like x_dev) or NULL; when given, loss_dev[0] += sum (yhat-y)^2,
+ *              loss_dev[1] += sum |yhat-y| over n*128 elements (loss_dev is zeroed first unless
+ *              accumulate != 0).  mse = loss_dev[0]/(128 n), mae = loss_dev[1]/(128 n). */
+int cs_mlp_forward(cs_mlp_t* h, const float* x_dev, const int64_t* row_idx_dev, int64_t n, int normalise,
+                   float* yhat_dev, const float* y_dev, float* loss_dev, int accumulate, void* stream);
+
+/* Forward + backward of one batch (the autodiff half of Model.train_step): fills the flat float32
+ * gradient buffer with d(sum of squared errors)/d(param) = UNSCALED sums; the 1/(128 n) of the
+ * 'mse' mean (and 1/world for data parallel) is applied by cs_mlp_apply's grad_scale.
+ * accumulate != 0 adds to the existing gradient/loss (micro-batching). */
+int cs_mlp_loss_grads(cs_mlp_t* h, const float* x_dev, const float* y_dev, const int64_t* row_idx_dev,
+                      int64_t n, int normalise, float* loss_dev, int accumulate, void* stream);
+
+/* Flat gradient buffer (internal parameter order, n = num_params floats) for an external
+ * all-reduce (RCCL via torch.distributed on a tensor aliasing it), or rebind it to caller memory. */
+int cs_mlp_grad_buffer(cs_mlp_t* h, void** dev_ptr, int64_t* n_floats);
+int cs_mlp_set_grad_buffer(cs_mlp_t* h, void* dev_ptr);
+
+/* optimizer.apply_gradients: g = grad * grad_scale; Keras-2.11 Adam / RMSprop / SGD or tfa-0.19
+ * RectifiedAdam update with learning rate `lr`; increments optimizer.iterations; re-casts bf16
+ * operand copies of the weights. */
+int cs_mlp_apply(cs_mlp_t* h, float lr, float grad_scale, void* stream);
+
+/* Model.train_step: loss_grads + apply(lr, 1/(128 n)). */
+int cs_mlp_train_step(cs_mlp_t* h, const float* x_dev, const float* y_dev, const int64_t* row_idx_dev,
+                      int64_t n, int normalise, float lr, float* loss_dev, void* stream);
+
+/* Diagnostics: bytes of device memory held by the handle. */
+int64_t cs_mlp_device_bytes(const cs_mlp_t* h);
+
+/* Measurement aid (bench.py's roofline leg): one cs_mlp_train_step with a hipEvent pair recorded
+ * on `stream` around every kernel launch; returns summed milliseconds and launch counts per
+ * kernel kind.  Synchronises the stream.  Same arithmetic as cs_mlp_train_step. */
+enum { CS_K_PREPARE = 0, CS_K_GEMM_FWD = 1, CS_K_GEMM_DGRAD = 2, CS_K_WGRAD = 3, CS_K_OPTIMIZER = 4,
+       CS_K_MEMSET = 5, CS_K_COUNT = 8 };
+typedef struct cs_kernel_times { float ms[CS_K_COUNT]; int32_t launches[CS_K_COUNT]; } cs_kernel_times;
+int cs_mlp_profile_step(cs_mlp_t* h, const float* x_dev, const float* y_dev, const int64_t* row_idx_dev,
+                        int64_t n, int normalise, float lr, float* loss_dev, void* stream,
+                        cs_kernel_times* out);
+
+/* Stand-alone loader-path kernel (data_utils.py:807-809 + :894-897 on device): out = (x-sub)/div,
+ * inf/nan -> 0, float32 -> float32; rows gathered through row_idx when given. */
+int cs_normalise_rows(const float* x_dev, const int64_t* row_idx_dev, int64_t n, int32_t width,
+                      const float* sub_dev, const float* div_dev, float* out_dev, void* stream);
+
+const char* cs_last_error(void);
+const char* cs_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CLIMSIM_HIP_H */
