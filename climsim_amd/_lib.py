@@ -17,8 +17,8 @@ OPT = {"Adam": 0, "RAdam": 1, "RMSprop": 2, "SGD": 3}
 class CsMlpCfg(C.Structure):
     _fields_ = [("n_in", C.c_int32), ("n_hidden", C.c_int32), ("hidden", C.c_int32 * CS_MAX_HIDDEN),
                 ("n_out_lin", C.c_int32), ("n_out_relu", C.c_int32), ("act", C.c_int32), ("alpha", C.c_float),
-                ("optimizer", C.c_int32), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
-                ("rho", C.c_float), ("max_batch", C.c_int32), ("device", C.c_int32), ("flags", C.c_int32)]
+                ("optimizer", C.c_int32), ("max_batch", C.c_int32), ("device", C.c_int32), ("flags", C.c_int32),
+                ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double), ("rho", C.c_double)]
 
 
 CS_K_COUNT = 8

@@ -136,17 +136,26 @@ int launch_optimizer(cs_mlp* h, float lr, float grad_scale, bool recast_only, hi
     a.n4 = h->n_params / 4;
     a.n_seg = h->n_seg; a.seg = h->seg_dev;
     a.kind = h->cfg.optimizer; a.lr = lr; a.grad_scale = grad_scale;
-    a.beta1 = h->cfg.beta1; a.beta2 = h->cfg.beta2; a.eps = h->cfg.eps; a.rho = h->cfg.rho;
     a.recast_only = recast_only ? 1 : 0;
-    const double t = (double)(h->iterations + 1);
-    const double b1 = h->cfg.beta1, b2 = h->cfg.beta2;
-    const double bc1 = 1.0 - std::pow(b1, t), bc2 = 1.0 - std::pow(b2, t);
-    a.bc1 = (float)bc1; a.bc2 = (float)bc2;
-    const double sma_inf = 2.0 / (1.0 - b2) - 1.0;
-    const double sma_t = sma_inf - 2.0 * t * std::pow(b2, t) / bc2;
-    a.radam_rect = sma_t >= 5.0 ? 1 : 0;
-    a.radam_r = a.radam_rect
-        ? (float)std::sqrt((sma_t - 4.0) / (sma_inf - 4.0) * (sma_t - 2.0) / (sma_inf - 2.0) * sma_inf / sma_t) : 0.f;
+    // float32 scalars, cast where TensorFlow casts (variable dtype float32)
+    const float b1 = (float)h->cfg.beta1, b2 = (float)h->cfg.beta2;
+    const float t = (float)(h->iterations + 1);
+    const float p1 = powf(b1, t), p2 = powf(b2, t);
+    a.beta1 = b1; a.beta2 = b2;
+    a.eps = (float)h->cfg.eps;
+    a.rho = (float)h->cfg.rho; a.omrho = (float)(1.0 - h->cfg.rho);
+    a.bc1 = 1.f - p1; a.bc2 = 1.f - p2;
+    if (a.kind == CS_OPT_ADAM) {
+        a.omb1 = (float)(1.0 - h->cfg.beta1); a.omb2 = (float)(1.0 - h->cfg.beta2);
+        a.alpha = lr * sqrtf(1.f - p2) / (1.f - p1);
+    } else {
+        a.omb1 = 1.f - b1; a.omb2 = 1.f - b2;
+        const float sma_inf = 2.f / (1.f - b2) - 1.f;
+        const float sma_t = sma_inf - 2.f * t * p2 / (1.f - p2);
+        a.radam_rect = sma_t >= 5.f ? 1 : 0;
+        a.radam_r = a.radam_rect
+            ? sqrtf((sma_t - 4.f) / (sma_inf - 4.f) * (sma_t - 2.f) / (sma_inf - 2.f) * sma_inf / sma_t) : 0.f;
+    }
     const int threads = 256;
     const int64_t blocks = (a.n4 + threads - 1) / threads;
     {
@@ -171,7 +180,7 @@ int run_forward(cs_mlp* h, const float* x, const int64_t* row_idx, int64_t n, in
         const Layer& ly = h->layers[l];
         GemmNT p{};
         p.A = ly.H; p.lda = ly.Kp; p.B = ly.Wt; p.ldb = ly.Kp; p.K = ly.Kp; p.N = ly.N;
-        p.act = h->cfg.act; p.alpha = h->cfg.alpha;
+        p.act = h->cfg.act; p.alpha = (h->cfg.act == CS_ACT_RELU) ? 0.f : h->cfg.alpha;
         p.bias = h->P + ly.b_off;
         const dim3 grid((unsigned)(m_pad / 128), (unsigned)(ly.N / 128));
         ProfScope ps(CS_K_GEMM_FWD, st);
@@ -211,7 +220,7 @@ int run_backward(cs_mlp* h, int64_t n, bool atomics_needed, hipStream_t st) {
         if (l > 0) {
             GemmNT p{};
             p.A = ly.dZ; p.lda = ly.N; p.B = ly.Wn; p.ldb = ly.N; p.K = ly.N; p.N = ly.Kp;
-            p.act = h->cfg.act; p.alpha = h->cfg.alpha;
+            p.act = h->cfg.act; p.alpha = (h->cfg.act == CS_ACT_RELU) ? 0.f : h->cfg.alpha;
             p.out = h->layers[l - 1].dZ; p.ldo = h->layers[l - 1].N;
             p.hprev = ly.H; p.ldh = ly.Kp;
             const dim3 g2((unsigned)(m_pad / 128), (unsigned)(ly.Kp / 128));

@@ -35,16 +35,14 @@ __device__ __forceinline__ float bf2f(u16 h) { return __uint_as_float(((unsigned
 __device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) {
     return make_uint2((unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16), (unsigned)f2bf(c) | ((unsigned)f2bf(d) << 16));
 }
-__device__ __forceinline__ float act_fwd(float z, int kind, float alpha) {
-    if (kind == ACT_RELU) return fmaxf(z, 0.f);
-    if (kind == ACT_LEAKY) return z > 0.f ? z : alpha * z;
-    return z > 0.f ? z : expm1f(z);
+// `slope` = 0 for ReLU, alpha for LeakyReLU (prepared by the host); ELU has alpha = 1.
+__device__ __forceinline__ float act_fwd(float z, int kind, float slope) {
+    if (kind == ACT_ELU) return z > 0.f ? z : expm1f(z);
+    return z > 0.f ? z : slope * z;
 }
 // d act/dz from the stored activation OUTPUT h (h>0 <=> z>0 for all three activations)
-__device__ __forceinline__ float act_bwd_from_h(float h, int kind, float alpha) {
-    if (kind == ACT_RELU) return h > 0.f ? 1.f : 0.f;
-    if (kind == ACT_LEAKY) return h > 0.f ? 1.f : alpha;
-    return h > 0.f ? 1.f : h + 1.f;
+__device__ __forceinline__ float act_bwd_from_h(float h, int kind, float slope) {
+    return h > 0.f ? 1.f : (kind == ACT_ELU ? h + 1.f : slope);
 }
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -139,64 +137,58 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const GemmNT p) {
     const int srow = tid >> 3, sch = tid & 7;          // staging: 4 rows (stride 32) x one 16-B chunk
     const u16* Ag = p.A + (m0 + srow) * p.lda + sch * 8;
     const u16* Bg = p.B + (int64_t)(n0 + srow) * p.ldb + sch * 8;
-    uint4 ra[4], rb[4];
-    f32x16_t acc[2][2];
+    // staging registers are named scalars on purpose: private arrays here get "promoted" to LDS by
+    // the compiler (AMDGPUPromoteAlloca), which serialises every global load behind a vmcnt(0).
+    uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+#define NT_GLOAD(koff)                                                                   \
+    ra0 = *reinterpret_cast<const uint4*>(Ag + (int64_t)0 * 32 * p.lda + (koff));        \
+    ra1 = *reinterpret_cast<const uint4*>(Ag + (int64_t)1 * 32 * p.lda + (koff));        \
+    ra2 = *reinterpret_cast<const uint4*>(Ag + (int64_t)2 * 32 * p.lda + (koff));        \
+    ra3 = *reinterpret_cast<const uint4*>(Ag + (int64_t)3 * 32 * p.lda + (koff));        \
+    rb0 = *reinterpret_cast<const uint4*>(Bg + (int64_t)0 * 32 * p.ldb + (koff));        \
+    rb1 = *reinterpret_cast<const uint4*>(Bg + (int64_t)1 * 32 * p.ldb + (koff));        \
+    rb2 = *reinterpret_cast<const uint4*>(Bg + (int64_t)2 * 32 * p.ldb + (koff));        \
+    rb3 = *reinterpret_cast<const uint4*>(Bg + (int64_t)3 * 32 * p.ldb + (koff));
+#define NT_SSTORE(buf)                                                                   \
+    *reinterpret_cast<uint4*>(&smem[buf][0][swz_nt(srow + 0, sch)]) = ra0;               \
+    *reinterpret_cast<uint4*>(&smem[buf][0][swz_nt(srow + 32, sch)]) = ra1;              \
+    *reinterpret_cast<uint4*>(&smem[buf][0][swz_nt(srow + 64, sch)]) = ra2;              \
+    *reinterpret_cast<uint4*>(&smem[buf][0][swz_nt(srow + 96, sch)]) = ra3;              \
+    *reinterpret_cast<uint4*>(&smem[buf][1][swz_nt(srow + 0, sch)]) = rb0;               \
+    *reinterpret_cast<uint4*>(&smem[buf][1][swz_nt(srow + 32, sch)]) = rb1;              \
+    *reinterpret_cast<uint4*>(&smem[buf][1][swz_nt(srow + 64, sch)]) = rb2;              \
+    *reinterpret_cast<uint4*>(&smem[buf][1][swz_nt(srow + 96, sch)]) = rb3;
+    f32x16_t acc00, acc01, acc10, acc11;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int r = 0; r < 16; ++r) { acc00[r] = 0.f; acc01[r] = 0.f; acc10[r] = 0.f; acc11[r] = 0.f; }
 
     const int nt = p.K >> 6;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        ra[i] = *reinterpret_cast<const uint4*>(Ag + (int64_t)i * 32 * p.lda);
-        rb[i] = *reinterpret_cast<const uint4*>(Bg + (int64_t)i * 32 * p.ldb);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        *reinterpret_cast<uint4*>(&smem[0][0][swz_nt(srow + 32 * i, sch)]) = ra[i];
-        *reinterpret_cast<uint4*>(&smem[0][1][swz_nt(srow + 32 * i, sch)]) = rb[i];
-    }
+    NT_GLOAD(0)
+    NT_SSTORE(0)
     __syncthreads();
     const int frow = lane & 31, fch = lane >> 5;
     for (int t = 0; t < nt; ++t) {
-        if (t + 1 < nt) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                ra[i] = *reinterpret_cast<const uint4*>(Ag + (int64_t)i * 32 * p.lda + (t + 1) * 64);
-                rb[i] = *reinterpret_cast<const uint4*>(Bg + (int64_t)i * 32 * p.ldb + (t + 1) * 64);
-            }
-        }
+        if (t + 1 < nt) { NT_GLOAD((t + 1) * 64) }
         const u16* As = smem[t & 1][0];
         const u16* Bs = smem[t & 1][1];
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            bf16x8_t fa[2], fb[2];
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                fa[j] = *reinterpret_cast<const bf16x8_t*>(&As[swz_nt(wm * 64 + j * 32 + frow, kk * 2 + fch)]);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-                fb[i] = *reinterpret_cast<const bf16x8_t*>(&Bs[swz_nt(wn * 64 + i * 32 + frow, kk * 2 + fch)]);
+            const bf16x8_t fa0 = *reinterpret_cast<const bf16x8_t*>(&As[swz_nt(wm * 64 + frow, kk * 2 + fch)]);
+            const bf16x8_t fa1 = *reinterpret_cast<const bf16x8_t*>(&As[swz_nt(wm * 64 + 32 + frow, kk * 2 + fch)]);
+            const bf16x8_t fb0 = *reinterpret_cast<const bf16x8_t*>(&Bs[swz_nt(wn * 64 + frow, kk * 2 + fch)]);
+            const bf16x8_t fb1 = *reinterpret_cast<const bf16x8_t*>(&Bs[swz_nt(wn * 64 + 32 + frow, kk * 2 + fch)]);
             // weights as the MFMA A operand (result rows = n), activations as B (result cols = m):
             // every lane then owns 4 consecutive n of one row m -> 8-byte bf16 stores.
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[i], fa[j], acc[i][j], 0, 0, 0);
+            acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb0, fa0, acc00, 0, 0, 0);
+            acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb0, fa1, acc01, 0, 0, 0);
+            acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb1, fa0, acc10, 0, 0, 0);
+            acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb1, fa1, acc11, 0, 0, 0);
         }
-        if (t + 1 < nt) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                *reinterpret_cast<uint4*>(&smem[(t + 1) & 1][0][swz_nt(srow + 32 * i, sch)]) = ra[i];
-                *reinterpret_cast<uint4*>(&smem[(t + 1) & 1][1][swz_nt(srow + 32 * i, sch)]) = rb[i];
-            }
-        }
+        if (t + 1 < nt) { NT_SSTORE((t + 1) & 1) }
         __syncthreads();
     }
+#undef NT_GLOAD
+#undef NT_SSTORE
 
     // ---- epilogue: lane owns row m = ..+(lane&31), columns n = ..+8q+4*(lane>>5)+{0..3}
     float sq = 0.f, ab = 0.f;
@@ -210,7 +202,8 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const GemmNT p) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int64_t m = m0 + wm * 64 + j * 32 + (lane & 31);
-                float v[4] = {acc[i][j][4 * q + 0], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                const f32x16_t& av = (i == 0) ? (j == 0 ? acc00 : acc01) : (j == 0 ? acc10 : acc11);
+                float v[4] = {av[4 * q + 0], av[4 * q + 1], av[4 * q + 2], av[4 * q + 3]};
                 if (EPI == EPI_HIDDEN) {
                     v[0] = act_fwd(v[0] + b4.x, p.act, p.alpha); v[1] = act_fwd(v[1] + b4.y, p.act, p.alpha);
                     v[2] = act_fwd(v[2] + b4.z, p.act, p.alpha); v[3] = act_fwd(v[3] + b4.w, p.act, p.alpha);
@@ -308,91 +301,84 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs p) {
     const int srow = tid >> 4, sc = (tid & 15) * 8;     // staging: 4 rows (stride 16) x one 16-B chunk
     const u16* Hg = p.H + (int64_t)srow * p.ldh + k0 + sc;
     const u16* Zg = p.Z + (int64_t)srow * p.ldz + n0 + sc;
-    uint4 rh[4], rz[4];
-    f32x16_t acc[2][2];
+    uint4 rh0, rh1, rh2, rh3, rz0, rz1, rz2, rz3;      // named scalars: see k_gemm_nt
+#define TN_GLOAD(step)                                                                              \
+    rh0 = *reinterpret_cast<const uint4*>(Hg + ((int64_t)(step) * 64 + 0) * p.ldh);                 \
+    rh1 = *reinterpret_cast<const uint4*>(Hg + ((int64_t)(step) * 64 + 16) * p.ldh);                \
+    rh2 = *reinterpret_cast<const uint4*>(Hg + ((int64_t)(step) * 64 + 32) * p.ldh);                \
+    rh3 = *reinterpret_cast<const uint4*>(Hg + ((int64_t)(step) * 64 + 48) * p.ldh);                \
+    rz0 = *reinterpret_cast<const uint4*>(Zg + ((int64_t)(step) * 64 + 0) * p.ldz);                 \
+    rz1 = *reinterpret_cast<const uint4*>(Zg + ((int64_t)(step) * 64 + 16) * p.ldz);                \
+    rz2 = *reinterpret_cast<const uint4*>(Zg + ((int64_t)(step) * 64 + 32) * p.ldz);                \
+    rz3 = *reinterpret_cast<const uint4*>(Zg + ((int64_t)(step) * 64 + 48) * p.ldz);
+#define TN_SSTORE(buf)                                                                              \
+    *reinterpret_cast<uint4*>(&smem[buf][0][swz_tn(srow + 0, sc)]) = rh0;                           \
+    *reinterpret_cast<uint4*>(&smem[buf][0][swz_tn(srow + 16, sc)]) = rh1;                          \
+    *reinterpret_cast<uint4*>(&smem[buf][0][swz_tn(srow + 32, sc)]) = rh2;                          \
+    *reinterpret_cast<uint4*>(&smem[buf][0][swz_tn(srow + 48, sc)]) = rh3;                          \
+    *reinterpret_cast<uint4*>(&smem[buf][1][swz_tn(srow + 0, sc)]) = rz0;                           \
+    *reinterpret_cast<uint4*>(&smem[buf][1][swz_tn(srow + 16, sc)]) = rz1;                          \
+    *reinterpret_cast<uint4*>(&smem[buf][1][swz_tn(srow + 32, sc)]) = rz2;                          \
+    *reinterpret_cast<uint4*>(&smem[buf][1][swz_tn(srow + 48, sc)]) = rz3;
+    f32x16_t acc00, acc01, acc10, acc11;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    float bsum[2] = {0.f, 0.f};
+    for (int r = 0; r < 16; ++r) { acc00[r] = 0.f; acc01[r] = 0.f; acc10[r] = 0.f; acc11[r] = 0.f; }
+    float bsum0 = 0.f, bsum1 = 0.f;
     const bool do_bias = (blockIdx.x == 0) && (wk == 0);
 
     if (s_begin < s_end) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            rh[i] = *reinterpret_cast<const uint4*>(Hg + ((int64_t)s_begin * 64 + i * 16) * p.ldh);
-            rz[i] = *reinterpret_cast<const uint4*>(Zg + ((int64_t)s_begin * 64 + i * 16) * p.ldz);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<uint4*>(&smem[0][0][swz_tn(srow + 16 * i, sc)]) = rh[i];
-            *reinterpret_cast<uint4*>(&smem[0][1][swz_tn(srow + 16 * i, sc)]) = rz[i];
-        }
+        TN_GLOAD(s_begin)
+        TN_SSTORE(0)
     }
     __syncthreads();
     for (int s = s_begin; s < s_end; ++s) {
         const int buf = (s - s_begin) & 1;
-        if (s + 1 < s_end) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                rh[i] = *reinterpret_cast<const uint4*>(Hg + ((int64_t)(s + 1) * 64 + i * 16) * p.ldh);
-                rz[i] = *reinterpret_cast<const uint4*>(Zg + ((int64_t)(s + 1) * 64 + i * 16) * p.ldz);
-            }
-        }
+        if (s + 1 < s_end) { TN_GLOAD(s + 1) }
         const u16* Hs = smem[buf][0];
         const u16* Zs = smem[buf][1];
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            bf16x8_t fh[2], fz[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) fh[i] = load_frag_tn<TR>(Hs, kk * 16, wk * 64 + i * 32, lane);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) fz[j] = load_frag_tn<TR>(Zs, kk * 16, wn * 64 + j * 32, lane);
+            const bf16x8_t fh0 = load_frag_tn<TR>(Hs, kk * 16, wk * 64, lane);
+            const bf16x8_t fh1 = load_frag_tn<TR>(Hs, kk * 16, wk * 64 + 32, lane);
+            const bf16x8_t fz0 = load_frag_tn<TR>(Zs, kk * 16, wn * 64, lane);
+            const bf16x8_t fz1 = load_frag_tn<TR>(Zs, kk * 16, wn * 64 + 32, lane);
             if (do_bias) {
+                union { bf16x8_t v; u16 s[8]; } u0, u1;
+                u0.v = fz0; u1.v = fz1;
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    union { bf16x8_t v; u16 s[8]; } u;
-                    u.v = fz[j];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) bsum[j] += bf2f(u.s[e]);
-                }
+                for (int e = 0; e < 8; ++e) { bsum0 += bf2f(u0.s[e]); bsum1 += bf2f(u1.s[e]); }
             }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[i], fz[j], acc[i][j], 0, 0, 0);
+            acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh0, fz0, acc00, 0, 0, 0);
+            acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh0, fz1, acc01, 0, 0, 0);
+            acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh1, fz0, acc10, 0, 0, 0);
+            acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh1, fz1, acc11, 0, 0, 0);
         }
-        if (s + 1 < s_end) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                *reinterpret_cast<uint4*>(&smem[buf ^ 1][0][swz_tn(srow + 16 * i, sc)]) = rh[i];
-                *reinterpret_cast<uint4*>(&smem[buf ^ 1][1][swz_tn(srow + 16 * i, sc)]) = rz[i];
-            }
-        }
+        if (s + 1 < s_end) { TN_SSTORE(buf ^ 1) }
         __syncthreads();
     }
+#undef TN_GLOAD
+#undef TN_SSTORE
     // D[i = k][j = n]: lane owns column n = ..+(lane&31), rows k = ..+(r&3)+8*(r>>2)+4*(lane>>5)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+            const f32x16_t& av = (i == 0) ? (j == 0 ? acc00 : acc01) : (j == 0 ? acc10 : acc11);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int k = k0 + wk * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (k < p.k_real) {
                     float* dst = p.dW + (int64_t)k * p.N + n;
-                    if (p.use_atomics) atomicAdd(dst, acc[i][j][r]); else *dst = acc[i][j][r];
+                    if (p.use_atomics) atomicAdd(dst, av[r]); else *dst = av[r];
                 }
             }
         }
     if (do_bias) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const float v = bsum[j] + __shfl_xor(bsum[j], 32, 64);
+            const float bj = j == 0 ? bsum0 : bsum1;
+            const float v = bj + __shfl_xor(bj, 32, 64);
             if (lane < 32) {
                 float* dst = p.db + n0 + wn * 64 + j * 32 + lane;
                 if (p.use_atomics) atomicAdd(dst, v); else *dst = v;
@@ -413,12 +399,24 @@ struct OptArgs {
     float* P; float* M; float* V; const float* G;
     int64_t n4;           // number of float4 groups
     int n_seg; const Segment* seg;
-    int kind; float lr, grad_scale, beta1, beta2, eps, rho;
-    float bc1, bc2;       // 1-beta1^t, 1-beta2^t
-    float radam_r; int radam_rect;   // rectification term and whether sma_t >= threshold
+    int kind; float lr, grad_scale;
+    // scalars prepared on the host in float32 arithmetic, at the points where TF casts:
+    float beta1, beta2;   // float32(beta)
+    float omb1, omb2;     // Adam: float32(1 - beta) of the Python doubles; RAdam: 1.f - float32(beta)
+    float eps, rho, omrho;
+    float alpha;          // Adam: lr * sqrt(1 - beta2^t) / (1 - beta1^t)
+    float bc1, bc2;       // RAdam: 1 - beta^t
+    float radam_r; int radam_rect;
     int recast_only;      // set_weights: only refresh the bf16 copies
 };
 
+// Update rules (float32, one thread = 4 parameters):
+//   Adam    (keras 2.11 optimizers/adam.py update_step):   m += (g-m)(1-b1); v += (g^2-v)(1-b2);
+//                                                           w -= (m*alpha)/(sqrt(v)+eps)
+//   RAdam   (tfa 0.19 rectified_adam.py _resource_apply_dense): m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+//            w -= lr * (rect ? r*(m/bc1)/(sqrt(v/bc2)+eps) : m/bc1)
+//   RMSprop (keras 2.11 optimizers/rmsprop.py): v = rho v + (1-rho) g^2; w -= lr*g*rsqrt(v+eps)
+//   SGD     : w -= lr*g
 __global__ __launch_bounds__(256) void k_optimizer(const OptArgs a) {
     const int64_t g4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g4 >= a.n4) return;
@@ -428,32 +426,33 @@ __global__ __launch_bounds__(256) void k_optimizer(const OptArgs a) {
     if (!a.recast_only) {
         const float4 g = *reinterpret_cast<const float4*>(a.G + i0);
         const float gv[4] = {g.x * a.grad_scale, g.y * a.grad_scale, g.z * a.grad_scale, g.w * a.grad_scale};
-        if (a.kind == 3) {                       // SGD
+        if (a.kind == 3) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) wv[e] -= a.lr * gv[e];
-        } else if (a.kind == 2) {                // RMSprop: v = rho v + (1-rho) g^2 ; w -= lr g / sqrt(v + eps)
+        } else if (a.kind == 2) {
             float4 v4 = *reinterpret_cast<const float4*>(a.V + i0);
             float vv[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                vv[e] = a.rho * vv[e] + (1.f - a.rho) * gv[e] * gv[e];
-                wv[e] -= a.lr * gv[e] / sqrtf(vv[e] + a.eps);
+                vv[e] = a.rho * vv[e] + a.omrho * (gv[e] * gv[e]);
+                wv[e] -= (a.lr * gv[e]) * (1.f / sqrtf(vv[e] + a.eps));
             }
             *reinterpret_cast<float4*>(a.V + i0) = make_float4(vv[0], vv[1], vv[2], vv[3]);
-        } else {                                 // Adam / RectifiedAdam
+        } else {
             float4 m4 = *reinterpret_cast<const float4*>(a.M + i0);
             float4 v4 = *reinterpret_cast<const float4*>(a.V + i0);
             float mv[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
-            const float alpha = a.lr * sqrtf(a.bc2) / a.bc1;      // Keras Adam: eps outside the correction
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                mv[e] += (gv[e] - mv[e]) * (1.f - a.beta1);
-                vv[e] += (gv[e] * gv[e] - vv[e]) * (1.f - a.beta2);
                 if (a.kind == 0) {
-                    wv[e] -= (mv[e] * alpha) / (sqrtf(vv[e]) + a.eps);
+                    mv[e] += (gv[e] - mv[e]) * a.omb1;
+                    vv[e] += (gv[e] * gv[e] - vv[e]) * a.omb2;
+                    wv[e] -= (mv[e] * a.alpha) / (sqrtf(vv[e]) + a.eps);
                 } else {
-                    const float mhat = mv[e] * (1.f / a.bc1);
-                    if (a.radam_rect) wv[e] -= a.lr * a.radam_r * mhat / (sqrtf(vv[e] * (1.f / a.bc2)) + a.eps);
+                    mv[e] = a.beta1 * mv[e] + a.omb1 * gv[e];
+                    vv[e] = a.beta2 * vv[e] + a.omb2 * (gv[e] * gv[e]);
+                    const float mhat = mv[e] / a.bc1;
+                    if (a.radam_rect) wv[e] -= a.lr * (a.radam_r * mhat / (sqrtf(vv[e] / a.bc2) + a.eps));
                     else wv[e] -= a.lr * mhat;
                 }
             }

@@ -48,11 +48,12 @@ typedef struct cs_mlp_cfg {
     int32_t act;                  /* cs_act                                                       */
     float   alpha;                /* LeakyReLU slope (0.15)                                       */
     int32_t optimizer;            /* cs_opt                                                       */
-    float   beta1, beta2, eps;    /* 0.9, 0.999, 1e-7 (Keras defaults)                            */
-    float   rho;                  /* RMSprop rho 0.9                                              */
     int32_t max_batch;            /* largest n accepted by forward / loss_grads                   */
     int32_t device;               /* HIP device ordinal                                           */
     int32_t flags;                /* CS_FLAG_*                                                    */
+    /* Optimiser hyper-parameters as the Python floats (doubles) Keras receives: 0.9, 0.999, 1e-7,
+     * rho 0.9.  They are cast to float32 exactly where TensorFlow casts them (see k_optimizer). */
+    double  beta1, beta2, eps, rho;
 } cs_mlp_cfg;
 
 #define CS_FLAG_NO_TR_READ 1      /* wgrad operands by 16-bit LDS gathers instead of ds_read_b64_tr_b16 */

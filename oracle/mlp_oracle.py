@@ -216,42 +216,46 @@ class Optimizer:
     v: list = field(default_factory=list)
 
     def apply(self, ws, grads, lr):
+        """One update.  Scalars are float32 and cast where TensorFlow casts them (float32 variables):
+        beta^t = pow(float32(beta), float32(t)); Keras Adam multiplies by float32(1-beta) of the
+        Python doubles, tfa RAdam by 1-float32(beta); RMSprop uses rsqrt(v+eps)."""
         if not self.m:
             self.m = [np.zeros_like(w) for w in ws]
             self.v = [np.zeros_like(w) for w in ws]
-        t = self.it + 1
+        t = F32(self.it + 1)
         lr = F32(lr)
+        one = F32(1)
         b1, b2, eps = F32(self.beta1), F32(self.beta2), F32(self.eps)
+        p1, p2 = np.power(b1, t, dtype=F32), np.power(b2, t, dtype=F32)
         out = []
         for i, (w, g) in enumerate(zip(ws, grads)):
             g = g.astype(F32)
             if self.kind == "SGD":
                 w = w - lr * g
             elif self.kind == "RMSprop":
-                self.v[i] = F32(self.rho) * self.v[i] + F32(1 - self.rho) * g * g
-                w = w - lr * g / np.sqrt(self.v[i] + eps)
-            else:
-                self.m[i] = self.m[i] + (g - self.m[i]) * (F32(1) - b1)
-                self.v[i] = self.v[i] + (g * g - self.v[i]) * (F32(1) - b2)
-                bc1 = 1.0 - self.beta1 ** t
-                bc2 = 1.0 - self.beta2 ** t
-                if self.kind == "Adam":
-                    alpha = F32(float(lr) * np.sqrt(bc2) / bc1)
-                    w = w - (self.m[i] * alpha) / (np.sqrt(self.v[i]) + eps)
-                elif self.kind == "RAdam":
-                    sma_inf = 2.0 / (1.0 - self.beta2) - 1.0
-                    sma_t = sma_inf - 2.0 * t * (self.beta2 ** t) / bc2
-                    m_hat = self.m[i] * F32(1.0 / bc1)
-                    if sma_t >= self.sma_threshold:
-                        r = np.sqrt((sma_t - 4) / (sma_inf - 4) * (sma_t - 2) / (sma_inf - 2) * sma_inf / sma_t)
-                        v_hat = np.sqrt(self.v[i] * F32(1.0 / bc2))
-                        w = w - lr * F32(r) * m_hat / (v_hat + eps)
-                    else:
-                        w = w - lr * m_hat
+                self.v[i] = F32(self.rho) * self.v[i] + F32(1 - self.rho) * (g * g)
+                w = w - (lr * g) * (one / np.sqrt(self.v[i] + eps))
+            elif self.kind == "Adam":
+                self.m[i] = self.m[i] + (g - self.m[i]) * F32(1 - self.beta1)
+                self.v[i] = self.v[i] + (g * g - self.v[i]) * F32(1 - self.beta2)
+                alpha = lr * np.sqrt(one - p2) / (one - p1)
+                w = w - (self.m[i] * alpha) / (np.sqrt(self.v[i]) + eps)
+            elif self.kind == "RAdam":
+                self.m[i] = b1 * self.m[i] + (one - b1) * g
+                self.v[i] = b2 * self.v[i] + (one - b2) * (g * g)
+                sma_inf = F32(2) / (one - b2) - one
+                sma_t = sma_inf - F32(2) * t * p2 / (one - p2)
+                m_hat = self.m[i] / (one - p1)
+                if sma_t >= F32(self.sma_threshold):
+                    r = np.sqrt((sma_t - F32(4)) / (sma_inf - F32(4)) * (sma_t - F32(2)) / (sma_inf - F32(2))
+                                * sma_inf / sma_t)
+                    w = w - lr * (r * m_hat / (np.sqrt(self.v[i] / (one - p2)) + eps))
                 else:
-                    raise ValueError(self.kind)
+                    w = w - lr * m_hat
+            else:
+                raise ValueError(self.kind)
             out.append(w.astype(F32))
-        self.it = t
+        self.it += 1
         return out
 
 
