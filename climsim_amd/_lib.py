@@ -9,6 +9,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libclimsim_hip.so")
 CS_MAX_HIDDEN = 16
 CS_FLAG_NO_TR_READ = 1
+CS_FLAG_NO_CHAIN = 2
+CS_FLAG_CHAIN_BM64 = 4
+CS_FLAG_CHAIN_BM128 = 8
 
 ACT = {"relu": 0, "elu": 1, "leakyrelu": 2}
 OPT = {"Adam": 0, "RAdam": 1, "RMSprop": 2, "SGD": 3}
@@ -22,7 +25,7 @@ class CsMlpCfg(C.Structure):
 
 
 CS_K_COUNT = 8
-KERNEL_KINDS = ["prepare_input", "gemm_fwd", "gemm_dgrad", "wgrad", "optimizer", "memset"]
+KERNEL_KINDS = ["prepare_input", "gemm_fwd", "gemm_dgrad", "wgrad", "optimizer", "memset", "chain_fwd", "chain_bwd"]
 
 
 class CsKernelTimes(C.Structure):

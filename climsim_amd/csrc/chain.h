@@ -1,0 +1,228 @@
+// Layer-chain kernels: the whole Dense stack of the MLP for one tile of BM columns in ONE launch.
+//
+// Why: the layers are narrow (<= 512 wide) and the batch is tall.  A per-layer GEMM re-reads the
+// activations of every layer from L2/HBM and pays a launch boundary per layer.  Here a workgroup
+// (8 waves) owns BM rows; their activations stay in LDS from the input to the heads (forward) or
+// from dz of the heads back to dz of the first hidden layer (backward).  The only streamed operand
+// is the weight matrix, read from L2 in "fragment-major" order straight into MFMA operand
+// registers (no LDS staging: every wave owns its own output columns, so nothing is shared),
+// 1 KiB fully coalesced per wave-instruction, prefetched CHAIN_D k-steps ahead.
+//   L2 -> CU traffic per workgroup = all weights once (2.39 MB fwd), i.e. BM FLOP per byte.
+//
+// Stage shapes supported: output width 512 (wave = all rows x 64 cols), 256 (all rows x 32 cols),
+// 128 (half the rows x 32 cols); contraction length a multiple of 64, <= 512.
+#pragma once
+#include "kernels.h"
+
+#define CHAIN_D 4            // weight prefetch depth in k16-steps
+#define CHAIN_MAX_STAGES 18
+#define CHAIN_PITCH 512      // LDS row pitch in bf16 elements (1 KiB)
+
+struct ChainStage {
+    const u16* wfrag;        // fragment-major weights: [n_tile][k16 step][lane][8]
+    const float* bias;       // [Nc] (forward) or null
+    u16* out; int ldo;       // global bf16 output rows [m_pad][ldo] (h of the next layer / dz of the previous)
+    const u16* hprev; int ldh;   // backward: activation output to differentiate through
+    int Kc, Nc;              // contraction length, output width
+    int epi;                 // EPI_HIDDEN / EPI_OUT / EPI_DGRAD
+};
+
+struct ChainArgs {
+    int n_stages;
+    ChainStage st[CHAIN_MAX_STAGES];
+    int backward;            // 0: X0 from x (gather + normalise + cast); 1: X0 = dz of the heads
+    // forward prologue
+    const float* x; const int64_t* row_idx; int n_in; int kp0;
+    const float* sub; const float* div; int normalise;
+    u16* h0; int ldh0;       // global copy of the prepared input (wgrad of the first layer reads it)
+    // backward prologue
+    const u16* dz_in; int ld_dz_in; int w_in;
+    int64_t n_rows;
+    int act; float slope;
+    // heads (EPI_OUT)
+    int n_lin; float* yhat; const float* y; float* loss; u16* dz_out; int ld_dz_out;
+};
+
+__device__ __forceinline__ int chain_lds_off(int row, int col) {   // element offset of (row, col)
+    return row * CHAIN_PITCH + ((((col >> 3) ^ (row & 15))) << 3) + (col & 7);
+}
+
+// One stage for one wave: acc[MT][NT] 32x32 tiles over contraction length Kc.
+template <int MT, int NT>
+__device__ __forceinline__ void chain_mma(const u16* __restrict__ X, const u16* __restrict__ wfrag, int ks_total,
+                                          int jt0, int mrow0, int lane, f32x16_t (&acc)[MT][NT]) {
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    const uint4* wp[NT];
+#pragma unroll
+    for (int b = 0; b < NT; ++b) wp[b] = reinterpret_cast<const uint4*>(wfrag) + ((int64_t)(jt0 + b) * ks_total) * 64 + lane;
+    uint4 bq[CHAIN_D][NT];
+#pragma unroll
+    for (int d = 0; d < CHAIN_D; ++d)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) bq[d][b] = wp[b][d * 64];
+    const int arow = mrow0 + (lane & 31), ahalf = lane >> 5;
+    for (int s0 = 0; s0 < ks_total; s0 += CHAIN_D) {
+#pragma unroll
+        for (int d = 0; d < CHAIN_D; ++d) {
+            const int s = s0 + d;
+            bf16x8_t bcur[NT];
+#pragma unroll
+            for (int b = 0; b < NT; ++b) bcur[b] = __builtin_bit_cast(bf16x8_t, bq[d][b]);
+            if (s + CHAIN_D < ks_total) {
+#pragma unroll
+                for (int b = 0; b < NT; ++b) bq[d][b] = wp[b][(s + CHAIN_D) * 64];
+            }
+            bf16x8_t af[MT];
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+                af[a] = *reinterpret_cast<const bf16x8_t*>(X + chain_lds_off(arow + a * 32, (2 * s + ahalf) * 8));
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int b = 0; b < NT; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bcur[b], af[a], acc[a][b], 0, 0, 0);
+        }
+    }
+}
+
+template <int MT, int NT, int EPI>
+__device__ __forceinline__ void chain_epilogue(u16* __restrict__ X, const ChainArgs& p, const ChainStage& S, bool last,
+                                               int64_t m0, int jt0, int mrow0, int lane, f32x16_t (&acc)[MT][NT],
+                                               float& sq, float& ab) {
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int n = (jt0 + b) * 32 + 8 * q + 4 * (lane >> 5);
+            float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (EPI != EPI_DGRAD) b4 = *reinterpret_cast<const float4*>(S.bias + n);
+#pragma unroll
+            for (int a = 0; a < MT; ++a) {
+                const int ml = mrow0 + a * 32 + (lane & 31);
+                const int64_t m = m0 + ml;
+                float v[4] = {acc[a][b][4 * q + 0], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
+                if (EPI == EPI_HIDDEN) {
+                    v[0] = act_fwd(v[0] + b4.x, p.act, p.slope); v[1] = act_fwd(v[1] + b4.y, p.act, p.slope);
+                    v[2] = act_fwd(v[2] + b4.z, p.act, p.slope); v[3] = act_fwd(v[3] + b4.w, p.act, p.slope);
+                    const uint2 pk = pack4(v[0], v[1], v[2], v[3]);
+                    if (S.out) *reinterpret_cast<uint2*>(S.out + m * S.ldo + n) = pk;
+                    if (!last) *reinterpret_cast<uint2*>(X + chain_lds_off(ml, n)) = pk;
+                } else if (EPI == EPI_DGRAD) {
+                    const uint2 hh = *reinterpret_cast<const uint2*>(S.hprev + m * S.ldh + n);
+                    v[0] *= act_bwd_from_h(bf2f((u16)(hh.x & 0xffff)), p.act, p.slope);
+                    v[1] *= act_bwd_from_h(bf2f((u16)(hh.x >> 16)), p.act, p.slope);
+                    v[2] *= act_bwd_from_h(bf2f((u16)(hh.y & 0xffff)), p.act, p.slope);
+                    v[3] *= act_bwd_from_h(bf2f((u16)(hh.y >> 16)), p.act, p.slope);
+                    const uint2 pk = pack4(v[0], v[1], v[2], v[3]);
+                    if (S.out) *reinterpret_cast<uint2*>(S.out + m * S.ldo + n) = pk;
+                    if (!last) *reinterpret_cast<uint2*>(X + chain_lds_off(ml, n)) = pk;
+                } else {  // EPI_OUT: heads
+                    v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+                    const bool valid = m < p.n_rows;
+                    float d[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (n >= p.n_lin) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    }
+                    if (valid && p.yhat)
+                        *reinterpret_cast<float4*>(p.yhat + m * S.Nc + n) = make_float4(v[0], v[1], v[2], v[3]);
+                    if (p.y && valid) {
+                        const int64_t src = p.row_idx ? p.row_idx[m] : m;
+                        const float4 t4 = *reinterpret_cast<const float4*>(p.y + src * S.Nc + n);
+                        const float e4[4] = {v[0] - t4.x, v[1] - t4.y, v[2] - t4.z, v[3] - t4.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            sq += e4[e] * e4[e];
+                            ab += fabsf(e4[e]);
+                            d[e] = 2.f * e4[e];
+                            if (n >= p.n_lin && !(v[e] > 0.f)) d[e] = 0.f;
+                        }
+                    }
+                    if (p.dz_out) *reinterpret_cast<uint2*>(p.dz_out + m * p.ld_dz_out + n) = pack4(d[0], d[1], d[2], d[3]);
+                }
+            }
+        }
+    }
+}
+
+template <int MT, int NT, int EPI>
+__device__ __forceinline__ void chain_stage(u16* X, const ChainArgs& p, const ChainStage& S, bool last, int64_t m0,
+                                            int jt0, int mrow0, int lane, float& sq, float& ab) {
+    f32x16_t acc[MT][NT];
+    chain_mma<MT, NT>(X, S.wfrag, S.Kc >> 4, jt0, mrow0, lane, acc);
+    __syncthreads();                         // every wave has finished reading X for this stage
+    chain_epilogue<MT, NT, EPI>(X, p, S, last, m0, jt0, mrow0, lane, acc, sq, ab);
+    __syncthreads();                         // X now holds this stage's output
+}
+
+template <int BM, bool BWD>
+__global__ __launch_bounds__(512) void k_chain(const ChainArgs p) {
+    extern __shared__ __attribute__((aligned(16))) u16 X[];      // [BM][CHAIN_PITCH]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int64_t m0 = (int64_t)blockIdx.x * BM;
+
+    // ---- prologue: fill X with the stage-0 input rows
+    if (!BWD) {
+        const int groups = p.kp0 >> 2;                           // 4 features per thread-iteration
+        for (int g = tid; g < BM * groups; g += 512) {
+            const int ml = g / groups, c = (g - ml * groups) * 4;
+            const int64_t m = m0 + ml;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (m < p.n_rows && c < p.n_in) {
+                const int64_t src = p.row_idx ? p.row_idx[m] : m;
+                const float* xr = p.x + src * p.n_in + c;
+                if (c + 3 < p.n_in && (p.n_in & 3) == 0) {
+                    const float4 t = *reinterpret_cast<const float4*>(xr);
+                    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+                } else {
+                    for (int j = 0; j < 4 && c + j < p.n_in; ++j) v[j] = xr[j];
+                }
+                if (p.normalise) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (c + j < p.n_in) {
+                            const float t = (v[j] - p.sub[c + j]) / p.div[c + j];
+                            v[j] = (fabsf(t) <= 3.402823466e38f) ? t : 0.f;
+                        }
+                }
+            }
+            const uint2 pk = pack4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<uint2*>(X + chain_lds_off(ml, c)) = pk;
+            *reinterpret_cast<uint2*>(p.h0 + m * p.ldh0 + c) = pk;
+        }
+    } else {
+        const int chunks = p.w_in >> 3;                          // 16-B chunks per row
+        for (int g = tid; g < BM * chunks; g += 512) {
+            const int ml = g / chunks, c = (g - ml * chunks) * 8;
+            *reinterpret_cast<uint4*>(X + chain_lds_off(ml, c)) =
+                *reinterpret_cast<const uint4*>(p.dz_in + (m0 + ml) * p.ld_dz_in + c);
+        }
+    }
+    __syncthreads();
+
+    float sq = 0.f, ab = 0.f;
+    for (int i = 0; i < p.n_stages; ++i) {
+        const ChainStage& S = p.st[i];
+        const bool last = (i + 1 == p.n_stages);
+        constexpr int E = BWD ? EPI_DGRAD : EPI_HIDDEN;
+        if (S.Nc == 512) {          // wave = all BM rows x 64 columns
+            chain_stage<BM / 32, 2, E>(X, p, S, last, m0, wid * 2, 0, lane, sq, ab);
+        } else if (S.Nc == 256) {   // wave = all BM rows x 32 columns
+            chain_stage<BM / 32, 1, E>(X, p, S, last, m0, wid, 0, lane, sq, ab);
+        } else if (!BWD && S.epi == EPI_OUT) {   // heads: 128 wide, wave = half the rows x 32 columns
+            chain_stage<BM / 64, 1, EPI_OUT>(X, p, S, last, m0, wid & 3, (wid >> 2) * (BM / 2), lane, sq, ab);
+        } else {                    // 128: wave = half the rows x 32 columns
+            chain_stage<BM / 64, 1, E>(X, p, S, last, m0, wid & 3, (wid >> 2) * (BM / 2), lane, sq, ab);
+        }
+    }
+    if (!BWD && p.y) {
+        sq = wave_sum(sq);
+        ab = wave_sum(ab);
+        if (lane == 0) { atomicAdd(p.loss, sq); atomicAdd(p.loss + 1, ab); }
+    }
+}

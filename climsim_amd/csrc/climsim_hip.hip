@@ -3,6 +3,7 @@
 // caller's stream.  No PyTorch types, no CPU fallback: every compute entry point runs HIP kernels.
 #include "../../include/climsim_hip.h"
 #include "kernels.h"
+#include "chain.h"
 
 #include <cmath>
 #include <cstdarg>
@@ -61,6 +62,7 @@ struct Layer {
     int K, Kp, N;
     int64_t w_off, b_off;      // offsets (floats) in the flat parameter buffer
     u16 *Wt, *Wn;              // bf16 operand copies [N][Kp], [Kp][N]
+    u16 *Wf = nullptr, *Wb = nullptr;   // fragment-major copies for the chain kernels
     u16 *H;                    // layer INPUT activations [m_pad_max][Kp]
     u16 *dZ;                   // d loss / d pre-activation of this layer [m_pad_max][N]
 };
@@ -81,6 +83,7 @@ struct cs_mlp {
     int n_seg = 0;
     int64_t iterations = 0;
     int64_t bytes = 0;
+    bool use_chain = false;
     std::vector<void*> allocs;
 };
 
@@ -166,10 +169,39 @@ int launch_optimizer(cs_mlp* h, float lr, float grad_scale, bool recast_only, hi
     return CS_OK;
 }
 
+int chain_bm(const cs_mlp* h, int64_t n) {
+    if (h->cfg.flags & CS_FLAG_CHAIN_BM64) return 64;
+    if (h->cfg.flags & CS_FLAG_CHAIN_BM128) return 128;
+    return n > 16384 ? 128 : 64;
+}
+
 int run_forward(cs_mlp* h, const float* x, const int64_t* row_idx, int64_t n, int normalise, float* yhat,
                 const float* y, float* loss, bool want_dz, hipStream_t st) {
     const int64_t m_pad = round_up(n, 128);
     const Layer& l0 = h->layers[0];
+    if (h->use_chain) {
+        ChainArgs c{};
+        c.n_stages = h->L;
+        for (int l = 0; l < h->L; ++l) {
+            const Layer& ly = h->layers[l];
+            ChainStage& S = c.st[l];
+            S.wfrag = ly.Wf; S.bias = h->P + ly.b_off; S.Kc = ly.Kp; S.Nc = ly.N;
+            if (l + 1 < h->L) { S.out = h->layers[l + 1].H; S.ldo = h->layers[l + 1].Kp; S.epi = EPI_HIDDEN; }
+            else { S.out = nullptr; S.ldo = 0; S.epi = EPI_OUT; }
+        }
+        c.backward = 0;
+        c.x = x; c.row_idx = row_idx; c.n_in = h->cfg.n_in; c.kp0 = l0.Kp; c.sub = h->sub; c.div = h->div;
+        c.normalise = normalise; c.h0 = l0.H; c.ldh0 = l0.Kp; c.n_rows = n;
+        c.act = h->cfg.act; c.slope = (h->cfg.act == CS_ACT_RELU) ? 0.f : h->cfg.alpha;
+        c.n_lin = h->cfg.n_out_lin; c.yhat = yhat; c.y = y; c.loss = loss;
+        c.dz_out = want_dz ? h->layers[h->L - 1].dZ : nullptr; c.ld_dz_out = 128;
+        const int bm = chain_bm(h, n);
+        ProfScope ps(CS_K_CHAIN_FWD, st);
+        if (bm == 128) hipLaunchKernelGGL((k_chain<128, false>), dim3((unsigned)(m_pad / 128)), dim3(512), 128 * CHAIN_PITCH * 2, st, c);
+        else hipLaunchKernelGGL((k_chain<64, false>), dim3((unsigned)(m_pad / 64)), dim3(512), 64 * CHAIN_PITCH * 2, st, c);
+        HIP_TRY(hipGetLastError());
+        return CS_OK;
+    }
     {
         const int64_t total = m_pad * (l0.Kp / 4);
         ProfScope ps(CS_K_PREPARE, st);
@@ -201,6 +233,24 @@ int run_backward(cs_mlp* h, int64_t n, bool atomics_needed, hipStream_t st) {
     const int64_t m_pad = round_up(n, 128);
     const int steps = (int)(m_pad / 64);
     const bool tr = !(h->cfg.flags & CS_FLAG_NO_TR_READ);
+    if (h->use_chain && h->L > 1) {
+        ChainArgs c{};
+        c.n_stages = h->L - 1;
+        for (int l = h->L - 1, i = 0; l >= 1; --l, ++i) {
+            const Layer& ly = h->layers[l];
+            ChainStage& S = c.st[i];
+            S.wfrag = ly.Wb; S.bias = nullptr; S.Kc = ly.N; S.Nc = ly.Kp;
+            S.out = h->layers[l - 1].dZ; S.ldo = h->layers[l - 1].N;
+            S.hprev = ly.H; S.ldh = ly.Kp; S.epi = EPI_DGRAD;
+        }
+        c.backward = 1;
+        c.dz_in = h->layers[h->L - 1].dZ; c.ld_dz_in = 128; c.w_in = 128;
+        c.n_rows = n; c.act = h->cfg.act; c.slope = (h->cfg.act == CS_ACT_RELU) ? 0.f : h->cfg.alpha;
+        const int bm = chain_bm(h, n);
+        ProfScope ps(CS_K_CHAIN_BWD, st);
+        if (bm == 128) hipLaunchKernelGGL((k_chain<128, true>), dim3((unsigned)(m_pad / 128)), dim3(512), 128 * CHAIN_PITCH * 2, st, c);
+        else hipLaunchKernelGGL((k_chain<64, true>), dim3((unsigned)(m_pad / 64)), dim3(512), 64 * CHAIN_PITCH * 2, st, c);
+    }
     for (int l = h->L - 1; l >= 0; --l) {
         const Layer& ly = h->layers[l];
         WgradArgs w{};
@@ -217,7 +267,7 @@ int run_backward(cs_mlp* h, int64_t n, bool atomics_needed, hipStream_t st) {
             if (tr) hipLaunchKernelGGL(k_wgrad<true>, grid, dim3(256), 0, st, w);
             else hipLaunchKernelGGL(k_wgrad<false>, grid, dim3(256), 0, st, w);
         }
-        if (l > 0) {
+        if (l > 0 && !h->use_chain) {
             GemmNT p{};
             p.A = ly.dZ; p.lda = ly.N; p.B = ly.Wn; p.ldb = ly.N; p.K = ly.N; p.N = ly.Kp;
             p.act = h->cfg.act; p.alpha = (h->cfg.act == CS_ACT_RELU) ? 0.f : h->cfg.alpha;
@@ -280,6 +330,18 @@ int cs_mlp_create(cs_mlp_t** out, const cs_mlp_cfg* cfg) {
         ly.b_off = off; off += ly.N;
     }
     h->n_params = off;
+    h->use_chain = !(cfg->flags & CS_FLAG_NO_CHAIN);
+    for (int l = 0; l < h->L; ++l) {
+        const Layer& ly = h->layers[l];
+        if (!(ly.N == 128 || ly.N == 256 || ly.N == 512) || ly.Kp > CHAIN_PITCH || ly.Kp % 64) h->use_chain = false;
+    }
+    if (2 * h->L > CHAIN_MAX_STAGES) h->use_chain = false;
+    if (h->use_chain) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain<128, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * CHAIN_PITCH * 2));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain<128, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * CHAIN_PITCH * 2));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain<64, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * CHAIN_PITCH * 2));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain<64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * CHAIN_PITCH * 2));
+    }
     int rc = CS_OK;
     auto A = [&](void** p, size_t b, bool z) { if (rc == CS_OK) rc = dev_alloc(h, p, b, z); };
     A((void**)&h->P, sizeof(float) * off, true);
@@ -295,8 +357,12 @@ int cs_mlp_create(cs_mlp_t** out, const cs_mlp_cfg* cfg) {
         A((void**)&ly.Wn, sizeof(u16) * ly.Kp * ly.N, true);
         A((void**)&ly.H, sizeof(u16) * h->m_pad_max * ly.Kp, true);
         A((void**)&ly.dZ, sizeof(u16) * h->m_pad_max * ly.N, true);
-        Segment sw{ly.w_off, (int64_t)ly.K * ly.N, ly.K, ly.N, ly.Kp, ly.Wt, ly.Wn};
-        Segment sb{ly.b_off, (int64_t)ly.N, 1, ly.N, 0, nullptr, nullptr};
+        if (h->use_chain) {
+            A((void**)&ly.Wf, sizeof(u16) * ly.N * ly.Kp, true);
+            if (l > 0) A((void**)&ly.Wb, sizeof(u16) * ly.Kp * ly.N, true);
+        }
+        Segment sw{ly.w_off, (int64_t)ly.K * ly.N, ly.K, ly.N, ly.Kp, ly.Wt, ly.Wn, ly.Wf, ly.Wb};
+        Segment sb{ly.b_off, (int64_t)ly.N, 1, ly.N, 0, nullptr, nullptr, nullptr, nullptr};
         segs.push_back(sw);
         segs.push_back(sb);
     }

@@ -394,6 +394,8 @@ struct Segment {          // one parameter tensor of the flat buffer
     int K, N, Kp;         // Kp: padded contraction length of the bf16 copies (0 for a bias)
     u16* Wt;              // [N][Kp]  (forward operand,  contraction k contiguous)
     u16* Wn;              // [Kp][N]  (dgrad operand,    contraction n contiguous)
+    u16* Wf;              // fragment-major forward operand  [n/32][k/16][lane][8]   (chain kernels) or null
+    u16* Wb;              // fragment-major backward operand [k/32][n/16][lane][8]   (chain kernels) or null
 };
 struct OptArgs {
     float* P; float* M; float* V; const float* G;
@@ -471,4 +473,17 @@ __global__ __launch_bounds__(256) void k_optimizer(const OptArgs a) {
     *reinterpret_cast<uint2*>(sg.Wn + (int64_t)k * sg.N + n) = pack4(wv[0], wv[1], wv[2], wv[3]);
 #pragma unroll
     for (int e = 0; e < 4; ++e) sg.Wt[(int64_t)(n + e) * sg.Kp + k] = f2bf(wv[e]);
+    if (sg.Wf) {          // lane (n&31) + 32*((k>>3)&1) of block (n>>5, k>>4) holds W[k..][n], element k&7
+        const int ks = sg.Kp >> 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int nn = n + e;
+            sg.Wf[((((int64_t)(nn >> 5) * ks + (k >> 4)) * 64 + (nn & 31) + 32 * ((k >> 3) & 1)) << 3) + (k & 7)] = f2bf(wv[e]);
+        }
+    }
+    if (sg.Wb) {          // lane (k&31) + 32*((n>>3)&1) of block (k>>5, n>>4) holds W[k][n..], elements n&7..
+        const int ns = sg.N >> 4;
+        *reinterpret_cast<uint2*>(sg.Wb + ((((int64_t)(k >> 5) * ns + (n >> 4)) * 64 + (k & 31) + 32 * ((n >> 3) & 1)) << 3) + (n & 7)) =
+            pack4(wv[0], wv[1], wv[2], wv[3]);
+    }
 }

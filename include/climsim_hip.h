@@ -57,6 +57,9 @@ typedef struct cs_mlp_cfg {
 } cs_mlp_cfg;
 
 #define CS_FLAG_NO_TR_READ 1      /* wgrad operands by 16-bit LDS gathers instead of ds_read_b64_tr_b16 */
+#define CS_FLAG_NO_CHAIN   2      /* one GEMM launch per layer instead of the fused layer-chain kernels    */
+#define CS_FLAG_CHAIN_BM64  4     /* force 64-row chain tiles  (default: by batch size)                    */
+#define CS_FLAG_CHAIN_BM128 8     /* force 128-row chain tiles                                             */
 
 /* keras.Model(...) + compile(): allocates weights (zero), optimiser state, workspace. */
 int  cs_mlp_create(cs_mlp_t** out, const cs_mlp_cfg* cfg);
@@ -115,7 +118,7 @@ int64_t cs_mlp_device_bytes(const cs_mlp_t* h);
  * on `stream` around every kernel launch; returns summed milliseconds and launch counts per
  * kernel kind.  Synchronises the stream.  Same arithmetic as cs_mlp_train_step. */
 enum { CS_K_PREPARE = 0, CS_K_GEMM_FWD = 1, CS_K_GEMM_DGRAD = 2, CS_K_WGRAD = 3, CS_K_OPTIMIZER = 4,
-       CS_K_MEMSET = 5, CS_K_COUNT = 8 };
+       CS_K_MEMSET = 5, CS_K_CHAIN_FWD = 6, CS_K_CHAIN_BWD = 7, CS_K_COUNT = 8 };
 typedef struct cs_kernel_times { float ms[CS_K_COUNT]; int32_t launches[CS_K_COUNT]; } cs_kernel_times;
 int cs_mlp_profile_step(cs_mlp_t* h, const float* x_dev, const float* y_dev, const int64_t* row_idx_dev,
                         int64_t n, int normalise, float lr, float* loss_dev, void* stream,

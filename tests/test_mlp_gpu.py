@@ -43,10 +43,12 @@ def make_model(M, units, act="leakyrelu", opt="Adam", max_batch=1024, seed=3, fl
     return m, cfg, ws
 
 
+# engine flags: 0 = layer-chain kernels (tile by batch), 2 = one GEMM per layer, 4/8 = chain with 64/128-row tiles
+@pytest.mark.parametrize("flags", [0, 2, 8])
 @pytest.mark.parametrize("act", ["relu", "elu", "leakyrelu"])
 @pytest.mark.parametrize("n", [1, 200, 384])
-def test_forward_matches_oracle(M, act, n):
-    m, cfg, ws = make_model(M, (128, 256), act=act)
+def test_forward_matches_oracle(M, act, n, flags):
+    m, cfg, ws = make_model(M, (128, 256, 512), act=act, flags=flags)
     x, _ = O.synth_columns(n, seed=11)
     got = m.predict(x)
     ref16 = O.forward(ws, x, cfg, bf16=True)
@@ -57,10 +59,11 @@ def test_forward_matches_oracle(M, act, n):
     assert np.all(got[:, 120:] >= 0)                      # relu head
 
 
-@pytest.mark.parametrize("flags", [0, 1])                 # 1 = CS_FLAG_NO_TR_READ
-@pytest.mark.parametrize("act,n", [("leakyrelu", 300), ("relu", 128), ("elu", 1000)])
-def test_loss_and_gradients_match_oracle(M, act, n, flags):
-    m, cfg, ws = make_model(M, (256, 128, 384), act=act, flags=flags)
+@pytest.mark.parametrize("flags", [0, 1, 2, 3, 8])        # +1 = CS_FLAG_NO_TR_READ
+@pytest.mark.parametrize("act,n,units", [("leakyrelu", 300, (256, 128, 512)), ("relu", 128, (512, 512)),
+                                         ("elu", 1000, (256, 128, 384))])   # 384: per-layer fallback
+def test_loss_and_gradients_match_oracle(M, act, n, units, flags):
+    m, cfg, ws = make_model(M, units, act=act, flags=flags)
     x, y = O.synth_columns(n, seed=7)
     xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
     m.gradient_tensor()
