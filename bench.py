@@ -24,7 +24,11 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 UNITS = (512, 512, 512, 512, 512)
-FLOPS_PER_COL = {"gemm_fwd": 2 * 1_193_984, "gemm_dgrad": 2 * 1_130_496, "wgrad": 2 * 1_193_984}
+# algorithmic FLOP per column of each kernel kind; chain_* are the fused-layer forms
+FLOPS_PER_COL = {"gemm_fwd": 2 * 1_193_984, "gemm_dgrad": 2 * 1_130_496, "wgrad": 2 * 1_193_984,
+                 "chain_fwd": 2 * 1_193_984, "chain_bwd": 2 * 1_130_496}
+KERNEL_NAMES = {"gemm_fwd": "k_gemm_nt<EPI_HIDDEN|EPI_OUT>", "gemm_dgrad": "k_gemm_nt<EPI_DGRAD>", "wgrad": "k_wgrad",
+                "chain_fwd": "k_chain<BM,false>", "chain_bwd": "k_chain<BM,true>"}
 TRAIN_FLOPS_PER_COL = 7_036_928
 HBM_BYTES_PER_COL = 1008                    # 496 B x + 512 B y (fp32 storage), SURVEY 8(d)
 PEAK_BF16_TFLOPS = 2500.0                   # dense MFMA peak, MI355X_MICROARCH.md
@@ -140,12 +144,13 @@ def main():
                 a[1] += cnt
         kernels = {k: {"ms_per_step": v[0] / reps, "launches_per_step": v[1] / reps,
                        "avg_us_per_launch": (v[0] / max(v[1], 1)) * 1e3} for k, v in agg.items()}
-        dom = max(FLOPS_PER_COL, key=lambda k: kernels[k]["ms_per_step"])
+        kernels = {k: v for k, v in kernels.items() if v["launches_per_step"] > 0}
+        dom = max((k for k in FLOPS_PER_COL if k in kernels), key=lambda k: kernels[k]["ms_per_step"])
         for k, f in FLOPS_PER_COL.items():
-            kernels[k]["tflops"] = f * B / (kernels[k]["ms_per_step"] * 1e-3) / 1e12
+            if k in kernels:
+                kernels[k]["tflops"] = f * B / (kernels[k]["ms_per_step"] * 1e-3) / 1e12
         achieved = kernels[dom]["tflops"]
-        roofline = {"kernel": {"gemm_fwd": "k_gemm_nt<EPI_HIDDEN|EPI_OUT>", "gemm_dgrad": "k_gemm_nt<EPI_DGRAD>",
-                               "wgrad": "k_wgrad"}[dom],
+        roofline = {"kernel": KERNEL_NAMES[dom],
                     "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
                     "avg_us_per_launch": round(kernels[dom]["avg_us_per_launch"], 2),
