@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -84,6 +85,7 @@ struct cs_mlp {
     int64_t iterations = 0;
     int64_t bytes = 0;
     bool use_chain = false;
+    int wgrad_splitk = 0;      // 0 = automatic (CS_WGRAD_SPLITK env overrides, for tuning runs)
     std::vector<void*> allocs;
 };
 
@@ -251,23 +253,9 @@ int run_backward(cs_mlp* h, int64_t n, bool atomics_needed, hipStream_t st) {
         if (bm == 128) hipLaunchKernelGGL((k_chain<128, true>), dim3((unsigned)(m_pad / 128)), dim3(512), 128 * CHAIN_PITCH * 2, st, c);
         else hipLaunchKernelGGL((k_chain<64, true>), dim3((unsigned)(m_pad / 64)), dim3(512), 64 * CHAIN_PITCH * 2, st, c);
     }
-    for (int l = h->L - 1; l >= 0; --l) {
-        const Layer& ly = h->layers[l];
-        WgradArgs w{};
-        w.H = ly.H; w.ldh = ly.Kp; w.Z = ly.dZ; w.ldz = ly.N; w.m_pad = m_pad;
-        w.dW = h->G + ly.w_off; w.N = ly.N; w.k_real = ly.K; w.db = h->G + ly.b_off;
-        const int tiles = (ly.Kp / 128) * (ly.N / 128);
-        int splitk = 256 / tiles;
-        if (splitk < 1) splitk = 1;
-        if (splitk > steps) splitk = steps;
-        w.use_atomics = (splitk > 1 || atomics_needed) ? 1 : 0;
-        const dim3 grid((unsigned)(ly.Kp / 128), (unsigned)(ly.N / 128), (unsigned)splitk);
-        {
-            ProfScope ps(CS_K_WGRAD, st);
-            if (tr) hipLaunchKernelGGL(k_wgrad<true>, grid, dim3(256), 0, st, w);
-            else hipLaunchKernelGGL(k_wgrad<false>, grid, dim3(256), 0, st, w);
-        }
-        if (l > 0 && !h->use_chain) {
+    if (!h->use_chain) {
+        for (int l = h->L - 1; l >= 1; --l) {
+            const Layer& ly = h->layers[l];
             GemmNT p{};
             p.A = ly.dZ; p.lda = ly.N; p.B = ly.Wn; p.ldb = ly.N; p.K = ly.N; p.N = ly.Kp;
             p.act = h->cfg.act; p.alpha = (h->cfg.act == CS_ACT_RELU) ? 0.f : h->cfg.alpha;
@@ -277,6 +265,29 @@ int run_backward(cs_mlp* h, int64_t n, bool atomics_needed, hipStream_t st) {
             ProfScope ps(CS_K_GEMM_DGRAD, st);
             hipLaunchKernelGGL(k_gemm_nt<EPI_DGRAD>, g2, dim3(256), 0, st, p);
         }
+    }
+    {   // weight/bias gradients of ALL layers in one grouped launch
+        WgradArgs w{};
+        w.n_layers = h->L; w.m_pad = m_pad;
+        int tiles = 0;
+        for (int l = 0; l < h->L; ++l) tiles += (h->layers[l].Kp / 128) * (h->layers[l].N / 128);
+        int splitk = h->wgrad_splitk > 0 ? h->wgrad_splitk : (512 + tiles / 2) / tiles;
+        if (splitk < 1) splitk = 1;
+        if (splitk > steps) splitk = steps;
+        w.splitk = splitk;
+        w.use_atomics = (splitk > 1 || atomics_needed) ? 1 : 0;
+        int wg = 0;
+        for (int l = 0; l < h->L; ++l) {
+            const Layer& ly = h->layers[l];
+            WgradLayer& d = w.L[l];
+            d.H = ly.H; d.ldh = ly.Kp; d.Z = ly.dZ; d.ldz = ly.N;
+            d.dW = h->G + ly.w_off; d.N = ly.N; d.k_real = ly.K; d.db = h->G + ly.b_off;
+            d.tiles_k = ly.Kp / 128; d.tiles_n = ly.N / 128; d.wg_begin = wg;
+            wg += d.tiles_k * d.tiles_n * splitk;
+        }
+        ProfScope ps(CS_K_WGRAD, st);
+        if (tr) hipLaunchKernelGGL(k_wgrad<true>, dim3((unsigned)wg), dim3(256), 0, st, w);
+        else hipLaunchKernelGGL(k_wgrad<false>, dim3((unsigned)wg), dim3(256), 0, st, w);
     }
     HIP_TRY(hipGetLastError());
     return CS_OK;
@@ -336,6 +347,8 @@ int cs_mlp_create(cs_mlp_t** out, const cs_mlp_cfg* cfg) {
         if (!(ly.N == 128 || ly.N == 256 || ly.N == 512) || ly.Kp > CHAIN_PITCH || ly.Kp % 64) h->use_chain = false;
     }
     if (2 * h->L > CHAIN_MAX_STAGES) h->use_chain = false;
+    if (h->L > WGRAD_MAX_LAYERS) { delete h; return fail(CS_ERR_INVALID, "too many layers"); }
+    if (const char* e = getenv("CS_WGRAD_SPLITK")) h->wgrad_splitk = atoi(e);
     if (h->use_chain) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain<128, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * CHAIN_PITCH * 2));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain<128, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * CHAIN_PITCH * 2));

@@ -250,14 +250,22 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const GemmNT p) {
 }
 
 // ---------------------------------------------------------------- TN GEMM (wgrad)
-struct WgradArgs {
+struct WgradLayer {
     const u16* H;  int ldh;      // [m_pad][ldh]  layer input activations (bf16)
     const u16* Z;  int ldz;      // [m_pad][ldz]  dz of the layer (bf16)
-    int64_t m_pad;               // multiple of 128; rows >= n hold zeros in Z
     float* dW;     int N;        // [K][N] fp32, Keras (in,out) layout
     int k_real;                  // rows of dW that exist (124 for the first layer, else Kp)
     float* db;                   // [N]
-    int use_atomics;             // gridDim.z > 1 or accumulate
+    int tiles_k, tiles_n;        // 128x128 output tiles
+    int wg_begin;                // first workgroup of this layer in the grouped grid
+};
+#define WGRAD_MAX_LAYERS 18
+struct WgradArgs {               // ALL layers of the step in one launch: grid.x = sum(tiles * splitk)
+    int n_layers;
+    WgradLayer L[WGRAD_MAX_LAYERS];
+    int64_t m_pad;               // multiple of 128; rows >= n hold zeros in Z
+    int splitk;                  // row-range splits per tile (same for every layer)
+    int use_atomics;             // splitk > 1 or accumulate
 };
 
 // LDS tile [64 m][128 cols] bf16 (256-B rows).  The four 64-B units of a row are XOR-swizzled with
@@ -290,14 +298,20 @@ __device__ __forceinline__ bf16x8_t load_frag_tn(const u16* tile, int mb, int cb
 }
 
 template <bool TR>
-__global__ __launch_bounds__(256) void k_wgrad(const WgradArgs p) {
+__global__ __launch_bounds__(256) void k_wgrad(const WgradArgs pa) {
     __shared__ __attribute__((aligned(16))) u16 smem[2][2][64 * 128];   // [buffer][H|Z] = 64 KiB
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wk = wid >> 1, wn = wid & 1;
-    const int k0 = blockIdx.x * 128, n0 = blockIdx.y * 128;
-    const int steps = (int)(p.m_pad >> 6);
-    const int s_begin = (int)((int64_t)steps * blockIdx.z / gridDim.z);
-    const int s_end = (int)((int64_t)steps * (blockIdx.z + 1) / gridDim.z);
+    int li = 0;
+    while (li + 1 < pa.n_layers && (int)blockIdx.x >= pa.L[li + 1].wg_begin) ++li;
+    const WgradLayer& p = pa.L[li];
+    const int rel = blockIdx.x - p.wg_begin;
+    const int ntile = p.tiles_k * p.tiles_n;
+    const int split = rel / ntile, tile = rel - split * ntile;
+    const int k0 = (tile % p.tiles_k) * 128, n0 = (tile / p.tiles_k) * 128;
+    const int steps = (int)(pa.m_pad >> 6);
+    const int s_begin = (int)((int64_t)steps * split / pa.splitk);
+    const int s_end = (int)((int64_t)steps * (split + 1) / pa.splitk);
     const int srow = tid >> 4, sc = (tid & 15) * 8;     // staging: 4 rows (stride 16) x one 16-B chunk
     const u16* Hg = p.H + (int64_t)srow * p.ldh + k0 + sc;
     const u16* Zg = p.Z + (int64_t)srow * p.ldz + n0 + sc;
@@ -324,7 +338,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc00[r] = 0.f; acc01[r] = 0.f; acc10[r] = 0.f; acc11[r] = 0.f; }
     float bsum0 = 0.f, bsum1 = 0.f;
-    const bool do_bias = (blockIdx.x == 0) && (wk == 0);
+    const bool do_bias = (k0 == 0) && (wk == 0);
 
     if (s_begin < s_end) {
         TN_GLOAD(s_begin)
@@ -370,7 +384,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs p) {
                 const int k = k0 + wk * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (k < p.k_real) {
                     float* dst = p.dW + (int64_t)k * p.N + n;
-                    if (p.use_atomics) atomicAdd(dst, av[r]); else *dst = av[r];
+                    if (pa.use_atomics) atomicAdd(dst, av[r]); else *dst = av[r];
                 }
             }
         }
@@ -381,7 +395,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs p) {
             const float v = bj + __shfl_xor(bj, 32, 64);
             if (lane < 32) {
                 float* dst = p.db + n0 + wn * 64 + j * 32 + lane;
-                if (p.use_atomics) atomicAdd(dst, v); else *dst = v;
+                if (pa.use_atomics) atomicAdd(dst, v); else *dst = v;
             }
         }
     }
@@ -394,8 +408,8 @@ struct Segment {          // one parameter tensor of the flat buffer
     int K, N, Kp;         // Kp: padded contraction length of the bf16 copies (0 for a bias)
     u16* Wt;              // [N][Kp]  (forward operand,  contraction k contiguous)
     u16* Wn;              // [Kp][N]  (dgrad operand,    contraction n contiguous)
-    u16* Wf;              // fragment-major forward operand  [n/32][k/16][lane][8]   (chain kernels) or null
-    u16* Wb;              // fragment-major backward operand [k/32][n/16][lane][8]   (chain kernels) or null
+    u16* Wf;              // fragment-major forward operand  [k/16][n/32][lane][8]   (chain kernels) or null
+    u16* Wb;              // fragment-major backward operand [n/16][k/32][lane][8]   (chain kernels) or null
 };
 struct OptArgs {
     float* P; float* M; float* V; const float* G;
@@ -473,17 +487,17 @@ __global__ __launch_bounds__(256) void k_optimizer(const OptArgs a) {
     *reinterpret_cast<uint2*>(sg.Wn + (int64_t)k * sg.N + n) = pack4(wv[0], wv[1], wv[2], wv[3]);
 #pragma unroll
     for (int e = 0; e < 4; ++e) sg.Wt[(int64_t)(n + e) * sg.Kp + k] = f2bf(wv[e]);
-    if (sg.Wf) {          // lane (n&31) + 32*((k>>3)&1) of block (n>>5, k>>4) holds W[k..][n], element k&7
-        const int ks = sg.Kp >> 4;
+    if (sg.Wf) {          // lane (n&31) + 32*((k>>3)&1) of block (k>>4, n>>5) holds W[k..][n], element k&7
+        const int nt = sg.N >> 5;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int nn = n + e;
-            sg.Wf[((((int64_t)(nn >> 5) * ks + (k >> 4)) * 64 + (nn & 31) + 32 * ((k >> 3) & 1)) << 3) + (k & 7)] = f2bf(wv[e]);
+            sg.Wf[((((int64_t)(k >> 4) * nt + (nn >> 5)) * 64 + (nn & 31) + 32 * ((k >> 3) & 1)) << 3) + (k & 7)] = f2bf(wv[e]);
         }
     }
-    if (sg.Wb) {          // lane (k&31) + 32*((n>>3)&1) of block (k>>5, n>>4) holds W[k][n..], elements n&7..
-        const int ns = sg.N >> 4;
-        *reinterpret_cast<uint2*>(sg.Wb + ((((int64_t)(k >> 5) * ns + (n >> 4)) * 64 + (k & 31) + 32 * ((n >> 3) & 1)) << 3) + (n & 7)) =
+    if (sg.Wb) {          // lane (k&31) + 32*((n>>3)&1) of block (n>>4, k>>5) holds W[k][n..], elements n&7..
+        const int kt = sg.Kp >> 5;
+        *reinterpret_cast<uint2*>(sg.Wb + ((((int64_t)(n >> 4) * kt + (k >> 5)) * 64 + (k & 31) + 32 * ((n >> 3) & 1)) << 3) + (n & 7)) =
             pack4(wv[0], wv[1], wv[2], wv[3]);
     }
 }
