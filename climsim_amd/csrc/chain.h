@@ -65,34 +65,54 @@ __device__ __forceinline__ void chain_mma(const u16* __restrict__ X, const u16* 
 #pragma unroll
     for (int b = 0; b < NT; ++b) wp[b] = reinterpret_cast<const uint4*>(wfrag) + (jt0 + b) * 64 + lane;
     const int sstride = ntiles * 64;             // uint4 per k16 step
-    uint4 bq[CHAIN_D][NT];
-#pragma unroll
-    for (int d = 0; d < CHAIN_D; ++d)
-#pragma unroll
-        for (int b = 0; b < NT; ++b) bq[d][b] = wp[b][d * sstride];
+    // The weight stream is issued with inline-asm loads and waited for with COUNTED vmcnt: hipcc's own
+    // bookkeeping falls back to vmcnt(0) at the loop header (and rotates the queue through v_mov's that
+    // need the data), which exposed the full memory latency on every 4 steps.  Protocol: slot d is
+    // refilled right after its last use; before its next use exactly NT*(CHAIN_D-1) younger loads have
+    // been issued by this wave, so vmcnt(NT*(CHAIN_D-1)) means "slot d has landed".  Loads are issued
+    // unconditionally (address clamped at the tail) to keep that count exact.
+    // queue slots are named scalars (tied asm operands cannot be array elements)
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;   // native vector: a plain VGPR tuple for asm
+    u32x4_t q00, q01, q10, q11, q20, q21, q30, q31;
+    static_assert(CHAIN_D == 4, "queue slots below are written out for depth 4");
+#define CHAIN_LOAD(Q0, Q1, step)                                                                              \
+    {                                                                                                          \
+        const int sn_ = min((step), ks_total - 1);                                                             \
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(Q0) : "v"(wp[0] + sn_ * sstride) : "memory");    \
+        if (NT == 2)                                                                                           \
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(Q1) : "v"(wp[NT - 1] + sn_ * sstride) : "memory"); \
+    }
+#define CHAIN_STEP(d, Q0, Q1)                                                                                  \
+    {                                                                                                          \
+        const int s = s0 + (d);                                                                                \
+        bf16x8_t af[MT];                                                                                       \
+        _Pragma("unroll") for (int a = 0; a < MT; ++a)                                                         \
+            af[a] = *reinterpret_cast<const bf16x8_t*>(X + chain_lds_off(arow + a * 32, (2 * s + ahalf) * 8)); \
+        if (NT == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(Q0), "+v"(Q1) : "i"(NT * (CHAIN_D - 1)) : "memory"); \
+        else asm volatile("s_waitcnt vmcnt(%1)" : "+v"(Q0) : "i"(NT * (CHAIN_D - 1)) : "memory");              \
+        _Pragma("unroll") for (int a = 0; a < MT; ++a) {                                                       \
+            acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, Q0), af[a], acc[a][0], 0, 0, 0); \
+            if (NT == 2)                                                                                       \
+                acc[a][NT - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, Q1), af[a], acc[a][NT - 1], 0, 0, 0); \
+        }                                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        CHAIN_LOAD(Q0, Q1, s + CHAIN_D)                                                                        \
+    }
+    CHAIN_LOAD(q00, q01, 0)
+    CHAIN_LOAD(q10, q11, 1)
+    CHAIN_LOAD(q20, q21, 2)
+    CHAIN_LOAD(q30, q31, 3)
     const int arow = mrow0 + (lane & 31), ahalf = lane >> 5;
     for (int s0 = 0; s0 < ks_total; s0 += CHAIN_D) {
-#pragma unroll
-        for (int d = 0; d < CHAIN_D; ++d) {
-            const int s = s0 + d;
-            bf16x8_t bcur[NT];
-#pragma unroll
-            for (int b = 0; b < NT; ++b) bcur[b] = __builtin_bit_cast(bf16x8_t, bq[d][b]);
-            if (s + CHAIN_D < ks_total) {
-#pragma unroll
-                for (int b = 0; b < NT; ++b) bq[d][b] = wp[b][(s + CHAIN_D) * sstride];
-            }
-            bf16x8_t af[MT];
-#pragma unroll
-            for (int a = 0; a < MT; ++a)
-                af[a] = *reinterpret_cast<const bf16x8_t*>(X + chain_lds_off(arow + a * 32, (2 * s + ahalf) * 8));
-#pragma unroll
-            for (int a = 0; a < MT; ++a)
-#pragma unroll
-                for (int b = 0; b < NT; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bcur[b], af[a], acc[a][b], 0, 0, 0);
-        }
+        CHAIN_STEP(0, q00, q01)
+        CHAIN_STEP(1, q10, q11)
+        CHAIN_STEP(2, q20, q21)
+        CHAIN_STEP(3, q30, q31)
     }
+#undef CHAIN_STEP
+#undef CHAIN_LOAD
+    // drain: the tail re-loads are still in flight and their destination registers are about to be reused
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 template <int MT, int NT, int EPI>
@@ -170,6 +190,23 @@ __global__ __launch_bounds__(512) void k_chain(const ChainArgs p) {
     extern __shared__ __attribute__((aligned(16))) u16 X[];      // [BM][CHAIN_PITCH]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int64_t m0 = (int64_t)blockIdx.x * BM;
+
+    // ---- L2 warm-up.  The bf16 weights were written by the optimiser kernel on other XCDs, so at
+    // launch they sit in HBM / Infinity Cache, not in this XCD's L2, and the k-loop's small prefetch
+    // window would stream them at memory latency (measured: 2.4 MB in ~75 us).  Instead the
+    // workgroups that share an XCD (block b runs on XCD b % 8 - a speed assumption only) each touch a
+    // distinct 1/Q of every stage's weights, one 4-byte load per 128-B line, all in flight at once.
+    {
+        const int Q = min(32, max(1, (int)(gridDim.x >> 3)));
+        const int q = (int)(blockIdx.x >> 3) % Q;
+        unsigned sink = 0;
+        for (int i = 0; i < p.n_stages; ++i) {
+            const unsigned* w = reinterpret_cast<const unsigned*>(p.st[i].wfrag);
+            const int lines = (p.st[i].Kc * p.st[i].Nc) >> 6;            // 128-B lines of bf16
+            for (int ln = q * 512 + tid; ln < lines; ln += Q * 512) sink ^= w[ln * 32];
+        }
+        asm volatile("" ::"v"(sink));
+    }
 
     // ---- prologue: fill X with the stage-0 input rows
     if (!BWD) {
