@@ -8,25 +8,35 @@
 // registers (no LDS staging: every wave owns its own output columns, so nothing is shared),
 // 1 KiB fully coalesced per wave-instruction, prefetched CHAIN_D k-steps ahead.  The layout is
 // [k16 step][n tile][lane][8]: at every step the 8 waves of a workgroup together read ONE
-// contiguous 16 KiB run, so the requests spread over all L2 channels (a per-tile-major layout put
-// the 16 concurrent streams 32 KiB apart - a power-of-two stride that lands on one or two channels;
-// measured 2.8 TB/s aggregate instead of >20).
+// contiguous 16 KiB run, so the requests spread over all L2 channels.
 //   L2 -> CU traffic per workgroup = all weights once (2.39 MB fwd), i.e. BM FLOP per byte.
+//
+// Nothing on the per-stage critical path waits for a *dependent* global load (measured: the first
+// version spent ~60 of 90 us in epilogues that loaded bias / previous activations one at a time):
+//   * all biases are staged into LDS once per workgroup,
+//   * the backward pass gets act'(z) from a 1-bit-per-element sign mask that the forward epilogue
+//     writes in the lane layout the backward epilogue uses (one 16-B load per lane per stage, issued
+//     before the k-loop); ELU needs the activation value and keeps a batched load path,
+//   * gathered row indices live in LDS; target rows are loaded in one batch.
 //
 // Stage shapes supported: output width 512 (wave = all rows x 64 cols), 256 (all rows x 32 cols),
 // 128 (half the rows x 32 cols); contraction length a multiple of 64, <= 512.
 #pragma once
 #include "kernels.h"
 
-#define CHAIN_D 4            // weight prefetch depth in k16-steps
+#define CHAIN_D 4              // weight prefetch depth in k16-steps
 #define CHAIN_MAX_STAGES 18
-#define CHAIN_PITCH 512      // LDS row pitch in bf16 elements (1 KiB)
+#define CHAIN_PITCH 512        // LDS row pitch in bf16 elements (1 KiB)
+#define CHAIN_MAX_BIAS 4096    // floats of bias staged in LDS (sum of layer widths)
+
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;   // native vector: a plain VGPR tuple for asm
 
 struct ChainStage {
     const u16* wfrag;        // fragment-major weights: [k16 step][n_tile][lane][8]
-    const float* bias;       // [Nc] (forward) or null
+    int bias_off;            // offset of this stage's bias in the LDS bias block (forward)
     u16* out; int ldo;       // global bf16 output rows [m_pad][ldo] (h of the next layer / dz of the previous)
-    const u16* hprev; int ldh;   // backward: activation output to differentiate through
+    const u16* hprev; int ldh;   // backward + ELU: activation output to differentiate through
+    u32x4_t* mask;           // sign mask of this stage's output tile: [row tile][512 threads] x 128 bit
     int Kc, Nc;              // contraction length, output width
     int epi;                 // EPI_HIDDEN / EPI_OUT / EPI_DGRAD
 };
@@ -34,27 +44,29 @@ struct ChainStage {
 struct ChainArgs {
     int n_stages;
     ChainStage st[CHAIN_MAX_STAGES];
-    int backward;            // 0: X0 from x (gather + normalise + cast); 1: X0 = dz of the heads
     // forward prologue
     const float* x; const int64_t* row_idx; int n_in; int kp0;
     const float* sub; const float* div; int normalise;
     u16* h0; int ldh0;       // global copy of the prepared input (wgrad of the first layer reads it)
+    const float* bias_src[CHAIN_MAX_STAGES]; int bias_len[CHAIN_MAX_STAGES];
     // backward prologue
     const u16* dz_in; int ld_dz_in; int w_in;
     int64_t n_rows;
     int act; float slope;
     // heads (EPI_OUT)
     int n_lin; float* yhat; const float* y; float* loss; u16* dz_out; int ld_dz_out;
+    int ablate;              // timing experiments only (CS_CHAIN_ABLATE): 1 no weight refills, 2 no MFMA, 4 no global stores, 8 no warm-up
 };
 
 __device__ __forceinline__ int chain_lds_off(int row, int col) {   // element offset of (row, col)
     return row * CHAIN_PITCH + ((((col >> 3) ^ (row & 15))) << 3) + (col & 7);
 }
+__device__ __forceinline__ unsigned bf_pos(unsigned h16) { return (unsigned)((h16 & 0xffffu) - 1u) < 0x7fffu; }   // bf16 > 0
 
 // One stage for one wave: acc[MT][NT] 32x32 tiles over contraction length Kc.
 template <int MT, int NT>
 __device__ __forceinline__ void chain_mma(const u16* __restrict__ X, const u16* __restrict__ wfrag, int ks_total, int ntiles,
-                                          int jt0, int mrow0, int lane, f32x16_t (&acc)[MT][NT]) {
+                                          int jt0, int mrow0, int lane, f32x16_t (&acc)[MT][NT], int ablate) {
 #pragma unroll
     for (int a = 0; a < MT; ++a)
 #pragma unroll
@@ -67,12 +79,10 @@ __device__ __forceinline__ void chain_mma(const u16* __restrict__ X, const u16* 
     const int sstride = ntiles * 64;             // uint4 per k16 step
     // The weight stream is issued with inline-asm loads and waited for with COUNTED vmcnt: hipcc's own
     // bookkeeping falls back to vmcnt(0) at the loop header (and rotates the queue through v_mov's that
-    // need the data), which exposed the full memory latency on every 4 steps.  Protocol: slot d is
-    // refilled right after its last use; before its next use exactly NT*(CHAIN_D-1) younger loads have
-    // been issued by this wave, so vmcnt(NT*(CHAIN_D-1)) means "slot d has landed".  Loads are issued
-    // unconditionally (address clamped at the tail) to keep that count exact.
-    // queue slots are named scalars (tied asm operands cannot be array elements)
-    typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;   // native vector: a plain VGPR tuple for asm
+    // need the data).  Protocol: slot d is refilled right after its last use; before its next use
+    // exactly NT*(CHAIN_D-1) younger loads have been issued by this wave, so vmcnt(NT*(CHAIN_D-1))
+    // means "slot d has landed".  Loads are issued unconditionally (address clamped at the tail) to
+    // keep that count exact.  Queue slots are named scalars (tied asm operands cannot be array elements).
     u32x4_t q00, q01, q10, q11, q20, q21, q30, q31;
     static_assert(CHAIN_D == 4, "queue slots below are written out for depth 4");
 #define CHAIN_LOAD(Q0, Q1, step)                                                                              \
@@ -90,14 +100,16 @@ __device__ __forceinline__ void chain_mma(const u16* __restrict__ X, const u16* 
             af[a] = *reinterpret_cast<const bf16x8_t*>(X + chain_lds_off(arow + a * 32, (2 * s + ahalf) * 8)); \
         if (NT == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(Q0), "+v"(Q1) : "i"(NT * (CHAIN_D - 1)) : "memory"); \
         else asm volatile("s_waitcnt vmcnt(%1)" : "+v"(Q0) : "i"(NT * (CHAIN_D - 1)) : "memory");              \
-        _Pragma("unroll") for (int a = 0; a < MT; ++a) {                                                       \
+        if (!(ablate & 2)) _Pragma("unroll") for (int a = 0; a < MT; ++a) {                                    \
             acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, Q0), af[a], acc[a][0], 0, 0, 0); \
             if (NT == 2)                                                                                       \
                 acc[a][NT - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, Q1), af[a], acc[a][NT - 1], 0, 0, 0); \
         }                                                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
-        CHAIN_LOAD(Q0, Q1, s + CHAIN_D)                                                                        \
+        if (!(ablate & 1)) CHAIN_LOAD(Q0, Q1, s + CHAIN_D)                                                     \
     }
+    // every older compiler-issued vector-memory op must be out of the queue before counting starts
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     CHAIN_LOAD(q00, q01, 0)
     CHAIN_LOAD(q10, q11, 1)
     CHAIN_LOAD(q20, q21, 2)
@@ -115,127 +127,214 @@ __device__ __forceinline__ void chain_mma(const u16* __restrict__ X, const u16* 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// Epilogue of a hidden / dgrad stage.  `msk` carries the 16 sign bits of tile t=(a*NT+b) in dword t>>1,
+// half t&1: written by the forward pass, consumed by the backward pass (same lane layout).
 template <int MT, int NT, int EPI>
-__device__ __forceinline__ void chain_epilogue(u16* __restrict__ X, const ChainArgs& p, const ChainStage& S, bool last,
-                                               int64_t m0, int jt0, int mrow0, int lane, f32x16_t (&acc)[MT][NT],
-                                               float& sq, float& ab) {
+__device__ __forceinline__ void chain_epilogue(u16* __restrict__ X, const float* __restrict__ bias_lds,
+                                               const ChainArgs& p, const ChainStage& S, bool last, int64_t m0, int jt0,
+                                               int mrow0, int lane, f32x16_t (&acc)[MT][NT], u32x4_t& msk) {
+    const bool elu = (p.act == ACT_ELU);
+    unsigned mk[4] = {msk[0], msk[1], msk[2], msk[3]};
+    if (EPI == EPI_HIDDEN) { mk[0] = 0u; mk[1] = 0u; mk[2] = 0u; mk[3] = 0u; }
 #pragma unroll
     for (int b = 0; b < NT; ++b) {
+        // ELU backward needs h itself: one batch of loads per column tile, issued together
+        uint2 hh[MT][4];
+        if (EPI == EPI_DGRAD && elu) {
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    hh[a][q] = *reinterpret_cast<const uint2*>(
+                        S.hprev + (m0 + mrow0 + a * 32 + (lane & 31)) * S.ldh + (jt0 + b) * 32 + 8 * q + 4 * (lane >> 5));
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int n = (jt0 + b) * 32 + 8 * q + 4 * (lane >> 5);
             float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (EPI != EPI_DGRAD) b4 = *reinterpret_cast<const float4*>(S.bias + n);
+            if (EPI == EPI_HIDDEN) b4 = *reinterpret_cast<const float4*>(bias_lds + S.bias_off + n);
 #pragma unroll
             for (int a = 0; a < MT; ++a) {
                 const int ml = mrow0 + a * 32 + (lane & 31);
                 const int64_t m = m0 + ml;
+                const int t = a * NT + b;                       // tile index within the wave
+                const int sh = (t & 1) * 16 + 4 * q;            // bit position of element e=0
                 float v[4] = {acc[a][b][4 * q + 0], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
+                uint2 pk;
                 if (EPI == EPI_HIDDEN) {
                     v[0] = act_fwd(v[0] + b4.x, p.act, p.slope); v[1] = act_fwd(v[1] + b4.y, p.act, p.slope);
                     v[2] = act_fwd(v[2] + b4.z, p.act, p.slope); v[3] = act_fwd(v[3] + b4.w, p.act, p.slope);
-                    const uint2 pk = pack4(v[0], v[1], v[2], v[3]);
-                    if (S.out) *reinterpret_cast<uint2*>(S.out + m * S.ldo + n) = pk;
-                    if (!last) *reinterpret_cast<uint2*>(X + chain_lds_off(ml, n)) = pk;
-                } else if (EPI == EPI_DGRAD) {
-                    const uint2 hh = *reinterpret_cast<const uint2*>(S.hprev + m * S.ldh + n);
-                    v[0] *= act_bwd_from_h(bf2f((u16)(hh.x & 0xffff)), p.act, p.slope);
-                    v[1] *= act_bwd_from_h(bf2f((u16)(hh.x >> 16)), p.act, p.slope);
-                    v[2] *= act_bwd_from_h(bf2f((u16)(hh.y & 0xffff)), p.act, p.slope);
-                    v[3] *= act_bwd_from_h(bf2f((u16)(hh.y >> 16)), p.act, p.slope);
-                    const uint2 pk = pack4(v[0], v[1], v[2], v[3]);
-                    if (S.out) *reinterpret_cast<uint2*>(S.out + m * S.ldo + n) = pk;
-                    if (!last) *reinterpret_cast<uint2*>(X + chain_lds_off(ml, n)) = pk;
-                } else {  // EPI_OUT: heads
-                    v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
-                    const bool valid = m < p.n_rows;
-                    float d[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (n >= p.n_lin) {
+                    pk = pack4(v[0], v[1], v[2], v[3]);
+                    const unsigned bits = bf_pos(pk.x) | (bf_pos(pk.x >> 16) << 1) | (bf_pos(pk.y) << 2) | (bf_pos(pk.y >> 16) << 3);
+                    mk[t >> 1] |= bits << sh;
+                } else {  // EPI_DGRAD
+                    if (elu) {
+                        const uint2 h2 = hh[a][q];
+                        v[0] *= act_bwd_from_h(bf2f((u16)(h2.x & 0xffff)), p.act, p.slope);
+                        v[1] *= act_bwd_from_h(bf2f((u16)(h2.x >> 16)), p.act, p.slope);
+                        v[2] *= act_bwd_from_h(bf2f((u16)(h2.y & 0xffff)), p.act, p.slope);
+                        v[3] *= act_bwd_from_h(bf2f((u16)(h2.y >> 16)), p.act, p.slope);
+                    } else {
+                        const unsigned bits = mk[t >> 1] >> sh;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                        for (int e = 0; e < 4; ++e) v[e] *= ((bits >> e) & 1u) ? 1.f : p.slope;
                     }
-                    if (valid && p.yhat)
-                        *reinterpret_cast<float4*>(p.yhat + m * S.Nc + n) = make_float4(v[0], v[1], v[2], v[3]);
-                    if (p.y && valid) {
-                        const int64_t src = p.row_idx ? p.row_idx[m] : m;
-                        const float4 t4 = *reinterpret_cast<const float4*>(p.y + src * S.Nc + n);
-                        const float e4[4] = {v[0] - t4.x, v[1] - t4.y, v[2] - t4.z, v[3] - t4.w};
+                    pk = pack4(v[0], v[1], v[2], v[3]);
+                }
+                if (S.out && !(p.ablate & 4)) *reinterpret_cast<uint2*>(S.out + m * S.ldo + n) = pk;
+                if (!last) *reinterpret_cast<uint2*>(X + chain_lds_off(ml, n)) = pk;
+            }
+        }
+    }
+    if (EPI == EPI_HIDDEN) msk = u32x4_t{mk[0], mk[1], mk[2], mk[3]};
+}
+
+// Heads: bias, per-column activation, yhat, squared/absolute error sums, dz of the heads.
+template <int MT>
+__device__ __forceinline__ void chain_heads(const float* __restrict__ bias_lds, const int64_t* __restrict__ rows_lds,
+                                            const ChainArgs& p, const ChainStage& S, int64_t m0, int jt0, int mrow0,
+                                            int lane, f32x16_t (&acc)[MT][1], float& sq, float& ab) {
+    float4 tgt[MT][4];
+    const bool have_y = p.y != nullptr;
+    if (have_y) {              // all target loads of this lane in flight together
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            sq += e4[e] * e4[e];
-                            ab += fabsf(e4[e]);
-                            d[e] = 2.f * e4[e];
-                            if (n >= p.n_lin && !(v[e] > 0.f)) d[e] = 0.f;
-                        }
-                    }
-                    if (p.dz_out) *reinterpret_cast<uint2*>(p.dz_out + m * p.ld_dz_out + n) = pack4(d[0], d[1], d[2], d[3]);
+        for (int a = 0; a < MT; ++a) {
+            const int ml = mrow0 + a * 32 + (lane & 31);
+            const int64_t r = rows_lds[ml];
+            const int64_t src = r >= 0 ? r : 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                tgt[a][q] = *reinterpret_cast<const float4*>(p.y + src * S.Nc + jt0 * 32 + 8 * q + 4 * (lane >> 5));
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int n = jt0 * 32 + 8 * q + 4 * (lane >> 5);
+        const float4 b4 = *reinterpret_cast<const float4*>(bias_lds + S.bias_off + n);
+#pragma unroll
+        for (int a = 0; a < MT; ++a) {
+            const int64_t m = m0 + mrow0 + a * 32 + (lane & 31);
+            float v[4] = {acc[a][0][4 * q + 0] + b4.x, acc[a][0][4 * q + 1] + b4.y, acc[a][0][4 * q + 2] + b4.z,
+                          acc[a][0][4 * q + 3] + b4.w};
+            const bool valid = m < p.n_rows;
+            float d[4] = {0.f, 0.f, 0.f, 0.f};
+            if (n >= p.n_lin) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            if (valid && p.yhat) *reinterpret_cast<float4*>(p.yhat + m * S.Nc + n) = make_float4(v[0], v[1], v[2], v[3]);
+            if (have_y && valid) {
+                const float4 t4 = tgt[a][q];
+                const float e4[4] = {v[0] - t4.x, v[1] - t4.y, v[2] - t4.z, v[3] - t4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    sq += e4[e] * e4[e];
+                    ab += fabsf(e4[e]);
+                    d[e] = 2.f * e4[e];
+                    if (n >= p.n_lin && !(v[e] > 0.f)) d[e] = 0.f;
                 }
             }
+            if (p.dz_out) *reinterpret_cast<uint2*>(p.dz_out + m * p.ld_dz_out + n) = pack4(d[0], d[1], d[2], d[3]);
         }
     }
 }
 
 template <int MT, int NT, int EPI>
-__device__ __forceinline__ void chain_stage(u16* X, const ChainArgs& p, const ChainStage& S, bool last, int64_t m0,
-                                            int jt0, int mrow0, int lane, float& sq, float& ab) {
+__device__ __forceinline__ void chain_stage(u16* X, const float* bias_lds, const int64_t* rows_lds, const ChainArgs& p,
+                                            const ChainStage& S, bool last, int64_t m0, int jt0, int mrow0, int tid,
+                                            float& sq, float& ab) {
+    const int lane = tid & 63;
     f32x16_t acc[MT][NT];
-    chain_mma<MT, NT>(X, S.wfrag, S.Kc >> 4, S.Nc >> 5, jt0, mrow0, lane, acc);
+    u32x4_t msk = u32x4_t{0u, 0u, 0u, 0u};
+    u32x4_t* mptr = S.mask ? S.mask + (int64_t)blockIdx.x * 512 + tid : nullptr;
+    if (EPI == EPI_DGRAD && p.act != ACT_ELU) msk = *mptr;     // lands during the k-loop
+    chain_mma<MT, NT>(X, S.wfrag, S.Kc >> 4, S.Nc >> 5, jt0, mrow0, lane, acc, p.ablate);
     __syncthreads();                         // every wave has finished reading X for this stage
-    chain_epilogue<MT, NT, EPI>(X, p, S, last, m0, jt0, mrow0, lane, acc, sq, ab);
+    if constexpr (EPI == EPI_OUT) {
+        chain_heads<MT>(bias_lds, rows_lds, p, S, m0, jt0, mrow0, lane, acc, sq, ab);
+    } else {
+        chain_epilogue<MT, NT, EPI>(X, bias_lds, p, S, last, m0, jt0, mrow0, lane, acc, msk);
+        if (EPI == EPI_HIDDEN && mptr) *mptr = msk;
+    }
     __syncthreads();                         // X now holds this stage's output
 }
+
+// dynamic LDS: [BM][CHAIN_PITCH] bf16 activations | CHAIN_MAX_BIAS floats | BM int64 row indices
+template <int BM>
+constexpr int chain_lds_bytes() { return BM * CHAIN_PITCH * 2 + CHAIN_MAX_BIAS * 4 + BM * 8; }
 
 template <int BM, bool BWD>
 __global__ __launch_bounds__(512) void k_chain(const ChainArgs p) {
     extern __shared__ __attribute__((aligned(16))) u16 X[];      // [BM][CHAIN_PITCH]
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    float* bias_lds = reinterpret_cast<float*>(X + BM * CHAIN_PITCH);
+    int64_t* rows_lds = reinterpret_cast<int64_t*>(bias_lds + CHAIN_MAX_BIAS);
+    const int tid = threadIdx.x, wid = tid >> 6;
     const int64_t m0 = (int64_t)blockIdx.x * BM;
 
     // ---- L2 warm-up.  The bf16 weights were written by the optimiser kernel on other XCDs, so at
-    // launch they sit in HBM / Infinity Cache, not in this XCD's L2, and the k-loop's small prefetch
-    // window would stream them at memory latency (measured: 2.4 MB in ~75 us).  Instead the
-    // workgroups that share an XCD (block b runs on XCD b % 8 - a speed assumption only) each touch a
-    // distinct 1/Q of every stage's weights, one 4-byte load per 128-B line, all in flight at once.
-    {
+    // launch they sit in HBM / Infinity Cache, not in this XCD's L2.  The workgroups that share an XCD
+    // (block b runs on XCD b % 8 - a speed assumption only) each touch a distinct 1/Q of every stage's
+    // weights, one 4-byte load per 128-B line, all in flight at once.
+    unsigned sink = 0;
+    if (!(p.ablate & 8)) {
         const int Q = min(32, max(1, (int)(gridDim.x >> 3)));
         const int q = (int)(blockIdx.x >> 3) % Q;
-        unsigned sink = 0;
         for (int i = 0; i < p.n_stages; ++i) {
             const unsigned* w = reinterpret_cast<const unsigned*>(p.st[i].wfrag);
             const int lines = (p.st[i].Kc * p.st[i].Nc) >> 6;            // 128-B lines of bf16
             for (int ln = q * 512 + tid; ln < lines; ln += Q * 512) sink ^= w[ln * 32];
         }
-        asm volatile("" ::"v"(sink));
     }
 
-    // ---- prologue: fill X with the stage-0 input rows
+    // ---- prologue: biases + row indices to LDS, then the stage-0 input rows
     if (!BWD) {
-        const int groups = p.kp0 >> 2;                           // 4 features per thread-iteration
-        for (int g = tid; g < BM * groups; g += 512) {
-            const int ml = g / groups, c = (g - ml * groups) * 4;
-            const int64_t m = m0 + ml;
-            float v[4] = {0.f, 0.f, 0.f, 0.f};
-            if (m < p.n_rows && c < p.n_in) {
-                const int64_t src = p.row_idx ? p.row_idx[m] : m;
-                const float* xr = p.x + src * p.n_in + c;
-                if (c + 3 < p.n_in && (p.n_in & 3) == 0) {
-                    const float4 t = *reinterpret_cast<const float4*>(xr);
-                    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-                } else {
-                    for (int j = 0; j < 4 && c + j < p.n_in; ++j) v[j] = xr[j];
+        for (int i = 0; i < p.n_stages; ++i)
+            for (int j = tid; j < p.bias_len[i]; j += 512) bias_lds[p.st[i].bias_off + j] = p.bias_src[i][j];
+        if (tid < BM) {
+            const int64_t m = m0 + tid;
+            rows_lds[tid] = (m < p.n_rows) ? (p.row_idx ? p.row_idx[m] : m) : -1;
+        }
+        __syncthreads();
+        const int groups = p.kp0 >> 2;                           // 4 features per item
+        const int items = BM * groups;
+        for (int g0 = tid; g0 < items; g0 += 4 * 512) {          // 4 independent items per thread in flight
+            float4 xv[4];
+            int mlv[4], cv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int g = g0 + u * 512;
+                mlv[u] = g / groups; cv[u] = (g - mlv[u] * groups) * 4;
+                xv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (g < items) {
+                    const int64_t src = rows_lds[mlv[u]];
+                    if (src >= 0 && cv[u] < p.n_in) {
+                        const float* xr = p.x + src * p.n_in + cv[u];
+                        if (cv[u] + 3 < p.n_in && (p.n_in & 3) == 0) xv[u] = *reinterpret_cast<const float4*>(xr);
+                        else {
+                            float t[4] = {0.f, 0.f, 0.f, 0.f};
+                            for (int j = 0; j < 4 && cv[u] + j < p.n_in; ++j) t[j] = xr[j];
+                            xv[u] = make_float4(t[0], t[1], t[2], t[3]);
+                        }
+                    }
                 }
-                if (p.normalise) {
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int g = g0 + u * 512;
+                if (g >= items) continue;
+                float v[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
+                if (p.normalise && rows_lds[mlv[u]] >= 0) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        if (c + j < p.n_in) {
-                            const float t = (v[j] - p.sub[c + j]) / p.div[c + j];
+                        if (cv[u] + j < p.n_in) {
+                            const float t = (v[j] - p.sub[cv[u] + j]) / p.div[cv[u] + j];
                             v[j] = (fabsf(t) <= 3.402823466e38f) ? t : 0.f;
                         }
                 }
+                const uint2 pk = pack4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<uint2*>(X + chain_lds_off(mlv[u], cv[u])) = pk;
+                *reinterpret_cast<uint2*>(p.h0 + (m0 + mlv[u]) * p.ldh0 + cv[u]) = pk;
             }
-            const uint2 pk = pack4(v[0], v[1], v[2], v[3]);
-            *reinterpret_cast<uint2*>(X + chain_lds_off(ml, c)) = pk;
-            *reinterpret_cast<uint2*>(p.h0 + m * p.ldh0 + c) = pk;
         }
     } else {
         const int chunks = p.w_in >> 3;                          // 16-B chunks per row
@@ -245,6 +344,7 @@ __global__ __launch_bounds__(512) void k_chain(const ChainArgs p) {
                 *reinterpret_cast<const uint4*>(p.dz_in + (m0 + ml) * p.ld_dz_in + c);
         }
     }
+    asm volatile("" ::"v"(sink));            // warm-up loads retire here (they overlapped the prologue)
     __syncthreads();
 
     float sq = 0.f, ab = 0.f;
@@ -253,18 +353,18 @@ __global__ __launch_bounds__(512) void k_chain(const ChainArgs p) {
         const bool last = (i + 1 == p.n_stages);
         constexpr int E = BWD ? EPI_DGRAD : EPI_HIDDEN;
         if (S.Nc == 512) {          // wave = all BM rows x 64 columns
-            chain_stage<BM / 32, 2, E>(X, p, S, last, m0, wid * 2, 0, lane, sq, ab);
+            chain_stage<BM / 32, 2, E>(X, bias_lds, rows_lds, p, S, last, m0, wid * 2, 0, tid, sq, ab);
         } else if (S.Nc == 256) {   // wave = all BM rows x 32 columns
-            chain_stage<BM / 32, 1, E>(X, p, S, last, m0, wid, 0, lane, sq, ab);
+            chain_stage<BM / 32, 1, E>(X, bias_lds, rows_lds, p, S, last, m0, wid, 0, tid, sq, ab);
         } else if (!BWD && S.epi == EPI_OUT) {   // heads: 128 wide, wave = half the rows x 32 columns
-            chain_stage<BM / 64, 1, EPI_OUT>(X, p, S, last, m0, wid & 3, (wid >> 2) * (BM / 2), lane, sq, ab);
+            chain_stage<BM / 64, 1, EPI_OUT>(X, bias_lds, rows_lds, p, S, last, m0, wid & 3, (wid >> 2) * (BM / 2), tid, sq, ab);
         } else {                    // 128: wave = half the rows x 32 columns
-            chain_stage<BM / 64, 1, E>(X, p, S, last, m0, wid & 3, (wid >> 2) * (BM / 2), lane, sq, ab);
+            chain_stage<BM / 64, 1, E>(X, bias_lds, rows_lds, p, S, last, m0, wid & 3, (wid >> 2) * (BM / 2), tid, sq, ab);
         }
     }
     if (!BWD && p.y) {
         sq = wave_sum(sq);
         ab = wave_sum(ab);
-        if (lane == 0) { atomicAdd(p.loss, sq); atomicAdd(p.loss + 1, ab); }
+        if ((tid & 63) == 0) { atomicAdd(p.loss, sq); atomicAdd(p.loss + 1, ab); }
     }
 }

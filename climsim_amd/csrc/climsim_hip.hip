@@ -65,6 +65,8 @@ struct Layer {
     int64_t w_off, b_off;      // offsets (floats) in the flat parameter buffer
     u16 *Wt, *Wn;              // bf16 operand copies [N][Kp], [Kp][N]
     u16 *Wf = nullptr, *Wb = nullptr;   // fragment-major copies for the chain kernels
+    u32x4_t* mask = nullptr;            // sign bits of this layer's OUTPUT activation (chain kernels)
+    int bias_off = 0;                   // offset of the bias in the chain kernels' LDS bias block
     u16 *H;                    // layer INPUT activations [m_pad_max][Kp]
     u16 *dZ;                   // d loss / d pre-activation of this layer [m_pad_max][N]
 };
@@ -86,6 +88,7 @@ struct cs_mlp {
     int64_t iterations = 0;
     int64_t bytes = 0;
     bool use_chain = false;
+    int chain_ablate = 0;      // CS_CHAIN_ABLATE env, timing experiments only
     int wgrad_splitk = 0;      // 0 = automatic (CS_WGRAD_SPLITK env overrides, for tuning runs)
     std::vector<void*> allocs;
 };
@@ -180,11 +183,12 @@ int run_forward(cs_mlp* h, const float* x, const int64_t* row_idx, int64_t n, in
         for (int l = 0; l < h->L; ++l) {
             const Layer& ly = h->layers[l];
             ChainStage& S = c.st[l];
-            S.wfrag = ly.Wf; S.bias = h->P + ly.b_off; S.Kc = ly.Kp; S.Nc = ly.N;
-            if (l + 1 < h->L) { S.out = h->layers[l + 1].H; S.ldo = h->layers[l + 1].Kp; S.epi = EPI_HIDDEN; }
-            else { S.out = nullptr; S.ldo = 0; S.epi = EPI_OUT; }
+            S.wfrag = ly.Wf; S.bias_off = ly.bias_off; S.Kc = ly.Kp; S.Nc = ly.N;
+            c.bias_src[l] = h->P + ly.b_off; c.bias_len[l] = ly.N;
+            if (l + 1 < h->L) { S.out = h->layers[l + 1].H; S.ldo = h->layers[l + 1].Kp; S.epi = EPI_HIDDEN; S.mask = want_dz ? ly.mask : nullptr; }
+            else { S.out = nullptr; S.ldo = 0; S.epi = EPI_OUT; S.mask = nullptr; }
         }
-        c.backward = 0;
+        c.ablate = h->chain_ablate;
         c.x = x; c.row_idx = row_idx; c.n_in = h->cfg.n_in; c.kp0 = l0.Kp; c.sub = h->sub; c.div = h->div;
         c.normalise = normalise; c.h0 = l0.H; c.ldh0 = l0.Kp; c.n_rows = n;
         c.act = h->cfg.act; c.slope = (h->cfg.act == CS_ACT_RELU) ? 0.f : h->cfg.alpha;
@@ -192,8 +196,8 @@ int run_forward(cs_mlp* h, const float* x, const int64_t* row_idx, int64_t n, in
         c.dz_out = want_dz ? h->layers[h->L - 1].dZ : nullptr; c.ld_dz_out = 128;
         const int bm = chain_bm(h, n);
         ProfScope ps(CS_K_CHAIN_FWD, st);
-        if (bm == 128) hipLaunchKernelGGL((k_chain<128, false>), dim3((unsigned)(m_pad / 128)), dim3(512), 128 * CHAIN_PITCH * 2, st, c);
-        else hipLaunchKernelGGL((k_chain<64, false>), dim3((unsigned)(m_pad / 64)), dim3(512), 64 * CHAIN_PITCH * 2, st, c);
+        if (bm == 128) hipLaunchKernelGGL((k_chain<128, false>), dim3((unsigned)(m_pad / 128)), dim3(512), chain_lds_bytes<128>(), st, c);
+        else hipLaunchKernelGGL((k_chain<64, false>), dim3((unsigned)(m_pad / 64)), dim3(512), chain_lds_bytes<64>(), st, c);
         HIP_TRY(hipGetLastError());
         return CS_OK;
     }
@@ -234,17 +238,17 @@ int run_backward(cs_mlp* h, int64_t n, bool atomics_needed, hipStream_t st) {
         for (int l = h->L - 1, i = 0; l >= 1; --l, ++i) {
             const Layer& ly = h->layers[l];
             ChainStage& S = c.st[i];
-            S.wfrag = ly.Wb; S.bias = nullptr; S.Kc = ly.N; S.Nc = ly.Kp;
+            S.wfrag = ly.Wb; S.bias_off = 0; S.Kc = ly.N; S.Nc = ly.Kp; S.mask = h->layers[l - 1].mask;
             S.out = h->layers[l - 1].dZ; S.ldo = h->layers[l - 1].N;
             S.hprev = ly.H; S.ldh = ly.Kp; S.epi = EPI_DGRAD;
         }
-        c.backward = 1;
+        c.ablate = h->chain_ablate;
         c.dz_in = h->layers[h->L - 1].dZ; c.ld_dz_in = 128; c.w_in = 128;
         c.n_rows = n; c.act = h->cfg.act; c.slope = (h->cfg.act == CS_ACT_RELU) ? 0.f : h->cfg.alpha;
         const int bm = chain_bm(h, n);
         ProfScope ps(CS_K_CHAIN_BWD, st);
-        if (bm == 128) hipLaunchKernelGGL((k_chain<128, true>), dim3((unsigned)(m_pad / 128)), dim3(512), 128 * CHAIN_PITCH * 2, st, c);
-        else hipLaunchKernelGGL((k_chain<64, true>), dim3((unsigned)(m_pad / 64)), dim3(512), 64 * CHAIN_PITCH * 2, st, c);
+        if (bm == 128) hipLaunchKernelGGL((k_chain<128, true>), dim3((unsigned)(m_pad / 128)), dim3(512), chain_lds_bytes<128>(), st, c);
+        else hipLaunchKernelGGL((k_chain<64, true>), dim3((unsigned)(m_pad / 64)), dim3(512), chain_lds_bytes<64>(), st, c);
     }
     if (!h->use_chain) {
         for (int l = h->L - 1; l >= 1; --l) {
@@ -340,13 +344,19 @@ int cs_mlp_create(cs_mlp_t** out, const cs_mlp_cfg* cfg) {
         if (!(ly.N == 128 || ly.N == 256 || ly.N == 512) || ly.Kp > CHAIN_PITCH || ly.Kp % 64) h->use_chain = false;
     }
     if (2 * h->L > CHAIN_MAX_STAGES) h->use_chain = false;
+    {
+        int boff = 0;
+        for (int l = 0; l < h->L; ++l) { h->layers[l].bias_off = boff; boff += h->layers[l].N; }
+        if (boff > CHAIN_MAX_BIAS) h->use_chain = false;
+    }
     if (h->L > WGRAD_MAX_LAYERS) { delete h; return fail(CS_ERR_INVALID, "too many layers"); }
     if (const char* e = getenv("CS_WGRAD_SPLITK")) h->wgrad_splitk = atoi(e);
+    if (const char* e = getenv("CS_CHAIN_ABLATE")) h->chain_ablate = atoi(e);
     if (h->use_chain) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain<128, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * CHAIN_PITCH * 2));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain<128, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * CHAIN_PITCH * 2));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain<64, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * CHAIN_PITCH * 2));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain<64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * CHAIN_PITCH * 2));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain<128, false>), hipFuncAttributeMaxDynamicSharedMemorySize, chain_lds_bytes<128>()));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain<128, true>), hipFuncAttributeMaxDynamicSharedMemorySize, chain_lds_bytes<128>()));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain<64, false>), hipFuncAttributeMaxDynamicSharedMemorySize, chain_lds_bytes<64>()));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain<64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, chain_lds_bytes<64>()));
     }
     // ONE arena for every device buffer of the handle: a single large hipMalloc gets 2-MiB-aligned
     // virtual memory backed by large page fragments.  (Many small hipMallocs measured ~2 us effective
@@ -369,6 +379,8 @@ int cs_mlp_create(cs_mlp_t** out, const cs_mlp_cfg* cfg) {
         }
     }
     A((void**)&h->seg_dev, sizeof(Segment) * 2 * h->L);
+    if (h->use_chain)
+        for (int l = 0; l + 1 < h->L; ++l) A((void**)&h->layers[l].mask, (size_t)(h->m_pad_max / 64) * 512 * 16);
     for (int l = 0; l < h->L; ++l) {       // activations last: the big, streamed part
         Layer& ly = h->layers[l];
         A((void**)&ly.H, sizeof(u16) * h->m_pad_max * ly.Kp);
