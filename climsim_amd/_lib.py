@@ -55,6 +55,7 @@ SIGNATURES = {
     "cs_mlp_apply": (C.c_int, [_P, _F, _F, _P]),
     "cs_mlp_train_step": (C.c_int, [_P, _P, _P, _P, _I64, C.c_int, _F, _P, _P]),
     "cs_mlp_profile_step": (C.c_int, [_P, _P, _P, _P, _I64, C.c_int, _F, _P, _P, C.POINTER(CsKernelTimes)]),
+    "cs_mlp_debug_stamps": (C.c_int, [_P, _P, _I64]),
     "cs_normalise_rows": (C.c_int, [_P, _P, _I64, _I32, _P, _P, _P, _P]),
     "cs_last_error": (C.c_char_p, []),
     "cs_version": (C.c_char_p, []),

@@ -56,6 +56,7 @@ struct ChainArgs {
     // heads (EPI_OUT)
     int n_lin; float* yhat; const float* y; float* loss; u16* dz_out; int ld_dz_out;
     int ablate;              // timing experiments only (CS_CHAIN_ABLATE): 1 no weight refills, 2 no MFMA, 4 no global stores, 8 no warm-up
+    unsigned long long* dbg; // optional [grid][64] s_memtime stamps (CS_CHAIN_DBG), null in production
 };
 
 __device__ __forceinline__ int chain_lds_off(int row, int col) {   // element offset of (row, col)
@@ -92,18 +93,20 @@ __device__ __forceinline__ void chain_mma(const u16* __restrict__ X, const u16* 
         if (NT == 2)                                                                                           \
             asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(Q1) : "v"(wp[NT - 1] + sn_ * sstride) : "memory"); \
     }
-#define CHAIN_STEP(d, Q0, Q1)                                                                                  \
+#define CHAIN_AF(dst, step)                                                                                    \
+    _Pragma("unroll") for (int a = 0; a < MT; ++a)                                                             \
+        dst[a] = *reinterpret_cast<const bf16x8_t*>(X + chain_lds_off(arow + a * 32, (2 * min((step), ks_total - 1) + ahalf) * 8));
+// A fragments of step s+1 are read from LDS while the MFMAs of step s run (AC = current, AN = next).
+#define CHAIN_STEP(d, Q0, Q1, AC, AN)                                                                          \
     {                                                                                                          \
         const int s = s0 + (d);                                                                                \
-        bf16x8_t af[MT];                                                                                       \
-        _Pragma("unroll") for (int a = 0; a < MT; ++a)                                                         \
-            af[a] = *reinterpret_cast<const bf16x8_t*>(X + chain_lds_off(arow + a * 32, (2 * s + ahalf) * 8)); \
+        if (MT <= 2) { CHAIN_AF(AN, s + 1) } else { CHAIN_AF(AC, s) }                                          \
         if (NT == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(Q0), "+v"(Q1) : "i"(NT * (CHAIN_D - 1)) : "memory"); \
         else asm volatile("s_waitcnt vmcnt(%1)" : "+v"(Q0) : "i"(NT * (CHAIN_D - 1)) : "memory");              \
         if (!(ablate & 2)) _Pragma("unroll") for (int a = 0; a < MT; ++a) {                                    \
-            acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, Q0), af[a], acc[a][0], 0, 0, 0); \
+            acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, Q0), AC[a], acc[a][0], 0, 0, 0); \
             if (NT == 2)                                                                                       \
-                acc[a][NT - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, Q1), af[a], acc[a][NT - 1], 0, 0, 0); \
+                acc[a][NT - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, Q1), AC[a], acc[a][NT - 1], 0, 0, 0); \
         }                                                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
         if (!(ablate & 1)) CHAIN_LOAD(Q0, Q1, s + CHAIN_D)                                                     \
@@ -115,74 +118,92 @@ __device__ __forceinline__ void chain_mma(const u16* __restrict__ X, const u16* 
     CHAIN_LOAD(q20, q21, 2)
     CHAIN_LOAD(q30, q31, 3)
     const int arow = mrow0 + (lane & 31), ahalf = lane >> 5;
+    // (double-buffered only for <= 2 row tiles per wave; with 4 the second buffer would spill)
+    bf16x8_t afA[MT], afB[MT <= 2 ? MT : 1];
+    if (MT <= 2) { CHAIN_AF(afA, 0) }
     for (int s0 = 0; s0 < ks_total; s0 += CHAIN_D) {
-        CHAIN_STEP(0, q00, q01)
-        CHAIN_STEP(1, q10, q11)
-        CHAIN_STEP(2, q20, q21)
-        CHAIN_STEP(3, q30, q31)
+        if (MT <= 2) {
+            CHAIN_STEP(0, q00, q01, afA, afB)
+            CHAIN_STEP(1, q10, q11, afB, afA)
+            CHAIN_STEP(2, q20, q21, afA, afB)
+            CHAIN_STEP(3, q30, q31, afB, afA)
+        } else {
+            CHAIN_STEP(0, q00, q01, afA, afA)
+            CHAIN_STEP(1, q10, q11, afA, afA)
+            CHAIN_STEP(2, q20, q21, afA, afA)
+            CHAIN_STEP(3, q30, q31, afA, afA)
+        }
     }
+#undef CHAIN_AF
 #undef CHAIN_STEP
 #undef CHAIN_LOAD
     // drain: the tail re-loads are still in flight and their destination registers are about to be reused
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-// Epilogue of a hidden / dgrad stage.  `msk` carries the 16 sign bits of tile t=(a*NT+b) in dword t>>1,
-// half t&1: written by the forward pass, consumed by the backward pass (same lane layout).
-template <int MT, int NT, int EPI>
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {   // 2 x f32 -> packed bf16, round-to-nearest-even
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+
+// Epilogue of a hidden / dgrad stage (VALU-lean: ~8 instructions per element; the first version spent
+// more time here than in the MFMA loop).  `msk` carries the 16 sign bits of tile t=(a*NT+b) in dword
+// t>>1, half t&1: written by the forward pass, consumed by the backward pass (same lane layout).
+//   forward : h = max(z, slope*z)  (ReLU: slope 0, LeakyReLU: slope alpha; valid for 0 <= slope <= 1)
+//   backward: dz *= bit ? 1 : slope
+// ELU keeps a generic path (needs expm1 forward and the activation value backward).
+template <int MT, int NT, int EPI, bool ELU>
 __device__ __forceinline__ void chain_epilogue(u16* __restrict__ X, const float* __restrict__ bias_lds,
                                                const ChainArgs& p, const ChainStage& S, bool last, int64_t m0, int jt0,
                                                int mrow0, int lane, f32x16_t (&acc)[MT][NT], u32x4_t& msk) {
-    const bool elu = (p.act == ACT_ELU);
     unsigned mk[4] = {msk[0], msk[1], msk[2], msk[3]};
     if (EPI == EPI_HIDDEN) { mk[0] = 0u; mk[1] = 0u; mk[2] = 0u; mk[3] = 0u; }
+    const int r15 = lane & 15, hi4 = 4 * (lane >> 5);
+    const int mlb = mrow0 + (lane & 31);
+    u16* xrow = X + mlb * CHAIN_PITCH + hi4;                         // LDS row of tile a = 0
+    const bool do_out = S.out && !(p.ablate & 4);
+    u16* orow = S.out + (m0 + mlb) * S.ldo + hi4;                   // global row of tile a = 0
+    const int ostep = 32 * S.ldo;
+    const float slope = p.slope;
 #pragma unroll
     for (int b = 0; b < NT; ++b) {
-        // ELU backward needs h itself: one batch of loads per column tile, issued together
-        uint2 hh[MT][4];
-        if (EPI == EPI_DGRAD && elu) {
-#pragma unroll
-            for (int a = 0; a < MT; ++a)
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    hh[a][q] = *reinterpret_cast<const uint2*>(
-                        S.hprev + (m0 + mrow0 + a * 32 + (lane & 31)) * S.ldh + (jt0 + b) * 32 + 8 * q + 4 * (lane >> 5));
-        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int n = (jt0 + b) * 32 + 8 * q + 4 * (lane >> 5);
+            const int c = (jt0 + b) * 4 + q;                        // 16-B chunk index of these columns
+            const int ldsoff = ((c ^ r15) << 3);                    // (row & 15) == (lane & 15) for every tile row
             float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (EPI == EPI_HIDDEN) b4 = *reinterpret_cast<const float4*>(bias_lds + S.bias_off + n);
+            if (EPI == EPI_HIDDEN) b4 = *reinterpret_cast<const float4*>(bias_lds + S.bias_off + c * 8 + hi4);
 #pragma unroll
             for (int a = 0; a < MT; ++a) {
-                const int ml = mrow0 + a * 32 + (lane & 31);
-                const int64_t m = m0 + ml;
-                const int t = a * NT + b;                       // tile index within the wave
-                const int sh = (t & 1) * 16 + 4 * q;            // bit position of element e=0
+                const int t = a * NT + b;                           // tile index within the wave
+                const int sh = (t & 1) * 16 + 4 * q;                // bit position of element e = 0
                 float v[4] = {acc[a][b][4 * q + 0], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
-                uint2 pk;
                 if (EPI == EPI_HIDDEN) {
-                    v[0] = act_fwd(v[0] + b4.x, p.act, p.slope); v[1] = act_fwd(v[1] + b4.y, p.act, p.slope);
-                    v[2] = act_fwd(v[2] + b4.z, p.act, p.slope); v[3] = act_fwd(v[3] + b4.w, p.act, p.slope);
-                    pk = pack4(v[0], v[1], v[2], v[3]);
-                    const unsigned bits = bf_pos(pk.x) | (bf_pos(pk.x >> 16) << 1) | (bf_pos(pk.y) << 2) | (bf_pos(pk.y >> 16) << 3);
-                    mk[t >> 1] |= bits << sh;
-                } else {  // EPI_DGRAD
-                    if (elu) {
-                        const uint2 h2 = hh[a][q];
-                        v[0] *= act_bwd_from_h(bf2f((u16)(h2.x & 0xffff)), p.act, p.slope);
-                        v[1] *= act_bwd_from_h(bf2f((u16)(h2.x >> 16)), p.act, p.slope);
-                        v[2] *= act_bwd_from_h(bf2f((u16)(h2.y & 0xffff)), p.act, p.slope);
-                        v[3] *= act_bwd_from_h(bf2f((u16)(h2.y >> 16)), p.act, p.slope);
-                    } else {
-                        const unsigned bits = mk[t >> 1] >> sh;
+                    v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+                    if (ELU) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] *= ((bits >> e) & 1u) ? 1.f : p.slope;
+                        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : __expf(v[e]) - 1.f;   // abs err 6e-8, below bf16 resolution
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], slope * v[e]);
                     }
-                    pk = pack4(v[0], v[1], v[2], v[3]);
+                    const unsigned bits = (v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u);
+                    mk[t >> 1] |= bits << sh;
+                } else if (ELU) {    // ELU backward needs h itself (generic, slower path)
+                    const uint2 h2 = *reinterpret_cast<const uint2*>(S.hprev + (m0 + mlb + a * 32) * S.ldh + c * 8 + hi4);
+                    v[0] *= act_bwd_from_h(bf2f((u16)(h2.x & 0xffff)), ACT_ELU, 1.f);
+                    v[1] *= act_bwd_from_h(bf2f((u16)(h2.x >> 16)), ACT_ELU, 1.f);
+                    v[2] *= act_bwd_from_h(bf2f((u16)(h2.y & 0xffff)), ACT_ELU, 1.f);
+                    v[3] *= act_bwd_from_h(bf2f((u16)(h2.y >> 16)), ACT_ELU, 1.f);
+                } else {
+                    const unsigned bits = mk[t >> 1] >> sh;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (bits & (1u << e)) ? v[e] : v[e] * slope;
                 }
-                if (S.out && !(p.ablate & 4)) *reinterpret_cast<uint2*>(S.out + m * S.ldo + n) = pk;
-                if (!last) *reinterpret_cast<uint2*>(X + chain_lds_off(ml, n)) = pk;
+                const uint2 pk = make_uint2(cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3]));
+                if (do_out) *reinterpret_cast<uint2*>(orow + a * ostep + c * 8) = pk;
+                if (!last) *reinterpret_cast<uint2*>(xrow + a * 32 * CHAIN_PITCH + ldsoff) = pk;
             }
         }
     }
@@ -234,15 +255,20 @@ __device__ __forceinline__ void chain_heads(const float* __restrict__ bias_lds, 
                     if (n >= p.n_lin && !(v[e] > 0.f)) d[e] = 0.f;
                 }
             }
-            if (p.dz_out) *reinterpret_cast<uint2*>(p.dz_out + m * p.ld_dz_out + n) = pack4(d[0], d[1], d[2], d[3]);
+            if (p.dz_out) *reinterpret_cast<uint2*>(p.dz_out + m * p.ld_dz_out + n) = make_uint2(cvt_pk_bf16(d[0], d[1]), cvt_pk_bf16(d[2], d[3]));
         }
     }
+}
+
+__device__ __forceinline__ void chain_stamp(const ChainArgs& p, int tid, int& slot) {
+    if (p.dbg && tid == 0 && slot < 64) p.dbg[(int64_t)blockIdx.x * 64 + slot] = __builtin_amdgcn_s_memtime();
+    ++slot;
 }
 
 template <int MT, int NT, int EPI>
 __device__ __forceinline__ void chain_stage(u16* X, const float* bias_lds, const int64_t* rows_lds, const ChainArgs& p,
                                             const ChainStage& S, bool last, int64_t m0, int jt0, int mrow0, int tid,
-                                            float& sq, float& ab) {
+                                            float& sq, float& ab, int& slot) {
     const int lane = tid & 63;
     f32x16_t acc[MT][NT];
     u32x4_t msk = u32x4_t{0u, 0u, 0u, 0u};
@@ -250,13 +276,16 @@ __device__ __forceinline__ void chain_stage(u16* X, const float* bias_lds, const
     if (EPI == EPI_DGRAD && p.act != ACT_ELU) msk = *mptr;     // lands during the k-loop
     chain_mma<MT, NT>(X, S.wfrag, S.Kc >> 4, S.Nc >> 5, jt0, mrow0, lane, acc, p.ablate);
     __syncthreads();                         // every wave has finished reading X for this stage
+    chain_stamp(p, tid, slot);
     if constexpr (EPI == EPI_OUT) {
         chain_heads<MT>(bias_lds, rows_lds, p, S, m0, jt0, mrow0, lane, acc, sq, ab);
     } else {
-        chain_epilogue<MT, NT, EPI>(X, bias_lds, p, S, last, m0, jt0, mrow0, lane, acc, msk);
+        if (p.act == ACT_ELU) chain_epilogue<MT, NT, EPI, true>(X, bias_lds, p, S, last, m0, jt0, mrow0, lane, acc, msk);
+        else chain_epilogue<MT, NT, EPI, false>(X, bias_lds, p, S, last, m0, jt0, mrow0, lane, acc, msk);
         if (EPI == EPI_HIDDEN && mptr) *mptr = msk;
     }
     __syncthreads();                         // X now holds this stage's output
+    chain_stamp(p, tid, slot);
 }
 
 // dynamic LDS: [BM][CHAIN_PITCH] bf16 activations | CHAIN_MAX_BIAS floats | BM int64 row indices
@@ -270,6 +299,8 @@ __global__ __launch_bounds__(512) void k_chain(const ChainArgs p) {
     int64_t* rows_lds = reinterpret_cast<int64_t*>(bias_lds + CHAIN_MAX_BIAS);
     const int tid = threadIdx.x, wid = tid >> 6;
     const int64_t m0 = (int64_t)blockIdx.x * BM;
+    int slot = 0;
+    chain_stamp(p, tid, slot);
 
     // ---- L2 warm-up.  The bf16 weights were written by the optimiser kernel on other XCDs, so at
     // launch they sit in HBM / Infinity Cache, not in this XCD's L2.  The workgroups that share an XCD
@@ -346,6 +377,7 @@ __global__ __launch_bounds__(512) void k_chain(const ChainArgs p) {
     }
     asm volatile("" ::"v"(sink));            // warm-up loads retire here (they overlapped the prologue)
     __syncthreads();
+    chain_stamp(p, tid, slot);
 
     float sq = 0.f, ab = 0.f;
     for (int i = 0; i < p.n_stages; ++i) {
@@ -353,13 +385,13 @@ __global__ __launch_bounds__(512) void k_chain(const ChainArgs p) {
         const bool last = (i + 1 == p.n_stages);
         constexpr int E = BWD ? EPI_DGRAD : EPI_HIDDEN;
         if (S.Nc == 512) {          // wave = all BM rows x 64 columns
-            chain_stage<BM / 32, 2, E>(X, bias_lds, rows_lds, p, S, last, m0, wid * 2, 0, tid, sq, ab);
+            chain_stage<BM / 32, 2, E>(X, bias_lds, rows_lds, p, S, last, m0, wid * 2, 0, tid, sq, ab, slot);
         } else if (S.Nc == 256) {   // wave = all BM rows x 32 columns
-            chain_stage<BM / 32, 1, E>(X, bias_lds, rows_lds, p, S, last, m0, wid, 0, tid, sq, ab);
+            chain_stage<BM / 32, 1, E>(X, bias_lds, rows_lds, p, S, last, m0, wid, 0, tid, sq, ab, slot);
         } else if (!BWD && S.epi == EPI_OUT) {   // heads: 128 wide, wave = half the rows x 32 columns
-            chain_stage<BM / 64, 1, EPI_OUT>(X, bias_lds, rows_lds, p, S, last, m0, wid & 3, (wid >> 2) * (BM / 2), tid, sq, ab);
+            chain_stage<BM / 64, 1, EPI_OUT>(X, bias_lds, rows_lds, p, S, last, m0, wid & 3, (wid >> 2) * (BM / 2), tid, sq, ab, slot);
         } else {                    // 128: wave = half the rows x 32 columns
-            chain_stage<BM / 64, 1, E>(X, bias_lds, rows_lds, p, S, last, m0, wid & 3, (wid >> 2) * (BM / 2), tid, sq, ab);
+            chain_stage<BM / 64, 1, E>(X, bias_lds, rows_lds, p, S, last, m0, wid & 3, (wid >> 2) * (BM / 2), tid, sq, ab, slot);
         }
     }
     if (!BWD && p.y) {
@@ -367,4 +399,5 @@ __global__ __launch_bounds__(512) void k_chain(const ChainArgs p) {
         ab = wave_sum(ab);
         if ((tid & 63) == 0) { atomicAdd(p.loss, sq); atomicAdd(p.loss + 1, ab); }
     }
+    chain_stamp(p, tid, slot);
 }

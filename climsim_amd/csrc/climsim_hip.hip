@@ -88,6 +88,7 @@ struct cs_mlp {
     int64_t iterations = 0;
     int64_t bytes = 0;
     bool use_chain = false;
+    unsigned long long* dbg = nullptr;   // CS_CHAIN_DBG: [2][grid_max][64] stamps (fwd, bwd)
     int chain_ablate = 0;      // CS_CHAIN_ABLATE env, timing experiments only
     int wgrad_splitk = 0;      // 0 = automatic (CS_WGRAD_SPLITK env overrides, for tuning runs)
     std::vector<void*> allocs;
@@ -170,7 +171,8 @@ int launch_optimizer(cs_mlp* h, float lr, float grad_scale, bool recast_only, hi
 int chain_bm(const cs_mlp* h, int64_t n) {
     if (h->cfg.flags & CS_FLAG_CHAIN_BM64) return 64;
     if (h->cfg.flags & CS_FLAG_CHAIN_BM128) return 128;
-    return n > 16384 ? 128 : 64;
+    (void)n;
+    return 64;     // 128-row tiles halve the L2 weight traffic but currently spill registers
 }
 
 int run_forward(cs_mlp* h, const float* x, const int64_t* row_idx, int64_t n, int normalise, float* yhat,
@@ -188,7 +190,7 @@ int run_forward(cs_mlp* h, const float* x, const int64_t* row_idx, int64_t n, in
             if (l + 1 < h->L) { S.out = h->layers[l + 1].H; S.ldo = h->layers[l + 1].Kp; S.epi = EPI_HIDDEN; S.mask = want_dz ? ly.mask : nullptr; }
             else { S.out = nullptr; S.ldo = 0; S.epi = EPI_OUT; S.mask = nullptr; }
         }
-        c.ablate = h->chain_ablate;
+        c.ablate = h->chain_ablate; c.dbg = h->dbg;
         c.x = x; c.row_idx = row_idx; c.n_in = h->cfg.n_in; c.kp0 = l0.Kp; c.sub = h->sub; c.div = h->div;
         c.normalise = normalise; c.h0 = l0.H; c.ldh0 = l0.Kp; c.n_rows = n;
         c.act = h->cfg.act; c.slope = (h->cfg.act == CS_ACT_RELU) ? 0.f : h->cfg.alpha;
@@ -242,7 +244,7 @@ int run_backward(cs_mlp* h, int64_t n, bool atomics_needed, hipStream_t st) {
             S.out = h->layers[l - 1].dZ; S.ldo = h->layers[l - 1].N;
             S.hprev = ly.H; S.ldh = ly.Kp; S.epi = EPI_DGRAD;
         }
-        c.ablate = h->chain_ablate;
+        c.ablate = h->chain_ablate; c.dbg = h->dbg ? h->dbg + (h->m_pad_max / 64) * 64 : nullptr;
         c.dz_in = h->layers[h->L - 1].dZ; c.ld_dz_in = 128; c.w_in = 128;
         c.n_rows = n; c.act = h->cfg.act; c.slope = (h->cfg.act == CS_ACT_RELU) ? 0.f : h->cfg.alpha;
         const int bm = chain_bm(h, n);
@@ -379,6 +381,7 @@ int cs_mlp_create(cs_mlp_t** out, const cs_mlp_cfg* cfg) {
         }
     }
     A((void**)&h->seg_dev, sizeof(Segment) * 2 * h->L);
+    if (getenv("CS_CHAIN_DBG")) A((void**)&h->dbg, (size_t)2 * (h->m_pad_max / 64) * 64 * 8);
     if (h->use_chain)
         for (int l = 0; l + 1 < h->L; ++l) A((void**)&h->layers[l].mask, (size_t)(h->m_pad_max / 64) * 512 * 16);
     for (int l = 0; l < h->L; ++l) {       // activations last: the big, streamed part
@@ -563,6 +566,15 @@ int cs_mlp_profile_step(cs_mlp_t* h, const float* x_dev, const float* y_dev, con
     }
     if (rc) return rc;
     if (e != hipSuccess) return fail(CS_ERR_HIP, "stream synchronize failed: %s", hipGetErrorString(e));
+    return CS_OK;
+}
+
+int cs_mlp_debug_stamps(cs_mlp_t* h, unsigned long long* host, int64_t n_words) {
+    if (!h || !host) return fail(CS_ERR_INVALID, "null argument");
+    if (!h->dbg) return fail(CS_ERR_STATE, "set CS_CHAIN_DBG=1 before cs_mlp_create");
+    const int64_t have = 2 * (h->m_pad_max / 64) * 64;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(host, h->dbg, sizeof(unsigned long long) * (n_words < have ? n_words : have), hipMemcpyDeviceToHost));
     return CS_OK;
 }
 

@@ -124,6 +124,10 @@ int cs_mlp_profile_step(cs_mlp_t* h, const float* x_dev, const float* y_dev, con
                         int64_t n, int normalise, float lr, float* loss_dev, void* stream,
                         cs_kernel_times* out);
 
+/* Development aid: s_memtime stamps of the chain kernels (needs CS_CHAIN_DBG=1 at create time):
+ * [fwd|bwd][workgroup][64 slots] shader-clock ticks.  Not for production use. */
+int cs_mlp_debug_stamps(cs_mlp_t* h, unsigned long long* host, int64_t n_words);
+
 /* Stand-alone loader-path kernel (data_utils.py:807-809 + :894-897 on device): out = (x-sub)/div,
  * inf/nan -> 0, float32 -> float32; rows gathered through row_idx when given. */
 int cs_normalise_rows(const float* x_dev, const int64_t* row_idx_dev, int64_t n, int32_t width,

@@ -3,8 +3,7 @@ set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out; export TMPDIR=/tmp
 timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
 for b in 1024 8192 65536; do
-  timeout 300 python bench.py --batch $b --steps 100 --warmup 10 --cpu-budget 0 2>/dev/null | python tests/summ.py v3
+  timeout 300 python bench.py --batch $b --steps 100 --warmup 10 --cpu-budget 0 2>/dev/null | python tests/summ.py v4
 done
-for ab in 1 2 4 7 15; do
-  CS_CHAIN_ABLATE=$ab timeout 300 python bench.py --batch 8192 --steps 50 --warmup 5 --cpu-budget 0 2>/dev/null | python tests/summ.py ablate=$ab
-done
+python tests/chain_stamps.py 8192
+python tests/chain_stamps.py 65536
