@@ -265,7 +265,7 @@ __device__ __forceinline__ void chain_stamp(const ChainArgs& p, int tid, int& sl
     ++slot;
 }
 
-template <int MT, int NT, int EPI>
+template <int MT, int NT, int EPI, bool ELU>
 __device__ __forceinline__ void chain_stage(u16* X, const float* bias_lds, const int64_t* rows_lds, const ChainArgs& p,
                                             const ChainStage& S, bool last, int64_t m0, int jt0, int mrow0, int tid,
                                             float& sq, float& ab, int& slot) {
@@ -273,15 +273,14 @@ __device__ __forceinline__ void chain_stage(u16* X, const float* bias_lds, const
     f32x16_t acc[MT][NT];
     u32x4_t msk = u32x4_t{0u, 0u, 0u, 0u};
     u32x4_t* mptr = S.mask ? S.mask + (int64_t)blockIdx.x * 512 + tid : nullptr;
-    if (EPI == EPI_DGRAD && p.act != ACT_ELU) msk = *mptr;     // lands during the k-loop
+    if (EPI == EPI_DGRAD && !ELU) msk = *mptr;                 // lands during the k-loop
     chain_mma<MT, NT>(X, S.wfrag, S.Kc >> 4, S.Nc >> 5, jt0, mrow0, lane, acc, p.ablate);
     __syncthreads();                         // every wave has finished reading X for this stage
     chain_stamp(p, tid, slot);
     if constexpr (EPI == EPI_OUT) {
         chain_heads<MT>(bias_lds, rows_lds, p, S, m0, jt0, mrow0, lane, acc, sq, ab);
     } else {
-        if (p.act == ACT_ELU) chain_epilogue<MT, NT, EPI, true>(X, bias_lds, p, S, last, m0, jt0, mrow0, lane, acc, msk);
-        else chain_epilogue<MT, NT, EPI, false>(X, bias_lds, p, S, last, m0, jt0, mrow0, lane, acc, msk);
+        chain_epilogue<MT, NT, EPI, ELU>(X, bias_lds, p, S, last, m0, jt0, mrow0, lane, acc, msk);
         if (EPI == EPI_HIDDEN && mptr) *mptr = msk;
     }
     __syncthreads();                         // X now holds this stage's output
@@ -292,7 +291,7 @@ __device__ __forceinline__ void chain_stage(u16* X, const float* bias_lds, const
 template <int BM>
 constexpr int chain_lds_bytes() { return BM * CHAIN_PITCH * 2 + CHAIN_MAX_BIAS * 4 + BM * 8; }
 
-template <int BM, bool BWD>
+template <int BM, bool BWD, bool ELU>
 __global__ __launch_bounds__(512) void k_chain(const ChainArgs p) {
     extern __shared__ __attribute__((aligned(16))) u16 X[];      // [BM][CHAIN_PITCH]
     float* bias_lds = reinterpret_cast<float*>(X + BM * CHAIN_PITCH);
@@ -385,13 +384,13 @@ __global__ __launch_bounds__(512) void k_chain(const ChainArgs p) {
         const bool last = (i + 1 == p.n_stages);
         constexpr int E = BWD ? EPI_DGRAD : EPI_HIDDEN;
         if (S.Nc == 512) {          // wave = all BM rows x 64 columns
-            chain_stage<BM / 32, 2, E>(X, bias_lds, rows_lds, p, S, last, m0, wid * 2, 0, tid, sq, ab, slot);
+            chain_stage<BM / 32, 2, E, ELU>(X, bias_lds, rows_lds, p, S, last, m0, wid * 2, 0, tid, sq, ab, slot);
         } else if (S.Nc == 256) {   // wave = all BM rows x 32 columns
-            chain_stage<BM / 32, 1, E>(X, bias_lds, rows_lds, p, S, last, m0, wid, 0, tid, sq, ab, slot);
+            chain_stage<BM / 32, 1, E, ELU>(X, bias_lds, rows_lds, p, S, last, m0, wid, 0, tid, sq, ab, slot);
         } else if (!BWD && S.epi == EPI_OUT) {   // heads: 128 wide, wave = half the rows x 32 columns
-            chain_stage<BM / 64, 1, EPI_OUT>(X, bias_lds, rows_lds, p, S, last, m0, wid & 3, (wid >> 2) * (BM / 2), tid, sq, ab, slot);
+            chain_stage<BM / 64, 1, EPI_OUT, ELU>(X, bias_lds, rows_lds, p, S, last, m0, wid & 3, (wid >> 2) * (BM / 2), tid, sq, ab, slot);
         } else {                    // 128: wave = half the rows x 32 columns
-            chain_stage<BM / 64, 1, E>(X, bias_lds, rows_lds, p, S, last, m0, wid & 3, (wid >> 2) * (BM / 2), tid, sq, ab, slot);
+            chain_stage<BM / 64, 1, E, ELU>(X, bias_lds, rows_lds, p, S, last, m0, wid & 3, (wid >> 2) * (BM / 2), tid, sq, ab, slot);
         }
     }
     if (!BWD && p.y) {

@@ -168,6 +168,26 @@ int launch_optimizer(cs_mlp* h, float lr, float grad_scale, bool recast_only, hi
     return CS_OK;
 }
 
+template <int BM>
+std::vector<const void*> chain_kernels() {
+    return {reinterpret_cast<const void*>(k_chain<BM, false, false>), reinterpret_cast<const void*>(k_chain<BM, false, true>),
+            reinterpret_cast<const void*>(k_chain<BM, true, false>), reinterpret_cast<const void*>(k_chain<BM, true, true>)};
+}
+
+template <bool BWD>
+void launch_chain(const cs_mlp* h, int bm, int64_t m_pad, const ChainArgs& c, hipStream_t st) {
+    const bool elu = h->cfg.act == CS_ACT_ELU;
+    if (bm == 128) {
+        const dim3 g((unsigned)(m_pad / 128));
+        if (elu) hipLaunchKernelGGL((k_chain<128, BWD, true>), g, dim3(512), chain_lds_bytes<128>(), st, c);
+        else hipLaunchKernelGGL((k_chain<128, BWD, false>), g, dim3(512), chain_lds_bytes<128>(), st, c);
+    } else {
+        const dim3 g((unsigned)(m_pad / 64));
+        if (elu) hipLaunchKernelGGL((k_chain<64, BWD, true>), g, dim3(512), chain_lds_bytes<64>(), st, c);
+        else hipLaunchKernelGGL((k_chain<64, BWD, false>), g, dim3(512), chain_lds_bytes<64>(), st, c);
+    }
+}
+
 int chain_bm(const cs_mlp* h, int64_t n) {
     if (h->cfg.flags & CS_FLAG_CHAIN_BM64) return 64;
     if (h->cfg.flags & CS_FLAG_CHAIN_BM128) return 128;
@@ -198,8 +218,7 @@ int run_forward(cs_mlp* h, const float* x, const int64_t* row_idx, int64_t n, in
         c.dz_out = want_dz ? h->layers[h->L - 1].dZ : nullptr; c.ld_dz_out = 128;
         const int bm = chain_bm(h, n);
         ProfScope ps(CS_K_CHAIN_FWD, st);
-        if (bm == 128) hipLaunchKernelGGL((k_chain<128, false>), dim3((unsigned)(m_pad / 128)), dim3(512), chain_lds_bytes<128>(), st, c);
-        else hipLaunchKernelGGL((k_chain<64, false>), dim3((unsigned)(m_pad / 64)), dim3(512), chain_lds_bytes<64>(), st, c);
+        launch_chain<false>(h, bm, m_pad, c, st);
         HIP_TRY(hipGetLastError());
         return CS_OK;
     }
@@ -249,8 +268,7 @@ int run_backward(cs_mlp* h, int64_t n, bool atomics_needed, hipStream_t st) {
         c.n_rows = n; c.act = h->cfg.act; c.slope = (h->cfg.act == CS_ACT_RELU) ? 0.f : h->cfg.alpha;
         const int bm = chain_bm(h, n);
         ProfScope ps(CS_K_CHAIN_BWD, st);
-        if (bm == 128) hipLaunchKernelGGL((k_chain<128, true>), dim3((unsigned)(m_pad / 128)), dim3(512), chain_lds_bytes<128>(), st, c);
-        else hipLaunchKernelGGL((k_chain<64, true>), dim3((unsigned)(m_pad / 64)), dim3(512), chain_lds_bytes<64>(), st, c);
+        launch_chain<true>(h, bm, m_pad, c, st);
     }
     if (!h->use_chain) {
         for (int l = h->L - 1; l >= 1; --l) {
@@ -355,10 +373,8 @@ int cs_mlp_create(cs_mlp_t** out, const cs_mlp_cfg* cfg) {
     if (const char* e = getenv("CS_WGRAD_SPLITK")) h->wgrad_splitk = atoi(e);
     if (const char* e = getenv("CS_CHAIN_ABLATE")) h->chain_ablate = atoi(e);
     if (h->use_chain) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain<128, false>), hipFuncAttributeMaxDynamicSharedMemorySize, chain_lds_bytes<128>()));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain<128, true>), hipFuncAttributeMaxDynamicSharedMemorySize, chain_lds_bytes<128>()));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain<64, false>), hipFuncAttributeMaxDynamicSharedMemorySize, chain_lds_bytes<64>()));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain<64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, chain_lds_bytes<64>()));
+        for (const void* f : chain_kernels<128>()) HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, chain_lds_bytes<128>()));
+        for (const void* f : chain_kernels<64>()) HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, chain_lds_bytes<64>()));
     }
     // ONE arena for every device buffer of the handle: a single large hipMalloc gets 2-MiB-aligned
     // virtual memory backed by large page fragments.  (Many small hipMallocs measured ~2 us effective
