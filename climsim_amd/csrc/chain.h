@@ -162,9 +162,6 @@ __device__ __forceinline__ void chain_epilogue(u16* __restrict__ X, const float*
     const int r15 = lane & 15, hi4 = 4 * (lane >> 5);
     const int mlb = mrow0 + (lane & 31);
     u16* xrow = X + mlb * CHAIN_PITCH + hi4;                         // LDS row of tile a = 0
-    const bool do_out = S.out && !(p.ablate & 4);
-    u16* orow = S.out + (m0 + mlb) * S.ldo + hi4;                   // global row of tile a = 0
-    const int ostep = 32 * S.ldo;
     const float slope = p.slope;
 #pragma unroll
     for (int b = 0; b < NT; ++b) {
@@ -202,8 +199,7 @@ __device__ __forceinline__ void chain_epilogue(u16* __restrict__ X, const float*
                     for (int e = 0; e < 4; ++e) v[e] = (bits & (1u << e)) ? v[e] : v[e] * slope;
                 }
                 const uint2 pk = make_uint2(cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3]));
-                if (do_out) *reinterpret_cast<uint2*>(orow + a * ostep + c * 8) = pk;
-                if (!last) *reinterpret_cast<uint2*>(xrow + a * 32 * CHAIN_PITCH + ldsoff) = pk;
+                *reinterpret_cast<uint2*>(xrow + a * 32 * CHAIN_PITCH + ldsoff) = pk;   // global copy: chain_copy_out
             }
         }
     }
@@ -260,12 +256,27 @@ __device__ __forceinline__ void chain_heads(const float* __restrict__ bias_lds, 
     }
 }
 
+// Stage output rows LDS -> global, fully coalesced (one wave-instruction = 1 KiB of one row).  The MFMA
+// result layout gives every lane 4 columns of ONE row, so storing from registers touches 32 rows per
+// instruction with 16-byte pieces - 8x the write requests for the same bytes.
+template <int BM>
+__device__ __forceinline__ void chain_copy_out(const u16* __restrict__ X, u16* __restrict__ out, int ldo, int width,
+                                               int64_t m0, int tid) {
+    const int cpr_shift = (width == 512) ? 6 : (width == 256 ? 5 : 4);       // 16-B chunks per row
+    const int total = BM << cpr_shift;
+    for (int g = tid; g < total; g += 512) {
+        const int r = g >> cpr_shift, c = g & ((1 << cpr_shift) - 1);
+        const uint4 v = *reinterpret_cast<const uint4*>(X + r * CHAIN_PITCH + ((c ^ (r & 15)) << 3));
+        *reinterpret_cast<uint4*>(out + (m0 + r) * ldo + c * 8) = v;
+    }
+}
+
 __device__ __forceinline__ void chain_stamp(const ChainArgs& p, int tid, int& slot) {
     if (p.dbg && tid == 0 && slot < 64) p.dbg[(int64_t)blockIdx.x * 64 + slot] = __builtin_amdgcn_s_memtime();
     ++slot;
 }
 
-template <int MT, int NT, int EPI, bool ELU>
+template <int BMROWS, int MT, int NT, int EPI, bool ELU>
 __device__ __forceinline__ void chain_stage(u16* X, const float* bias_lds, const int64_t* rows_lds, const ChainArgs& p,
                                             const ChainStage& S, bool last, int64_t m0, int jt0, int mrow0, int tid,
                                             float& sq, float& ab, int& slot) {
@@ -284,6 +295,7 @@ __device__ __forceinline__ void chain_stage(u16* X, const float* bias_lds, const
         if (EPI == EPI_HIDDEN && mptr) *mptr = msk;
     }
     __syncthreads();                         // X now holds this stage's output
+    if (EPI != EPI_OUT && S.out && !(p.ablate & 4)) chain_copy_out<BMROWS>(X, S.out, S.ldo, S.Nc, m0, tid);
     chain_stamp(p, tid, slot);
 }
 
@@ -384,13 +396,13 @@ __global__ __launch_bounds__(512) void k_chain(const ChainArgs p) {
         const bool last = (i + 1 == p.n_stages);
         constexpr int E = BWD ? EPI_DGRAD : EPI_HIDDEN;
         if (S.Nc == 512) {          // wave = all BM rows x 64 columns
-            chain_stage<BM / 32, 2, E, ELU>(X, bias_lds, rows_lds, p, S, last, m0, wid * 2, 0, tid, sq, ab, slot);
+            chain_stage<BM, BM / 32, 2, E, ELU>(X, bias_lds, rows_lds, p, S, last, m0, wid * 2, 0, tid, sq, ab, slot);
         } else if (S.Nc == 256) {   // wave = all BM rows x 32 columns
-            chain_stage<BM / 32, 1, E, ELU>(X, bias_lds, rows_lds, p, S, last, m0, wid, 0, tid, sq, ab, slot);
+            chain_stage<BM, BM / 32, 1, E, ELU>(X, bias_lds, rows_lds, p, S, last, m0, wid, 0, tid, sq, ab, slot);
         } else if (!BWD && S.epi == EPI_OUT) {   // heads: 128 wide, wave = half the rows x 32 columns
-            chain_stage<BM / 64, 1, EPI_OUT, ELU>(X, bias_lds, rows_lds, p, S, last, m0, wid & 3, (wid >> 2) * (BM / 2), tid, sq, ab, slot);
+            chain_stage<BM, BM / 64, 1, EPI_OUT, ELU>(X, bias_lds, rows_lds, p, S, last, m0, wid & 3, (wid >> 2) * (BM / 2), tid, sq, ab, slot);
         } else {                    // 128: wave = half the rows x 32 columns
-            chain_stage<BM / 64, 1, E, ELU>(X, bias_lds, rows_lds, p, S, last, m0, wid & 3, (wid >> 2) * (BM / 2), tid, sq, ab, slot);
+            chain_stage<BM, BM / 64, 1, E, ELU>(X, bias_lds, rows_lds, p, S, last, m0, wid & 3, (wid >> 2) * (BM / 2), tid, sq, ab, slot);
         }
     }
     if (!BWD && p.y) {
