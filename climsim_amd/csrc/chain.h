@@ -6,7 +6,7 @@
 // from dz of the heads back to dz of the first hidden layer (backward).  The only streamed operand
 // is the weight matrix, read from L2 in "fragment-major" order straight into MFMA operand
 // registers (no LDS staging: every wave owns its own output columns, so nothing is shared),
-// 1 KiB fully coalesced per wave-instruction, prefetched CHAIN_D k-steps ahead.  The layout is
+// 1 KiB fully coalesced per wave-instruction, prefetched 4-8 k-steps ahead.  The layout is
 // [k16 step][n tile][lane][8]: at every step the 8 waves of a workgroup together read ONE
 // contiguous 16 KiB run, so the requests spread over all L2 channels.
 //   L2 -> CU traffic per workgroup = all weights once (2.39 MB fwd), i.e. BM FLOP per byte.
@@ -24,7 +24,6 @@
 #pragma once
 #include "kernels.h"
 
-#define CHAIN_D 4              // weight prefetch depth in k16-steps
 #define CHAIN_MAX_STAGES 18
 #define CHAIN_PITCH 512        // LDS row pitch in bf16 elements (1 KiB)
 #define CHAIN_MAX_BIAS 4096    // floats of bias staged in LDS (sum of layer widths)
@@ -65,9 +64,11 @@ __device__ __forceinline__ int chain_lds_off(int row, int col) {   // element of
 __device__ __forceinline__ unsigned bf_pos(unsigned h16) { return (unsigned)((h16 & 0xffffu) - 1u) < 0x7fffu; }   // bf16 > 0
 
 // One stage for one wave: acc[MT][NT] 32x32 tiles over contraction length Kc.
-template <int MT, int NT>
+// D = weight prefetch depth in k16-steps (4 or 8; 8 needs 32 more VGPRs).
+template <int MT, int NT, int D>
 __device__ __forceinline__ void chain_mma(const u16* __restrict__ X, const u16* __restrict__ wfrag, int ks_total, int ntiles,
                                           int jt0, int mrow0, int lane, f32x16_t (&acc)[MT][NT], int ablate) {
+    static_assert(D == 4 || D == 8, "queue slots are written out for depth 4 and 8");
 #pragma unroll
     for (int a = 0; a < MT; ++a)
 #pragma unroll
@@ -81,11 +82,10 @@ __device__ __forceinline__ void chain_mma(const u16* __restrict__ X, const u16* 
     // The weight stream is issued with inline-asm loads and waited for with COUNTED vmcnt: hipcc's own
     // bookkeeping falls back to vmcnt(0) at the loop header (and rotates the queue through v_mov's that
     // need the data).  Protocol: slot d is refilled right after its last use; before its next use
-    // exactly NT*(CHAIN_D-1) younger loads have been issued by this wave, so vmcnt(NT*(CHAIN_D-1))
-    // means "slot d has landed".  Loads are issued unconditionally (address clamped at the tail) to
-    // keep that count exact.  Queue slots are named scalars (tied asm operands cannot be array elements).
-    u32x4_t q00, q01, q10, q11, q20, q21, q30, q31;
-    static_assert(CHAIN_D == 4, "queue slots below are written out for depth 4");
+    // exactly NT*(D-1) younger loads have been issued by this wave, so vmcnt(NT*(D-1)) means "slot d
+    // has landed".  Loads are issued unconditionally (address clamped at the tail) to keep that count
+    // exact.  Queue slots are named scalars (tied asm operands cannot be array elements).
+    u32x4_t q00, q01, q10, q11, q20, q21, q30, q31, q40, q41, q50, q51, q60, q61, q70, q71;
 #define CHAIN_LOAD(Q0, Q1, step)                                                                              \
     {                                                                                                          \
         const int sn_ = min((step), ks_total - 1);                                                             \
@@ -101,15 +101,15 @@ __device__ __forceinline__ void chain_mma(const u16* __restrict__ X, const u16* 
     {                                                                                                          \
         const int s = s0 + (d);                                                                                \
         if (MT <= 2) { CHAIN_AF(AN, s + 1) } else { CHAIN_AF(AC, s) }                                          \
-        if (NT == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(Q0), "+v"(Q1) : "i"(NT * (CHAIN_D - 1)) : "memory"); \
-        else asm volatile("s_waitcnt vmcnt(%1)" : "+v"(Q0) : "i"(NT * (CHAIN_D - 1)) : "memory");              \
+        if (NT == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(Q0), "+v"(Q1) : "i"(NT * (D - 1)) : "memory");  \
+        else asm volatile("s_waitcnt vmcnt(%1)" : "+v"(Q0) : "i"(NT * (D - 1)) : "memory");                    \
         if (!(ablate & 2)) _Pragma("unroll") for (int a = 0; a < MT; ++a) {                                    \
             acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, Q0), AC[a], acc[a][0], 0, 0, 0); \
             if (NT == 2)                                                                                       \
                 acc[a][NT - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, Q1), AC[a], acc[a][NT - 1], 0, 0, 0); \
         }                                                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
-        if (!(ablate & 1)) CHAIN_LOAD(Q0, Q1, s + CHAIN_D)                                                     \
+        if (!(ablate & 1)) CHAIN_LOAD(Q0, Q1, s + D)                                                           \
     }
     // every older compiler-issued vector-memory op must be out of the queue before counting starts
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -117,21 +117,39 @@ __device__ __forceinline__ void chain_mma(const u16* __restrict__ X, const u16* 
     CHAIN_LOAD(q10, q11, 1)
     CHAIN_LOAD(q20, q21, 2)
     CHAIN_LOAD(q30, q31, 3)
+    if (D == 8) {
+        CHAIN_LOAD(q40, q41, 4)
+        CHAIN_LOAD(q50, q51, 5)
+        CHAIN_LOAD(q60, q61, 6)
+        CHAIN_LOAD(q70, q71, 7)
+    }
     const int arow = mrow0 + (lane & 31), ahalf = lane >> 5;
     // (double-buffered only for <= 2 row tiles per wave; with 4 the second buffer would spill)
     bf16x8_t afA[MT], afB[MT <= 2 ? MT : 1];
     if (MT <= 2) { CHAIN_AF(afA, 0) }
-    for (int s0 = 0; s0 < ks_total; s0 += CHAIN_D) {
+    for (int s0 = 0; s0 < ks_total; s0 += D) {     // contraction lengths are multiples of 64 = 4 steps; D=8 needs 128
         if (MT <= 2) {
             CHAIN_STEP(0, q00, q01, afA, afB)
             CHAIN_STEP(1, q10, q11, afB, afA)
             CHAIN_STEP(2, q20, q21, afA, afB)
             CHAIN_STEP(3, q30, q31, afB, afA)
+            if (D == 8) {
+                CHAIN_STEP(4, q40, q41, afA, afB)
+                CHAIN_STEP(5, q50, q51, afB, afA)
+                CHAIN_STEP(6, q60, q61, afA, afB)
+                CHAIN_STEP(7, q70, q71, afB, afA)
+            }
         } else {
             CHAIN_STEP(0, q00, q01, afA, afA)
             CHAIN_STEP(1, q10, q11, afA, afA)
             CHAIN_STEP(2, q20, q21, afA, afA)
             CHAIN_STEP(3, q30, q31, afA, afA)
+            if (D == 8) {
+                CHAIN_STEP(4, q40, q41, afA, afA)
+                CHAIN_STEP(5, q50, q51, afA, afA)
+                CHAIN_STEP(6, q60, q61, afA, afA)
+                CHAIN_STEP(7, q70, q71, afA, afA)
+            }
         }
     }
 #undef CHAIN_AF
@@ -285,7 +303,9 @@ __device__ __forceinline__ void chain_stage(u16* X, const float* bias_lds, const
     u32x4_t msk = u32x4_t{0u, 0u, 0u, 0u};
     u32x4_t* mptr = S.mask ? S.mask + (int64_t)blockIdx.x * 512 + tid : nullptr;
     if (EPI == EPI_DGRAD && !ELU) msk = *mptr;                 // lands during the k-loop
-    chain_mma<MT, NT>(X, S.wfrag, S.Kc >> 4, S.Nc >> 5, jt0, mrow0, lane, acc, p.ablate);
+    // deep prefetch (8 steps = 16 KiB per wave in flight) where registers allow and the contraction is long enough
+    if (MT <= 2 && (S.Kc & 127) == 0) chain_mma<MT, NT, 8>(X, S.wfrag, S.Kc >> 4, S.Nc >> 5, jt0, mrow0, lane, acc, p.ablate);
+    else chain_mma<MT, NT, 4>(X, S.wfrag, S.Kc >> 4, S.Nc >> 5, jt0, mrow0, lane, acc, p.ablate);
     __syncthreads();                         // every wave has finished reading X for this stage
     chain_stamp(p, tid, slot);
     if constexpr (EPI == EPI_OUT) {
@@ -330,11 +350,17 @@ __global__ __launch_bounds__(512) void k_chain(const ChainArgs p) {
 
     // ---- prologue: biases + row indices to LDS, then the stage-0 input rows
     if (!BWD) {
-        for (int i = 0; i < p.n_stages; ++i)
-            for (int j = tid; j < p.bias_len[i]; j += 512) bias_lds[p.st[i].bias_off + j] = p.bias_src[i][j];
-        if (tid < BM) {
-            const int64_t m = m0 + tid;
-            rows_lds[tid] = (m < p.n_rows) ? (p.row_idx ? p.row_idx[m] : m) : -1;
+        {   // all bias loads and the row-index load in flight together (one memory latency, not eight)
+            float bv[CHAIN_MAX_STAGES / 2];
+            int64_t rv = -1;
+            if (tid < BM && m0 + tid < p.n_rows) rv = p.row_idx ? p.row_idx[m0 + tid] : m0 + tid;
+#pragma unroll
+            for (int i = 0; i < CHAIN_MAX_STAGES / 2; ++i)
+                bv[i] = (i < p.n_stages && tid < p.bias_len[i]) ? p.bias_src[i][tid] : 0.f;
+#pragma unroll
+            for (int i = 0; i < CHAIN_MAX_STAGES / 2; ++i)
+                if (i < p.n_stages && tid < p.bias_len[i]) bias_lds[p.st[i].bias_off + tid] = bv[i];
+            if (tid < BM) rows_lds[tid] = rv;
         }
         __syncthreads();
         const int groups = p.kp0 >> 2;                           // 4 features per item

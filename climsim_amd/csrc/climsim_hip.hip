@@ -63,7 +63,7 @@ struct ProfScope {
 struct Layer {
     int K, Kp, N;
     int64_t w_off, b_off;      // offsets (floats) in the flat parameter buffer
-    u16 *Wt, *Wn;              // bf16 operand copies [N][Kp], [Kp][N]
+    u16 *Wt = nullptr, *Wn = nullptr;   // bf16 operand copies [N][Kp], [Kp][N] (per-layer kernels)
     u16 *Wf = nullptr, *Wb = nullptr;   // fragment-major copies for the chain kernels
     u32x4_t* mask = nullptr;            // sign bits of this layer's OUTPUT activation (chain kernels)
     int bias_off = 0;                   // offset of the bias in the chain kernels' LDS bias block
@@ -88,6 +88,7 @@ struct cs_mlp {
     int64_t iterations = 0;
     int64_t bytes = 0;
     bool use_chain = false;
+    bool grads_dirty = true;   // G may hold non-zero values (cleared by cs_mlp_apply)
     unsigned long long* dbg = nullptr;   // CS_CHAIN_DBG: [2][grid_max][64] stamps (fwd, bwd)
     int chain_ablate = 0;      // CS_CHAIN_ABLATE env, timing experiments only
     int wgrad_splitk = 0;      // 0 = automatic (CS_WGRAD_SPLITK env overrides, for tuning runs)
@@ -389,9 +390,10 @@ int cs_mlp_create(cs_mlp_t** out, const cs_mlp_cfg* cfg) {
     A((void**)&h->div, sizeof(float) * cfg->n_in);
     for (int l = 0; l < h->L; ++l) {
         Layer& ly = h->layers[l];
-        A((void**)&ly.Wt, sizeof(u16) * ly.N * ly.Kp);
-        A((void**)&ly.Wn, sizeof(u16) * ly.Kp * ly.N);
-        if (h->use_chain) {
+        if (!h->use_chain) {
+            A((void**)&ly.Wt, sizeof(u16) * ly.N * ly.Kp);
+            A((void**)&ly.Wn, sizeof(u16) * ly.Kp * ly.N);
+        } else {
             A((void**)&ly.Wf, sizeof(u16) * ly.N * ly.Kp);
             if (l > 0) A((void**)&ly.Wb, sizeof(u16) * ly.Kp * ly.N);
         }
@@ -525,8 +527,11 @@ int cs_mlp_loss_grads(cs_mlp_t* h, const float* x_dev, const float* y_dev, const
     if (!accumulate) {
         ProfScope ps(CS_K_MEMSET, st);
         HIP_TRY(hipMemsetAsync(loss_dev, 0, 2 * sizeof(float), st));
-        HIP_TRY(hipMemsetAsync(h->G, 0, sizeof(float) * h->n_params, st));
+        // the optimiser kernel leaves G zeroed; a memset is only needed when the last gradients were
+        // never applied (or the buffer was just rebound)
+        if (h->grads_dirty) HIP_TRY(hipMemsetAsync(h->G, 0, sizeof(float) * h->n_params, st));
     }
+    h->grads_dirty = true;
     rc = run_forward(h, x_dev, row_idx_dev, n, normalise, nullptr, y_dev, loss_dev, true, st);
     if (rc) return rc;
     return run_backward(h, n, accumulate != 0, st);
@@ -544,13 +549,14 @@ int cs_mlp_set_grad_buffer(cs_mlp_t* h, void* dev_ptr) {
     if (((uintptr_t)dev_ptr) & 15) return fail(CS_ERR_INVALID, "gradient buffer must be 16-byte aligned");
     h->G = (float*)dev_ptr;
     h->own_G = false;
+    h->grads_dirty = true;
     return CS_OK;
 }
 
 int cs_mlp_apply(cs_mlp_t* h, float lr, float grad_scale, void* stream) {
     if (!h) return fail(CS_ERR_INVALID, "null handle");
     int rc = launch_optimizer(h, lr, grad_scale, false, (hipStream_t)stream);
-    if (rc == CS_OK) h->iterations += 1;
+    if (rc == CS_OK) { h->iterations += 1; h->grads_dirty = false; }
     return rc;
 }
 

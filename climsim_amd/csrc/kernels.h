@@ -412,7 +412,7 @@ struct Segment {          // one parameter tensor of the flat buffer
     u16* Wb;              // fragment-major backward operand [n/16][k/32][lane][8]   (chain kernels) or null
 };
 struct OptArgs {
-    float* P; float* M; float* V; const float* G;
+    float* P; float* M; float* V; float* G;   // G is consumed: zeroed after the update (no memset launch per step)
     int64_t n4;           // number of float4 groups
     int n_seg; const Segment* seg;
     int kind; float lr, grad_scale;
@@ -476,6 +476,7 @@ __global__ __launch_bounds__(256) void k_optimizer(const OptArgs a) {
             *reinterpret_cast<float4*>(a.V + i0) = make_float4(vv[0], vv[1], vv[2], vv[3]);
         }
         *reinterpret_cast<float4*>(a.P + i0) = make_float4(wv[0], wv[1], wv[2], wv[3]);
+        *reinterpret_cast<float4*>(a.G + i0) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     // bf16 operand copies of weight tensors
     int s = 0;
@@ -484,9 +485,11 @@ __global__ __launch_bounds__(256) void k_optimizer(const OptArgs a) {
     if (sg.Kp == 0) return;
     const int64_t rel = i0 - sg.off;
     const int k = (int)(rel / sg.N), n = (int)(rel - (int64_t)k * sg.N);
-    *reinterpret_cast<uint2*>(sg.Wn + (int64_t)k * sg.N + n) = pack4(wv[0], wv[1], wv[2], wv[3]);
+    if (sg.Wn) *reinterpret_cast<uint2*>(sg.Wn + (int64_t)k * sg.N + n) = pack4(wv[0], wv[1], wv[2], wv[3]);
+    if (sg.Wt) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) sg.Wt[(int64_t)(n + e) * sg.Kp + k] = f2bf(wv[e]);
+        for (int e = 0; e < 4; ++e) sg.Wt[(int64_t)(n + e) * sg.Kp + k] = f2bf(wv[e]);
+    }
     if (sg.Wf) {          // lane (n&31) + 32*((k>>3)&1) of block (k>>4, n>>5) holds W[k..][n], element k&7
         const int nt = sg.N >> 5;
 #pragma unroll
