@@ -54,7 +54,7 @@ struct ChainArgs {
     int act; float slope;
     // heads (EPI_OUT)
     int n_lin; float* yhat; const float* y; float* loss; u16* dz_out; int ld_dz_out;
-    int ablate;              // timing experiments only (CS_CHAIN_ABLATE): 1 no weight refills, 2 no MFMA, 4 no global stores, 8 no warm-up
+    int ablate;              // timing experiments only (CS_CHAIN_ABLATE): 4 no global stores, 8 no warm-up
     unsigned long long* dbg; // optional [grid][64] s_memtime stamps (CS_CHAIN_DBG), null in production
 };
 
@@ -103,13 +103,13 @@ __device__ __forceinline__ void chain_mma(const u16* __restrict__ X, const u16* 
         if (MT <= 2) { CHAIN_AF(AN, s + 1) } else { CHAIN_AF(AC, s) }                                          \
         if (NT == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(Q0), "+v"(Q1) : "i"(NT * (D - 1)) : "memory");  \
         else asm volatile("s_waitcnt vmcnt(%1)" : "+v"(Q0) : "i"(NT * (D - 1)) : "memory");                    \
-        if (!(ablate & 2)) _Pragma("unroll") for (int a = 0; a < MT; ++a) {                                    \
+        _Pragma("unroll") for (int a = 0; a < MT; ++a) {                                                       \
             acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, Q0), AC[a], acc[a][0], 0, 0, 0); \
             if (NT == 2)                                                                                       \
                 acc[a][NT - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, Q1), AC[a], acc[a][NT - 1], 0, 0, 0); \
         }                                                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
-        if (!(ablate & 1)) CHAIN_LOAD(Q0, Q1, s + D)                                                           \
+        CHAIN_LOAD(Q0, Q1, s + D)                                                                              \
     }
     // every older compiler-issued vector-memory op must be out of the queue before counting starts
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -13,7 +13,8 @@ from climsim_amd import _lib  # noqa: E402
 from climsim_amd.mlp import MLPEmulator  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
-m = MLPEmulator(units=(512,) * 5, max_batch=B, seed=0)
+FLAGS = int(os.environ.get("CS_FLAGS", "0"))
+m = MLPEmulator(units=(512,) * 5, max_batch=B, seed=0, flags=FLAGS)
 x = torch.randn(B, 124, device="cuda") * 0.2
 y = torch.randn(B, 128, device="cuda") * 0.05
 for _ in range(5):
@@ -23,7 +24,7 @@ mp = (B + 127) // 128 * 128
 words = 2 * (mp // 64) * 64
 buf = np.zeros(words, dtype=np.uint64)
 _lib.check(m.lib.cs_mlp_debug_stamps(m._h, buf.ctypes.data_as(C.c_void_p), words))
-bm = 128 if B > 16384 else 64
+bm = 128 if FLAGS & 8 else 64
 grid = mp // bm
 for name, base in (("fwd", 0), ("bwd", (mp // 64) * 64)):
     st = buf[base:base + grid * 64].reshape(grid, 64).astype(np.int64)
