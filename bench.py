@@ -103,11 +103,17 @@ def main():
     perm = torch.randperm(args.rows, device=device, generator=gen)
     nb = args.rows // B
 
+    from climsim_amd.dp import DataParallel
+    dp = DataParallel(model, dist if world > 1 else None)
+    dp.broadcast_weights()
+
     def step(i):
+        # every rank owns its own HBM-resident shard of the split, so its local batch is a slice of
+        # its own permutation (equivalent to the round-robin deal of a global permutation)
         idx = perm[(i % nb) * B:(i % nb + 1) * B]
         if world > 1:
             model.loss_grads(x, y, row_idx=idx, loss=loss)
-            dist.all_reduce(grad)
+            dist.all_reduce(grad)                                   # ONE RCCL all-reduce per step
             model.apply_gradients(lr, scale)
         else:
             model.train_on_batch(x, y, lr, row_idx=idx, loss=loss)

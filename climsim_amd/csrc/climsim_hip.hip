@@ -192,8 +192,9 @@ void launch_chain(const cs_mlp* h, int bm, int64_t m_pad, const ChainArgs& c, hi
 int chain_bm(const cs_mlp* h, int64_t n) {
     if (h->cfg.flags & CS_FLAG_CHAIN_BM64) return 64;
     if (h->cfg.flags & CS_FLAG_CHAIN_BM128) return 128;
-    (void)n;
-    return 64;     // 128-row tiles halve the L2 weight traffic but currently spill registers
+    // 128-row tiles halve the weight bytes per FLOP (the per-CU vector-memory path tops out near
+    // 64 B/clk, which is exactly the MFMA rate at 64 rows) but need >= 256 tiles to fill the chip.
+    return n >= 32768 ? 128 : 64;
 }
 
 int run_forward(cs_mlp* h, const float* x, const int64_t* row_idx, int64_t n, int normalise, float* yhat,

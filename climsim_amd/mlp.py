@@ -337,11 +337,14 @@ class MLPEmulator:
         sched = learning_rate or ConstantLearningRate(1e-3)
         if not callable(sched):
             sched = ConstantLearningRate(float(sched))
-        rank, world = 0, 1
+        from .dp import DataParallel, shard_of_batch
+        dist = None
         if distributed:
             import torch.distributed as dist
-            rank, world = dist.get_rank(), dist.get_world_size()
-            grad = self.gradient_tensor()
+        dp = DataParallel(self, dist, self.output_length)
+        rank, world = dp.rank, dp.world
+        if distributed:
+            dp.broadcast_weights()
         if batch_size % world:
             raise ValueError("global batch_size must be divisible by the world size")
         local_bs = batch_size // world
@@ -365,7 +368,6 @@ class MLPEmulator:
                 writer.writerow(["epoch", *history.keys()])
         epoch_sum = torch.zeros(2, dtype=torch.float32, device=self.device)
         step_loss = torch.zeros(2, dtype=torch.float32, device=self.device)
-        scale = 1.0 / (self.output_length * batch_size)
         self.stop_training = False
         for epoch in range(epochs):
             gen.manual_seed(seed + epoch)            # identical permutation on every rank
@@ -374,14 +376,10 @@ class MLPEmulator:
             lr = sched(self.iterations)
             for s in range(steps):
                 lr = sched(self.iterations)
-                idx = perm[s * batch_size + rank:(s + 1) * batch_size:world]
-                if world > 1:
-                    idx = idx.contiguous()
                 if distributed:
-                    self.loss_grads(x, y, row_idx=idx, normalise=normalise, loss=step_loss)
-                    dist.all_reduce(grad)
-                    self.apply_gradients(lr, scale)
+                    dp.train_step(x, y, perm, s, batch_size, lr, loss=step_loss, normalise=normalise)
                 else:
+                    idx = shard_of_batch(perm, s, batch_size, 0, 1)
                     self.train_on_batch(x, y, lr, row_idx=idx, normalise=normalise, loss=step_loss)
                 epoch_sum += step_loss
             if distributed:
