@@ -4,6 +4,7 @@
 #include "../../include/climsim_hip.h"
 #include "kernels.h"
 #include "chain.h"
+#include "wgrad2.h"
 
 #include <cmath>
 #include <cstdarg>
@@ -91,6 +92,7 @@ struct cs_mlp {
     bool grads_dirty = true;   // G may hold non-zero values (cleared by cs_mlp_apply)
     unsigned long long* dbg = nullptr;   // CS_CHAIN_DBG: [2][grid_max][64] stamps (fwd, bwd)
     int chain_ablate = 0;      // CS_CHAIN_ABLATE env, timing experiments only
+    int wgrad2_mode = -1;      // CS_WGRAD2 env: 0 never, 1 always, -1 by batch size
     int wgrad_splitk = 0;      // 0 = automatic (CS_WGRAD_SPLITK env overrides, for tuning runs)
     std::vector<void*> allocs;
 };
@@ -286,26 +288,32 @@ int run_backward(cs_mlp* h, int64_t n, bool atomics_needed, hipStream_t st) {
         }
     }
     {   // weight/bias gradients of ALL layers in one grouped launch
+        const bool big = h->wgrad2_mode == 1 || (h->wgrad2_mode < 0 && n >= 16384);   // 256x256 tiles + LDS-DMA ring
+        const int tdim = big ? 256 : 128;
+        const int msteps = big ? (int)(m_pad / WG2_ROWS) : steps;
         WgradArgs w{};
         w.n_layers = h->L; w.m_pad = m_pad;
         int tiles = 0;
-        for (int l = 0; l < h->L; ++l) tiles += (h->layers[l].Kp / 128) * (h->layers[l].N / 128);
-        int splitk = h->wgrad_splitk > 0 ? h->wgrad_splitk : (512 + tiles / 2) / tiles;
+        for (int l = 0; l < h->L; ++l)
+            tiles += ((h->layers[l].Kp + tdim - 1) / tdim) * ((h->layers[l].N + tdim - 1) / tdim);
+        const int target = big ? 256 : 512;               // workgroups: 1 (128 KiB LDS) or 2 per CU
+        int splitk = h->wgrad_splitk > 0 ? h->wgrad_splitk : (target + tiles / 2) / tiles;
         if (splitk < 1) splitk = 1;
-        if (splitk > steps) splitk = steps;
+        if (splitk > msteps) splitk = msteps;
         w.splitk = splitk;
-        w.use_atomics = (splitk > 1 || atomics_needed) ? 1 : 0;
+        w.use_atomics = (big || splitk > 1 || atomics_needed) ? 1 : 0;
         int wg = 0;
         for (int l = 0; l < h->L; ++l) {
             const Layer& ly = h->layers[l];
             WgradLayer& d = w.L[l];
             d.H = ly.H; d.ldh = ly.Kp; d.Z = ly.dZ; d.ldz = ly.N;
             d.dW = h->G + ly.w_off; d.N = ly.N; d.k_real = ly.K; d.db = h->G + ly.b_off;
-            d.tiles_k = ly.Kp / 128; d.tiles_n = ly.N / 128; d.wg_begin = wg;
+            d.tiles_k = (ly.Kp + tdim - 1) / tdim; d.tiles_n = (ly.N + tdim - 1) / tdim; d.wg_begin = wg;
             wg += d.tiles_k * d.tiles_n * splitk;
         }
         ProfScope ps(CS_K_WGRAD, st);
-        if (tr) hipLaunchKernelGGL(k_wgrad<true>, dim3((unsigned)wg), dim3(256), 0, st, w);
+        if (big) hipLaunchKernelGGL(k_wgrad2, dim3((unsigned)wg), dim3(512), WG2_LDS_BYTES, st, w);
+        else if (tr) hipLaunchKernelGGL(k_wgrad<true>, dim3((unsigned)wg), dim3(256), 0, st, w);
         else hipLaunchKernelGGL(k_wgrad<false>, dim3((unsigned)wg), dim3(256), 0, st, w);
     }
     HIP_TRY(hipGetLastError());
@@ -374,6 +382,8 @@ int cs_mlp_create(cs_mlp_t** out, const cs_mlp_cfg* cfg) {
     if (h->L > WGRAD_MAX_LAYERS) { delete h; return fail(CS_ERR_INVALID, "too many layers"); }
     if (const char* e = getenv("CS_WGRAD_SPLITK")) h->wgrad_splitk = atoi(e);
     if (const char* e = getenv("CS_CHAIN_ABLATE")) h->chain_ablate = atoi(e);
+    if (const char* e = getenv("CS_WGRAD2")) h->wgrad2_mode = atoi(e);
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad2), hipFuncAttributeMaxDynamicSharedMemorySize, WG2_LDS_BYTES));
     if (h->use_chain) {
         for (const void* f : chain_kernels<128>()) HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, chain_lds_bytes<128>()));
         for (const void* f : chain_kernels<64>()) HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, chain_lds_bytes<64>()));
@@ -408,7 +418,7 @@ int cs_mlp_create(cs_mlp_t** out, const cs_mlp_cfg* cfg) {
         A((void**)&ly.H, sizeof(u16) * h->m_pad_max * ly.Kp);
         A((void**)&ly.dZ, sizeof(u16) * h->m_pad_max * ly.N);
     }
-    size_t total = 0;
+    size_t total = 65536;                    // tail pad: clipped wgrad tiles read a little past a buffer
     for (auto& r : req) total += r.second;
     int rc = CS_OK;
     char* arena = nullptr;

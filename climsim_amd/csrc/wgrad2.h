@@ -1,0 +1,156 @@
+// Weight-gradient kernel, large-batch form: dW[K,N] += H[M,K]^T dZ[M,N] for ALL layers in one launch.
+//
+//   * 256(k) x 256(n) output tile per workgroup, 8 waves of 64(k) x 128(n) (acc = 2x4 MFMA tiles =
+//     128 VGPRs): 128 FLOP per operand byte, i.e. 32 B/clk/CU of loads at full MFMA rate - half of
+//     what the vector-memory path delivers (128x128 tiles need all of it and were load-bound).
+//   * operands stream HBM -> LDS with `global_load_lds_dwordx4` (LDS-DMA, no VGPR staging) into a
+//     4-slot ring of 32-row stages (32 KiB each), three stages in flight, counted `vmcnt` + raw
+//     `s_barrier` (hipcc would drain the DMA queue at every __syncthreads()).
+//   * the LDS image is lane-linear per 1-KiB DMA piece, so the bank swizzle is applied on the
+//     per-lane SOURCE address (64-B units XOR (row & 3)) and again on the `ds_read_b64_tr_b16`
+//     address: transposition happens in the LDS read, there are no transposed copies in HBM.
+//   * row range split over the grid; fp32 atomics into the flat gradient buffer.
+#pragma once
+#include "kernels.h"
+
+#define WG2_STAGES 4
+#define WG2_ROWS 32                       // rows (contraction) per stage
+#define WG2_STAGE_ELEMS (2 * WG2_ROWS * 256)   // H tile + Z tile, bf16 elements
+#define WG2_LDS_BYTES (WG2_STAGES * WG2_STAGE_ELEMS * 2)
+
+__device__ __forceinline__ int swz_w2(int m, int col) {       // element offset inside a [32][256] tile
+    return m * 256 + ((((col >> 5) ^ (m & 3))) << 5) + (col & 31);
+}
+
+__device__ __forceinline__ bf16x8_t frag_w2(const u16* tile, int mb, int cb, int lane) {
+    // lane l needs X[mb + 8*(l>>5) + 0..7][cb + (l&31)]; two transposing 4x16 reads (see load_frag_tn)
+    union { bf16x8_t v; s16x4_t h[2]; } u;
+    const int col = cb + 16 * ((lane >> 4) & 1) + (lane & 3) * 4;
+    const int m = mb + 8 * (lane >> 5) + ((lane & 15) >> 2);
+    typedef s16x4_t __attribute__((address_space(3))) * lds_v4;
+    u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(tile + swz_w2(m, col)));
+    u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(tile + swz_w2(m + 4, col)));
+    return u.v;
+}
+
+// one 1-KiB LDS-DMA piece: lane i -> LDS byte lds_dst + 16*i  (M0 carries the wave-uniform base)
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+__global__ __launch_bounds__(512) void k_wgrad2(const WgradArgs pa) {
+    extern __shared__ __attribute__((aligned(16))) u16 ring[];    // [stage][H|Z][32][256]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wk = wid >> 1, wn = wid & 1;
+    int li = 0;
+    while (li + 1 < pa.n_layers && (int)blockIdx.x >= pa.L[li + 1].wg_begin) ++li;
+    const WgradLayer& p = pa.L[li];
+    const int rel = blockIdx.x - p.wg_begin;
+    const int ntile = p.tiles_k * p.tiles_n;
+    const int split = rel / ntile, tile = rel - split * ntile;
+    const int k0 = (tile % p.tiles_k) * 256, n0 = (tile / p.tiles_k) * 256;
+    const int steps = (int)(pa.m_pad / WG2_ROWS);
+    const int s_begin = (int)((int64_t)steps * split / pa.splitk);
+    const int s_end = (int)((int64_t)steps * (split + 1) / pa.splitk);
+    const int nst = s_end - s_begin;
+
+    // DMA source of this lane within a 2-row piece: row i>>5, physical 16-B chunk i&31 holds logical
+    // chunk (((p>>2) ^ (m&3)) << 2) | (p&3); pieces 2*wid, 2*wid+1 of each operand belong to this wave.
+    const int prow = lane >> 5, pch = lane & 31;
+    const u16* hsrc[2]; const u16* zsrc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int ml = 2 * (2 * wid + j) + prow;                    // row inside the stage
+        const int c = ((((pch >> 2) ^ (ml & 3)) << 2) | (pch & 3)) * 8;
+        hsrc[j] = p.H + (int64_t)ml * p.ldh + k0 + c;
+        zsrc[j] = p.Z + (int64_t)ml * p.ldz + n0 + c;
+    }
+    typedef u16 __attribute__((address_space(3))) * lds_p;
+    const unsigned lds0 = (unsigned)(uintptr_t)((lds_p)ring);
+    const unsigned my_piece = __builtin_amdgcn_readfirstlane((unsigned)(2 * wid) * 1024u);
+
+    f32x16_t acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool do_bias = (k0 == 0) && (wk == 0);
+    const bool k_live = (k0 + wk * 64) < ((p.k_real + 63) & ~63), n_live = (n0 + wn * 128) < p.N;
+
+    if (nst > 0) {
+#define WG2_ISSUE(st)                                                                                  \
+    {                                                                                                   \
+        const int sc_ = min((st), nst - 1);                                                             \
+        const int64_t roff = (int64_t)(s_begin + sc_) * WG2_ROWS;                                       \
+        const unsigned base = lds0 + (unsigned)((st) & (WG2_STAGES - 1)) * (WG2_STAGE_ELEMS * 2) + my_piece; \
+        dma16(hsrc[0] + roff * p.ldh, base);                                                            \
+        dma16(hsrc[1] + roff * p.ldh, base + 1024u);                                                    \
+        dma16(zsrc[0] + roff * p.ldz, base + WG2_ROWS * 512u);                                          \
+        dma16(zsrc[1] + roff * p.ldz, base + WG2_ROWS * 512u + 1024u);                                  \
+    }
+        WG2_ISSUE(0)
+        WG2_ISSUE(1)
+        WG2_ISSUE(2)
+        for (int s = 0; s < nst; ++s) {
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // this wave's 4 pieces of stage s have landed
+            __builtin_amdgcn_s_barrier();                       // ... and everyone's; slot (s-1)&3 is free
+            WG2_ISSUE(s + 3)
+            const u16* Hs = ring + (s & (WG2_STAGES - 1)) * WG2_STAGE_ELEMS;
+            const u16* Zs = Hs + WG2_ROWS * 256;
+            if (k_live && n_live) {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    bf16x8_t fh[2], fz[4];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) fh[i] = frag_w2(Hs, kk * 16, wk * 64 + i * 32, lane);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) fz[j] = frag_w2(Zs, kk * 16, wn * 128 + j * 32, lane);
+                    if (do_bias) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            union { bf16x8_t v; u16 s[8]; } u;
+                            u.v = fz[j];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) bsum[j] += bf2f(u.s[e]);
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[i], fz[j], acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+#undef WG2_ISSUE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // tail re-loads
+    }
+    if (!(k_live && n_live)) return;
+    // D[i = k][j = n]: lane owns column n = ..+(lane&31), rows k = ..+(r&3)+8*(r>>2)+4*(lane>>5)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 128 + j * 32 + (lane & 31);
+            if (n >= p.N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = k0 + wk * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (k < p.k_real) atomicAdd(p.dW + (int64_t)k * p.N + n, acc[i][j][r]);
+            }
+        }
+    if (do_bias) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float v = bsum[j] + __shfl_xor(bsum[j], 32, 64);
+            const int n = n0 + wn * 128 + j * 32 + lane;
+            if (lane < 32 && n < p.N) atomicAdd(p.db + n, v);
+        }
+    }
+}
