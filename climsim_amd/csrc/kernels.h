@@ -297,15 +297,25 @@ __device__ __forceinline__ bf16x8_t load_frag_tn(const u16* tile, int mb, int cb
     return u.v;
 }
 
+// Workgroups that read the same operand rows (the tiles of one (layer, split)) get consecutive WORK ids;
+// the hardware deals consecutive BLOCK ids round-robin over the 8 XCDs (private L2s).  This bijective
+// remap gives every XCD a contiguous run of work ids so that sharers hit in one L2 instead of each
+// fetching the rows from HBM (speed only - any placement is correct).
+__device__ __forceinline__ int xcd_work_id(int b, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, x = b & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+}
+
 template <bool TR>
 __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs pa) {
     __shared__ __attribute__((aligned(16))) u16 smem[2][2][64 * 128];   // [buffer][H|Z] = 64 KiB
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wk = wid >> 1, wn = wid & 1;
+    const int work = xcd_work_id(blockIdx.x, gridDim.x);
     int li = 0;
-    while (li + 1 < pa.n_layers && (int)blockIdx.x >= pa.L[li + 1].wg_begin) ++li;
+    while (li + 1 < pa.n_layers && work >= pa.L[li + 1].wg_begin) ++li;
     const WgradLayer& p = pa.L[li];
-    const int rel = blockIdx.x - p.wg_begin;
+    const int rel = work - p.wg_begin;
     const int ntile = p.tiles_k * p.tiles_n;
     const int split = rel / ntile, tile = rel - split * ntile;
     const int k0 = (tile % p.tiles_k) * 128, n0 = (tile / p.tiles_k) * 128;

@@ -45,10 +45,11 @@ __global__ __launch_bounds__(512) void k_wgrad2(const WgradArgs pa) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wk = wid >> 1, wn = wid & 1;
+    const int work = xcd_work_id(blockIdx.x, gridDim.x);     // operand sharers on one XCD (kernels.h)
     int li = 0;
-    while (li + 1 < pa.n_layers && (int)blockIdx.x >= pa.L[li + 1].wg_begin) ++li;
+    while (li + 1 < pa.n_layers && work >= pa.L[li + 1].wg_begin) ++li;
     const WgradLayer& p = pa.L[li];
-    const int rel = blockIdx.x - p.wg_begin;
+    const int rel = work - p.wg_begin;
     const int ntile = p.tiles_k * p.tiles_n;
     const int split = rel / ntile, tile = rel - split * ntile;
     const int k0 = (tile % p.tiles_k) * 256, n0 = (tile / p.tiles_k) * 256;
