@@ -308,14 +308,16 @@ __device__ __forceinline__ void chain_stage(u16* X, const float* bias_lds, const
     else chain_mma<MT, NT, 4>(X, S.wfrag, S.Kc >> 4, S.Nc >> 5, jt0, mrow0, lane, acc, p.ablate);
     __syncthreads();                         // every wave has finished reading X for this stage
     chain_stamp(p, tid, slot);
-    if constexpr (EPI == EPI_OUT) {
+    if (p.ablate & 16) {                     // timing experiment: no epilogue at all
+        asm volatile("" :: "v"(acc[0][0][0]));
+    } else if constexpr (EPI == EPI_OUT) {
         chain_heads<MT>(bias_lds, rows_lds, p, S, m0, jt0, mrow0, lane, acc, sq, ab);
     } else {
         chain_epilogue<MT, NT, EPI, ELU>(X, bias_lds, p, S, last, m0, jt0, mrow0, lane, acc, msk);
         if (EPI == EPI_HIDDEN && mptr) *mptr = msk;
     }
     __syncthreads();                         // X now holds this stage's output
-    if (EPI != EPI_OUT && S.out && !(p.ablate & 4)) chain_copy_out<BMROWS>(X, S.out, S.ldo, S.Nc, m0, tid);
+    if (EPI != EPI_OUT && S.out && !(p.ablate & (4 | 16))) chain_copy_out<BMROWS>(X, S.out, S.ldo, S.Nc, m0, tid);
     chain_stamp(p, tid, slot);
 }
 
