@@ -32,6 +32,11 @@ class CsKernelTimes(C.Structure):
     _fields_ = [("ms", C.c_float * CS_K_COUNT), ("launches", C.c_int32 * CS_K_COUNT)]
 
 
+class CsCnnCfg(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ("depth", "channels", "kernel", "seq", "c_in", "c_out", "n_lin", "max_batch",
+                                         "device", "flags")]
+
+
 class EngineError(RuntimeError):
     pass
 
@@ -57,6 +62,11 @@ SIGNATURES = {
     "cs_mlp_profile_step": (C.c_int, [_P, _P, _P, _P, _I64, C.c_int, _F, _P, _P, C.POINTER(CsKernelTimes)]),
     "cs_mlp_debug_stamps": (C.c_int, [_P, _P, _I64]),
     "cs_normalise_rows": (C.c_int, [_P, _P, _I64, _I32, _P, _P, _P, _P]),
+    "cs_cnn_create": (C.c_int, [C.POINTER(_P), C.POINTER(CsCnnCfg)]),
+    "cs_cnn_destroy": (None, [_P]),
+    "cs_cnn_num_params": (_I64, [_P]),
+    "cs_cnn_set_weights": (C.c_int, [_P, _P, _I64, _P]),
+    "cs_cnn_forward": (C.c_int, [_P, _P, C.c_int, _I64, _P, _P, _P]),
     "cs_last_error": (C.c_char_p, []),
     "cs_version": (C.c_char_p, []),
 }

@@ -12,7 +12,8 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "climsim_hip.hip")
-DEPS = [SRC, os.path.join(HERE, "csrc", "kernels.h"), os.path.join(os.path.dirname(HERE), "include", "climsim_hip.h")]
+DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in ("kernels.h", "chain.h", "wgrad2.h", "cnn.h", "cnn_api.h")] + [
+    os.path.join(os.path.dirname(HERE), "include", "climsim_hip.h")]
 OUT = os.path.join(HERE, "libclimsim_hip.so")
 ARCH = "gfx950"
 

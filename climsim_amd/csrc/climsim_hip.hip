@@ -623,3 +623,5 @@ int cs_normalise_rows(const float* x_dev, const int64_t* row_idx_dev, int64_t n,
 }
 
 }  // extern "C"
+
+#include "cnn_api.h"

@@ -133,6 +133,33 @@ int cs_mlp_debug_stamps(cs_mlp_t* h, unsigned long long* host, int64_t n_words);
 int cs_normalise_rows(const float* x_dev, const int64_t* row_idx_dev, int64_t n, int32_t width,
                       const float* sub_dev, const float* div_dev, float* out_dev, void* stream);
 
+/* ---- level-axis 1-D CNN (baseline_models/CNN/training/hpo_train.py:124-200), prediction path ----
+ * ResNet-style: depth x { Conv1D(C,3,'same')+ReLU, Conv1D(C,3,'same')+ReLU, + Conv1D(C,1)(block input) },
+ * Conv1D(10,1)+ELU, per-level Dense(10->n_lin) || Dense(10->10-n_lin, relu).  Dropout is identity at
+ * prediction time.  Weights in Keras order (kernels (k, c_in, c_out)).  Training entry points follow. */
+typedef struct cs_cnn cs_cnn_t;
+typedef struct cs_cnn_cfg {
+    int32_t depth;       /* hp_depth = 12            */
+    int32_t channels;    /* hp_channel_width = 406   */
+    int32_t kernel;      /* hp_kernel_width = 3      */
+    int32_t seq;         /* 60 levels                */
+    int32_t c_in;        /* 6  input channels        */
+    int32_t c_out;       /* 10 output channels       */
+    int32_t n_lin;       /* 2 linear heads, rest relu */
+    int32_t max_batch;   /* columns per call          */
+    int32_t device;
+    int32_t flags;
+} cs_cnn_cfg;
+int  cs_cnn_create(cs_cnn_t** out, const cs_cnn_cfg* cfg);            /* CNNHyperModel().build()   */
+void cs_cnn_destroy(cs_cnn_t* h);
+int64_t cs_cnn_num_params(const cs_cnn_t* h);                          /* model.count_params()      */
+int  cs_cnn_set_weights(cs_cnn_t* h, const float* host, int64_t n, void* stream);   /* model.set_weights */
+/* model.predict: x_dev is (n,124) flat rows (layout3d = 0; the reshape of data_utils.reshape_input_for_cnn
+ * happens in the first kernel) or (n,60,6) (layout3d = 1).  Outputs: (n,60,10) f32 and/or the flat
+ * (n,128) form of data_utils.reshape_target_from_cnn; either may be NULL. */
+int  cs_cnn_forward(cs_cnn_t* h, const float* x_dev, int layout3d, int64_t n, float* out3d_dev, float* out_flat_dev,
+                    void* stream);
+
 const char* cs_last_error(void);
 const char* cs_version(void);
 

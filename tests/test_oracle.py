@@ -117,3 +117,18 @@ def test_bf16_mode_close_to_fp32():
     l16, _, g16, y16 = O.loss_and_grads(ws, x, y, cfg, bf16=True)
     assert abs(l16 - l32) < 0.02 * l32
     assert np.max(np.abs(y16 - y32)) < 0.02 * np.max(np.abs(y32))
+
+
+def test_cnn_oracle_known_answers():
+    from oracle import cnn_oracle as CO
+    shapes = CO.cnn_shapes()
+    assert sum(int(np.prod(s)) for s in shapes) == 13_215_420          # BASELINE.md CNN model size
+    ws = CO.glorot_cnn(seed=1, depth=2, channels=32)
+    x3 = np.random.default_rng(0).normal(0, 0.3, (3, 60, 6)).astype(np.float32)
+    y = CO.forward(ws, x3, depth=2)
+    assert y.shape == (3, 60, 10) and np.all(y[:, :, 2:] >= 0)
+    # 'same' zero padding never mixes columns: predictions of a column do not depend on its neighbours
+    y1 = CO.forward(ws, x3[1:2], depth=2)
+    np.testing.assert_allclose(y[1:2], y1, rtol=1e-6, atol=1e-7)
+    t = np.zeros_like(y)
+    assert CO.mae_adjusted(t, y) == pytest.approx(np.abs(y[:, :, :2]).mean() * 120 / 128 + np.abs(y[:, :, 2:]).mean() * 8 / 128)
