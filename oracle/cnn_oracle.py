@@ -31,7 +31,7 @@ def cnn_shapes(depth=12, channels=406, c_in=6, c_out=10, n_lin=2, k=3):
     return shapes
 
 
-def glorot_cnn(seed=0, bias_scale=0.0, **kw):
+def glorot_cnn(seed=0, bias_scale=0.0, gain=1.0, **kw):
     rng = np.random.default_rng(seed)
     ws = []
     for s in cnn_shapes(**kw):
@@ -40,7 +40,7 @@ def glorot_cnn(seed=0, bias_scale=0.0, **kw):
         else:
             rf = int(np.prod(s[:-2])) if len(s) == 3 else 1
             lim = np.sqrt(6.0 / (rf * s[-2] + rf * s[-1]))
-            ws.append(rng.uniform(-lim, lim, s).astype(np.float32))
+            ws.append((rng.uniform(-lim, lim, s) * gain).astype(np.float32))
     return ws
 
 

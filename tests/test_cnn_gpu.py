@@ -1,6 +1,5 @@
 """GPU parity of the CNN prediction path against the torch-CPU oracle (bf16-emulating and fp32).
-Tolerances: bf16-emulating oracle max|d| <= 5e-3*max|ref| (accumulation order + rare bf16 flips through
-37 conv layers); fp32 oracle <= 6e-2*max|ref| (bf16 operand rounding)."""
+Tolerances are stated at the test (they depend on depth: see the comment there)."""
 import numpy as np
 import pytest
 
@@ -26,26 +25,37 @@ def make_input(n, seed):
     return x
 
 
-@pytest.mark.parametrize("depth,width,n", [(2, 128, 5), (3, 406, 37), (12, 406, 16)])
-def test_cnn_forward_matches_oracle(CNN, depth, width, n):
+def rms_rel(a, b):
+    return float(np.sqrt(np.mean((a - b) ** 2)) / np.sqrt(np.mean(b ** 2)))
+
+
+# Measured on MI355X (tests/cnn_dbg.py): GPU vs bf16-emulating oracle 3e-5 at depth 1, 8e-5 at depth 2; the
+# two bf16 computations then decorrelate with depth (1-ulp flips from different accumulation orders) until
+# their distance equals the distance of either to the fp32 result (2e-3 at depth 12).  So: shallow models
+# are held to the tight tolerance; deep ones must be as close to the fp32 oracle as the emulating oracle is.
+@pytest.mark.parametrize("depth,width,n,gain", [(1, 128, 5, 1.0), (2, 406, 37, 1.0), (12, 406, 16, 0.6), (12, 406, 16, 1.0)])
+def test_cnn_forward_matches_oracle(CNN, depth, width, n, gain):
     from climsim_amd.data_utils import data_utils
-    ws = CO.glorot_cnn(seed=depth, bias_scale=0.05, depth=depth, channels=width)
+    ws = CO.glorot_cnn(seed=depth, bias_scale=0.05, gain=gain, depth=depth, channels=width)
     m = CNN.CNNEmulator(depth=depth, channel_width=width, max_batch=16)
     assert m.count_params() == sum(w.size for w in ws)
     m.set_weights(ws)
     x = make_input(n, 40 + depth)
     x3 = data_utils.reshape_input_for_cnn(x)
     got_flat_in = m.predict(x)                       # (N,124) rows: reshape happens on the GPU
-    got_3d_in = m.predict(x3)                        # materialised (N,60,6)
-    np.testing.assert_array_equal(got_flat_in, got_3d_in)
+    got = m.predict(x3)                              # materialised (N,60,6)
+    np.testing.assert_array_equal(got_flat_in, got)
     ref16 = CO.forward(ws, x3, depth=depth, bf16=True)
     ref32 = CO.forward(ws, x3, depth=depth, bf16=False)
-    assert got_3d_in.shape == (n, 60, 10)
-    assert np.max(np.abs(got_3d_in - ref16)) <= 5e-3 * np.max(np.abs(ref16))
-    assert np.max(np.abs(got_3d_in - ref32)) <= 6e-2 * np.max(np.abs(ref32))
-    assert np.all(got_3d_in[:, :, 2:] >= 0)
+    assert got.shape == (n, 60, 10)
+    if depth <= 2:
+        assert rms_rel(got, ref16) <= 5e-4
+        assert np.max(np.abs(got - ref16)) <= 5e-3 * np.max(np.abs(ref16))
+    assert rms_rel(got, ref32) <= 1.3 * rms_rel(ref16, ref32) + 1e-4       # as accurate as the emulating oracle
+    assert rms_rel(got, ref16) <= 3.0 * rms_rel(ref16, ref32) + 1e-4
+    assert np.all(got[:, :, 2:] >= 0)
     flat = m.predict(x, flat_output=True)
-    np.testing.assert_allclose(flat, data_utils.reshape_target_from_cnn(got_3d_in), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(flat, data_utils.reshape_target_from_cnn(got), rtol=1e-5, atol=1e-6)
 
 
 def test_cnn_param_count_published_model(CNN):
