@@ -35,6 +35,16 @@ PEAK_BF16_TFLOPS = 2500.0                   # dense MFMA peak, MI355X_MICROARCH.
 PEAK_HBM_GBS = 8000.0
 
 
+def pmc_traffic(kernel, batch):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r01_pmc_hbm_traffic.json:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 x2 read correction), or None when no pass matches."""
+    try:
+        with open(os.path.join(REPO, "profiles", "r01_pmc_hbm_traffic.json")) as f:
+            return json.load(f)[str(batch)][kernel]["traffic_bytes"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def synth_on_device(torch, n, seed, device):
     """Low-res-shaped synthetic columns (SURVEY.md 8d recipe), generated on the GPU."""
     g = torch.Generator(device=device)
@@ -163,7 +173,7 @@ def main():
                     "avg_us_per_launch": round(kernels[dom]["avg_us_per_launch"], 2),
                     "launches_per_step": kernels[dom]["launches_per_step"],
                     "flops_per_launch": FLOPS_PER_COL[dom] * B / kernels[dom]["launches_per_step"],
-                    "traffic": None,
+                    "traffic": pmc_traffic(KERNEL_NAMES[dom], B),
                     "whole_step": {"achieved": round(TRAIN_FLOPS_PER_COL * B / (ms_per_step * 1e-3) / 1e12, 2),
                                    "frac": round(TRAIN_FLOPS_PER_COL * B / (ms_per_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
                                    "hbm_algorithmic_GBs": round(HBM_BYTES_PER_COL * B / (ms_per_step * 1e-3) / 1e9, 1)}}

@@ -13,11 +13,13 @@ from climsim_amd import build  # noqa: E402
 
 build.build()
 from climsim_amd.cnn import CNNEmulator  # noqa: E402
-from oracle import cnn_oracle as CO  # noqa: E402
+from climsim_amd.cnn import _shapes  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 m = CNNEmulator(depth=12, channel_width=406, max_batch=B)
-m.set_weights(CO.glorot_cnn(seed=0, gain=0.6))
+rng = np.random.default_rng(0)
+m.set_weights([(rng.standard_normal(s) * (0.6 * (2.0 / (np.prod(s[:-1]) + s[-1])) ** 0.5 if len(s) > 1 else 0.0)).astype(np.float32)
+               for s in _shapes(12, 406)])
 x = (torch.rand((B, 124), device="cuda") - 0.5).contiguous()
 for _ in range(3):
     m.predict(x, as_numpy=False)
