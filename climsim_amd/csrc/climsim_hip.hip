@@ -92,6 +92,7 @@ struct cs_mlp {
     bool grads_dirty = true;   // G may hold non-zero values (cleared by cs_mlp_apply)
     unsigned long long* dbg = nullptr;   // CS_CHAIN_DBG: [2][grid_max][64] stamps (fwd, bwd)
     int chain_ablate = 0;      // CS_CHAIN_ABLATE env, timing experiments only
+    bool wgrad3 = true;        // small-batch wgrad through the LDS-DMA ring (CS_WGRAD3=0: register-staged k_wgrad)
     int wgrad2_mode = -1;      // CS_WGRAD2 env: 0 never, 1 always, -1 by batch size
     int wgrad_splitk = 0;      // 0 = automatic (CS_WGRAD_SPLITK env overrides, for tuning runs)
     std::vector<void*> allocs;
@@ -288,9 +289,11 @@ int run_backward(cs_mlp* h, int64_t n, bool atomics_needed, hipStream_t st) {
         }
     }
     {   // weight/bias gradients of ALL layers in one grouped launch
+        const bool atomics_needed_plain = false;   // k_wgrad3 always accumulates atomically into the zeroed buffer
         const bool big = h->wgrad2_mode == 1 || (h->wgrad2_mode < 0 && n >= 16384);   // 256x256 tiles + LDS-DMA ring
         const int tdim = big ? 256 : 128;
-        const int msteps = big ? (int)(m_pad / WG2_ROWS) : steps;
+        const bool dma_small = !big && tr && h->wgrad3 && !atomics_needed_plain;
+        const int msteps = (big || dma_small) ? (int)(m_pad / WG2_ROWS) : steps;
         WgradArgs w{};
         w.n_layers = h->L; w.m_pad = m_pad;
         int tiles = 0;
@@ -301,7 +304,7 @@ int run_backward(cs_mlp* h, int64_t n, bool atomics_needed, hipStream_t st) {
         if (splitk < 1) splitk = 1;
         if (splitk > msteps) splitk = msteps;
         w.splitk = splitk;
-        w.use_atomics = (big || splitk > 1 || atomics_needed) ? 1 : 0;
+        w.use_atomics = (big || dma_small || splitk > 1 || atomics_needed) ? 1 : 0;
         int wg = 0;
         for (int l = 0; l < h->L; ++l) {
             const Layer& ly = h->layers[l];
@@ -313,6 +316,7 @@ int run_backward(cs_mlp* h, int64_t n, bool atomics_needed, hipStream_t st) {
         }
         ProfScope ps(CS_K_WGRAD, st);
         if (big) hipLaunchKernelGGL(k_wgrad2, dim3((unsigned)wg), dim3(512), WG2_LDS_BYTES, st, w);
+        else if (dma_small) hipLaunchKernelGGL(k_wgrad3, dim3((unsigned)wg), dim3(256), WG3_LDS_BYTES, st, w);
         else if (tr) hipLaunchKernelGGL(k_wgrad<true>, dim3((unsigned)wg), dim3(256), 0, st, w);
         else hipLaunchKernelGGL(k_wgrad<false>, dim3((unsigned)wg), dim3(256), 0, st, w);
     }
@@ -384,6 +388,8 @@ int cs_mlp_create(cs_mlp_t** out, const cs_mlp_cfg* cfg) {
     if (const char* e = getenv("CS_CHAIN_ABLATE")) h->chain_ablate = atoi(e);
     if (const char* e = getenv("CS_WGRAD2")) h->wgrad2_mode = atoi(e);
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad2), hipFuncAttributeMaxDynamicSharedMemorySize, WG2_LDS_BYTES));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad3), hipFuncAttributeMaxDynamicSharedMemorySize, WG3_LDS_BYTES));
+    if (const char* e = getenv("CS_WGRAD3")) h->wgrad3 = atoi(e) != 0;
     if (h->use_chain) {
         for (const void* f : chain_kernels<128>()) HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, chain_lds_bytes<128>()));
         for (const void* f : chain_kernels<64>()) HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, chain_lds_bytes<64>()));

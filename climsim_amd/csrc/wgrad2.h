@@ -155,3 +155,130 @@ __global__ __launch_bounds__(512) void k_wgrad2(const WgradArgs pa) {
         }
     }
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Small-batch form with the same LDS-DMA pipeline: 128(k) x 128(n) tiles, 4 waves of 64 x 64, 32-row
+// stages of 16 KiB, 4-slot ring = 64 KiB -> two workgroups per CU, each with three stages in flight.
+// (The register-staged k_wgrad has one stage in flight and spends ~10x the MFMA time waiting on loads;
+// 256x256 tiles would need 4x the split partial sums, i.e. 4x the atomics, at this size.)
+#define WG3_STAGE_ELEMS (2 * WG2_ROWS * 128)
+#define WG3_LDS_BYTES (WG2_STAGES * WG3_STAGE_ELEMS * 2)
+
+__device__ __forceinline__ bf16x8_t frag_w3(const u16* tile, int mb, int cb, int lane) {
+    union { bf16x8_t v; s16x4_t h[2]; } u;
+    const int col = cb + 16 * ((lane >> 4) & 1) + (lane & 3) * 4;
+    const int m = mb + 8 * (lane >> 5) + ((lane & 15) >> 2);
+    typedef s16x4_t __attribute__((address_space(3))) * lds_v4;
+    u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(tile + swz_tn(m, col)));
+    u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(tile + swz_tn(m + 4, col)));
+    return u.v;
+}
+
+__global__ __launch_bounds__(256) void k_wgrad3(const WgradArgs pa) {
+    extern __shared__ __attribute__((aligned(16))) u16 ring[];    // [stage][H|Z][32][128]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wk = wid >> 1, wn = wid & 1;
+    const int work = xcd_work_id(blockIdx.x, gridDim.x);
+    int li = 0;
+    while (li + 1 < pa.n_layers && work >= pa.L[li + 1].wg_begin) ++li;
+    const WgradLayer& p = pa.L[li];
+    const int rel = work - p.wg_begin;
+    const int ntile = p.tiles_k * p.tiles_n;
+    const int split = rel / ntile, tile = rel - split * ntile;
+    const int k0 = (tile % p.tiles_k) * 128, n0 = (tile / p.tiles_k) * 128;
+    const int steps = (int)(pa.m_pad / WG2_ROWS);
+    const int s_begin = (int)((int64_t)steps * split / pa.splitk);
+    const int s_end = (int)((int64_t)steps * (split + 1) / pa.splitk);
+    const int nst = s_end - s_begin;
+
+    // a 1-KiB DMA piece = 4 rows of 256 B; lane i -> row i>>4, physical chunk i&15, which holds logical
+    // chunk (((p>>2) ^ (m&3)) << 2) | (p&3)  (swz_tn).  Pieces 2*wid, 2*wid+1 of each operand per wave.
+    const int prow = lane >> 4, pch = lane & 15;
+    const u16* hsrc[2]; const u16* zsrc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int ml = 4 * (2 * wid + j) + prow;
+        const int c = ((((pch >> 2) ^ (ml & 3)) << 2) | (pch & 3)) * 8;
+        hsrc[j] = p.H + (int64_t)ml * p.ldh + k0 + c;
+        zsrc[j] = p.Z + (int64_t)ml * p.ldz + n0 + c;
+    }
+    typedef u16 __attribute__((address_space(3))) * lds_p;
+    const unsigned lds0 = (unsigned)(uintptr_t)((lds_p)ring);
+    const unsigned my_piece = __builtin_amdgcn_readfirstlane((unsigned)(2 * wid) * 1024u);
+
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float bsum[2] = {0.f, 0.f};
+    const bool do_bias = (k0 == 0) && (wk == 0);
+
+    if (nst > 0) {
+#define WG3_ISSUE(st)                                                                                  \
+    {                                                                                                   \
+        const int sc_ = min((st), nst - 1);                                                             \
+        const int64_t roff = (int64_t)(s_begin + sc_) * WG2_ROWS;                                       \
+        const unsigned base = lds0 + (unsigned)((st) & (WG2_STAGES - 1)) * (WG3_STAGE_ELEMS * 2) + my_piece; \
+        dma16(hsrc[0] + roff * p.ldh, base);                                                            \
+        dma16(hsrc[1] + roff * p.ldh, base + 1024u);                                                    \
+        dma16(zsrc[0] + roff * p.ldz, base + WG2_ROWS * 256u);                                          \
+        dma16(zsrc[1] + roff * p.ldz, base + WG2_ROWS * 256u + 1024u);                                  \
+    }
+        WG3_ISSUE(0)
+        WG3_ISSUE(1)
+        WG3_ISSUE(2)
+        for (int s = 0; s < nst; ++s) {
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            WG3_ISSUE(s + 3)
+            const u16* Hs = ring + (s & (WG2_STAGES - 1)) * WG3_STAGE_ELEMS;
+            const u16* Zs = Hs + WG2_ROWS * 128;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8_t fh[2], fz[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) fh[i] = frag_w3(Hs, kk * 16, wk * 64 + i * 32, lane);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) fz[j] = frag_w3(Zs, kk * 16, wn * 64 + j * 32, lane);
+                if (do_bias) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        union { bf16x8_t v; u16 s[8]; } u;
+                        u.v = fz[j];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) bsum[j] += bf2f(u.s[e]);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[i], fz[j], acc[i][j], 0, 0, 0);
+            }
+        }
+#undef WG3_ISSUE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = k0 + wk * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (k < p.k_real) atomicAdd(p.dW + (int64_t)k * p.N + n, acc[i][j][r]);
+            }
+        }
+    if (do_bias) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float v = bsum[j] + __shfl_xor(bsum[j], 32, 64);
+            if (lane < 32) atomicAdd(p.db + n0 + wn * 64 + j * 32 + lane, v);
+        }
+    }
+}
