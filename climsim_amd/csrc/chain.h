@@ -63,11 +63,31 @@ __device__ __forceinline__ int chain_lds_off(int row, int col) {   // element of
 }
 __device__ __forceinline__ unsigned bf_pos(unsigned h16) { return (unsigned)((h16 & 0xffffu) - 1u) < 0x7fffu; }   // bf16 > 0
 
+// Stage output rows LDS -> global, fully coalesced (one wave-instruction = 1 KiB of one row).  The MFMA
+// result layout gives every lane 4 columns of ONE row, so storing from registers touches 32 rows per
+// instruction with 16-byte pieces - 8x the write requests for the same bytes.
+template <int BM>
+__device__ __forceinline__ void chain_copy_out(const u16* __restrict__ X, u16* __restrict__ out, int ldo, int width,
+                                               int64_t m0, int tid) {
+    const int cpr_shift = (width == 512) ? 6 : (width == 256 ? 5 : 4);       // 16-B chunks per row
+    const int total = BM << cpr_shift;
+    for (int g = tid; g < total; g += 512) {
+        const int r = g >> cpr_shift, c = g & ((1 << cpr_shift) - 1);
+        const uint4 v = *reinterpret_cast<const uint4*>(X + r * CHAIN_PITCH + ((c ^ (r & 15)) << 3));
+        *reinterpret_cast<uint4*>(out + (m0 + r) * ldo + c * 8) = v;
+    }
+}
+
+struct ChainPending {          // stage output still to be copied LDS -> global (done by the NEXT stage, see chain_mma)
+    u16* out; int ldo; int width;
+};
+
 // One stage for one wave: acc[MT][NT] 32x32 tiles over contraction length Kc.
 // D = weight prefetch depth in k16-steps (4 or 8; 8 needs 32 more VGPRs).
-template <int MT, int NT, int D>
+template <int BMROWS, int MT, int NT, int D>
 __device__ __forceinline__ void chain_mma(const u16* __restrict__ X, const u16* __restrict__ wfrag, int ks_total, int ntiles,
-                                          int jt0, int mrow0, int lane, f32x16_t (&acc)[MT][NT], int ablate) {
+                                          int jt0, int mrow0, int tid, f32x16_t (&acc)[MT][NT], ChainPending& pend, int64_t m0) {
+    const int lane = tid & 63;
     static_assert(D == 4 || D == 8, "queue slots are written out for depth 4 and 8");
 #pragma unroll
     for (int a = 0; a < MT; ++a)
@@ -111,8 +131,8 @@ __device__ __forceinline__ void chain_mma(const u16* __restrict__ X, const u16* 
         __builtin_amdgcn_sched_barrier(0);                                                                     \
         CHAIN_LOAD(Q0, Q1, s + D)                                                                              \
     }
-    // every older compiler-issued vector-memory op must be out of the queue before counting starts
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // Older compiler-issued memory ops need no explicit drain: completion is in order, so the first counted
+    // wait below also covers them.
     CHAIN_LOAD(q00, q01, 0)
     CHAIN_LOAD(q10, q11, 1)
     CHAIN_LOAD(q20, q21, 2)
@@ -122,6 +142,13 @@ __device__ __forceinline__ void chain_mma(const u16* __restrict__ X, const u16* 
         CHAIN_LOAD(q50, q51, 5)
         CHAIN_LOAD(q60, q61, 6)
         CHAIN_LOAD(q70, q71, 7)
+    }
+    // The previous stage's output (= this stage's input, still intact in X) goes to global memory NOW, behind
+    // the queue-priming loads: its stores are younger than every primed slot, so the counted waits never
+    // wait for a store acknowledgement (waiting vmcnt(0) for them before priming cost ~1 us per stage).
+    if (pend.out) {
+        chain_copy_out<BMROWS>(X, pend.out, pend.ldo, pend.width, m0, tid);
+        pend.out = nullptr;
     }
     const int arow = mrow0 + (lane & 31), ahalf = lane >> 5;
     // (double-buffered only for <= 2 row tiles per wave; with 4 the second buffer would spill)
@@ -226,22 +253,10 @@ __device__ __forceinline__ void chain_epilogue(u16* __restrict__ X, const float*
 
 // Heads: bias, per-column activation, yhat, squared/absolute error sums, dz of the heads.
 template <int MT>
-__device__ __forceinline__ void chain_heads(const float* __restrict__ bias_lds, const int64_t* __restrict__ rows_lds,
+__device__ __forceinline__ void chain_heads(const float* __restrict__ bias_lds, const float4 (&tgt)[MT][4],
                                             const ChainArgs& p, const ChainStage& S, int64_t m0, int jt0, int mrow0,
                                             int lane, f32x16_t (&acc)[MT][1], float& sq, float& ab) {
-    float4 tgt[MT][4];
     const bool have_y = p.y != nullptr;
-    if (have_y) {              // all target loads of this lane in flight together
-#pragma unroll
-        for (int a = 0; a < MT; ++a) {
-            const int ml = mrow0 + a * 32 + (lane & 31);
-            const int64_t r = rows_lds[ml];
-            const int64_t src = r >= 0 ? r : 0;
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                tgt[a][q] = *reinterpret_cast<const float4*>(p.y + src * S.Nc + jt0 * 32 + 8 * q + 4 * (lane >> 5));
-        }
-    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int n = jt0 * 32 + 8 * q + 4 * (lane >> 5);
@@ -274,21 +289,6 @@ __device__ __forceinline__ void chain_heads(const float* __restrict__ bias_lds, 
     }
 }
 
-// Stage output rows LDS -> global, fully coalesced (one wave-instruction = 1 KiB of one row).  The MFMA
-// result layout gives every lane 4 columns of ONE row, so storing from registers touches 32 rows per
-// instruction with 16-byte pieces - 8x the write requests for the same bytes.
-template <int BM>
-__device__ __forceinline__ void chain_copy_out(const u16* __restrict__ X, u16* __restrict__ out, int ldo, int width,
-                                               int64_t m0, int tid) {
-    const int cpr_shift = (width == 512) ? 6 : (width == 256 ? 5 : 4);       // 16-B chunks per row
-    const int total = BM << cpr_shift;
-    for (int g = tid; g < total; g += 512) {
-        const int r = g >> cpr_shift, c = g & ((1 << cpr_shift) - 1);
-        const uint4 v = *reinterpret_cast<const uint4*>(X + r * CHAIN_PITCH + ((c ^ (r & 15)) << 3));
-        *reinterpret_cast<uint4*>(out + (m0 + r) * ldo + c * 8) = v;
-    }
-}
-
 __device__ __forceinline__ void chain_stamp(const ChainArgs& p, int tid, int& slot) {
     if (p.dbg && tid == 0 && slot < 64) p.dbg[(int64_t)blockIdx.x * 64 + slot] = __builtin_amdgcn_s_memtime();
     ++slot;
@@ -297,27 +297,42 @@ __device__ __forceinline__ void chain_stamp(const ChainArgs& p, int tid, int& sl
 template <int BMROWS, int MT, int NT, int EPI, bool ELU>
 __device__ __forceinline__ void chain_stage(u16* X, const float* bias_lds, const int64_t* rows_lds, const ChainArgs& p,
                                             const ChainStage& S, bool last, int64_t m0, int jt0, int mrow0, int tid,
-                                            float& sq, float& ab, int& slot) {
+                                            float& sq, float& ab, int& slot, ChainPending& pend) {
     const int lane = tid & 63;
     f32x16_t acc[MT][NT];
+    float4 tgt[MT][4];                                         // heads: target rows, in flight during the k-loop
+    if constexpr (EPI == EPI_OUT) {
+        if (p.y) {
+#pragma unroll
+            for (int a = 0; a < MT; ++a) {
+                const int64_t r = rows_lds[mrow0 + a * 32 + (lane & 31)];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    tgt[a][q] = *reinterpret_cast<const float4*>(p.y + (r >= 0 ? r : 0) * S.Nc + jt0 * 32 + 8 * q + 4 * (lane >> 5));
+            }
+        }
+    }
     u32x4_t msk = u32x4_t{0u, 0u, 0u, 0u};
     u32x4_t* mptr = S.mask ? S.mask + (int64_t)blockIdx.x * 512 + tid : nullptr;
     if (EPI == EPI_DGRAD && !ELU) msk = *mptr;                 // lands during the k-loop
     // deep prefetch (8 steps = 16 KiB per wave in flight) where registers allow and the contraction is long enough
-    if (MT <= 2 && (S.Kc & 127) == 0) chain_mma<MT, NT, 8>(X, S.wfrag, S.Kc >> 4, S.Nc >> 5, jt0, mrow0, lane, acc, p.ablate);
-    else chain_mma<MT, NT, 4>(X, S.wfrag, S.Kc >> 4, S.Nc >> 5, jt0, mrow0, lane, acc, p.ablate);
+    if (MT <= 2 && (S.Kc & 127) == 0) chain_mma<BMROWS, MT, NT, 8>(X, S.wfrag, S.Kc >> 4, S.Nc >> 5, jt0, mrow0, tid, acc, pend, m0);
+    else chain_mma<BMROWS, MT, NT, 4>(X, S.wfrag, S.Kc >> 4, S.Nc >> 5, jt0, mrow0, tid, acc, pend, m0);
     __syncthreads();                         // every wave has finished reading X for this stage
     chain_stamp(p, tid, slot);
     if (p.ablate & 16) {                     // timing experiment: no epilogue at all
         asm volatile("" :: "v"(acc[0][0][0]));
     } else if constexpr (EPI == EPI_OUT) {
-        chain_heads<MT>(bias_lds, rows_lds, p, S, m0, jt0, mrow0, lane, acc, sq, ab);
+        chain_heads<MT>(bias_lds, tgt, p, S, m0, jt0, mrow0, lane, acc, sq, ab);
     } else {
         chain_epilogue<MT, NT, EPI, ELU>(X, bias_lds, p, S, last, m0, jt0, mrow0, lane, acc, msk);
         if (EPI == EPI_HIDDEN && mptr) *mptr = msk;
     }
     __syncthreads();                         // X now holds this stage's output
-    if (EPI != EPI_OUT && S.out && !(p.ablate & (4 | 16))) chain_copy_out<BMROWS>(X, S.out, S.ldo, S.Nc, m0, tid);
+    if (EPI != EPI_OUT && S.out && !(p.ablate & (4 | 16))) {
+        if (last) chain_copy_out<BMROWS>(X, S.out, S.ldo, S.Nc, m0, tid);     // nobody comes after: copy now
+        else pend = ChainPending{S.out, S.ldo, S.Nc};                         // the next stage copies it
+    }
     chain_stamp(p, tid, slot);
 }
 
@@ -419,18 +434,19 @@ __global__ __launch_bounds__(512) void k_chain(const ChainArgs p) {
     chain_stamp(p, tid, slot);
 
     float sq = 0.f, ab = 0.f;
+    ChainPending pend{nullptr, 0, 0};
     for (int i = 0; i < p.n_stages; ++i) {
         const ChainStage& S = p.st[i];
         const bool last = (i + 1 == p.n_stages);
         constexpr int E = BWD ? EPI_DGRAD : EPI_HIDDEN;
         if (S.Nc == 512) {          // wave = all BM rows x 64 columns
-            chain_stage<BM, BM / 32, 2, E, ELU>(X, bias_lds, rows_lds, p, S, last, m0, wid * 2, 0, tid, sq, ab, slot);
+            chain_stage<BM, BM / 32, 2, E, ELU>(X, bias_lds, rows_lds, p, S, last, m0, wid * 2, 0, tid, sq, ab, slot, pend);
         } else if (S.Nc == 256) {   // wave = all BM rows x 32 columns
-            chain_stage<BM, BM / 32, 1, E, ELU>(X, bias_lds, rows_lds, p, S, last, m0, wid, 0, tid, sq, ab, slot);
+            chain_stage<BM, BM / 32, 1, E, ELU>(X, bias_lds, rows_lds, p, S, last, m0, wid, 0, tid, sq, ab, slot, pend);
         } else if (!BWD && S.epi == EPI_OUT) {   // heads: 128 wide, wave = half the rows x 32 columns
-            chain_stage<BM, BM / 64, 1, EPI_OUT, ELU>(X, bias_lds, rows_lds, p, S, last, m0, wid & 3, (wid >> 2) * (BM / 2), tid, sq, ab, slot);
+            chain_stage<BM, BM / 64, 1, EPI_OUT, ELU>(X, bias_lds, rows_lds, p, S, last, m0, wid & 3, (wid >> 2) * (BM / 2), tid, sq, ab, slot, pend);
         } else {                    // 128: wave = half the rows x 32 columns
-            chain_stage<BM, BM / 64, 1, E, ELU>(X, bias_lds, rows_lds, p, S, last, m0, wid & 3, (wid >> 2) * (BM / 2), tid, sq, ab, slot);
+            chain_stage<BM, BM / 64, 1, E, ELU>(X, bias_lds, rows_lds, p, S, last, m0, wid & 3, (wid >> 2) * (BM / 2), tid, sq, ab, slot, pend);
         }
     }
     if (!BWD && p.y) {

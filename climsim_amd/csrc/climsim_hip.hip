@@ -299,7 +299,7 @@ int run_backward(cs_mlp* h, int64_t n, bool atomics_needed, hipStream_t st) {
         int tiles = 0;
         for (int l = 0; l < h->L; ++l)
             tiles += ((h->layers[l].Kp + tdim - 1) / tdim) * ((h->layers[l].N + tdim - 1) / tdim);
-        const int target = big ? 256 : 512;               // workgroups: 1 (128 KiB LDS) or 2 per CU
+        const int target = big ? 256 : 365;               // workgroups: ~1 per CU (128 KiB LDS) or ~1.4 (atomics grow with splits)
         int splitk = h->wgrad_splitk > 0 ? h->wgrad_splitk : (target + tiles / 2) / tiles;
         if (splitk < 1) splitk = 1;
         if (splitk > msteps) splitk = msteps;
