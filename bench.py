@@ -149,6 +149,13 @@ def main():
 
     # ---- untimed: held-out error of the model that was just trained, per-kernel timing, CPU baseline
     held = model.evaluate(xv, yv)
+    # model.predict throughput (reference: 36.6k-46.7k columns/s on an A100, step3_inference.ipynb) - secondary figure
+    n_pred = min(args.rows, 1_681_920)
+    torch.cuda.synchronize()
+    tp = time.perf_counter()
+    model.predict(x[:n_pred], as_numpy=False)
+    torch.cuda.synchronize()
+    predict_cps = n_pred / (time.perf_counter() - tp)
     roofline, kernels = None, None
     if not args.no_profile and rank == 0:
         agg = {}
@@ -195,6 +202,7 @@ def main():
                           "per_gpu_batch": B, "global_batch": B * world, "rows_resident_per_gpu": args.rows,
                           "parallelism": f"dp{world}", "params": model.count_params()},
                "heldout": {"mse": held["mse"], "mae": held["mae"], "rows": 65536},
+               "predict": {"columns_per_s": round(predict_cps, 1), "rows": n_pred, "batch": B},
                "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu}
         print(json.dumps(out), flush=True)
     if dist:

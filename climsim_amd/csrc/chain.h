@@ -418,7 +418,7 @@ __global__ __launch_bounds__(512) void k_chain(const ChainArgs p) {
                 }
                 const uint2 pk = pack4(v[0], v[1], v[2], v[3]);
                 *reinterpret_cast<uint2*>(X + chain_lds_off(mlv[u], cv[u])) = pk;
-                *reinterpret_cast<uint2*>(p.h0 + (m0 + mlv[u]) * p.ldh0 + cv[u]) = pk;
+                if (p.h0) *reinterpret_cast<uint2*>(p.h0 + (m0 + mlv[u]) * p.ldh0 + cv[u]) = pk;
             }
         }
     } else {

@@ -212,12 +212,13 @@ int run_forward(cs_mlp* h, const float* x, const int64_t* row_idx, int64_t n, in
             ChainStage& S = c.st[l];
             S.wfrag = ly.Wf; S.bias_off = ly.bias_off; S.Kc = ly.Kp; S.Nc = ly.N;
             c.bias_src[l] = h->P + ly.b_off; c.bias_len[l] = ly.N;
-            if (l + 1 < h->L) { S.out = h->layers[l + 1].H; S.ldo = h->layers[l + 1].Kp; S.epi = EPI_HIDDEN; S.mask = want_dz ? ly.mask : nullptr; }
+            // prediction / evaluation keeps nothing for a backward pass: no activation copies, no sign masks
+            if (l + 1 < h->L) { S.out = want_dz ? h->layers[l + 1].H : nullptr; S.ldo = h->layers[l + 1].Kp; S.epi = EPI_HIDDEN; S.mask = want_dz ? ly.mask : nullptr; }
             else { S.out = nullptr; S.ldo = 0; S.epi = EPI_OUT; S.mask = nullptr; }
         }
         c.ablate = h->chain_ablate; c.dbg = h->dbg;
         c.x = x; c.row_idx = row_idx; c.n_in = h->cfg.n_in; c.kp0 = l0.Kp; c.sub = h->sub; c.div = h->div;
-        c.normalise = normalise; c.h0 = l0.H; c.ldh0 = l0.Kp; c.n_rows = n;
+        c.normalise = normalise; c.h0 = want_dz ? l0.H : nullptr; c.ldh0 = l0.Kp; c.n_rows = n;
         c.act = h->cfg.act; c.slope = (h->cfg.act == CS_ACT_RELU) ? 0.f : h->cfg.alpha;
         c.n_lin = h->cfg.n_out_lin; c.yhat = yhat; c.y = y; c.loss = loss;
         c.dz_out = want_dz ? h->layers[h->L - 1].dZ : nullptr; c.ld_dz_out = 128;
