@@ -33,8 +33,9 @@ class CsKernelTimes(C.Structure):
 
 
 class CsCnnCfg(C.Structure):
-    _fields_ = [(k, C.c_int32) for k in ("depth", "channels", "kernel", "seq", "c_in", "c_out", "n_lin", "max_batch",
-                                         "device", "flags")]
+    _fields_ = ([(k, C.c_int32) for k in ("depth", "channels", "kernel", "seq", "c_in", "c_out", "n_lin", "max_batch",
+                                          "device", "flags", "train", "optimizer", "loss", "reserved")]
+                + [(k, C.c_double) for k in ("dropout", "beta1", "beta2", "eps")] + [("seed", C.c_uint64)])
 
 
 class EngineError(RuntimeError):
@@ -66,7 +67,16 @@ SIGNATURES = {
     "cs_cnn_destroy": (None, [_P]),
     "cs_cnn_num_params": (_I64, [_P]),
     "cs_cnn_set_weights": (C.c_int, [_P, _P, _I64, _P]),
+    "cs_cnn_get_weights": (C.c_int, [_P, _P, _I64, _P]),
+    "cs_cnn_get_opt_state": (C.c_int, [_P, _P, _P, _I64, C.POINTER(_I64), _P]),
+    "cs_cnn_set_opt_state": (C.c_int, [_P, _P, _P, _I64, _I64, _P]),
     "cs_cnn_forward": (C.c_int, [_P, _P, C.c_int, _I64, _P, _P, _P]),
+    "cs_cnn_evaluate": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, _P, _I64, _P, C.c_int, _P]),
+    "cs_cnn_loss_grads": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, _P, _I64, _P, _P]),
+    "cs_cnn_grad_buffer": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_I64)]),
+    "cs_cnn_set_grad_buffer": (C.c_int, [_P, _P, _I64]),
+    "cs_cnn_apply": (C.c_int, [_P, _F, _F, _P]),
+    "cs_cnn_train_step": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, _P, _I64, _F, _P, _P]),
     "cs_last_error": (C.c_char_p, []),
     "cs_version": (C.c_char_p, []),
 }

@@ -9,20 +9,40 @@
 #include "kernels.h"
 
 enum { CACT_NONE = 0, CACT_RELU = 1, CACT_ELU = 2 };
+enum { CONV_PREDICT = 0, CONV_TRAIN_FWD = 1, CONV_BWD = 2 };
 
-struct ConvNT {
-    const u16* A; int lda;       // [m_pad][lda] input rows
-    const u16* B; int ldb;       // [N][taps*cin_p] packed weights
-    int cin_p, taps, seq;        // padded input channels (multiple of 64), 1|3, levels per column
-    int64_t m_rows;              // valid rows (n*seq); rows beyond read as zero
-    int N;                       // output channels padded to a multiple of 128
-    const float* bias;           // [N] (zero beyond the real channels)
+// One tap-GEMM:  acc[m][n] = sum_t sum_c A_t[m + sh_t][c] * B[n][t*kpt + c],  rows whose shifted level
+// falls outside 0..seq-1 (or m >= m_rows) read as zero.  Forward convs use one source with shifts -1,0,+1;
+// the backward data pass of a block reads dz at shifts -1,0,+1 against the tap-flipped weights and, as a
+// 4th "tap", the gradient of the residual projection (shift 0) - one launch, one accumulator.
+struct ConvArgs {
+    const u16 *A0, *A1, *A2, *A3; int sh0, sh1, sh2, sh3;
+    int lda;
+    const u16* B; int ldb;       // [N][taps*kpt] packed bf16 weights
+    int kpt, taps, seq;          // padded contraction length per tap (multiple of 64)
+    int64_t m_rows;              // valid rows (n*seq)
+    const float* bias;           // [N] (zero beyond the real channels); unused by CONV_BWD
     int act;
-    const u16* add; int ldadd;   // optional residual added AFTER the activation
-    u16* out; int ldo;
+    unsigned drop_key, drop_thr; float drop_scale;   // CONV_TRAIN_FWD: keep iff hash>>8 >= drop_thr, scale 1/keep
+    const u16* add; int ldadd;   // optional residual added AFTER activation and dropout
+    u16* out; int ldo;           // PREDICT/TRAIN_FWD: result ; BWD: raw sum g (may be null)
+    u16* out2; int ldo2;         // TRAIN_FWD: value before the residual add (may be null) ; BWD: masked gradient
+    const u16* mask; int ldmask; float mscale;       // BWD: out2 = acc * (mask != 0) * mscale
 };
 
-__global__ __launch_bounds__(256) void k_conv_nt(const ConvNT p) {
+__device__ __forceinline__ unsigned lowbias32(unsigned x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+// Dropout decision of element (row m, channel n): shared with oracle/cnn_oracle.py dropout_keep.
+__device__ __forceinline__ bool drop_keep(int64_t m, int n, unsigned key, unsigned thr) {
+    unsigned k = (unsigned)m * 512u + (unsigned)n;
+    k ^= (unsigned)(m >> 23) * 0x9e3779b9u;
+    return (lowbias32(k ^ key) >> 8) >= thr;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_conv(const ConvArgs p) {
     __shared__ __attribute__((aligned(16))) u16 smem[2][2][128 * 64];   // [buffer][A|B] = 64 KiB
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
@@ -30,8 +50,7 @@ __global__ __launch_bounds__(256) void k_conv_nt(const ConvNT p) {
     const int n0 = blockIdx.y * 128;
     const int srow = tid >> 3, sch = tid & 7;
     const u16* Bg = p.B + (int64_t)(n0 + srow) * p.ldb + sch * 8;
-    const int kc_per_tap = p.cin_p >> 6;
-    const int half = p.taps >> 1;
+    const int kc_per_tap = p.kpt >> 6;
     // level index of the 4 rows this thread stages
     int lev0, lev1, lev2, lev3;
     {
@@ -44,12 +63,15 @@ __global__ __launch_bounds__(256) void k_conv_nt(const ConvNT p) {
     {                                                                                                   \
         const int64_t m = m0 + srow + 32 * (i);                                                         \
         const int ls = (lev) + dt;                                                                      \
-        dst = (m < p.m_rows && ls >= 0 && ls < p.seq)                                                   \
-                  ? *reinterpret_cast<const uint4*>(p.A + (m + dt) * p.lda + c0 + sch * 8) : zero4;     \
+        dst = zero4;                                                                                    \
+        if (m < p.m_rows && ls >= 0 && ls < p.seq)                                                      \
+            dst = *reinterpret_cast<const uint4*>(As_ + (m + dt) * p.lda + c0 + sch * 8);               \
     }
 #define CV_GLOAD(t)                                                                                    \
     {                                                                                                   \
-        const int tap = (t) / kc_per_tap, c0 = ((t) - tap * kc_per_tap) * 64, dt = tap - half;          \
+        const int tap = (t) / kc_per_tap, c0 = ((t) - tap * kc_per_tap) * 64;                           \
+        const int dt = tap == 0 ? p.sh0 : tap == 1 ? p.sh1 : tap == 2 ? p.sh2 : p.sh3;                  \
+        const u16* As_ = tap == 0 ? p.A0 : tap == 1 ? p.A1 : tap == 2 ? p.A2 : p.A3;                    \
         CV_ALOAD(ra0, 0, lev0) CV_ALOAD(ra1, 1, lev1) CV_ALOAD(ra2, 2, lev2) CV_ALOAD(ra3, 3, lev3)     \
         rb0 = *reinterpret_cast<const uint4*>(Bg + (int64_t)0 * 32 * p.ldb + (t) * 64);                 \
         rb1 = *reinterpret_cast<const uint4*>(Bg + (int64_t)1 * 32 * p.ldb + (t) * 64);                 \
@@ -100,25 +122,43 @@ __global__ __launch_bounds__(256) void k_conv_nt(const ConvNT p) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int n = n0 + wn * 64 + i * 32 + 8 * q + 4 * (lane >> 5);
-            const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n);
+            float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (MODE != CONV_BWD) b4 = *reinterpret_cast<const float4*>(p.bias + n);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int64_t m = m0 + wm * 64 + j * 32 + (lane & 31);
                 const f32x16_t& av = (i == 0) ? (j == 0 ? acc00 : acc01) : (j == 0 ? acc10 : acc11);
                 float v[4] = {av[4 * q + 0] + b4.x, av[4 * q + 1] + b4.y, av[4 * q + 2] + b4.z, av[4 * q + 3] + b4.w};
-                if (p.act == CACT_RELU) {
+                if (MODE == CONV_BWD) {
+                    if (p.out) *reinterpret_cast<uint2*>(p.out + m * p.ldo + n) = pack4(v[0], v[1], v[2], v[3]);
+                    const uint2 k2 = *reinterpret_cast<const uint2*>(p.mask + m * p.ldmask + n);
+                    v[0] = (k2.x & 0x7fffu) ? v[0] * p.mscale : 0.f;
+                    v[1] = (k2.x & 0x7fff0000u) ? v[1] * p.mscale : 0.f;
+                    v[2] = (k2.y & 0x7fffu) ? v[2] * p.mscale : 0.f;
+                    v[3] = (k2.y & 0x7fff0000u) ? v[3] * p.mscale : 0.f;
+                    *reinterpret_cast<uint2*>(p.out2 + m * p.ldo2 + n) = pack4(v[0], v[1], v[2], v[3]);
+                } else {
+                    if (p.act == CACT_RELU) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                } else if (p.act == CACT_ELU) {
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    } else if (p.act == CACT_ELU) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : expm1f(v[e]);
+                        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : expm1f(v[e]);
+                    }
+                    if (MODE == CONV_TRAIN_FWD) {
+                        if (p.drop_thr) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = drop_keep(m, n + e, p.drop_key, p.drop_thr) ? v[e] * p.drop_scale : 0.f;
+                        }
+                        if (p.out2) *reinterpret_cast<uint2*>(p.out2 + m * p.ldo2 + n) = pack4(v[0], v[1], v[2], v[3]);
+                    }
+                    if (p.add) {
+                        const uint2 r2 = *reinterpret_cast<const uint2*>(p.add + m * p.ldadd + n);
+                        v[0] += bf2f((u16)(r2.x & 0xffff)); v[1] += bf2f((u16)(r2.x >> 16));
+                        v[2] += bf2f((u16)(r2.y & 0xffff)); v[3] += bf2f((u16)(r2.y >> 16));
+                    }
+                    *reinterpret_cast<uint2*>(p.out + m * p.ldo + n) = pack4(v[0], v[1], v[2], v[3]);
                 }
-                if (p.add) {
-                    const uint2 r2 = *reinterpret_cast<const uint2*>(p.add + m * p.ldadd + n);
-                    v[0] += bf2f((u16)(r2.x & 0xffff)); v[1] += bf2f((u16)(r2.x >> 16));
-                    v[2] += bf2f((u16)(r2.y & 0xffff)); v[3] += bf2f((u16)(r2.y >> 16));
-                }
-                *reinterpret_cast<uint2*>(p.out + m * p.ldo + n) = pack4(v[0], v[1], v[2], v[3]);
             }
         }
     }
@@ -127,14 +167,15 @@ __global__ __launch_bounds__(256) void k_conv_nt(const ConvNT p) {
 // (n,124) flat inputs (or materialised (n,60,6)) -> channels-last bf16 rows [n*60][64]:
 // ch0 = state_t[l], ch1 = state_q0001[l], ch2..5 = the four scalars broadcast over the levels
 // (data_utils.reshape_input_for_cnn, data_utils.py:1692-1712), zero padding beyond.
-__global__ __launch_bounds__(256) void k_cnn_input(const float* __restrict__ x, int layout3d, int64_t n_rows, int64_t m_pad,
-                                                   int seq, u16* __restrict__ a0, int lda) {
+__global__ __launch_bounds__(256) void k_cnn_input(const float* __restrict__ x, const int64_t* __restrict__ row_idx, int layout3d,
+                                                   int64_t n_rows, int64_t m_pad, int seq, u16* __restrict__ a0, int lda) {
     const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= m_pad) return;
     float c[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (m < n_rows) {
-        const int64_t b = m / seq;
-        const int l = (int)(m - b * seq);
+        const int64_t bb = m / seq;
+        const int l = (int)(m - bb * seq);
+        const int64_t b = row_idx ? row_idx[bb] : bb;
         if (layout3d) {
             const float* r = x + (b * seq + l) * 6;
 #pragma unroll

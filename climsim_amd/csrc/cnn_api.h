@@ -1,30 +1,156 @@
-// C-ABI of the level-axis CNN (forward / prediction path; training is the next step of §8 a12-a14).
+// C-ABI of the level-axis CNN: prediction, evaluation and training.
 #pragma once
-#include "cnn.h"
+#include "cnn_train.h"
 
 struct CnnConv {
     int cin, cin_p, cout, taps;
-    u16* W;            // packed bf16 [512][taps*cin_p] (or [128][...] for the 10-channel conv)
-    float* bias;       // fp32, zero padded to the tile multiple
+    u16* W;            // forward pack, bf16 [n_pad][taps*cin_p]
+    float* bias;       // fp32 copy, zero padded to n_pad
     int n_pad;
+    int64_t w_off, b_off;              // offsets of kernel / bias in the flat Keras-order buffers
+    u16* Wd; int ldd, kpd, slot0;      // data-gradient pack this kernel is written into (training), or null
 };
+struct CnnBlockBufs { u16 *A1, *A2, *XS, *DZ1, *DZ2, *GG; };
 
 struct cs_cnn {
     cs_cnn_cfg cfg;
     int64_t m_pad_max = 0, n_params = 0;
-    std::vector<CnnConv> convs;      // per block: a, r, b ; then the 10-channel conv
-    u16 *A0 = nullptr, *X = nullptr, *A1 = nullptr, *R = nullptr, *XN = nullptr, *O10 = nullptr;
+    std::vector<CnnConv> convs;      // per block: a, b, r ; then the 10-channel conv
+    u16 *A0 = nullptr, *X = nullptr, *A1 = nullptr, *R = nullptr, *XN = nullptr, *O10 = nullptr, *DZO = nullptr;
     float *wd = nullptr, *bd = nullptr;  // fused heads: [10][10], [10]
+    float *P = nullptr, *M = nullptr, *V = nullptr, *G = nullptr, *G_own = nullptr;
+    CnnSeg* seg_dev = nullptr; int n_seg = 0;
+    ConvWgradItem* items_dev = nullptr; int n_items = 0, total_tiles = 0;
+    std::vector<CnnBlockBufs> blk;
+    std::vector<u16*> Wd_a, Wd_b;    // per block data-gradient packs: [512][4*cp] (a flipped + r), [512][3*cp]
+    u16* Wd_o = nullptr;             // [512][64]
+    int64_t off_wl = 0, off_bl = 0, off_wr = 0, off_br = 0;
+    int64_t iterations = 0, drop_calls = 0;
+    bool grads_dirty = false;
     std::vector<void*> allocs;
 };
 
 namespace {
 constexpr int CNN_CP = 512;          // activation row pitch / padded output channels of the wide convs
-inline u16 host_f2bf(float f) {
-    unsigned u; memcpy(&u, &f, 4);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (u16)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (u16)(u >> 16);
+constexpr int CNN_A0_LD = 128;       // pitch of the 6-channel input rows
+inline unsigned host_lowbias32(unsigned x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+
+int cnn_upload_items(cs_cnn* h) {
+    std::vector<ConvWgradItem> it;
+    const int C = h->cfg.channels, depth = h->cfg.depth;
+    int tiles = 0;
+    auto push = [&](const u16* H, int ldh, int shift, const u16* Z, int ldz, float* dW, int n_pitch, int k_real, int n_real, float* db) {
+        ConvWgradItem w{};
+        w.H = H; w.ldh = ldh; w.shift = shift; w.Z = Z; w.ldz = ldz; w.dW = dW; w.n_pitch = n_pitch; w.k_real = k_real; w.n_real = n_real;
+        w.db = db; w.tiles_k = (k_real + 127) / 128; w.tiles_n = (n_real + 127) / 128; w.wg_begin = tiles;
+        tiles += w.tiles_k * w.tiles_n;
+        it.push_back(w);
+    };
+    for (int b = 0; b < depth; ++b) {
+        const CnnConv &ca = h->convs[3 * b], &cb = h->convs[3 * b + 1], &cr = h->convs[3 * b + 2];
+        const u16* xin = b == 0 ? h->A0 : h->blk[b - 1].XS;
+        const int ldx = b == 0 ? CNN_A0_LD : CNN_CP;
+        for (int t = 0; t < 3; ++t)
+            push(xin, ldx, t - 1, h->blk[b].DZ1, CNN_CP, h->G + ca.w_off + (int64_t)t * ca.cin * C, C, ca.cin, C, t == 1 ? h->G + ca.b_off : nullptr);
+        for (int t = 0; t < 3; ++t)
+            push(h->blk[b].A1, CNN_CP, t - 1, h->blk[b].DZ2, CNN_CP, h->G + cb.w_off + (int64_t)t * C * C, C, C, C, t == 1 ? h->G + cb.b_off : nullptr);
+        push(xin, ldx, 0, h->blk[b].GG, CNN_CP, h->G + cr.w_off, C, cr.cin, C, h->G + cr.b_off);
+    }
+    const CnnConv& co = h->convs.back();
+    push(h->blk[depth - 1].XS, CNN_CP, 0, h->DZO, 128, h->G + co.w_off, co.cout, C, co.cout, h->G + co.b_off);
+    h->n_items = (int)it.size();
+    h->total_tiles = tiles;
+    HIP_TRY(hipMemcpy(h->items_dev, it.data(), it.size() * sizeof(ConvWgradItem), hipMemcpyHostToDevice));
+    return CS_OK;
+}
+
+int cnn_launch_optimizer(cs_cnn* h, float lr, float grad_scale, bool recast_only, hipStream_t st) {
+    CnnOptArgs a{};
+    a.P = h->P; a.M = h->M; a.V = h->V; a.G = h->G; a.n = h->n_params; a.seg = h->seg_dev; a.n_seg = h->n_seg;
+    a.kind = h->cfg.optimizer; a.lr = lr; a.grad_scale = grad_scale; a.recast_only = recast_only ? 1 : 0;
+    // float32 scalars cast where TensorFlow casts them (see launch_optimizer of the MLP engine)
+    const float b1 = (float)h->cfg.beta1, b2 = (float)h->cfg.beta2;
+    const float t = (float)(h->iterations + 1);
+    a.omb1 = (float)(1.0 - h->cfg.beta1); a.omb2 = (float)(1.0 - h->cfg.beta2);
+    a.alpha = lr * sqrtf(1.f - powf(b2, t)) / (1.f - powf(b1, t));
+    a.eps = (float)h->cfg.eps;
+    hipLaunchKernelGGL(k_cnn_optimizer, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, st, a);
+    HIP_TRY(hipGetLastError());
+    return CS_OK;
+}
+
+void cnn_fill_conv(const cs_cnn* h, ConvArgs& p, const CnnConv& c, const u16* in, int ld_in, int64_t m_rows) {
+    p.A0 = p.A1 = p.A2 = p.A3 = in;
+    if (c.taps == 3) { p.sh0 = -1; p.sh1 = 0; p.sh2 = 1; p.sh3 = 0; } else { p.sh0 = p.sh1 = p.sh2 = p.sh3 = 0; }
+    p.lda = ld_in; p.B = c.W; p.ldb = c.taps * c.cin_p; p.kpt = c.cin_p; p.taps = c.taps; p.seq = h->cfg.seq;
+    p.m_rows = m_rows; p.bias = c.bias;
+}
+
+// inference-mode conv (dropout is identity): out = act(conv(in)) (+ add)
+void launch_conv(const cs_cnn* h, const CnnConv& c, const u16* in, int ld_in, int act, const u16* add, u16* out,
+                 int ld_out, int64_t m_rows, int64_t m_pad, hipStream_t st) {
+    ConvArgs p{};
+    cnn_fill_conv(h, p, c, in, ld_in, m_rows);
+    p.act = act; p.add = add; p.ldadd = CNN_CP; p.out = out; p.ldo = ld_out;
+    hipLaunchKernelGGL((k_conv<CONV_PREDICT>), dim3((unsigned)(m_pad / 128), (unsigned)(c.n_pad / 128)), dim3(256), 0, st, p);
+}
+
+// training-mode conv: out2 = dropout(act(conv(in))), out = out2 + add
+void launch_conv_train(const cs_cnn* h, const CnnConv& c, const u16* in, int ld_in, int layer, unsigned seed, const u16* add,
+                       u16* out, u16* out2, int64_t m_rows, int64_t m_pad, hipStream_t st) {
+    ConvArgs p{};
+    cnn_fill_conv(h, p, c, in, ld_in, m_rows);
+    p.act = CACT_RELU; p.add = add; p.ldadd = CNN_CP; p.out = out; p.ldo = CNN_CP; p.out2 = out2; p.ldo2 = CNN_CP;
+    p.drop_key = host_lowbias32(seed + 0x9e3779b9u * (unsigned)(layer + 1));
+    p.drop_thr = (unsigned)(h->cfg.dropout * 16777216.0);
+    p.drop_scale = 1.f / (1.f - (float)h->cfg.dropout);
+    hipLaunchKernelGGL((k_conv<CONV_TRAIN_FWD>), dim3((unsigned)(m_pad / 128), (unsigned)(c.n_pad / 128)), dim3(256), 0, st, p);
+}
+
+// data gradient: g = sum_slots A_s[m+sh_s] * Wd ; out (raw g, optional) ; out2 = g * (mask != 0) * mscale
+void launch_conv_bwd(const cs_cnn* h, const u16* dz3, const u16* g1, int lda, int kpt, const u16* Wd, int slots, const u16* mask,
+                     u16* out, u16* out2, int64_t m_rows, int64_t m_pad, hipStream_t st) {
+    ConvArgs p{};
+    p.A0 = p.A1 = p.A2 = dz3; p.A3 = g1;
+    if (slots == 1) { p.sh0 = p.sh1 = p.sh2 = p.sh3 = 0; } else { p.sh0 = -1; p.sh1 = 0; p.sh2 = 1; p.sh3 = 0; }
+    p.lda = lda; p.B = Wd; p.ldb = slots * kpt; p.kpt = kpt; p.taps = slots; p.seq = h->cfg.seq; p.m_rows = m_rows;
+    p.out = out; p.ldo = CNN_CP; p.out2 = out2; p.ldo2 = CNN_CP; p.mask = mask; p.ldmask = CNN_CP;
+    p.mscale = h->cfg.dropout > 0 ? 1.f / (1.f - (float)h->cfg.dropout) : 1.f;
+    hipLaunchKernelGGL((k_conv<CONV_BWD>), dim3((unsigned)(m_pad / 128), (unsigned)(CNN_CP / 128)), dim3(256), 0, st, p);
+}
+
+int cnn_check_batch(const cs_cnn* h, int64_t n) {
+    if (!h) return fail(CS_ERR_INVALID, "null handle");
+    if (n <= 0 || n > h->cfg.max_batch) return fail(CS_ERR_INVALID, "n=%lld outside 1..max_batch=%d", (long long)n, h->cfg.max_batch);
+    return CS_OK;
+}
+
+// inference-mode trunk: leaves the ELU'd 10-channel rows in O10
+void cnn_trunk_predict(cs_cnn* h, const float* x_dev, const int64_t* row_idx, int layout3d, int64_t n, hipStream_t st) {
+    const int seq = h->cfg.seq;
+    const int64_t m_rows = n * seq, m_pad = round_up(m_rows, 128);
+    hipLaunchKernelGGL(k_cnn_input, dim3((unsigned)((m_pad + 255) / 256)), dim3(256), 0, st, x_dev, row_idx, layout3d, m_rows, m_pad,
+                       seq, h->A0, CNN_A0_LD);
+    const u16* x = h->A0;
+    int ldx = CNN_A0_LD;
+    u16 *X = h->X, *XN = h->XN;
+    for (int b = 0; b < h->cfg.depth; ++b) {
+        const CnnConv &ca = h->convs[3 * b], &cb = h->convs[3 * b + 1], &cr = h->convs[3 * b + 2];
+        launch_conv(h, ca, x, ldx, CACT_RELU, nullptr, h->A1, CNN_CP, m_rows, m_pad, st);
+        launch_conv(h, cr, x, ldx, CACT_NONE, nullptr, h->R, CNN_CP, m_rows, m_pad, st);
+        launch_conv(h, cb, h->A1, CNN_CP, CACT_RELU, h->R, XN, CNN_CP, m_rows, m_pad, st);
+        x = XN; ldx = CNN_CP;
+        std::swap(X, XN);
+    }
+    launch_conv(h, h->convs.back(), x, ldx, CACT_ELU, nullptr, h->O10, 128, m_rows, m_pad, st);
+}
+
+void cnn_loss_factors(const cs_cnn* h, float& f_p, float& f_s) {
+    f_p = (float)((120.0 / 128.0) / h->cfg.n_lin);
+    f_s = (float)((8.0 / 128.0) / (10 - h->cfg.n_lin));
 }
 }  // namespace
 
@@ -36,9 +162,16 @@ int cs_cnn_create(cs_cnn_t** out, const cs_cnn_cfg* cfg) {
     if (cfg->depth < 1 || cfg->depth > 64) return fail(CS_ERR_INVALID, "depth out of range");
     if (cfg->channels < 1 || cfg->channels > 448) return fail(CS_ERR_INVALID, "channels must be 1..448");
     if (cfg->kernel != 3) return fail(CS_ERR_INVALID, "only kernel width 3 is supported");
-    if (cfg->seq < 1 || cfg->seq > 64 || cfg->c_in != 6 || cfg->c_out != 10 || cfg->n_lin < 0 || cfg->n_lin > 10)
-        return fail(CS_ERR_INVALID, "expects 6 input channels, 10 output channels, <= 64 levels");
+    if (cfg->seq < 1 || cfg->seq > 64 || cfg->c_in != 6 || cfg->c_out != 10 || cfg->n_lin < 1 || cfg->n_lin > 9)
+        return fail(CS_ERR_INVALID, "expects 6 input channels, 10 output channels (1..9 linear), <= 64 levels");
     if (cfg->max_batch <= 0) return fail(CS_ERR_INVALID, "max_batch must be positive");
+    if (cfg->train) {
+        if (cfg->optimizer != CS_OPT_ADAM && cfg->optimizer != CS_OPT_SGD) return fail(CS_ERR_INVALID, "CNN optimizer must be Adam or SGD");
+        if (cfg->loss != CNN_LOSS_MAE && cfg->loss != CNN_LOSS_MSE) return fail(CS_ERR_INVALID, "unknown loss %d", cfg->loss);
+        if (!(cfg->dropout >= 0.0 && cfg->dropout < 1.0)) return fail(CS_ERR_INVALID, "dropout rate must be in [0,1)");
+        if (!(cfg->beta1 >= 0 && cfg->beta1 < 1 && cfg->beta2 >= 0 && cfg->beta2 < 1 && cfg->eps > 0))
+            return fail(CS_ERR_INVALID, "bad Adam hyper-parameters");
+    }
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (cfg->device < 0 || cfg->device >= ndev) return fail(CS_ERR_INVALID, "device %d not in 0..%d", cfg->device, ndev - 1);
@@ -46,23 +179,31 @@ int cs_cnn_create(cs_cnn_t** out, const cs_cnn_cfg* cfg) {
     cs_cnn* h = new cs_cnn();
     h->cfg = *cfg;
     h->m_pad_max = round_up((int64_t)cfg->max_batch * cfg->seq, 128);
-    const int C = cfg->channels, cp = (int)round_up(C, 64);
+    const int C = cfg->channels, cp = (int)round_up(C, 64), depth = cfg->depth;
+    const bool train = cfg->train != 0;
     std::vector<std::pair<void**, size_t>> req;
     auto A = [&](void** p, size_t b) { req.emplace_back(p, (size_t)round_up((int64_t)b, 4096)); };
     int64_t np = 0;
     auto add_conv = [&](int cin, int cin_p, int cout, int taps, int n_pad) {
-        CnnConv c{cin, cin_p, cout, taps, nullptr, nullptr, n_pad};
+        CnnConv c{};
+        c.cin = cin; c.cin_p = cin_p; c.cout = cout; c.taps = taps; c.n_pad = n_pad;
+        c.w_off = np; np += (int64_t)taps * cin * cout;
+        c.b_off = np; np += cout;
         h->convs.push_back(c);
-        np += (int64_t)taps * cin * cout + cout;
     };
-    for (int b = 0; b < cfg->depth; ++b) {
+    // Keras creates (and orders) the layers of a block as conv a, conv b, residual projection
+    for (int b = 0; b < depth; ++b) {
         const int cin = b == 0 ? cfg->c_in : C, cin_p = b == 0 ? 64 : cp;
-        add_conv(cin, cin_p, C, 3, CNN_CP);    // first conv of the block
-        add_conv(C, cp, C, 3, CNN_CP);         // second conv
-        add_conv(cin, cin_p, C, 1, CNN_CP);    // residual projection
+        add_conv(cin, cin_p, C, 3, CNN_CP);
+        add_conv(C, cp, C, 3, CNN_CP);
+        add_conv(cin, cin_p, C, 1, CNN_CP);
     }
     add_conv(C, cp, cfg->c_out, 1, 128);
-    np += 10 * cfg->n_lin + cfg->n_lin + 10 * (10 - cfg->n_lin) + (10 - cfg->n_lin);
+    const int nl = cfg->n_lin, nr = 10 - nl;
+    h->off_wl = np; np += 10 * nl;
+    h->off_bl = np; np += nl;
+    h->off_wr = np; np += 10 * nr;
+    h->off_br = np; np += nr;
     h->n_params = np;
     for (auto& c : h->convs) {
         A((void**)&c.W, sizeof(u16) * c.n_pad * c.taps * c.cin_p);
@@ -70,9 +211,29 @@ int cs_cnn_create(cs_cnn_t** out, const cs_cnn_cfg* cfg) {
     }
     A((void**)&h->wd, sizeof(float) * 100);
     A((void**)&h->bd, sizeof(float) * 16);
-    A((void**)&h->A0, sizeof(u16) * h->m_pad_max * 64);
+    A((void**)&h->A0, sizeof(u16) * h->m_pad_max * CNN_A0_LD);
     A((void**)&h->O10, sizeof(u16) * h->m_pad_max * 128);
     for (u16** b : {&h->X, &h->A1, &h->R, &h->XN}) A((void**)b, sizeof(u16) * h->m_pad_max * CNN_CP);
+    A((void**)&h->P, sizeof(float) * np);
+    h->n_seg = (int)h->convs.size() * 2 + 4;
+    A((void**)&h->seg_dev, sizeof(CnnSeg) * h->n_seg);
+    if (train) {
+        A((void**)&h->M, sizeof(float) * np);
+        A((void**)&h->V, sizeof(float) * np);
+        A((void**)&h->G_own, sizeof(float) * np);
+        A((void**)&h->DZO, sizeof(u16) * h->m_pad_max * 128);
+        A((void**)&h->items_dev, sizeof(ConvWgradItem) * (7 * depth + 1));
+        h->blk.resize(depth);
+        h->Wd_a.assign(depth, nullptr);
+        h->Wd_b.assign(depth, nullptr);
+        for (int b = 0; b < depth; ++b) {
+            for (u16** t : {&h->blk[b].A1, &h->blk[b].A2, &h->blk[b].XS, &h->blk[b].DZ1, &h->blk[b].DZ2, &h->blk[b].GG})
+                A((void**)t, sizeof(u16) * h->m_pad_max * CNN_CP);
+            if (b > 0) A((void**)&h->Wd_a[b], sizeof(u16) * CNN_CP * 4 * cp);
+            A((void**)&h->Wd_b[b], sizeof(u16) * CNN_CP * 3 * cp);
+        }
+        A((void**)&h->Wd_o, sizeof(u16) * CNN_CP * 64);
+    }
     size_t total = 65536;
     for (auto& r : req) total += r.second;
     char* arena = nullptr;
@@ -81,6 +242,38 @@ int cs_cnn_create(cs_cnn_t** out, const cs_cnn_cfg* cfg) {
     if (hipMemset(arena, 0, total) != hipSuccess) { (void)hipFree(arena); delete h; return fail(CS_ERR_HIP, "hipMemset failed"); }
     size_t at = 0;
     for (auto& r : req) { *r.first = arena + at; at += r.second; }
+    h->G = h->G_own;
+    // segment table of the flat Keras-order buffers
+    std::vector<CnnSeg> segs;
+    for (size_t i = 0; i < h->convs.size(); ++i) {
+        CnnConv& c = h->convs[i];
+        if (train) {
+            const int b = (int)(i / 3), role = (int)(i % 3);
+            if (i + 1 == h->convs.size()) { c.Wd = h->Wd_o; c.ldd = 64; c.kpd = 64; c.slot0 = 0; }
+            else if (role == 1) { c.Wd = h->Wd_b[b]; c.ldd = 3 * cp; c.kpd = cp; c.slot0 = 0; }
+            else if (b > 0) { c.Wd = h->Wd_a[b]; c.ldd = 4 * cp; c.kpd = cp; c.slot0 = role == 0 ? 0 : 3; }
+        }
+        CnnSeg w{};
+        w.off = c.w_off; w.size = (int64_t)c.taps * c.cin * c.cout; w.kind = 0; w.cin = c.cin; w.cout = c.cout; w.taps = c.taps;
+        w.Wf = c.W; w.ldf = c.taps * c.cin_p; w.kpf = c.cin_p;
+        w.Wd = c.Wd; w.ldd = c.ldd; w.kpd = c.kpd; w.slot0 = c.slot0; w.flip = c.taps == 3 ? 1 : 0;
+        segs.push_back(w);
+        CnnSeg bs{};
+        bs.off = c.b_off; bs.size = c.cout; bs.kind = 1; bs.dst = c.bias;
+        segs.push_back(bs);
+    }
+    {
+        CnnSeg s{};
+        s.off = h->off_wl; s.size = 10 * nl; s.kind = 2; s.dst = h->wd; s.dst_off = 0; s.ncols = nl; segs.push_back(s);
+        s.off = h->off_bl; s.size = nl; s.kind = 3; s.dst = h->bd; s.dst_off = 0; s.ncols = nl; segs.push_back(s);
+        s.off = h->off_wr; s.size = 10 * nr; s.kind = 2; s.dst = h->wd; s.dst_off = nl; s.ncols = nr; segs.push_back(s);
+        s.off = h->off_br; s.size = nr; s.kind = 3; s.dst = h->bd; s.dst_off = nl; s.ncols = nr; segs.push_back(s);
+    }
+    if (hipMemcpy(h->seg_dev, segs.data(), segs.size() * sizeof(CnnSeg), hipMemcpyHostToDevice) != hipSuccess) {
+        cs_cnn_destroy(h);
+        return fail(CS_ERR_HIP, "segment table upload failed");
+    }
+    if (train && cnn_upload_items(h) != CS_OK) { cs_cnn_destroy(h); return CS_ERR_HIP; }
     *out = h;
     return CS_OK;
 }
@@ -99,72 +292,166 @@ int cs_cnn_set_weights(cs_cnn_t* h, const float* host, int64_t n, void* stream) 
     if (!h || !host) return fail(CS_ERR_INVALID, "null argument");
     if (n != h->n_params) return fail(CS_ERR_INVALID, "expected %lld floats, got %lld", (long long)h->n_params, (long long)n);
     hipStream_t st = (hipStream_t)stream;
-    const float* src = host;
-    // Keras creates the layers in the order a, b, r; the engine stores them a, b, r as well
-    for (size_t i = 0; i < h->convs.size(); ++i) {
-        CnnConv& c = h->convs[i];
-        const int kw = c.taps * c.cin_p;
-        std::vector<u16> w((size_t)c.n_pad * kw, 0);
-        std::vector<float> b((size_t)c.n_pad, 0.f);
-        for (int t = 0; t < c.taps; ++t)
-            for (int ci = 0; ci < c.cin; ++ci)
-                for (int co = 0; co < c.cout; ++co)
-                    w[(size_t)co * kw + t * c.cin_p + ci] = host_f2bf(src[((size_t)t * c.cin + ci) * c.cout + co]);
-        src += (size_t)c.taps * c.cin * c.cout;
-        for (int co = 0; co < c.cout; ++co) b[co] = src[co];
-        src += c.cout;
-        HIP_TRY(hipMemcpyAsync(c.W, w.data(), w.size() * sizeof(u16), hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemcpyAsync(c.bias, b.data(), b.size() * sizeof(float), hipMemcpyHostToDevice, st));
-        HIP_TRY(hipStreamSynchronize(st));
-    }
-    const int nl = h->cfg.n_lin, nr = 10 - nl;
-    float wd[100], bd[16] = {0};
-    const float* wl = src; const float* bl = wl + 10 * nl; const float* wr = bl + nl; const float* br = wr + 10 * nr;
-    for (int c = 0; c < 10; ++c) {
-        for (int j = 0; j < nl; ++j) wd[c * 10 + j] = wl[c * nl + j];
-        for (int j = 0; j < nr; ++j) wd[c * 10 + nl + j] = wr[c * nr + j];
-    }
-    for (int j = 0; j < nl; ++j) bd[j] = bl[j];
-    for (int j = 0; j < nr; ++j) bd[nl + j] = br[j];
-    HIP_TRY(hipMemcpyAsync(h->wd, wd, sizeof wd, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(h->bd, bd, sizeof bd, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(h->P, host, sizeof(float) * n, hipMemcpyHostToDevice, st));
+    int rc = cnn_launch_optimizer(h, 0.f, 0.f, true, st);
+    if (rc != CS_OK) return rc;
     HIP_TRY(hipStreamSynchronize(st));
     return CS_OK;
 }
 
-static int launch_conv(const cs_cnn* h, const CnnConv& c, const u16* in, int ld_in, int act, const u16* add, u16* out,
-                       int ld_out, int64_t m_rows, int64_t m_pad, hipStream_t st) {
-    ConvNT p{};
-    p.A = in; p.lda = ld_in; p.B = c.W; p.ldb = c.taps * c.cin_p; p.cin_p = c.cin_p; p.taps = c.taps; p.seq = h->cfg.seq;
-    p.m_rows = m_rows; p.N = c.n_pad; p.bias = c.bias; p.act = act; p.add = add; p.ldadd = CNN_CP; p.out = out; p.ldo = ld_out;
-    hipLaunchKernelGGL(k_conv_nt, dim3((unsigned)(m_pad / 128), (unsigned)(c.n_pad / 128)), dim3(256), 0, st, p);
+int cs_cnn_get_weights(cs_cnn_t* h, float* host, int64_t n, void* stream) {
+    if (!h || !host) return fail(CS_ERR_INVALID, "null argument");
+    if (n != h->n_params) return fail(CS_ERR_INVALID, "expected %lld floats, got %lld", (long long)h->n_params, (long long)n);
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(host, h->P, sizeof(float) * n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return CS_OK;
+}
+
+int cs_cnn_get_opt_state(cs_cnn_t* h, float* host_m, float* host_v, int64_t n, int64_t* iterations, void* stream) {
+    if (!h || !host_m || !host_v) return fail(CS_ERR_INVALID, "null argument");
+    if (!h->cfg.train) return fail(CS_ERR_STATE, "handle was created without training state");
+    if (n != h->n_params) return fail(CS_ERR_INVALID, "expected %lld floats, got %lld", (long long)h->n_params, (long long)n);
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(host_m, h->M, sizeof(float) * n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(host_v, h->V, sizeof(float) * n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (iterations) *iterations = h->iterations;
+    return CS_OK;
+}
+
+int cs_cnn_set_opt_state(cs_cnn_t* h, const float* host_m, const float* host_v, int64_t n, int64_t iterations, void* stream) {
+    if (!h || !host_m || !host_v) return fail(CS_ERR_INVALID, "null argument");
+    if (!h->cfg.train) return fail(CS_ERR_STATE, "handle was created without training state");
+    if (n != h->n_params) return fail(CS_ERR_INVALID, "expected %lld floats, got %lld", (long long)h->n_params, (long long)n);
+    if (iterations < 0) return fail(CS_ERR_INVALID, "negative iteration count");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(h->M, host_m, sizeof(float) * n, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(h->V, host_v, sizeof(float) * n, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    h->iterations = iterations;
     return CS_OK;
 }
 
 int cs_cnn_forward(cs_cnn_t* h, const float* x_dev, int layout3d, int64_t n, float* out3d_dev, float* out_flat_dev, void* stream) {
     if (!h || !x_dev) return fail(CS_ERR_INVALID, "null argument");
-    if (n <= 0 || n > h->cfg.max_batch) return fail(CS_ERR_INVALID, "n=%lld outside 1..max_batch=%d", (long long)n, h->cfg.max_batch);
+    int rc = cnn_check_batch(h, n);
+    if (rc != CS_OK) return rc;
     if (!out3d_dev && !out_flat_dev) return fail(CS_ERR_INVALID, "no output buffer");
     hipStream_t st = (hipStream_t)stream;
-    const int seq = h->cfg.seq;
-    const int64_t m_rows = n * seq, m_pad = round_up(m_rows, 128);
-    hipLaunchKernelGGL(k_cnn_input, dim3((unsigned)((m_pad + 255) / 256)), dim3(256), 0, st, x_dev, layout3d, m_rows, m_pad, seq, h->A0, 64);
-    const u16* x = h->A0;
-    int ldx = 64;
-    u16 *X = h->X, *XN = h->XN;
-    for (int b = 0; b < h->cfg.depth; ++b) {
-        const CnnConv &ca = h->convs[3 * b], &cb = h->convs[3 * b + 1], &cr = h->convs[3 * b + 2];
-        launch_conv(h, ca, x, ldx, CACT_RELU, nullptr, h->A1, CNN_CP, m_rows, m_pad, st);
-        launch_conv(h, cr, x, ldx, CACT_NONE, nullptr, h->R, CNN_CP, m_rows, m_pad, st);
-        launch_conv(h, cb, h->A1, CNN_CP, CACT_RELU, h->R, XN, CNN_CP, m_rows, m_pad, st);
-        x = XN; ldx = CNN_CP;
-        std::swap(X, XN);
-    }
-    launch_conv(h, h->convs.back(), x, ldx, CACT_ELU, nullptr, h->O10, 128, m_rows, m_pad, st);
-    hipLaunchKernelGGL(k_cnn_heads, dim3((unsigned)n), dim3(64), 0, st, h->O10, 128, h->wd, h->bd, h->cfg.n_lin, seq, n,
+    cnn_trunk_predict(h, x_dev, nullptr, layout3d, n, st);
+    hipLaunchKernelGGL(k_cnn_heads, dim3((unsigned)n), dim3(64), 0, st, h->O10, 128, h->wd, h->bd, h->cfg.n_lin, h->cfg.seq, n,
                        out3d_dev, out_flat_dev);
     HIP_TRY(hipGetLastError());
     return CS_OK;
+}
+
+int cs_cnn_evaluate(cs_cnn_t* h, const float* x_dev, int x3d, const float* y_dev, int y3d, const int64_t* row_idx_dev, int64_t n,
+                    float* loss_dev, int accumulate, void* stream) {
+    if (!h || !x_dev || !y_dev || !loss_dev) return fail(CS_ERR_INVALID, "null argument");
+    int rc = cnn_check_batch(h, n);
+    if (rc != CS_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (!accumulate) HIP_TRY(hipMemsetAsync(loss_dev, 0, 4 * sizeof(float), st));
+    cnn_trunk_predict(h, x_dev, row_idx_dev, x3d, n, st);
+    float f_p, f_s;
+    cnn_loss_factors(h, f_p, f_s);
+    hipLaunchKernelGGL(k_cnn_loss_heads, dim3((unsigned)n), dim3(64), 0, st, h->O10, 128, h->wd, h->bd, h->cfg.n_lin, h->cfg.seq, n,
+                       y_dev, row_idx_dev, y3d, 0, f_p, f_s, loss_dev, (u16*)nullptr, 0, (float*)nullptr, (float*)nullptr,
+                       (float*)nullptr, (float*)nullptr);
+    HIP_TRY(hipGetLastError());
+    return CS_OK;
+}
+
+int cs_cnn_loss_grads(cs_cnn_t* h, const float* x_dev, int x3d, const float* y_dev, int y3d, const int64_t* row_idx_dev, int64_t n,
+                      float* loss_dev, void* stream) {
+    if (!h || !x_dev || !y_dev || !loss_dev) return fail(CS_ERR_INVALID, "null argument");
+    if (!h->cfg.train) return fail(CS_ERR_STATE, "handle was created without training state");
+    int rc = cnn_check_batch(h, n);
+    if (rc != CS_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int seq = h->cfg.seq, depth = h->cfg.depth, cp = (int)round_up(h->cfg.channels, 64);
+    const int64_t m_rows = n * seq, m_pad = round_up(m_rows, 128);
+    const unsigned seed = (unsigned)((h->cfg.seed + (uint64_t)h->drop_calls) & 0xffffffffu);
+    h->drop_calls++;
+    HIP_TRY(hipMemsetAsync(loss_dev, 0, 4 * sizeof(float), st));
+    if (h->grads_dirty) HIP_TRY(hipMemsetAsync(h->G, 0, sizeof(float) * h->n_params, st));
+    h->grads_dirty = true;
+    // ---- forward, training mode
+    hipLaunchKernelGGL(k_cnn_input, dim3((unsigned)((m_pad + 255) / 256)), dim3(256), 0, st, x_dev, row_idx_dev, x3d, m_rows, m_pad,
+                       seq, h->A0, CNN_A0_LD);
+    const u16* x = h->A0;
+    int ldx = CNN_A0_LD;
+    for (int b = 0; b < depth; ++b) {
+        const CnnConv &ca = h->convs[3 * b], &cb = h->convs[3 * b + 1], &cr = h->convs[3 * b + 2];
+        CnnBlockBufs& B = h->blk[b];
+        launch_conv_train(h, ca, x, ldx, 2 * b, seed, nullptr, B.A1, nullptr, m_rows, m_pad, st);
+        launch_conv(h, cr, x, ldx, CACT_NONE, nullptr, h->R, CNN_CP, m_rows, m_pad, st);
+        launch_conv_train(h, cb, B.A1, CNN_CP, 2 * b + 1, seed, h->R, B.XS, B.A2, m_rows, m_pad, st);
+        x = B.XS; ldx = CNN_CP;
+    }
+    launch_conv(h, h->convs.back(), x, ldx, CACT_ELU, nullptr, h->O10, 128, m_rows, m_pad, st);
+    // ---- loss, heads backward
+    float f_p, f_s;
+    cnn_loss_factors(h, f_p, f_s);
+    hipLaunchKernelGGL(k_cnn_loss_heads, dim3((unsigned)n), dim3(64), 0, st, h->O10, 128, h->wd, h->bd, h->cfg.n_lin, seq, n, y_dev,
+                       row_idx_dev, y3d, h->cfg.loss, f_p, f_s, loss_dev, h->DZO, 128, h->G + h->off_wl, h->G + h->off_bl,
+                       h->G + h->off_wr, h->G + h->off_br);
+    // ---- data gradients, last block to first
+    launch_conv_bwd(h, h->DZO, h->DZO, 128, 64, h->Wd_o, 1, h->blk[depth - 1].A2, h->blk[depth - 1].GG, h->blk[depth - 1].DZ2,
+                    m_rows, m_pad, st);
+    for (int b = depth - 1; b >= 0; --b) {
+        CnnBlockBufs& B = h->blk[b];
+        launch_conv_bwd(h, B.DZ2, B.DZ2, CNN_CP, cp, h->Wd_b[b], 3, B.A1, nullptr, B.DZ1, m_rows, m_pad, st);
+        if (b > 0) launch_conv_bwd(h, B.DZ1, B.GG, CNN_CP, cp, h->Wd_a[b], 4, h->blk[b - 1].A2, h->blk[b - 1].GG, h->blk[b - 1].DZ2,
+                                   m_rows, m_pad, st);
+    }
+    // ---- weight gradients: one grouped launch
+    ConvWgradArgs wa{};
+    wa.items = h->items_dev; wa.n_items = h->n_items; wa.m_rows = m_rows; wa.m_pad = m_pad; wa.seq = seq;
+    const int steps = (int)(m_pad / 64);
+    int splitk = (1024 + h->total_tiles - 1) / h->total_tiles;
+    if (splitk > steps) splitk = steps;
+    if (splitk < 1) splitk = 1;
+    wa.splitk = splitk; wa.use_atomics = splitk > 1;
+    hipLaunchKernelGGL(k_conv_wgrad, dim3((unsigned)(h->total_tiles * splitk)), dim3(256), 0, st, wa);
+    HIP_TRY(hipGetLastError());
+    return CS_OK;
+}
+
+int cs_cnn_grad_buffer(cs_cnn_t* h, void** grad_dev, int64_t* n_floats) {
+    if (!h || !grad_dev || !n_floats) return fail(CS_ERR_INVALID, "null argument");
+    if (!h->cfg.train) return fail(CS_ERR_STATE, "handle was created without training state");
+    *grad_dev = h->G; *n_floats = h->n_params;
+    return CS_OK;
+}
+
+int cs_cnn_set_grad_buffer(cs_cnn_t* h, float* grad_dev, int64_t n_floats) {
+    if (!h) return fail(CS_ERR_INVALID, "null handle");
+    if (!h->cfg.train) return fail(CS_ERR_STATE, "handle was created without training state");
+    if (grad_dev && n_floats != h->n_params) return fail(CS_ERR_INVALID, "expected %lld floats, got %lld", (long long)h->n_params, (long long)n_floats);
+    HIP_TRY(hipDeviceSynchronize());
+    h->G = grad_dev ? grad_dev : h->G_own;
+    HIP_TRY(hipMemset(h->G, 0, sizeof(float) * h->n_params));
+    h->grads_dirty = false;
+    return cnn_upload_items(h);
+}
+
+int cs_cnn_apply(cs_cnn_t* h, float lr, float grad_scale, void* stream) {
+    if (!h) return fail(CS_ERR_INVALID, "null handle");
+    if (!h->cfg.train) return fail(CS_ERR_STATE, "handle was created without training state");
+    int rc = cnn_launch_optimizer(h, lr, grad_scale, false, (hipStream_t)stream);
+    if (rc != CS_OK) return rc;
+    h->iterations++;
+    h->grads_dirty = false;
+    return CS_OK;
+}
+
+int cs_cnn_train_step(cs_cnn_t* h, const float* x_dev, int x3d, const float* y_dev, int y3d, const int64_t* row_idx_dev, int64_t n,
+                      float lr, float* loss_dev, void* stream) {
+    int rc = cs_cnn_loss_grads(h, x_dev, x3d, y_dev, y3d, row_idx_dev, n, loss_dev, stream);
+    if (rc != CS_OK) return rc;
+    return cs_cnn_apply(h, lr, 1.f / (float)(n * h->cfg.seq), stream);
 }
 
 }  // extern "C"

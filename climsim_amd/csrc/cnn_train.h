@@ -1,0 +1,291 @@
+// Level-axis CNN - training kernels: loss + heads backward, grouped conv weight gradients, optimiser.
+// (Keras autodiff of CNNHyperModel.build, baseline_models/CNN/training/hpo_train.py:159-236, with the
+// losses of :114-121.)  The data-gradient GEMMs are k_conv<CONV_BWD> in cnn.h.
+//
+// Gradient scaling: every gradient tensor holds the gradient of
+//     S = sum_{b,l} [ f_p * sum_{j<n_lin} loss(e_j) + f_s * sum_{j>=n_lin} loss(e_j) ],
+//     f_p = (120/128)/n_lin,  f_s = (8/128)/(10-n_lin)        (both exact in bf16 for n_lin = 2)
+// so that mae_adjusted / mse_adjusted = S / (B*seq); the optimiser multiplies by 1/(B*seq*world).
+#pragma once
+#include "cnn.h"
+
+enum { CNN_LOSS_MAE = 0, CNN_LOSS_MSE = 1 };
+
+// One workgroup per column, one lane per level.  Recomputes the heads from the stored ELU output,
+// accumulates the four loss sums [sum|e| profiles, sum|e| scalars, sum e^2 profiles, sum e^2 scalars] and,
+// when dzo is given, the head gradients and dL/d(pre-ELU) rows (bf16, 16 channels written, 10 used).
+__global__ __launch_bounds__(64) void k_cnn_loss_heads(const u16* __restrict__ o10, int ld, const float* __restrict__ wd,
+                                                       const float* __restrict__ bd, int n_lin, int seq, int64_t n_cols,
+                                                       const float* __restrict__ y, const int64_t* __restrict__ row_idx, int y3d,
+                                                       int loss_kind, float f_p, float f_s, float* __restrict__ loss,
+                                                       u16* __restrict__ dzo, int lddz, float* __restrict__ g_wl,
+                                                       float* __restrict__ g_bl, float* __restrict__ g_wr, float* __restrict__ g_br) {
+    const int64_t b = blockIdx.x;
+    if (b >= n_cols) return;
+    const int l = threadIdx.x;
+    const bool live = l < seq;
+    float o[10], dy[10];
+    float s_ap = 0.f, s_as = 0.f, s_qp = 0.f, s_qs = 0.f;
+#pragma unroll
+    for (int j = 0; j < 10; ++j) { o[j] = 0.f; dy[j] = 0.f; }
+    if (live) {
+        const u16* r = o10 + (b * seq + l) * ld;
+#pragma unroll
+        for (int c = 0; c < 10; ++c) o[c] = bf2f(r[c]);
+        const int64_t yb = row_idx ? row_idx[b] : b;
+#pragma unroll
+        for (int j = 0; j < 10; ++j) {
+            float s = bd[j];
+#pragma unroll
+            for (int c = 0; c < 10; ++c) s += o[c] * wd[c * 10 + j];
+            const bool lin = j < n_lin;
+            const float pred = lin ? s : fmaxf(s, 0.f);
+            const float t = y3d ? y[(yb * seq + l) * 10 + j]
+                                : (j < 2 ? y[yb * (2 * seq + 8) + j * seq + l] : y[yb * (2 * seq + 8) + 2 * seq + (j - 2)]);
+            const float e = pred - t;
+            if (lin) { s_ap += fabsf(e); s_qp += e * e; } else { s_as += fabsf(e); s_qs += e * e; }
+            float g = loss_kind == CNN_LOSS_MAE ? (e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f)) : 2.f * e;
+            g *= lin ? f_p : f_s;
+            if (!lin && !(s > 0.f)) g = 0.f;
+            dy[j] = g;
+        }
+    }
+    s_ap = wave_sum(s_ap); s_as = wave_sum(s_as); s_qp = wave_sum(s_qp); s_qs = wave_sum(s_qs);
+    if (l == 0) { atomicAdd(loss + 0, s_ap); atomicAdd(loss + 1, s_as); atomicAdd(loss + 2, s_qp); atomicAdd(loss + 3, s_qs); }
+    if (!dzo) return;
+    if (live) {
+        float dz[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) dz[c] = 0.f;
+#pragma unroll
+        for (int c = 0; c < 10; ++c) {
+            float d = 0.f;
+#pragma unroll
+            for (int j = 0; j < 10; ++j) d += dy[j] * wd[c * 10 + j];
+            dz[c] = d * (o[c] > 0.f ? 1.f : o[c] + 1.f);          // ELU'(z) = 1 | exp(z) = elu(z) + 1
+        }
+        uint2* dst = reinterpret_cast<uint2*>(dzo + (b * seq + l) * lddz);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dst[q] = pack4(dz[4 * q], dz[4 * q + 1], dz[4 * q + 2], dz[4 * q + 3]);
+    }
+    const int n_relu = 10 - n_lin;
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {
+        const float gb = wave_sum(dy[j]);
+        if (l == 0) atomicAdd(j < n_lin ? g_bl + j : g_br + (j - n_lin), gb);
+#pragma unroll
+        for (int c = 0; c < 10; ++c) {
+            const float gw = wave_sum(o[c] * dy[j]);
+            if (l == 0) atomicAdd(j < n_lin ? g_wl + c * n_lin + j : g_wr + c * n_relu + (j - n_lin), gw);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- grouped conv weight gradients
+// dW[tap][ci][co] = sum_m X[m + tap - 1][ci] * dZ[m][co]  (rows whose shifted level leaves the column read
+// as zero), db[co] = sum_m dZ[m][co].  Every (conv, tap) of the step is one item of a device-resident
+// table; one launch covers them all: 128x128 output tiles x row splits, workgroups of one item adjacent
+// after the XCD remap so they share the operand rows in one L2.
+struct ConvWgradItem {
+    const u16* H; int ldh; int shift;
+    const u16* Z; int ldz;
+    float* dW; int n_pitch;          // fp32 [k_real][n_pitch] (Keras (tap, c_in, c_out) slice)
+    int k_real, n_real;
+    float* db;                       // [n_real] or null
+    int tiles_k, tiles_n, wg_begin;  // wg_begin counted in tiles (multiply by splitk)
+};
+struct ConvWgradArgs {
+    const ConvWgradItem* items; int n_items;
+    int64_t m_rows, m_pad;
+    int splitk, use_atomics, seq;
+};
+
+__global__ __launch_bounds__(256) void k_conv_wgrad(const ConvWgradArgs pa) {
+    __shared__ __attribute__((aligned(16))) u16 smem[2][2][64 * 128];   // [buffer][H|Z] = 64 KiB
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wk = wid >> 1, wn = wid & 1;
+    const int work = xcd_work_id(blockIdx.x, gridDim.x);
+    int lo = 0, hi = pa.n_items - 1;
+    while (lo < hi) {                       // last item with wg_begin*splitk <= work
+        const int mid = (lo + hi + 1) >> 1;
+        if (pa.items[mid].wg_begin * pa.splitk <= work) lo = mid; else hi = mid - 1;
+    }
+    const ConvWgradItem p = pa.items[lo];
+    const int rel = work - p.wg_begin * pa.splitk;
+    const int ntile = p.tiles_k * p.tiles_n;
+    const int split = rel / ntile, tile = rel - split * ntile;
+    const int k0 = (tile % p.tiles_k) * 128, n0 = (tile / p.tiles_k) * 128;
+    const int steps = (int)(pa.m_pad >> 6);
+    const int s_begin = (int)((int64_t)steps * split / pa.splitk);
+    const int s_end = (int)((int64_t)steps * (split + 1) / pa.splitk);
+    const int srow = tid >> 4, sc = (tid & 15) * 8;
+    const u16* Hg = p.H + k0 + sc;
+    const u16* Zg = p.Z + n0 + sc;
+    const int sh = p.shift, seq = pa.seq, linc = 64 % seq;
+    int lev0, lev1, lev2, lev3;
+    {
+        const int64_t r0 = (int64_t)s_begin * 64 + srow;
+        lev0 = (int)(r0 % seq); lev1 = (int)((r0 + 16) % seq); lev2 = (int)((r0 + 32) % seq); lev3 = (int)((r0 + 48) % seq);
+    }
+    uint4 rh0, rh1, rh2, rh3, rz0, rz1, rz2, rz3;
+    const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+#define CW_LOAD(dh, dz, i, lev)                                                                        \
+    {                                                                                                   \
+        const int64_t m = (int64_t)step_ * 64 + srow + 16 * (i);                                        \
+        const int ls = (lev) + sh;                                                                      \
+        const bool in = m < pa.m_rows;                                                                  \
+        dh = zero4; dz = zero4;                                                                         \
+        if (in) dz = *reinterpret_cast<const uint4*>(Zg + m * p.ldz);                                   \
+        if (in && ls >= 0 && ls < seq) dh = *reinterpret_cast<const uint4*>(Hg + (m + sh) * p.ldh);     \
+        lev += linc; if (lev >= seq) lev -= seq;                                                        \
+    }
+#define CW_GLOAD(step)                                                                                 \
+    {                                                                                                   \
+        const int step_ = (step);                                                                       \
+        CW_LOAD(rh0, rz0, 0, lev0) CW_LOAD(rh1, rz1, 1, lev1) CW_LOAD(rh2, rz2, 2, lev2) CW_LOAD(rh3, rz3, 3, lev3) \
+    }
+#define CW_SSTORE(buf)                                                                              \
+    *reinterpret_cast<uint4*>(&smem[buf][0][swz_tn(srow + 0, sc)]) = rh0;                           \
+    *reinterpret_cast<uint4*>(&smem[buf][0][swz_tn(srow + 16, sc)]) = rh1;                          \
+    *reinterpret_cast<uint4*>(&smem[buf][0][swz_tn(srow + 32, sc)]) = rh2;                          \
+    *reinterpret_cast<uint4*>(&smem[buf][0][swz_tn(srow + 48, sc)]) = rh3;                          \
+    *reinterpret_cast<uint4*>(&smem[buf][1][swz_tn(srow + 0, sc)]) = rz0;                           \
+    *reinterpret_cast<uint4*>(&smem[buf][1][swz_tn(srow + 16, sc)]) = rz1;                          \
+    *reinterpret_cast<uint4*>(&smem[buf][1][swz_tn(srow + 32, sc)]) = rz2;                          \
+    *reinterpret_cast<uint4*>(&smem[buf][1][swz_tn(srow + 48, sc)]) = rz3;
+    f32x16_t acc00, acc01, acc10, acc11;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc00[r] = 0.f; acc01[r] = 0.f; acc10[r] = 0.f; acc11[r] = 0.f; }
+    float bsum0 = 0.f, bsum1 = 0.f;
+    const bool do_bias = p.db && (k0 == 0) && (wk == 0);
+
+    if (s_begin < s_end) {
+        CW_GLOAD(s_begin)
+        CW_SSTORE(0)
+    }
+    __syncthreads();
+    for (int s = s_begin; s < s_end; ++s) {
+        const int buf = (s - s_begin) & 1;
+        if (s + 1 < s_end) { CW_GLOAD(s + 1) }
+        const u16* Hs = smem[buf][0];
+        const u16* Zs = smem[buf][1];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const bf16x8_t fh0 = load_frag_tn<true>(Hs, kk * 16, wk * 64, lane);
+            const bf16x8_t fh1 = load_frag_tn<true>(Hs, kk * 16, wk * 64 + 32, lane);
+            const bf16x8_t fz0 = load_frag_tn<true>(Zs, kk * 16, wn * 64, lane);
+            const bf16x8_t fz1 = load_frag_tn<true>(Zs, kk * 16, wn * 64 + 32, lane);
+            if (do_bias) {
+                union { bf16x8_t v; u16 s[8]; } u0, u1;
+                u0.v = fz0; u1.v = fz1;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { bsum0 += bf2f(u0.s[e]); bsum1 += bf2f(u1.s[e]); }
+            }
+            acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh0, fz0, acc00, 0, 0, 0);
+            acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh0, fz1, acc01, 0, 0, 0);
+            acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh1, fz0, acc10, 0, 0, 0);
+            acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh1, fz1, acc11, 0, 0, 0);
+        }
+        if (s + 1 < s_end) { CW_SSTORE(buf ^ 1) }
+        __syncthreads();
+    }
+#undef CW_LOAD
+#undef CW_GLOAD
+#undef CW_SSTORE
+    // D[i = k][j = n]: lane owns column n = ..+(lane&31), rows k = ..+(r&3)+8*(r>>2)+4*(lane>>5)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+            const f32x16_t& av = (i == 0) ? (j == 0 ? acc00 : acc01) : (j == 0 ? acc10 : acc11);
+            if (n < p.n_real) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int k = k0 + wk * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (k < p.k_real) {
+                        float* dst = p.dW + (int64_t)k * p.n_pitch + n;
+                        if (pa.use_atomics) atomicAdd(dst, av[r]); else *dst = av[r];
+                    }
+                }
+            }
+        }
+    if (do_bias) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float bj = j == 0 ? bsum0 : bsum1;
+            const float v = bj + __shfl_xor(bj, 32, 64);
+            const int n = n0 + wn * 64 + j * 32 + lane;
+            if (lane < 32 && n < p.n_real) {
+                if (pa.use_atomics) atomicAdd(p.db + n, v); else p.db[n] = v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- optimiser
+// Flat fp32 parameters / slots / gradients in KERAS order (so get/set_weights and the gradient
+// all-reduce are plain copies).  One thread per parameter: update (Adam of keras 2.10 with float32
+// scalars as in kernels.h, or SGD), zero the gradient, refresh the bf16 GEMM operands:
+//   forward pack  Wf[co][t*kpf + ci]
+//   data-grad pack Wd[ci][(slot0 + (flip ? taps-1-t : t))*kpd + co]     (tap-flipped transpose)
+// and the fp32 bias / head copies the kernels read.
+struct CnnSeg {
+    int64_t off, size;
+    int kind;                 // 0 conv kernel, 1 fp32 vector copy (conv bias), 2 head kernel, 3 head bias
+    int cin, cout, taps;
+    u16* Wf; int ldf, kpf;
+    u16* Wd; int ldd, kpd, slot0, flip;
+    float* dst; int dst_off, ncols;     // kind 1: dst[i]; kind 2: dst[c*10 + dst_off + j]; kind 3: dst[dst_off + j]
+};
+struct CnnOptArgs {
+    float *P, *M, *V, *G;
+    int64_t n;
+    const CnnSeg* seg; int n_seg;
+    int kind;                 // CS_OPT_ADAM (0) | CS_OPT_SGD (3)
+    float lr, grad_scale, omb1, omb2, alpha, eps;
+    int recast_only;
+};
+
+__global__ __launch_bounds__(256) void k_cnn_optimizer(const CnnOptArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    float w = a.P[i];
+    if (!a.recast_only) {
+        const float g = a.G[i] * a.grad_scale;
+        if (a.kind == 3) {
+            w -= a.lr * g;
+        } else {
+            float m = a.M[i], v = a.V[i];
+            m += (g - m) * a.omb1;
+            v += (g * g - v) * a.omb2;
+            w -= (m * a.alpha) / (sqrtf(v) + a.eps);
+            a.M[i] = m; a.V[i] = v;
+        }
+        a.P[i] = w;
+        a.G[i] = 0.f;
+    }
+    int lo = 0, hi = a.n_seg - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (a.seg[mid].off <= i) lo = mid; else hi = mid - 1;
+    }
+    const CnnSeg& s = a.seg[lo];
+    const int64_t rel = i - s.off;
+    if (s.kind == 0) {
+        const int per_tap = s.cin * s.cout;
+        const int t = (int)(rel / per_tap);
+        const int r2 = (int)(rel - (int64_t)t * per_tap);
+        const int ci = r2 / s.cout, co = r2 - ci * s.cout;
+        const u16 wb = f2bf(w);
+        s.Wf[(int64_t)co * s.ldf + t * s.kpf + ci] = wb;
+        if (s.Wd) s.Wd[(int64_t)ci * s.ldd + (s.slot0 + (s.flip ? s.taps - 1 - t : t)) * s.kpd + co] = wb;
+    } else if (s.kind == 1) {
+        s.dst[rel] = w;
+    } else if (s.kind == 2) {
+        const int c = (int)(rel / s.ncols), j = (int)(rel - (int64_t)c * s.ncols);
+        s.dst[c * 10 + s.dst_off + j] = w;
+    } else {
+        s.dst[s.dst_off + rel] = w;
+    }
+}

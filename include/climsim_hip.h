@@ -133,11 +133,15 @@ int cs_mlp_debug_stamps(cs_mlp_t* h, unsigned long long* host, int64_t n_words);
 int cs_normalise_rows(const float* x_dev, const int64_t* row_idx_dev, int64_t n, int32_t width,
                       const float* sub_dev, const float* div_dev, float* out_dev, void* stream);
 
-/* ---- level-axis 1-D CNN (baseline_models/CNN/training/hpo_train.py:124-200), prediction path ----
- * ResNet-style: depth x { Conv1D(C,3,'same')+ReLU, Conv1D(C,3,'same')+ReLU, + Conv1D(C,1)(block input) },
- * Conv1D(10,1)+ELU, per-level Dense(10->n_lin) || Dense(10->10-n_lin, relu).  Dropout is identity at
- * prediction time.  Weights in Keras order (kernels (k, c_in, c_out)).  Training entry points follow. */
+/* ---- level-axis 1-D CNN (baseline_models/CNN/training/hpo_train.py:124-236) ----
+ * ResNet-style: depth x { Conv1D(C,3,'same')+ReLU+Dropout, Conv1D(C,3,'same')+ReLU+Dropout, + Conv1D(C,1)(block input) },
+ * Conv1D(10,1)+ELU, per-level Dense(10->n_lin) || Dense(10->10-n_lin, relu).  Weights, optimiser slots and
+ * gradients are flat float32 buffers in Keras order (kernels (k, c_in, c_out); per block conv a, conv b,
+ * projection).  Inputs are (n,124) flat rows (x3d = 0; the reshape of data_utils.reshape_input_for_cnn,
+ * data_utils.py:1692-1712, happens in the first kernel) or (n,60,6) (x3d = 1); targets (n,128) flat
+ * (y3d = 0; reshape_target_for_cnn :1714-1738 applied on the fly) or (n,60,10) (y3d = 1). */
 typedef struct cs_cnn cs_cnn_t;
+typedef enum { CS_CNN_LOSS_MAE_ADJUSTED = 0, CS_CNN_LOSS_MSE_ADJUSTED = 1 } cs_cnn_loss_kind;   /* hpo_train.py:114-121 */
 typedef struct cs_cnn_cfg {
     int32_t depth;       /* hp_depth = 12            */
     int32_t channels;    /* hp_channel_width = 406   */
@@ -149,16 +153,41 @@ typedef struct cs_cnn_cfg {
     int32_t max_batch;   /* columns per call          */
     int32_t device;
     int32_t flags;
+    int32_t train;       /* 1: allocate activations, gradients and optimiser slots */
+    int32_t optimizer;   /* CS_OPT_ADAM | CS_OPT_SGD   (hpo_train.py:215-219)      */
+    int32_t loss;        /* cs_cnn_loss_kind; hp_loss "mean_absolute_error" -> mae_adjusted */
+    int32_t reserved;
+    double dropout;      /* hp_dropout = 0.175 */
+    double beta1, beta2, eps;   /* keras.optimizers.Adam defaults 0.9, 0.999, 1e-7 */
+    uint64_t seed;       /* dropout stream: call k of cs_cnn_loss_grads uses seed + k */
 } cs_cnn_cfg;
 int  cs_cnn_create(cs_cnn_t** out, const cs_cnn_cfg* cfg);            /* CNNHyperModel().build()   */
 void cs_cnn_destroy(cs_cnn_t* h);
 int64_t cs_cnn_num_params(const cs_cnn_t* h);                          /* model.count_params()      */
 int  cs_cnn_set_weights(cs_cnn_t* h, const float* host, int64_t n, void* stream);   /* model.set_weights */
-/* model.predict: x_dev is (n,124) flat rows (layout3d = 0; the reshape of data_utils.reshape_input_for_cnn
- * happens in the first kernel) or (n,60,6) (layout3d = 1).  Outputs: (n,60,10) f32 and/or the flat
- * (n,128) form of data_utils.reshape_target_from_cnn; either may be NULL. */
-int  cs_cnn_forward(cs_cnn_t* h, const float* x_dev, int layout3d, int64_t n, float* out3d_dev, float* out_flat_dev,
+int  cs_cnn_get_weights(cs_cnn_t* h, float* host, int64_t n, void* stream);         /* model.get_weights */
+int  cs_cnn_get_opt_state(cs_cnn_t* h, float* host_m, float* host_v, int64_t n, int64_t* iterations, void* stream);
+int  cs_cnn_set_opt_state(cs_cnn_t* h, const float* host_m, const float* host_v, int64_t n, int64_t iterations, void* stream);
+/* model.predict (dropout = identity).  Outputs: (n,60,10) f32 and/or the flat (n,128) form of
+ * data_utils.reshape_target_from_cnn (data_utils.py:1740-1761); either may be NULL. */
+int  cs_cnn_forward(cs_cnn_t* h, const float* x_dev, int x3d, int64_t n, float* out3d_dev, float* out_flat_dev,
                     void* stream);
+/* model.evaluate / validation pass: loss_dev[4] (+)= [sum|e| profile channels, sum|e| scalar channels,
+ * sum e^2 profile, sum e^2 scalar] over the n columns;  mae_adjusted = s0/(n*seq*n_lin)*(120/128) +
+ * s1/(n*seq*(10-n_lin))*(8/128), mse_adjusted likewise from s2, s3. */
+int  cs_cnn_evaluate(cs_cnn_t* h, const float* x_dev, int x3d, const float* y_dev, int y3d, const int64_t* row_idx_dev,
+                     int64_t n, float* loss_dev, int accumulate, void* stream);
+/* Training-mode forward (dropout on) + backward.  Gradients (of n*seq*loss, i.e. unscaled sums) overwrite
+ * the flat gradient buffer; loss_dev[4] as above. */
+int  cs_cnn_loss_grads(cs_cnn_t* h, const float* x_dev, int x3d, const float* y_dev, int y3d, const int64_t* row_idx_dev,
+                       int64_t n, float* loss_dev, void* stream);
+int  cs_cnn_grad_buffer(cs_cnn_t* h, void** grad_dev, int64_t* n_floats);     /* payload of the DP all-reduce */
+int  cs_cnn_set_grad_buffer(cs_cnn_t* h, float* grad_dev, int64_t n_floats);  /* bind a caller-owned buffer (NULL: own) */
+/* optimizer.apply_gradients: w -= update(grad_scale * G); grad_scale = 1/(n*seq*world_size); zeroes G. */
+int  cs_cnn_apply(cs_cnn_t* h, float lr, float grad_scale, void* stream);
+/* one Model.train_step of model.fit (hpo_train.py:231-236) */
+int  cs_cnn_train_step(cs_cnn_t* h, const float* x_dev, int x3d, const float* y_dev, int y3d, const int64_t* row_idx_dev,
+                       int64_t n, float lr, float* loss_dev, void* stream);
 
 const char* cs_last_error(void);
 const char* cs_version(void);

@@ -80,3 +80,113 @@ def mae_adjusted(y_true, y_pred):
 def mse_adjusted(y_true, y_pred):
     se = (y_pred - y_true) ** 2
     return float(se[:, :, 0:2].mean() * (120 / 128) + se[:, :, 2:10].mean() * (8 / 128))
+
+
+# ------------------------------------------------------------------------------------------------
+# Training path (hpo_train.py:159-236 model + :114-121 losses; Keras autodiff restated with torch
+# autograd on CPU).  PARITY UNPINNED like the forward: Keras' Dropout draws from TF's own random
+# stream, which no other implementation can reproduce; the engine and this oracle share a
+# counter-based hash instead (same Bernoulli(keep = 1-rate) law, same 1/keep scaling as
+# keras.layers.Dropout).
+# ------------------------------------------------------------------------------------------------
+ROW_PITCH = 512          # channel pitch of the engine's activation rows (element id = row*512 + channel)
+
+
+def lowbias32(x):
+    x = np.asarray(x, dtype=np.uint32).copy()
+    x ^= x >> np.uint32(16)
+    x *= np.uint32(0x7FEB352D)
+    x ^= x >> np.uint32(15)
+    x *= np.uint32(0x846CA68B)
+    x ^= x >> np.uint32(16)
+    return x
+
+
+def dropout_key(seed, layer):
+    """Per (step seed, dropout layer) key; layer = 2*block + {0: after conv a, 1: after conv b}."""
+    with np.errstate(over="ignore"):
+        return lowbias32(np.uint32(seed & 0xFFFFFFFF) + np.uint32(0x9E3779B9) * np.uint32(layer + 1))
+
+
+def dropout_keep(seed, layer, m_rows, channels, rate):
+    """Boolean keep mask (m_rows, channels): keep iff the top 24 hash bits >= floor(rate * 2^24)."""
+    m = np.arange(m_rows, dtype=np.uint64)[:, None]
+    n = np.arange(channels, dtype=np.uint64)[None, :]
+    with np.errstate(over="ignore"):
+        k = ((m * np.uint64(ROW_PITCH) + n) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        k ^= ((m >> np.uint64(23)).astype(np.uint32) * np.uint32(0x9E3779B9))
+        h = lowbias32(k ^ dropout_key(seed, layer))
+    return (h >> np.uint32(8)) >= np.uint32(int(rate * (1 << 24)))
+
+
+class _RoundGrad(torch.autograd.Function):
+    """Identity whose gradient is rounded to bfloat16 (a stored bf16 gradient tensor of the engine)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return torch.from_numpy(bf16_round(g.numpy()))
+
+
+def _st(t, bf16):
+    """Straight-through bf16 rounding of a stored activation."""
+    return t + (_q(t, True) - t).detach() if bf16 else t
+
+
+def _rg(t, bf16):
+    return _RoundGrad.apply(t) if bf16 else t
+
+
+def _tconv(x, w, b, bf16):
+    wq = _st(w, bf16).permute(2, 1, 0)
+    return F.conv1d(x.permute(0, 2, 1), wq, None, padding=w.shape[0] // 2).permute(0, 2, 1) + b
+
+
+def loss_and_grads(ws, x3, y3, depth=12, n_lin=2, loss="mae", rate=0.0, seed=0, bf16=False):
+    """One training-mode pass.  x3 (B,60,6), y3 (B,60,10) float32.
+    Returns (dict of loss values, list of gradients of the chosen loss in Keras weight order)."""
+    B, L, _ = x3.shape
+    P = [torch.from_numpy(np.ascontiguousarray(w, np.float32)).requires_grad_(True) for w in ws]
+    x = _q(torch.from_numpy(np.ascontiguousarray(x3, np.float32)), bf16)
+    keep_p = np.float32(1.0) - np.float32(rate)
+
+    def drop(t, layer):
+        if rate <= 0:
+            return t
+        C = t.shape[-1]
+        k = torch.from_numpy(dropout_keep(seed, layer, B * L, C, rate).reshape(B, L, C))
+        return torch.where(k, t * torch.tensor(np.float32(1.0) / keep_p), torch.zeros((), dtype=t.dtype))
+
+    i = 0
+    for blk in range(depth):
+        wa, ba, wb, bb, wr, br = P[i:i + 6]
+        i += 6
+        za = _rg(_tconv(x, wa, ba, bf16), bf16)                       # dz1 is stored bf16
+        a1 = _st(drop(torch.relu(za), 2 * blk), bf16)
+        r = _rg(_st(_tconv(x, wr, br, bf16), bf16), bf16)             # projection branch sees the stored bf16 g
+        zb = _rg(_tconv(a1, wb, bb, bf16), bf16)                      # dz2 = round(g_fp32 * mask / keep)
+        x = _st(drop(torch.relu(zb), 2 * blk + 1) + r, bf16)
+    wo, bo, wl, bl, wrel, brel = P[i:i + 6]
+    zo = _rg(_tconv(x, wo, bo, bf16), bf16)
+    o = _st(F.elu(zo), bf16)
+    pred = torch.cat([o @ wl + bl, torch.relu(o @ wrel + brel)], dim=-1)
+    e = pred - torch.from_numpy(np.ascontiguousarray(y3, np.float32))
+    wp, ws_ = 120.0 / 128.0, 8.0 / 128.0
+    mae = e[:, :, :n_lin].abs().mean() * wp + e[:, :, n_lin:].abs().mean() * ws_
+    mse = (e[:, :, :n_lin] ** 2).mean() * wp + (e[:, :, n_lin:] ** 2).mean() * ws_
+    (mae if loss == "mae" else mse).backward()
+    out = {"mae_adjusted": float(mae.detach()), "mse_adjusted": float(mse.detach()), "pred": pred.detach().numpy()}
+    return out, [p.grad.numpy().copy() if p.grad is not None else np.zeros(p.shape, np.float32) for p in P]
+
+
+def synth_cnn_columns(n, seed=7):
+    """Flat low-res-shaped columns (see mlp_oracle.synth_columns) in the (n,60,6)/(n,60,10) CNN layout of
+    data_utils.reshape_input_for_cnn / reshape_target_for_cnn."""
+    from .mlp_oracle import synth_columns
+    x, y = synth_columns(n, seed=seed)
+    x3 = np.concatenate([x[:, 0:60, None], x[:, 60:120, None], np.repeat(x[:, None, 120:124], 60, axis=1)], axis=2)
+    y3 = np.concatenate([y[:, 0:60, None], y[:, 60:120, None], np.repeat(y[:, None, 120:128], 60, axis=1)], axis=2)
+    return x, y, np.ascontiguousarray(x3, np.float32), np.ascontiguousarray(y3, np.float32)

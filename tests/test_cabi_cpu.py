@@ -29,6 +29,7 @@ def test_header_symbols_all_bound_and_exported(lib):
 def test_cfg_struct_layout_matches_header():
     # 26 int32/float fields (2 + 16 hidden + 8) then 4 doubles, naturally aligned, no padding
     assert C.sizeof(_lib.CsMlpCfg) == 4 * 26 + 8 * 4
+    assert C.sizeof(_lib.CsCnnCfg) == 4 * 14 + 8 * 4 + 8          # struct cs_cnn_cfg
     assert _lib.CsMlpCfg.beta1.offset == 104 and _lib.CsMlpCfg.flags.offset == 100
 
 

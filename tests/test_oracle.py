@@ -132,3 +132,29 @@ def test_cnn_oracle_known_answers():
     np.testing.assert_allclose(y[1:2], y1, rtol=1e-6, atol=1e-7)
     t = np.zeros_like(y)
     assert CO.mae_adjusted(t, y) == pytest.approx(np.abs(y[:, :, :2]).mean() * 120 / 128 + np.abs(y[:, :, 2:]).mean() * 8 / 128)
+
+
+def test_cnn_oracle_gradients_vs_finite_differences():
+    """The CNN training oracle (torch autograd) against central differences of its own forward loss, and the
+    dropout hash against its Bernoulli law."""
+    from oracle import cnn_oracle as CO
+    ws = CO.glorot_cnn(seed=2, bias_scale=0.05, depth=2, channels=16)
+    _, _, x3, y3 = CO.synth_cnn_columns(4, seed=1)
+    out, g = CO.loss_and_grads(ws, x3, y3, depth=2, loss="mse", rate=0.25, seed=4)
+    rng = np.random.default_rng(0)
+    for trial in range(3):                       # directional derivatives over all tensors at once
+        d = [rng.normal(0, 1, w.shape).astype(np.float32) for w in ws]
+        eps = 2e-3
+        vals = []
+        for sgn in (+1, -1):
+            w2 = [a + np.float32(sgn * eps) * b for a, b in zip(ws, d)]
+            vals.append(CO.loss_and_grads(w2, x3, y3, depth=2, loss="mse", rate=0.25, seed=4)[0]["mse_adjusted"])
+        fd = (vals[0] - vals[1]) / (2 * eps)
+        an = float(sum((a.astype(np.float64) * b).sum() for a, b in zip(g, d)))
+        assert abs(fd - an) <= 3e-2 * abs(an) + 1e-5, (trial, fd, an)
+    keep = CO.dropout_keep(123, 3, 600, 406, 0.175)
+    assert abs(keep.mean() - 0.825) < 3e-3
+    assert not np.array_equal(keep, CO.dropout_keep(124, 3, 600, 406, 0.175))
+    # inference forward == training forward at rate 0
+    np.testing.assert_allclose(CO.loss_and_grads(ws, x3, y3, depth=2)[0]["pred"], CO.forward(ws, x3, depth=2), atol=1e-6)
+    assert abs(out["mae_adjusted"] - CO.mae_adjusted(y3, out["pred"])) < 1e-6
