@@ -199,3 +199,26 @@ def test_cnn_error_paths(CNN):
     mt = CNN.CNNEmulator(depth=1, channel_width=64, max_batch=2, trainable=True)
     with pytest.raises(Exception, match="max_batch"):
         mt.loss_grads(x3, y3)
+
+
+def test_cnn_full_depth_gradients(CNN):
+    """The published shape (depth 12, width 406): gradients against the emulating oracle.  With depth the two bf16
+    computations decorrelate (see the forward test), so the bar is cosine >= 0.97 per tensor with a norm ratio
+    within 10 %, and the loss within 1 %."""
+    depth, width, n = 12, 406, 4
+    ws = CO.glorot_cnn(seed=5, bias_scale=0.02, gain=0.8, depth=depth, channels=width)
+    m = CNN.CNNEmulator(depth=depth, channel_width=width, max_batch=4, trainable=True, loss="mse", dropout=0.175, seed=1)
+    assert m.count_params() == 13215420
+    m.set_weights(ws)
+    x3, y3 = make_xy(n, 2)
+    got = m._losses(m.loss_grads(x3, y3).cpu().numpy(), n)
+    grads = m.get_gradients(1.0 / (n * 60))
+    ref, gref = CO.loss_and_grads(ws, x3, y3, depth=depth, loss="mse", rate=0.175, seed=1, bf16=True)
+    assert abs(got["mse_adjusted"] - ref["mse_adjusted"]) <= 1e-2 * ref["mse_adjusted"]
+    worst = (1.0, 0, 1.0)
+    for i, (g, r) in enumerate(zip(grads, gref)):
+        c, ratio = cos_rel(g, r)
+        if c < worst[0]:
+            worst = (c, i, ratio)
+        assert c >= 0.97 and abs(ratio - 1) <= 0.1, (i, c, ratio)
+    print("worst cosine", worst)
