@@ -28,6 +28,7 @@ struct ConvArgs {
     u16* out; int ldo;           // PREDICT/TRAIN_FWD: result ; BWD: raw sum g (may be null)
     u16* out2; int ldo2;         // TRAIN_FWD: value before the residual add (may be null) ; BWD: masked gradient
     const u16* mask; int ldmask; float mscale;       // BWD: out2 = acc * (mask != 0) * mscale
+    const u16* zeros; int n_tiles;                   // k_conv2 only: zero page for out-of-column rows, channel tiles
 };
 
 __device__ __forceinline__ unsigned lowbias32(unsigned x) {

@@ -1,6 +1,7 @@
 // C-ABI of the level-axis CNN: prediction, evaluation and training.
 #pragma once
 #include "cnn_train.h"
+#include "conv2.h"
 
 struct CnnConv {
     int cin, cin_p, cout, taps;
@@ -18,6 +19,9 @@ struct cs_cnn {
     std::vector<CnnConv> convs;      // per block: a, b, r ; then the 10-channel conv
     u16 *A0 = nullptr, *X = nullptr, *A1 = nullptr, *R = nullptr, *XN = nullptr, *O10 = nullptr, *DZO = nullptr;
     float *wd = nullptr, *bd = nullptr;  // fused heads: [10][10], [10]
+    u16* zeros = nullptr;                // zero page (k_conv2 fetches out-of-column rows from it)
+    bool tile128 = false;                // CS_CNN_FLAG_TILE128: the 128x128 kernels everywhere (A/B and parity runs)
+    int cpw = 0;                         // contraction pad of the trunk channels (32- or 64-granular)
     float *P = nullptr, *M = nullptr, *V = nullptr, *G = nullptr, *G_own = nullptr;
     CnnSeg* seg_dev = nullptr; int n_seg = 0;
     ConvWgradItem* items_dev = nullptr; int n_items = 0, total_tiles = 0;
@@ -89,13 +93,24 @@ void cnn_fill_conv(const cs_cnn* h, ConvArgs& p, const CnnConv& c, const u16* in
     p.m_rows = m_rows; p.bias = c.bias;
 }
 
+template <int MODE>
+void cnn_dispatch(const cs_cnn* h, ConvArgs& p, bool wide, int n_pad, int64_t m_pad, hipStream_t st) {
+    if (wide && !h->tile128) {
+        p.zeros = h->zeros;
+        p.n_tiles = (h->cfg.channels + CV2_BN - 1) / CV2_BN;
+        hipLaunchKernelGGL((k_conv2<MODE>), dim3((unsigned)(m_pad / CV2_BM) * p.n_tiles), dim3(512), CV2_LDS_BYTES, st, p);
+    } else {
+        hipLaunchKernelGGL((k_conv<MODE>), dim3((unsigned)(m_pad / 128), (unsigned)(n_pad / 128)), dim3(256), 0, st, p);
+    }
+}
+
 // inference-mode conv (dropout is identity): out = act(conv(in)) (+ add)
 void launch_conv(const cs_cnn* h, const CnnConv& c, const u16* in, int ld_in, int act, const u16* add, u16* out,
                  int ld_out, int64_t m_rows, int64_t m_pad, hipStream_t st) {
     ConvArgs p{};
     cnn_fill_conv(h, p, c, in, ld_in, m_rows);
     p.act = act; p.add = add; p.ldadd = CNN_CP; p.out = out; p.ldo = ld_out;
-    hipLaunchKernelGGL((k_conv<CONV_PREDICT>), dim3((unsigned)(m_pad / 128), (unsigned)(c.n_pad / 128)), dim3(256), 0, st, p);
+    cnn_dispatch<CONV_PREDICT>(h, p, c.n_pad == CNN_CP, c.n_pad, m_pad, st);
 }
 
 // training-mode conv: out2 = dropout(act(conv(in))), out = out2 + add
@@ -107,7 +122,7 @@ void launch_conv_train(const cs_cnn* h, const CnnConv& c, const u16* in, int ld_
     p.drop_key = host_lowbias32(seed + 0x9e3779b9u * (unsigned)(layer + 1));
     p.drop_thr = (unsigned)(h->cfg.dropout * 16777216.0);
     p.drop_scale = 1.f / (1.f - (float)h->cfg.dropout);
-    hipLaunchKernelGGL((k_conv<CONV_TRAIN_FWD>), dim3((unsigned)(m_pad / 128), (unsigned)(c.n_pad / 128)), dim3(256), 0, st, p);
+    cnn_dispatch<CONV_TRAIN_FWD>(h, p, true, c.n_pad, m_pad, st);
 }
 
 // data gradient: g = sum_slots A_s[m+sh_s] * Wd ; out (raw g, optional) ; out2 = g * (mask != 0) * mscale
@@ -119,7 +134,7 @@ void launch_conv_bwd(const cs_cnn* h, const u16* dz3, const u16* g1, int lda, in
     p.lda = lda; p.B = Wd; p.ldb = slots * kpt; p.kpt = kpt; p.taps = slots; p.seq = h->cfg.seq; p.m_rows = m_rows;
     p.out = out; p.ldo = CNN_CP; p.out2 = out2; p.ldo2 = CNN_CP; p.mask = mask; p.ldmask = CNN_CP;
     p.mscale = h->cfg.dropout > 0 ? 1.f / (1.f - (float)h->cfg.dropout) : 1.f;
-    hipLaunchKernelGGL((k_conv<CONV_BWD>), dim3((unsigned)(m_pad / 128), (unsigned)(CNN_CP / 128)), dim3(256), 0, st, p);
+    cnn_dispatch<CONV_BWD>(h, p, true, CNN_CP, m_pad, st);
 }
 
 int cnn_check_batch(const cs_cnn* h, int64_t n) {
@@ -131,7 +146,7 @@ int cnn_check_batch(const cs_cnn* h, int64_t n) {
 // inference-mode trunk: leaves the ELU'd 10-channel rows in O10
 void cnn_trunk_predict(cs_cnn* h, const float* x_dev, const int64_t* row_idx, int layout3d, int64_t n, hipStream_t st) {
     const int seq = h->cfg.seq;
-    const int64_t m_rows = n * seq, m_pad = round_up(m_rows, 128);
+    const int64_t m_rows = n * seq, m_pad = round_up(m_rows, 256);
     hipLaunchKernelGGL(k_cnn_input, dim3((unsigned)((m_pad + 255) / 256)), dim3(256), 0, st, x_dev, row_idx, layout3d, m_rows, m_pad,
                        seq, h->A0, CNN_A0_LD);
     const u16* x = h->A0;
@@ -178,9 +193,15 @@ int cs_cnn_create(cs_cnn_t** out, const cs_cnn_cfg* cfg) {
     HIP_TRY(hipSetDevice(cfg->device));
     cs_cnn* h = new cs_cnn();
     h->cfg = *cfg;
-    h->m_pad_max = round_up((int64_t)cfg->max_batch * cfg->seq, 128);
-    const int C = cfg->channels, cp = (int)round_up(C, 64), depth = cfg->depth;
+    h->m_pad_max = round_up((int64_t)cfg->max_batch * cfg->seq, 256);
+    h->tile128 = (cfg->flags & CS_CNN_FLAG_TILE128) != 0;
+    const int kgran = h->tile128 ? 64 : 32;                       // contraction slab of the trunk kernels
+    const int C = cfg->channels, cp = (int)round_up(C, kgran), depth = cfg->depth;
+    h->cpw = cp;
     const bool train = cfg->train != 0;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv2<CONV_PREDICT>), hipFuncAttributeMaxDynamicSharedMemorySize, CV2_LDS_BYTES));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv2<CONV_TRAIN_FWD>), hipFuncAttributeMaxDynamicSharedMemorySize, CV2_LDS_BYTES));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv2<CONV_BWD>), hipFuncAttributeMaxDynamicSharedMemorySize, CV2_LDS_BYTES));
     std::vector<std::pair<void**, size_t>> req;
     auto A = [&](void** p, size_t b) { req.emplace_back(p, (size_t)round_up((int64_t)b, 4096)); };
     int64_t np = 0;
@@ -193,12 +214,12 @@ int cs_cnn_create(cs_cnn_t** out, const cs_cnn_cfg* cfg) {
     };
     // Keras creates (and orders) the layers of a block as conv a, conv b, residual projection
     for (int b = 0; b < depth; ++b) {
-        const int cin = b == 0 ? cfg->c_in : C, cin_p = b == 0 ? 64 : cp;
+        const int cin = b == 0 ? cfg->c_in : C, cin_p = b == 0 ? kgran : cp;
         add_conv(cin, cin_p, C, 3, CNN_CP);
         add_conv(C, cp, C, 3, CNN_CP);
         add_conv(cin, cin_p, C, 1, CNN_CP);
     }
-    add_conv(C, cp, cfg->c_out, 1, 128);
+    add_conv(C, (int)round_up(C, 64), cfg->c_out, 1, 128);         // 10-channel conv: the 128x128 kernel, 64-wide slabs
     const int nl = cfg->n_lin, nr = 10 - nl;
     h->off_wl = np; np += 10 * nl;
     h->off_bl = np; np += nl;
@@ -211,6 +232,7 @@ int cs_cnn_create(cs_cnn_t** out, const cs_cnn_cfg* cfg) {
     }
     A((void**)&h->wd, sizeof(float) * 100);
     A((void**)&h->bd, sizeof(float) * 16);
+    A((void**)&h->zeros, 4096);
     A((void**)&h->A0, sizeof(u16) * h->m_pad_max * CNN_A0_LD);
     A((void**)&h->O10, sizeof(u16) * h->m_pad_max * 128);
     for (u16** b : {&h->X, &h->A1, &h->R, &h->XN}) A((void**)b, sizeof(u16) * h->m_pad_max * CNN_CP);
@@ -232,7 +254,7 @@ int cs_cnn_create(cs_cnn_t** out, const cs_cnn_cfg* cfg) {
             if (b > 0) A((void**)&h->Wd_a[b], sizeof(u16) * CNN_CP * 4 * cp);
             A((void**)&h->Wd_b[b], sizeof(u16) * CNN_CP * 3 * cp);
         }
-        A((void**)&h->Wd_o, sizeof(u16) * CNN_CP * 64);
+        A((void**)&h->Wd_o, sizeof(u16) * CNN_CP * 64);           // [512][kgran]
     }
     size_t total = 65536;
     for (auto& r : req) total += r.second;
@@ -249,7 +271,7 @@ int cs_cnn_create(cs_cnn_t** out, const cs_cnn_cfg* cfg) {
         CnnConv& c = h->convs[i];
         if (train) {
             const int b = (int)(i / 3), role = (int)(i % 3);
-            if (i + 1 == h->convs.size()) { c.Wd = h->Wd_o; c.ldd = 64; c.kpd = 64; c.slot0 = 0; }
+            if (i + 1 == h->convs.size()) { c.Wd = h->Wd_o; c.ldd = kgran; c.kpd = kgran; c.slot0 = 0; }
             else if (role == 1) { c.Wd = h->Wd_b[b]; c.ldd = 3 * cp; c.kpd = cp; c.slot0 = 0; }
             else if (b > 0) { c.Wd = h->Wd_a[b]; c.ldd = 4 * cp; c.kpd = cp; c.slot0 = role == 0 ? 0 : 3; }
         }
@@ -370,8 +392,8 @@ int cs_cnn_loss_grads(cs_cnn_t* h, const float* x_dev, int x3d, const float* y_d
     int rc = cnn_check_batch(h, n);
     if (rc != CS_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
-    const int seq = h->cfg.seq, depth = h->cfg.depth, cp = (int)round_up(h->cfg.channels, 64);
-    const int64_t m_rows = n * seq, m_pad = round_up(m_rows, 128);
+    const int seq = h->cfg.seq, depth = h->cfg.depth, cp = h->cpw, kgran = h->tile128 ? 64 : 32;
+    const int64_t m_rows = n * seq, m_pad = round_up(m_rows, 256);
     const unsigned seed = (unsigned)((h->cfg.seed + (uint64_t)h->drop_calls) & 0xffffffffu);
     h->drop_calls++;
     HIP_TRY(hipMemsetAsync(loss_dev, 0, 4 * sizeof(float), st));
@@ -398,7 +420,7 @@ int cs_cnn_loss_grads(cs_cnn_t* h, const float* x_dev, int x3d, const float* y_d
                        row_idx_dev, y3d, h->cfg.loss, f_p, f_s, loss_dev, h->DZO, 128, h->G + h->off_wl, h->G + h->off_bl,
                        h->G + h->off_wr, h->G + h->off_br);
     // ---- data gradients, last block to first
-    launch_conv_bwd(h, h->DZO, h->DZO, 128, 64, h->Wd_o, 1, h->blk[depth - 1].A2, h->blk[depth - 1].GG, h->blk[depth - 1].DZ2,
+    launch_conv_bwd(h, h->DZO, h->DZO, 128, kgran, h->Wd_o, 1, h->blk[depth - 1].A2, h->blk[depth - 1].GG, h->blk[depth - 1].DZ2,
                     m_rows, m_pad, st);
     for (int b = depth - 1; b >= 0; --b) {
         CnnBlockBufs& B = h->blk[b];

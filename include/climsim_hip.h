@@ -142,6 +142,7 @@ int cs_normalise_rows(const float* x_dev, const int64_t* row_idx_dev, int64_t n,
  * (y3d = 0; reshape_target_for_cnn :1714-1738 applied on the fly) or (n,60,10) (y3d = 1). */
 typedef struct cs_cnn cs_cnn_t;
 typedef enum { CS_CNN_LOSS_MAE_ADJUSTED = 0, CS_CNN_LOSS_MSE_ADJUSTED = 1 } cs_cnn_loss_kind;   /* hpo_train.py:114-121 */
+#define CS_CNN_FLAG_TILE128 1   /* development: run every conv on the 128x128-tile kernel (A/B runs, parity cross-check) */
 typedef struct cs_cnn_cfg {
     int32_t depth;       /* hp_depth = 12            */
     int32_t channels;    /* hp_channel_width = 406   */
