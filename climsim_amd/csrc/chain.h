@@ -186,11 +186,6 @@ __device__ __forceinline__ void chain_mma(const u16* __restrict__ X, const u16* 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {   // 2 x f32 -> packed bf16, round-to-nearest-even
-    unsigned r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
-}
 
 // Epilogue of a hidden / dgrad stage (VALU-lean: ~8 instructions per element; the first version spent
 // more time here than in the MFMA loop).  `msk` carries the 16 sign bits of tile t=(a*NT+b) in dword

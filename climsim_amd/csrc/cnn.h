@@ -23,23 +23,29 @@ struct ConvArgs {
     int64_t m_rows;              // valid rows (n*seq)
     const float* bias;           // [N] (zero beyond the real channels); unused by CONV_BWD
     int act;
-    unsigned drop_key, drop_thr; float drop_scale;   // CONV_TRAIN_FWD: keep iff hash>>8 >= drop_thr, scale 1/keep
+    unsigned drop_key, drop_thr; float drop_scale;   // CONV_TRAIN_FWD: keep iff 16 hash bits >= drop_thr, scale 1/keep
     const u16* add; int ldadd;   // optional residual added AFTER activation and dropout
     u16* out; int ldo;           // PREDICT/TRAIN_FWD: result ; BWD: raw sum g (may be null)
     u16* out2; int ldo2;         // TRAIN_FWD: value before the residual add (may be null) ; BWD: masked gradient
     const u16* mask; int ldmask; float mscale;       // BWD: out2 = acc * (mask != 0) * mscale
     const u16* zeros; int n_tiles;                   // k_conv2 only: zero page for out-of-column rows, channel tiles
+    int ablate;                                      // development (CS_CONV_ABLATE): 1 no DMA in the loop, 2 no MFMA, 4 no epilogue
 };
 
 __device__ __forceinline__ unsigned lowbias32(unsigned x) {
     x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
     return x;
 }
-// Dropout decision of element (row m, channel n): shared with oracle/cnn_oracle.py dropout_keep.
+// Dropout decisions of the channel pair (n, n+1), n even, of row m: one 32-bit hash, 16 bits per element;
+// keep iff its 16 bits >= thr16 = floor(rate * 65536).  Shared with oracle/cnn_oracle.py dropout_keep.
+__device__ __forceinline__ unsigned drop_hash2(int64_t m, int n, unsigned key) {
+    unsigned k = (unsigned)m * 256u + ((unsigned)n >> 1);
+    k ^= (unsigned)(m >> 24) * 0x9e3779b9u;
+    return lowbias32(k ^ key);
+}
 __device__ __forceinline__ bool drop_keep(int64_t m, int n, unsigned key, unsigned thr) {
-    unsigned k = (unsigned)m * 512u + (unsigned)n;
-    k ^= (unsigned)(m >> 23) * 0x9e3779b9u;
-    return (lowbias32(k ^ key) >> 8) >= thr;
+    const unsigned h = drop_hash2(m, n, key);
+    return ((n & 1) ? (h >> 16) : (h & 0xffffu)) >= thr;
 }
 
 template <int MODE>

@@ -21,6 +21,7 @@ struct cs_cnn {
     float *wd = nullptr, *bd = nullptr;  // fused heads: [10][10], [10]
     u16* zeros = nullptr;                // zero page (k_conv2 fetches out-of-column rows from it)
     bool tile128 = false;                // CS_CNN_FLAG_TILE128: the 128x128 kernels everywhere (A/B and parity runs)
+    int conv_ablate = 0;                 // CS_CONV_ABLATE (development)
     int cpw = 0;                         // contraction pad of the trunk channels (32- or 64-granular)
     float *P = nullptr, *M = nullptr, *V = nullptr, *G = nullptr, *G_own = nullptr;
     CnnSeg* seg_dev = nullptr; int n_seg = 0;
@@ -97,6 +98,7 @@ template <int MODE>
 void cnn_dispatch(const cs_cnn* h, ConvArgs& p, bool wide, int n_pad, int64_t m_pad, hipStream_t st) {
     if (wide && !h->tile128) {
         p.zeros = h->zeros;
+        p.ablate = h->conv_ablate;
         p.n_tiles = (h->cfg.channels + CV2_BN - 1) / CV2_BN;
         hipLaunchKernelGGL((k_conv2<MODE>), dim3((unsigned)(m_pad / CV2_BM) * p.n_tiles), dim3(512), CV2_LDS_BYTES, st, p);
     } else {
@@ -120,7 +122,7 @@ void launch_conv_train(const cs_cnn* h, const CnnConv& c, const u16* in, int ld_
     cnn_fill_conv(h, p, c, in, ld_in, m_rows);
     p.act = CACT_RELU; p.add = add; p.ldadd = CNN_CP; p.out = out; p.ldo = CNN_CP; p.out2 = out2; p.ldo2 = CNN_CP;
     p.drop_key = host_lowbias32(seed + 0x9e3779b9u * (unsigned)(layer + 1));
-    p.drop_thr = (unsigned)(h->cfg.dropout * 16777216.0);
+    p.drop_thr = (unsigned)(h->cfg.dropout * 65536.0);
     p.drop_scale = 1.f / (1.f - (float)h->cfg.dropout);
     cnn_dispatch<CONV_TRAIN_FWD>(h, p, true, c.n_pad, m_pad, st);
 }
@@ -195,6 +197,7 @@ int cs_cnn_create(cs_cnn_t** out, const cs_cnn_cfg* cfg) {
     h->cfg = *cfg;
     h->m_pad_max = round_up((int64_t)cfg->max_batch * cfg->seq, 256);
     h->tile128 = (cfg->flags & CS_CNN_FLAG_TILE128) != 0;
+    if (const char* e = getenv("CS_CONV_ABLATE")) h->conv_ablate = atoi(e);
     const int kgran = h->tile128 ? 64 : 32;                       // contraction slab of the trunk kernels
     const int C = cfg->channels, cp = (int)round_up(C, kgran), depth = cfg->depth;
     h->cpw = cp;

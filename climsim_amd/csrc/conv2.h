@@ -6,8 +6,8 @@
 //     256 CUs.  8 waves of 64 x 112, v_mfma_f32_16x16x32_bf16: 4 x 7 tiles = 112 accumulator VGPRs,
 //     11 LDS fragment reads per 28 MFMAs (the 2x2 32x32 arrangement needed 16 per 16).
 //   * contraction in slabs of 32 (channel pad 416 instead of 448), operands stream global -> LDS with
-//     `global_load_lds_dwordx4` into a 4-slot ring (30 KiB per slot, three slots in flight), counted
-//     `vmcnt` + raw `s_barrier`.  Rows that fall outside their column (tap shift at level 0 / 59) or past
+//     `global_load_lds_dwordx4` into a 4-slot ring (30 KiB per slot): two slabs are consumed per barrier
+//     while the next two stream in, `vmcnt` + raw `s_barrier`.  Rows that fall outside their column (tap shift at level 0 / 59) or past
 //     the batch fetch from a zero page instead of being predicated, so every wave issues the same number
 //     of DMA pieces per slab.
 //   * LDS image is lane-linear per 1-KiB piece (16 rows x 64 B); the bank swizzle (16-B chunk ^ (row>>2)&3)
@@ -42,35 +42,43 @@ __global__ __launch_bounds__(512) void k_conv2(const ConvArgs p) {
     const int prow = lane >> 2, pos = lane & 3;
     const int cl = (pos ^ ((prow >> 2) & 3)) * 8;
     const int64_t am0 = m0 + wid * 16 + prow, am1 = am0 + 128;
-    const int alev0 = (int)(am0 % p.seq), alev1 = (int)(am1 % p.seq);
     const int pb1 = wid + 8 < 14 ? wid + 8 : 13;
-    const u16* bsrc0 = p.B + (int64_t)(n0 + wid * 16 + prow) * p.ldb + cl;
-    const u16* bsrc1 = p.B + (int64_t)(n0 + pb1 * 16 + prow) * p.ldb + cl;
+    const char* bsrc0 = reinterpret_cast<const char*>(p.B + (int64_t)(n0 + wid * 16 + prow) * p.ldb + cl);
+    const char* bsrc1 = reinterpret_cast<const char*>(p.B + (int64_t)(n0 + pb1 * 16 + prow) * p.ldb + cl);
+    // per-lane byte offset of its two rows, and which of the 4 tap shifts keep them inside their column
+    const int64_t arow0 = (am0 * p.lda + cl) * 2, arow1 = (am1 * p.lda + cl) * 2;
+    unsigned ok0 = 0u, ok1 = 0u;
+    {
+        const int l0 = (int)(am0 % p.seq), l1 = (int)(am1 % p.seq);
+        const int shs[4] = {p.sh0, p.sh1, p.sh2, p.sh3};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (am0 < p.m_rows && l0 + shs[t] >= 0 && l0 + shs[t] < p.seq) ok0 |= 1u << t;
+            if (am1 < p.m_rows && l1 + shs[t] >= 0 && l1 + shs[t] < p.seq) ok1 |= 1u << t;
+        }
+    }
     typedef unsigned char __attribute__((address_space(3))) * lds_b;
     const unsigned lds0 = (unsigned)(uintptr_t)((lds_b)cv2_ring);
     const unsigned a_piece0 = __builtin_amdgcn_readfirstlane((unsigned)wid * 1024u);
     const unsigned b_piece1 = __builtin_amdgcn_readfirstlane((unsigned)pb1 * 1024u);
     const int kc = p.kpt >> 5;
     const int nt = p.taps * kc;
+    const char* zsrc = reinterpret_cast<const char*>(p.zeros);
 
-#define CV2_ASRC(dst, am, alev)                                                                        \
-    {                                                                                                   \
-        const int ls = (alev) + sh_;                                                                    \
-        dst = ((am) < p.m_rows && ls >= 0 && ls < p.seq) ? S_ + ((am) + sh_) * p.lda + c0_ + cl : p.zeros; \
-    }
 #define CV2_ISSUE(st)                                                                                  \
     {                                                                                                   \
         const int sc_ = min((st), nt - 1);                                                              \
         const int tap_ = sc_ / kc, c0_ = (sc_ - tap_ * kc) * 32;                                        \
         const int sh_ = tap_ == 0 ? p.sh0 : tap_ == 1 ? p.sh1 : tap_ == 2 ? p.sh2 : p.sh3;              \
         const u16* S_ = tap_ == 0 ? p.A0 : tap_ == 1 ? p.A1 : tap_ == 2 ? p.A2 : p.A3;                  \
-        const u16 *s0_, *s1_;                                                                           \
-        CV2_ASRC(s0_, am0, alev0) CV2_ASRC(s1_, am1, alev1)                                             \
+        const char* Sb_ = reinterpret_cast<const char*>(S_) + ((int64_t)sh_ * p.lda + c0_) * 2;         \
+        const char* s0_ = ((ok0 >> tap_) & 1u) ? Sb_ + arow0 : zsrc;                                    \
+        const char* s1_ = ((ok1 >> tap_) & 1u) ? Sb_ + arow1 : zsrc;                                    \
         const unsigned base_ = lds0 + (unsigned)((st) & (CV2_STAGES - 1)) * CV2_STAGE_BYTES;            \
         dma16(s0_, base_ + a_piece0);                                                                   \
         dma16(s1_, base_ + a_piece0 + 8192u);                                                           \
-        dma16(bsrc0 + sc_ * 32, base_ + CV2_A_BYTES + a_piece0);                                        \
-        dma16(bsrc1 + sc_ * 32, base_ + CV2_A_BYTES + b_piece1);                                        \
+        dma16(bsrc0 + sc_ * 64, base_ + CV2_A_BYTES + a_piece0);                                        \
+        dma16(bsrc1 + sc_ * 64, base_ + CV2_A_BYTES + b_piece1);                                        \
     }
 
     f32x4_t acc[4][7];
@@ -84,68 +92,138 @@ __global__ __launch_bounds__(512) void k_conv2(const ConvArgs p) {
     const unsigned a_off = (unsigned)((wm * 64 + (lane & 15)) * 64) + sw;
     const unsigned b_off = (unsigned)(CV2_A_BYTES + (wn * 112 + (lane & 15)) * 64) + sw;
 
+#define CV2_COMPUTE(slab)                                                                              \
+    {                                                                                                   \
+        const unsigned char* st_ = cv2_ring + ((slab) & (CV2_STAGES - 1)) * CV2_STAGE_BYTES;            \
+        bf16x8_t fa[4], fw[7];                                                                          \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(st_ + a_off + i * 1024); \
+        _Pragma("unroll") for (int j = 0; j < 7; ++j) fw[j] = *reinterpret_cast<const bf16x8_t*>(st_ + b_off + j * 1024); \
+        _Pragma("unroll") for (int j = 0; j < 7; ++j)                                                   \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                               \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0);  \
+    }
+
+    // two slabs per barrier: slabs s, s+1 are consumed while s+2, s+3 stream into the other half of the ring
     CV2_ISSUE(0)
     CV2_ISSUE(1)
-    CV2_ISSUE(2)
-    for (int s = 0; s < nt; ++s) {
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // this wave's pieces of slab s have landed
-        __builtin_amdgcn_s_barrier();                       // ... everyone's; slot (s-1)&3 is free again
-        CV2_ISSUE(s + 3)
-        const unsigned char* st = cv2_ring + (s & (CV2_STAGES - 1)) * CV2_STAGE_BYTES;
-        bf16x8_t fa[4], fw[7];
+    // bias of this lane's 7 channel quads, fetched now: a load issued in the epilogue costs a full L2 round
+    // trip per dependent use, and there is nothing left to hide it behind
+    float4 bq[7];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(st + a_off + i * 1024);
-#pragma unroll
-        for (int j = 0; j < 7; ++j) fw[j] = *reinterpret_cast<const bf16x8_t*>(st + b_off + j * 1024);
-#pragma unroll
-        for (int j = 0; j < 7; ++j)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the clamped tail pieces must not outlive the kernel
-#undef CV2_ASRC
-#undef CV2_ISSUE
-
-    // ---- epilogue: D[channel][row]: lane owns row ..+(lane&15), channels ..+4*(lane>>4)+{0..3}
-#pragma unroll
-    for (int j = 0; j < 7; ++j) {
-        const int n = n0 + wn * 112 + j * 16 + 4 * (lane >> 4);
-        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (MODE != CONV_BWD) b4 = *reinterpret_cast<const float4*>(p.bias + n);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int64_t m = m0 + wm * 64 + i * 16 + (lane & 15);
-            float v[4] = {acc[i][j][0] + b4.x, acc[i][j][1] + b4.y, acc[i][j][2] + b4.z, acc[i][j][3] + b4.w};
-            if (MODE == CONV_BWD) {
-                if (p.out) *reinterpret_cast<uint2*>(p.out + m * p.ldo + n) = pack4(v[0], v[1], v[2], v[3]);
-                const uint2 k2 = *reinterpret_cast<const uint2*>(p.mask + m * p.ldmask + n);
-                v[0] = (k2.x & 0x7fffu) ? v[0] * p.mscale : 0.f;
-                v[1] = (k2.x & 0x7fff0000u) ? v[1] * p.mscale : 0.f;
-                v[2] = (k2.y & 0x7fffu) ? v[2] * p.mscale : 0.f;
-                v[3] = (k2.y & 0x7fff0000u) ? v[3] * p.mscale : 0.f;
-                *reinterpret_cast<uint2*>(p.out2 + m * p.ldo2 + n) = pack4(v[0], v[1], v[2], v[3]);
-            } else {
-                if (p.act == CACT_RELU) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                } else if (p.act == CACT_ELU) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : expm1f(v[e]);
-                }
-                if (MODE == CONV_TRAIN_FWD) {
-                    if (p.drop_thr) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = drop_keep(m, n + e, p.drop_key, p.drop_thr) ? v[e] * p.drop_scale : 0.f;
-                    }
-                    if (p.out2) *reinterpret_cast<uint2*>(p.out2 + m * p.ldo2 + n) = pack4(v[0], v[1], v[2], v[3]);
-                }
-                if (p.add) {
-                    const uint2 r2 = *reinterpret_cast<const uint2*>(p.add + m * p.ldadd + n);
-                    v[0] += bf2f((u16)(r2.x & 0xffff)); v[1] += bf2f((u16)(r2.x >> 16));
-                    v[2] += bf2f((u16)(r2.y & 0xffff)); v[3] += bf2f((u16)(r2.y >> 16));
-                }
-                *reinterpret_cast<uint2*>(p.out + m * p.ldo + n) = pack4(v[0], v[1], v[2], v[3]);
-            }
+    for (int j = 0; j < 7; ++j)
+        bq[j] = MODE != CONV_BWD ? *reinterpret_cast<const float4*>(p.bias + n0 + wn * 112 + j * 16 + 4 * (lane >> 4))
+                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < nt; s += 2) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's pieces of slabs s, s+1 have landed
+        __builtin_amdgcn_s_barrier();                       // ... everyone's; slots of s-2, s-1 are free again
+        if (!(p.ablate & 1)) {
+            CV2_ISSUE(s + 2)
+            CV2_ISSUE(s + 3)
+        }
+        if (!(p.ablate & 2)) {
+            CV2_COMPUTE(s)
+            if (s + 1 < nt) CV2_COMPUTE(s + 1)
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the clamped tail pieces have landed ...
+    __builtin_amdgcn_s_barrier();                           // ... and nobody reads the ring any more
+#undef CV2_ISSUE
+#undef CV2_COMPUTE
+
+    if (p.ablate & 4) return;
+    // ---- epilogue.  D[channel][row]: lane owns row ..+(lane&15), channels ..+4*(lane>>4)+{0..3}.
+    // The accumulators are transformed in place; each output tensor then goes wave-tile by wave-tile through
+    // a private LDS region (64 rows x 240-B pitch) so that the global stores are 16 B per lane along 224-B row
+    // segments (row-per-lane 8-B stores were store-issue bound: 13 us of a 58 us conv).
+    unsigned char* reg = cv2_ring + wid * (64 * 240);
+    const int64_t mw = m0 + wm * 64;
+    const int nw = n0 + wn * 112;
+#define CV2_STORE_TILE(dst, ld)                                                                         \
+    {                                                                                                    \
+        _Pragma("unroll") for (int j = 0; j < 7; ++j)                                                    \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                \
+                *reinterpret_cast<uint2*>(reg + (i * 16 + (lane & 15)) * 240 + (j * 16 + 4 * (lane >> 4)) * 2) = \
+                    pack4_hw(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);                    \
+        /* 4 rows per instruction, 14 of 16 lanes per row carry one 16-B chunk: no division by 14 */     \
+        u16* g_ = (dst) + (mw + (lane >> 4)) * (ld) + nw + (lane & 15) * 8;                              \
+        const unsigned char* l_ = reg + (lane >> 4) * 240 + (lane & 15) * 16;                            \
+        if ((lane & 15) < 14) {                                                                          \
+            _Pragma("unroll") for (int it = 0; it < 16; ++it) {                                          \
+                const uint4 v_ = *reinterpret_cast<const uint4*>(l_ + it * 960);                         \
+                if (!(p.ablate & 8)) *reinterpret_cast<uint4*>(g_ + (int64_t)it * 4 * (ld)) = v_;        \
+                else if (v_.x == 0x12345678u) reg[0] = 1;                                                \
+            }                                                                                            \
+        }                                                                                                \
+    }
+
+    if (MODE == CONV_BWD) {
+        if (p.out) CV2_STORE_TILE(p.out, p.ldo)
+#pragma unroll
+        for (int jh = 0; jh < 7; jh += 4) {                 // all loads of a half first, then their uses
+            uint2 k2[4][4];
+#pragma unroll
+            for (int j = jh; j < jh + 4 && j < 7; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    k2[j - jh][i] = *reinterpret_cast<const uint2*>(p.mask + (mw + i * 16 + (lane & 15)) * p.ldmask + nw + j * 16 + 4 * (lane >> 4));
+#pragma unroll
+            for (int j = jh; j < jh + 4 && j < 7; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint2 k = k2[j - jh][i];
+                    acc[i][j][0] = (k.x & 0x7fffu) ? acc[i][j][0] * p.mscale : 0.f;
+                    acc[i][j][1] = (k.x & 0x7fff0000u) ? acc[i][j][1] * p.mscale : 0.f;
+                    acc[i][j][2] = (k.y & 0x7fffu) ? acc[i][j][2] * p.mscale : 0.f;
+                    acc[i][j][3] = (k.y & 0x7fff0000u) ? acc[i][j][3] * p.mscale : 0.f;
+                }
+        }
+        CV2_STORE_TILE(p.out2, p.ldo2)
+    } else {
+        // trunk convs are ReLU or linear (the ELU conv has 10 channels and runs on k_conv): one max against
+        // 0 or -inf instead of a per-element switch (which unrolled into ~8k instructions of cold code)
+        const float act_floor = p.act == CACT_RELU ? 0.f : -__builtin_huge_valf();
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const int n = nw + j * 16 + 4 * (lane >> 4);
+            const float4 b4 = bq[j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int64_t m = mw + i * 16 + (lane & 15);
+                float v[4] = {acc[i][j][0] + b4.x, acc[i][j][1] + b4.y, acc[i][j][2] + b4.z, acc[i][j][3] + b4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], act_floor);      // ReLU | identity, branch-free
+                if (MODE == CONV_TRAIN_FWD && p.drop_thr) {
+                    const unsigned h0 = drop_hash2(m, n, p.drop_key), h1 = drop_hash2(m, n + 2, p.drop_key);
+                    v[0] = (h0 & 0xffffu) >= p.drop_thr ? v[0] * p.drop_scale : 0.f;
+                    v[1] = (h0 >> 16) >= p.drop_thr ? v[1] * p.drop_scale : 0.f;
+                    v[2] = (h1 & 0xffffu) >= p.drop_thr ? v[2] * p.drop_scale : 0.f;
+                    v[3] = (h1 >> 16) >= p.drop_thr ? v[3] * p.drop_scale : 0.f;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][j][e] = v[e];
+            }
+        }
+        if (MODE == CONV_TRAIN_FWD && p.out2) CV2_STORE_TILE(p.out2, p.ldo2)
+        if (p.add) {
+#pragma unroll
+            for (int jh = 0; jh < 7; jh += 4) {
+                uint2 r2[4][4];
+#pragma unroll
+                for (int j = jh; j < jh + 4 && j < 7; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        r2[j - jh][i] = *reinterpret_cast<const uint2*>(p.add + (mw + i * 16 + (lane & 15)) * p.ldadd + nw + j * 16 + 4 * (lane >> 4));
+#pragma unroll
+                for (int j = jh; j < jh + 4 && j < 7; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const uint2 r = r2[j - jh][i];
+                        acc[i][j][0] += bf2f((u16)(r.x & 0xffff)); acc[i][j][1] += bf2f((u16)(r.x >> 16));
+                        acc[i][j][2] += bf2f((u16)(r.y & 0xffff)); acc[i][j][3] += bf2f((u16)(r.y >> 16));
+                    }
+            }
+        }
+        CV2_STORE_TILE(p.out, p.ldo)
+    }
+#undef CV2_STORE_TILE
 }

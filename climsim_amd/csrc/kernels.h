@@ -36,6 +36,12 @@ __device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) {
     return make_uint2((unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16), (unsigned)f2bf(c) | ((unsigned)f2bf(d) << 16));
 }
 // `slope` = 0 for ReLU, alpha for LeakyReLU (prepared by the host); ELU has alpha = 1.
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {   // 2 x f32 -> packed bf16, round-to-nearest-even
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ uint2 pack4_hw(float a, float b, float c, float d) { return make_uint2(cvt_pk_bf16(a, b), cvt_pk_bf16(c, d)); }
 __device__ __forceinline__ float act_fwd(float z, int kind, float slope) {
     if (kind == ACT_ELU) return z > 0.f ? z : expm1f(z);
     return z > 0.f ? z : slope * z;

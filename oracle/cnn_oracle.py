@@ -109,14 +109,16 @@ def dropout_key(seed, layer):
 
 
 def dropout_keep(seed, layer, m_rows, channels, rate):
-    """Boolean keep mask (m_rows, channels): keep iff the top 24 hash bits >= floor(rate * 2^24)."""
+    """Boolean keep mask (m_rows, channels).  One 32-bit hash per channel pair (n, n+1) of a row, 16 bits per
+    element: keep iff its 16 bits >= floor(rate * 65536)."""
     m = np.arange(m_rows, dtype=np.uint64)[:, None]
     n = np.arange(channels, dtype=np.uint64)[None, :]
     with np.errstate(over="ignore"):
-        k = ((m * np.uint64(ROW_PITCH) + n) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
-        k ^= ((m >> np.uint64(23)).astype(np.uint32) * np.uint32(0x9E3779B9))
+        k = ((m * np.uint64(ROW_PITCH // 2) + (n >> np.uint64(1))) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        k ^= ((m >> np.uint64(24)).astype(np.uint32) * np.uint32(0x9E3779B9))
         h = lowbias32(k ^ dropout_key(seed, layer))
-    return (h >> np.uint32(8)) >= np.uint32(int(rate * (1 << 24)))
+    bits = np.where((n & np.uint64(1)).astype(bool), h >> np.uint32(16), h & np.uint32(0xFFFF))
+    return bits >= np.uint32(int(rate * (1 << 16)))
 
 
 class _RoundGrad(torch.autograd.Function):
