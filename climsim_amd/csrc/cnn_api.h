@@ -2,6 +2,7 @@
 #pragma once
 #include "cnn_train.h"
 #include "conv2.h"
+#include "conv_wgrad2.h"
 
 struct CnnConv {
     int cin, cin_p, cout, taps;
@@ -26,6 +27,7 @@ struct cs_cnn {
     float *P = nullptr, *M = nullptr, *V = nullptr, *G = nullptr, *G_own = nullptr;
     CnnSeg* seg_dev = nullptr; int n_seg = 0;
     ConvWgradItem* items_dev = nullptr; int n_items = 0, total_tiles = 0;
+    CwTile* cw_tiles_dev = nullptr; int n_cw_tiles = 0, n_cu = 256;      // stream-K wgrad (conv_wgrad2.h)
     std::vector<CnnBlockBufs> blk;
     std::vector<u16*> Wd_a, Wd_b;    // per block data-gradient packs: [512][4*cp] (a flipped + r), [512][3*cp]
     u16* Wd_o = nullptr;             // [512][64]
@@ -45,6 +47,7 @@ inline unsigned host_lowbias32(unsigned x) {
 
 int cnn_upload_items(cs_cnn* h) {
     std::vector<ConvWgradItem> it;
+    std::vector<CwTile> cw;
     const int C = h->cfg.channels, depth = h->cfg.depth;
     int tiles = 0;
     auto push = [&](const u16* H, int ldh, int shift, const u16* Z, int ldz, float* dW, int n_pitch, int k_real, int n_real, float* db) {
@@ -54,21 +57,40 @@ int cnn_upload_items(cs_cnn* h) {
         tiles += w.tiles_k * w.tiles_n;
         it.push_back(w);
     };
+    // stream-K tiles of one conv: 256-wide slices of the (tap, c_in) axis x 224-wide slices of c_out
+    auto push_cw = [&](const u16* H, int ldh, const u16* Z, const CnnConv& c) {
+        const int kpt = (int)round_up(c.cin, 32);
+        for (int n0 = 0; n0 < c.cout; n0 += 224)
+            for (int k0 = 0; k0 < c.taps * kpt; k0 += 256) {
+                CwTile t{};
+                t.H = H; t.Z = Z; t.dW = h->G + c.w_off; t.db = h->G + c.b_off; t.ldh = ldh; t.ldz = CNN_CP;
+                t.cin = c.cin; t.cout = c.cout; t.taps = c.taps; t.kpt = kpt; t.k0 = k0; t.n0 = n0;
+                cw.push_back(t);
+            }
+    };
     for (int b = 0; b < depth; ++b) {
         const CnnConv &ca = h->convs[3 * b], &cb = h->convs[3 * b + 1], &cr = h->convs[3 * b + 2];
         const u16* xin = b == 0 ? h->A0 : h->blk[b - 1].XS;
         const int ldx = b == 0 ? CNN_A0_LD : CNN_CP;
-        for (int t = 0; t < 3; ++t)
-            push(xin, ldx, t - 1, h->blk[b].DZ1, CNN_CP, h->G + ca.w_off + (int64_t)t * ca.cin * C, C, ca.cin, C, t == 1 ? h->G + ca.b_off : nullptr);
-        for (int t = 0; t < 3; ++t)
-            push(h->blk[b].A1, CNN_CP, t - 1, h->blk[b].DZ2, CNN_CP, h->G + cb.w_off + (int64_t)t * C * C, C, C, C, t == 1 ? h->G + cb.b_off : nullptr);
-        push(xin, ldx, 0, h->blk[b].GG, CNN_CP, h->G + cr.w_off, C, cr.cin, C, h->G + cr.b_off);
+        if (h->tile128) {
+            for (int t = 0; t < 3; ++t)
+                push(xin, ldx, t - 1, h->blk[b].DZ1, CNN_CP, h->G + ca.w_off + (int64_t)t * ca.cin * C, C, ca.cin, C, t == 1 ? h->G + ca.b_off : nullptr);
+            for (int t = 0; t < 3; ++t)
+                push(h->blk[b].A1, CNN_CP, t - 1, h->blk[b].DZ2, CNN_CP, h->G + cb.w_off + (int64_t)t * C * C, C, C, C, t == 1 ? h->G + cb.b_off : nullptr);
+            push(xin, ldx, 0, h->blk[b].GG, CNN_CP, h->G + cr.w_off, C, cr.cin, C, h->G + cr.b_off);
+        } else {
+            push_cw(xin, ldx, h->blk[b].DZ1, ca);
+            push_cw(h->blk[b].A1, CNN_CP, h->blk[b].DZ2, cb);
+            push_cw(xin, ldx, h->blk[b].GG, cr);
+        }
     }
     const CnnConv& co = h->convs.back();
     push(h->blk[depth - 1].XS, CNN_CP, 0, h->DZO, 128, h->G + co.w_off, co.cout, C, co.cout, h->G + co.b_off);
     h->n_items = (int)it.size();
     h->total_tiles = tiles;
     HIP_TRY(hipMemcpy(h->items_dev, it.data(), it.size() * sizeof(ConvWgradItem), hipMemcpyHostToDevice));
+    h->n_cw_tiles = (int)cw.size();
+    if (!cw.empty()) HIP_TRY(hipMemcpy(h->cw_tiles_dev, cw.data(), cw.size() * sizeof(CwTile), hipMemcpyHostToDevice));
     return CS_OK;
 }
 
@@ -205,6 +227,12 @@ int cs_cnn_create(cs_cnn_t** out, const cs_cnn_cfg* cfg) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv2<CONV_PREDICT>), hipFuncAttributeMaxDynamicSharedMemorySize, CV2_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv2<CONV_TRAIN_FWD>), hipFuncAttributeMaxDynamicSharedMemorySize, CV2_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv2<CONV_BWD>), hipFuncAttributeMaxDynamicSharedMemorySize, CV2_LDS_BYTES));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wgrad2), hipFuncAttributeMaxDynamicSharedMemorySize, CW2_LDS_BYTES));
+    {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, cfg->device));
+        h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
     std::vector<std::pair<void**, size_t>> req;
     auto A = [&](void** p, size_t b) { req.emplace_back(p, (size_t)round_up((int64_t)b, 4096)); };
     int64_t np = 0;
@@ -248,6 +276,7 @@ int cs_cnn_create(cs_cnn_t** out, const cs_cnn_cfg* cfg) {
         A((void**)&h->G_own, sizeof(float) * np);
         A((void**)&h->DZO, sizeof(u16) * h->m_pad_max * 128);
         A((void**)&h->items_dev, sizeof(ConvWgradItem) * (7 * depth + 1));
+        A((void**)&h->cw_tiles_dev, sizeof(CwTile) * (32 * depth));
         h->blk.resize(depth);
         h->Wd_a.assign(depth, nullptr);
         h->Wd_b.assign(depth, nullptr);
@@ -381,7 +410,7 @@ int cs_cnn_evaluate(cs_cnn_t* h, const float* x_dev, int x3d, const float* y_dev
     cnn_trunk_predict(h, x_dev, row_idx_dev, x3d, n, st);
     float f_p, f_s;
     cnn_loss_factors(h, f_p, f_s);
-    hipLaunchKernelGGL(k_cnn_loss_heads, dim3((unsigned)n), dim3(64), 0, st, h->O10, 128, h->wd, h->bd, h->cfg.n_lin, h->cfg.seq, n,
+    hipLaunchKernelGGL(k_cnn_loss_heads, dim3((unsigned)std::min<int64_t>((n + 3) / 4, 64)), dim3(256), 0, st, h->O10, 128, h->wd, h->bd, h->cfg.n_lin, h->cfg.seq, n,
                        y_dev, row_idx_dev, y3d, 0, f_p, f_s, loss_dev, (u16*)nullptr, 0, (float*)nullptr, (float*)nullptr,
                        (float*)nullptr, (float*)nullptr);
     HIP_TRY(hipGetLastError());
@@ -419,7 +448,7 @@ int cs_cnn_loss_grads(cs_cnn_t* h, const float* x_dev, int x3d, const float* y_d
     // ---- loss, heads backward
     float f_p, f_s;
     cnn_loss_factors(h, f_p, f_s);
-    hipLaunchKernelGGL(k_cnn_loss_heads, dim3((unsigned)n), dim3(64), 0, st, h->O10, 128, h->wd, h->bd, h->cfg.n_lin, seq, n, y_dev,
+    hipLaunchKernelGGL(k_cnn_loss_heads, dim3((unsigned)std::min<int64_t>((n + 3) / 4, 64)), dim3(256), 0, st, h->O10, 128, h->wd, h->bd, h->cfg.n_lin, seq, n, y_dev,
                        row_idx_dev, y3d, h->cfg.loss, f_p, f_s, loss_dev, h->DZO, 128, h->G + h->off_wl, h->G + h->off_bl,
                        h->G + h->off_wr, h->G + h->off_br);
     // ---- data gradients, last block to first
@@ -431,14 +460,22 @@ int cs_cnn_loss_grads(cs_cnn_t* h, const float* x_dev, int x3d, const float* y_d
         if (b > 0) launch_conv_bwd(h, B.DZ1, B.GG, CNN_CP, cp, h->Wd_a[b], 4, h->blk[b - 1].A2, h->blk[b - 1].GG, h->blk[b - 1].DZ2,
                                    m_rows, m_pad, st);
     }
-    // ---- weight gradients: one grouped launch
+    // ---- weight gradients: stream-K over every conv of the step (conv_wgrad2.h) + the 10-channel conv
+    if (h->n_cw_tiles > 0) {
+        CwArgs ca{};
+        ca.tiles = h->cw_tiles_dev; ca.n_tiles = h->n_cw_tiles; ca.m_rows = m_rows; ca.slabs = (int)(m_pad / 32); ca.seq = seq;
+        ca.zeros = h->zeros;
+        const int64_t total = (int64_t)ca.n_tiles * ca.slabs;
+        const int grid = (int)std::min<int64_t>(h->n_cu, std::max<int64_t>(1, total / 8));
+        hipLaunchKernelGGL(k_conv_wgrad2, dim3((unsigned)grid), dim3(512), CW2_LDS_BYTES, st, ca);
+    }
     ConvWgradArgs wa{};
     wa.items = h->items_dev; wa.n_items = h->n_items; wa.m_rows = m_rows; wa.m_pad = m_pad; wa.seq = seq;
     const int steps = (int)(m_pad / 64);
-    int splitk = (1024 + h->total_tiles - 1) / h->total_tiles;
+    int splitk = ((h->tile128 ? 1024 : 64) + h->total_tiles - 1) / h->total_tiles;
     if (splitk > steps) splitk = steps;
     if (splitk < 1) splitk = 1;
-    wa.splitk = splitk; wa.use_atomics = splitk > 1;
+    wa.splitk = splitk; wa.use_atomics = 1;
     hipLaunchKernelGGL(k_conv_wgrad, dim3((unsigned)(h->total_tiles * splitk)), dim3(256), 0, st, wa);
     HIP_TRY(hipGetLastError());
     return CS_OK;

@@ -11,24 +11,30 @@
 
 enum { CNN_LOSS_MAE = 0, CNN_LOSS_MSE = 1 };
 
-// One workgroup per column, one lane per level.  Recomputes the heads from the stored ELU output,
-// accumulates the four loss sums [sum|e| profiles, sum|e| scalars, sum e^2 profiles, sum e^2 scalars] and,
-// when dzo is given, the head gradients and dL/d(pre-ELU) rows (bf16, 16 channels written, 10 used).
-__global__ __launch_bounds__(64) void k_cnn_loss_heads(const u16* __restrict__ o10, int ld, const float* __restrict__ wd,
-                                                       const float* __restrict__ bd, int n_lin, int seq, int64_t n_cols,
-                                                       const float* __restrict__ y, const int64_t* __restrict__ row_idx, int y3d,
-                                                       int loss_kind, float f_p, float f_s, float* __restrict__ loss,
-                                                       u16* __restrict__ dzo, int lddz, float* __restrict__ g_wl,
-                                                       float* __restrict__ g_bl, float* __restrict__ g_wr, float* __restrict__ g_br) {
-    const int64_t b = blockIdx.x;
-    if (b >= n_cols) return;
-    const int l = threadIdx.x;
+// One wave per column at a time, one lane per level; a workgroup of 4 waves strides over the batch.
+// Recomputes the heads from the stored ELU output, accumulates the four loss sums [sum|e| profiles,
+// sum|e| scalars, sum e^2 profiles, sum e^2 scalars] and, when dzo is given, the head gradients and
+// dL/d(pre-ELU) rows (bf16, 16 channels written, 10 used).  Partial sums stay in registers until the end:
+// one wave reduction + one atomic per value and WORKGROUP (a workgroup per column made 512 x 114
+// same-address atomics per step: 0.24 ms).
+__global__ __launch_bounds__(256) void k_cnn_loss_heads(const u16* __restrict__ o10, int ld, const float* __restrict__ wd,
+                                                        const float* __restrict__ bd, int n_lin, int seq, int64_t n_cols,
+                                                        const float* __restrict__ y, const int64_t* __restrict__ row_idx, int y3d,
+                                                        int loss_kind, float f_p, float f_s, float* __restrict__ loss,
+                                                        u16* __restrict__ dzo, int lddz, float* __restrict__ g_wl,
+                                                        float* __restrict__ g_bl, float* __restrict__ g_wr, float* __restrict__ g_br) {
+    __shared__ float red[4][114];
+    const int l = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const bool live = l < seq;
-    float o[10], dy[10];
-    float s_ap = 0.f, s_as = 0.f, s_qp = 0.f, s_qs = 0.f;
+    float s4[4] = {0.f, 0.f, 0.f, 0.f};
+    float gw[100], gb[10];
 #pragma unroll
-    for (int j = 0; j < 10; ++j) { o[j] = 0.f; dy[j] = 0.f; }
-    if (live) {
+    for (int q = 0; q < 100; ++q) gw[q] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 10; ++q) gb[q] = 0.f;
+    for (int64_t b = (int64_t)blockIdx.x * 4 + wv; b < n_cols; b += (int64_t)gridDim.x * 4) {
+        if (!live) continue;
+        float o[10], dy[10];
         const u16* r = o10 + (b * seq + l) * ld;
 #pragma unroll
         for (int c = 0; c < 10; ++c) o[c] = bf2f(r[c]);
@@ -43,17 +49,13 @@ __global__ __launch_bounds__(64) void k_cnn_loss_heads(const u16* __restrict__ o
             const float t = y3d ? y[(yb * seq + l) * 10 + j]
                                 : (j < 2 ? y[yb * (2 * seq + 8) + j * seq + l] : y[yb * (2 * seq + 8) + 2 * seq + (j - 2)]);
             const float e = pred - t;
-            if (lin) { s_ap += fabsf(e); s_qp += e * e; } else { s_as += fabsf(e); s_qs += e * e; }
+            if (lin) { s4[0] += fabsf(e); s4[2] += e * e; } else { s4[1] += fabsf(e); s4[3] += e * e; }
             float g = loss_kind == CNN_LOSS_MAE ? (e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f)) : 2.f * e;
             g *= lin ? f_p : f_s;
             if (!lin && !(s > 0.f)) g = 0.f;
             dy[j] = g;
         }
-    }
-    s_ap = wave_sum(s_ap); s_as = wave_sum(s_as); s_qp = wave_sum(s_qp); s_qs = wave_sum(s_qs);
-    if (l == 0) { atomicAdd(loss + 0, s_ap); atomicAdd(loss + 1, s_as); atomicAdd(loss + 2, s_qp); atomicAdd(loss + 3, s_qs); }
-    if (!dzo) return;
-    if (live) {
+        if (!dzo) continue;
         float dz[16];
 #pragma unroll
         for (int c = 0; c < 16; ++c) dz[c] = 0.f;
@@ -67,17 +69,30 @@ __global__ __launch_bounds__(64) void k_cnn_loss_heads(const u16* __restrict__ o
         uint2* dst = reinterpret_cast<uint2*>(dzo + (b * seq + l) * lddz);
 #pragma unroll
         for (int q = 0; q < 4; ++q) dst[q] = pack4(dz[4 * q], dz[4 * q + 1], dz[4 * q + 2], dz[4 * q + 3]);
-    }
-    const int n_relu = 10 - n_lin;
 #pragma unroll
-    for (int j = 0; j < 10; ++j) {
-        const float gb = wave_sum(dy[j]);
-        if (l == 0) atomicAdd(j < n_lin ? g_bl + j : g_br + (j - n_lin), gb);
+        for (int j = 0; j < 10; ++j) {
+            gb[j] += dy[j];
 #pragma unroll
-        for (int c = 0; c < 10; ++c) {
-            const float gw = wave_sum(o[c] * dy[j]);
-            if (l == 0) atomicAdd(j < n_lin ? g_wl + c * n_lin + j : g_wr + c * n_relu + (j - n_lin), gw);
+            for (int c = 0; c < 10; ++c) gw[c * 10 + j] += o[c] * dy[j];
         }
+    }
+    // wave reductions -> LDS -> one atomic per value and workgroup
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const float v = wave_sum(s4[q]); if (l == 0) red[wv][q] = v; }
+    if (dzo) {
+#pragma unroll
+        for (int q = 0; q < 10; ++q) { const float v = wave_sum(gb[q]); if (l == 0) red[wv][4 + q] = v; }
+#pragma unroll
+        for (int q = 0; q < 100; ++q) { const float v = wave_sum(gw[q]); if (l == 0) red[wv][14 + q] = v; }
+    }
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t < (dzo ? 114 : 4)) {
+        const float v = red[0][t] + red[1][t] + red[2][t] + red[3][t];
+        const int n_relu = 10 - n_lin;
+        if (t < 4) atomicAdd(loss + t, v);
+        else if (t < 14) { const int j = t - 4; atomicAdd(j < n_lin ? g_bl + j : g_br + (j - n_lin), v); }
+        else { const int c = (t - 14) / 10, j = (t - 14) % 10; atomicAdd(j < n_lin ? g_wl + c * n_lin + j : g_wr + c * n_relu + (j - n_lin), v); }
     }
 }
 
