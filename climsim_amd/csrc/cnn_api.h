@@ -27,7 +27,8 @@ struct cs_cnn {
     float *P = nullptr, *M = nullptr, *V = nullptr, *G = nullptr, *G_own = nullptr;
     CnnSeg* seg_dev = nullptr; int n_seg = 0;
     ConvWgradItem* items_dev = nullptr; int n_items = 0, total_tiles = 0;
-    CwTile* cw_tiles_dev = nullptr; int n_cw_tiles = 0, n_cu = 256;      // stream-K wgrad (conv_wgrad2.h)
+    CwTile* cw_tiles_dev = nullptr; int n_cw_tiles = 0, n_cu = 256;      // conv_wgrad2.h
+    int* cw_prefix_dev = nullptr; int n_cw_convs = 0, cw_splits = 0;
     std::vector<CnnBlockBufs> blk;
     std::vector<u16*> Wd_a, Wd_b;    // per block data-gradient packs: [512][4*cp] (a flipped + r), [512][3*cp]
     u16* Wd_o = nullptr;             // [512][64]
@@ -48,6 +49,7 @@ inline unsigned host_lowbias32(unsigned x) {
 int cnn_upload_items(cs_cnn* h) {
     std::vector<ConvWgradItem> it;
     std::vector<CwTile> cw;
+    std::vector<int> prefix;
     const int C = h->cfg.channels, depth = h->cfg.depth;
     int tiles = 0;
     auto push = [&](const u16* H, int ldh, int shift, const u16* Z, int ldz, float* dW, int n_pitch, int k_real, int n_real, float* db) {
@@ -60,6 +62,7 @@ int cnn_upload_items(cs_cnn* h) {
     // stream-K tiles of one conv: 256-wide slices of the (tap, c_in) axis x 224-wide slices of c_out
     auto push_cw = [&](const u16* H, int ldh, const u16* Z, const CnnConv& c) {
         const int kpt = (int)round_up(c.cin, 32);
+        prefix.push_back((int)cw.size());
         for (int n0 = 0; n0 < c.cout; n0 += 224)
             for (int k0 = 0; k0 < c.taps * kpt; k0 += 256) {
                 CwTile t{};
@@ -90,7 +93,12 @@ int cnn_upload_items(cs_cnn* h) {
     h->total_tiles = tiles;
     HIP_TRY(hipMemcpy(h->items_dev, it.data(), it.size() * sizeof(ConvWgradItem), hipMemcpyHostToDevice));
     h->n_cw_tiles = (int)cw.size();
-    if (!cw.empty()) HIP_TRY(hipMemcpy(h->cw_tiles_dev, cw.data(), cw.size() * sizeof(CwTile), hipMemcpyHostToDevice));
+    if (!cw.empty()) {
+        h->n_cw_convs = (int)prefix.size();
+        prefix.push_back((int)cw.size());
+        HIP_TRY(hipMemcpy(h->cw_tiles_dev, cw.data(), cw.size() * sizeof(CwTile), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(h->cw_prefix_dev, prefix.data(), prefix.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
     return CS_OK;
 }
 
@@ -220,6 +228,7 @@ int cs_cnn_create(cs_cnn_t** out, const cs_cnn_cfg* cfg) {
     h->m_pad_max = round_up((int64_t)cfg->max_batch * cfg->seq, 256);
     h->tile128 = (cfg->flags & CS_CNN_FLAG_TILE128) != 0;
     if (const char* e = getenv("CS_CONV_ABLATE")) h->conv_ablate = atoi(e);
+    if (const char* e = getenv("CS_CNN_WGRAD_SPLITS")) h->cw_splits = atoi(e);
     const int kgran = h->tile128 ? 64 : 32;                       // contraction slab of the trunk kernels
     const int C = cfg->channels, cp = (int)round_up(C, kgran), depth = cfg->depth;
     h->cpw = cp;
@@ -277,6 +286,7 @@ int cs_cnn_create(cs_cnn_t** out, const cs_cnn_cfg* cfg) {
         A((void**)&h->DZO, sizeof(u16) * h->m_pad_max * 128);
         A((void**)&h->items_dev, sizeof(ConvWgradItem) * (7 * depth + 1));
         A((void**)&h->cw_tiles_dev, sizeof(CwTile) * (32 * depth));
+        A((void**)&h->cw_prefix_dev, sizeof(int) * (3 * depth + 2));
         h->blk.resize(depth);
         h->Wd_a.assign(depth, nullptr);
         h->Wd_b.assign(depth, nullptr);
@@ -465,8 +475,12 @@ int cs_cnn_loss_grads(cs_cnn_t* h, const float* x_dev, int x3d, const float* y_d
         CwArgs ca{};
         ca.tiles = h->cw_tiles_dev; ca.n_tiles = h->n_cw_tiles; ca.m_rows = m_rows; ca.slabs = (int)(m_pad / 32); ca.seq = seq;
         ca.zeros = h->zeros;
-        const int64_t total = (int64_t)ca.n_tiles * ca.slabs;
-        const int grid = (int)std::min<int64_t>(h->n_cu, std::max<int64_t>(1, total / 8));
+        ca.conv_prefix = h->cw_prefix_dev; ca.n_convs = h->n_cw_convs;
+        // row splits: enough workgroups for >= 4 rounds of the CUs (tail loss <= ~1/8), at least 8 slabs each
+        int splits = h->cw_splits > 0 ? h->cw_splits : (4 * h->n_cu + ca.n_tiles - 1) / ca.n_tiles;
+        splits = std::max(1, std::min(splits, ca.slabs / 8 > 0 ? ca.slabs / 8 : 1));
+        ca.splits = splits;
+        const int grid = ca.n_tiles * splits;
         hipLaunchKernelGGL(k_conv_wgrad2, dim3((unsigned)grid), dim3(512), CW2_LDS_BYTES, st, ca);
     }
     ConvWgradArgs wa{};

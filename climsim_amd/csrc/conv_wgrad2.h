@@ -8,11 +8,11 @@
 //   * 256(kk) x 224(n) tiles, 8 waves of 64 x 112 (4 x 7 v_mfma_f32_16x16x32_bf16, 112 accumulators),
 //     operands stream with LDS-DMA in 32-row slabs through a 4-slot ring; fragments come out of LDS already
 //     transposed (ds_read_b64_tr_b16) - rows of the batch are the contraction index of both operands.
-//   * stream-K: the (tile, slab) sequence of ALL convs is cut into gridDim equal ranges, one per workgroup
-//     (one workgroup per CU).  ~270 tiles of 960 slabs do not divide over 256 CUs (53 % efficiency as whole
-//     tiles, and a fixed split of the rows needs >= 4 partial sums per element to reach 85 %); a range that
-//     ends inside a tile flushes its partial sums with fp32 atomics and the DMA ring keeps streaming the
-//     next tile meanwhile.
+//   * work = (conv, row split, tile): the tiles of one conv over the same row range are consecutive work ids,
+//     and the XCD remap puts them on one L2 at about the same time - each operand slab is then fetched from
+//     HBM once and hit by the other tiles of the conv (5 use the same dZ columns, 2 the same H columns).
+//     (A stream-K cut of the tile-major sequence balanced the CUs perfectly but left every workgroup at a
+//     different row: 8.5 GB of operand traffic per step, HBM-bound at 1.76 ms.)  Partial sums: fp32 atomics.
 #pragma once
 #include "cnn_train.h"
 #include "wgrad2.h"
@@ -26,6 +26,8 @@ struct CwTile {                  // one output tile of one conv
 };
 struct CwArgs {
     const CwTile* tiles; int n_tiles;
+    const int* conv_prefix; int n_convs;   // tiles of conv c: [conv_prefix[c], conv_prefix[c+1])
+    int splits;                             // row ranges per tile
     int64_t m_rows; int slabs;   // 32-row slabs per tile (m_pad / 32)
     int seq;
     const u16* zeros;
@@ -50,8 +52,18 @@ __global__ __launch_bounds__(512) void k_conv_wgrad2(const CwArgs pa) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid >> 1, wn = wid & 1;
-    const int64_t total = (int64_t)pa.n_tiles * pa.slabs;
-    const int64_t g0 = total * blockIdx.x / gridDim.x, g1 = total * (blockIdx.x + 1) / gridDim.x;
+    // work id -> (conv, split, tile of the conv)
+    const int work = xcd_work_id(blockIdx.x, gridDim.x);
+    int lo = 0, hi = pa.n_convs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (pa.conv_prefix[mid] * pa.splits <= work) lo = mid; else hi = mid - 1;
+    }
+    const int cfirst = pa.conv_prefix[lo], ctiles = pa.conv_prefix[lo + 1] - cfirst;
+    const int rel = work - cfirst * pa.splits;
+    const int split = rel / ctiles, tile0 = cfirst + (rel - split * ctiles);
+    const int64_t g0 = (int64_t)tile0 * pa.slabs + (int64_t)pa.slabs * split / pa.splits;
+    const int64_t g1 = (int64_t)tile0 * pa.slabs + (int64_t)pa.slabs * (split + 1) / pa.splits;
     if (g0 >= g1) return;
 
     // ---- DMA side.  A 1-KiB piece = 2 rows of 512 B; lane -> row lane>>5, physical chunk lane&31, which holds
