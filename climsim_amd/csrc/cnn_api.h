@@ -64,7 +64,7 @@ int cnn_upload_items(cs_cnn* h) {
         const int kpt = (int)round_up(c.cin, 32);
         prefix.push_back((int)cw.size());
         for (int n0 = 0; n0 < c.cout; n0 += 224)
-            for (int k0 = 0; k0 < c.taps * kpt; k0 += 256) {
+            for (int k0 = 0; k0 < c.taps * kpt + 8; k0 += 256) {    // + the ones chunk (bias gradient) behind the last tap
                 CwTile t{};
                 t.H = H; t.Z = Z; t.dW = h->G + c.w_off; t.db = h->G + c.b_off; t.ldh = ldh; t.ldz = CNN_CP;
                 t.cin = c.cin; t.cout = c.cout; t.taps = c.taps; t.kpt = kpt; t.k0 = k0; t.n0 = n0;
@@ -307,6 +307,13 @@ int cs_cnn_create(cs_cnn_t** out, const cs_cnn_cfg* cfg) {
     size_t at = 0;
     for (auto& r : req) { *r.first = arena + at; at += r.second; }
     h->G = h->G_own;
+    {
+        const u16 one = 0x3f80;                                   // bf16 1.0 at byte 64 of the zero page: the "ones chunk"
+        if (hipMemcpy(reinterpret_cast<char*>(h->zeros) + 64, &one, sizeof one, hipMemcpyHostToDevice) != hipSuccess) {
+            cs_cnn_destroy(h);
+            return fail(CS_ERR_HIP, "zero page setup failed");
+        }
+    }
     // segment table of the flat Keras-order buffers
     std::vector<CnnSeg> segs;
     for (size_t i = 0; i < h->convs.size(); ++i) {
@@ -480,6 +487,7 @@ int cs_cnn_loss_grads(cs_cnn_t* h, const float* x_dev, int x3d, const float* y_d
         int splits = h->cw_splits > 0 ? h->cw_splits : (4 * h->n_cu + ca.n_tiles - 1) / ca.n_tiles;
         splits = std::max(1, std::min(splits, ca.slabs / 8 > 0 ? ca.slabs / 8 : 1));
         ca.splits = splits;
+        if (const char* e = getenv("CS_CW_ABLATE")) ca.ablate = atoi(e);
         const int grid = ca.n_tiles * splits;
         hipLaunchKernelGGL(k_conv_wgrad2, dim3((unsigned)grid), dim3(512), CW2_LDS_BYTES, st, ca);
     }

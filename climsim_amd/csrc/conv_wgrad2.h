@@ -28,6 +28,7 @@ struct CwArgs {
     const CwTile* tiles; int n_tiles;
     const int* conv_prefix; int n_convs;   // tiles of conv c: [conv_prefix[c], conv_prefix[c+1])
     int splits;                             // row ranges per tile
+    int ablate;                             // development: 1 no DMA in the loop, 2 no MFMA/LDS reads, 4 no flush
     int64_t m_rows; int slabs;   // 32-row slabs per tile (m_pad / 32)
     int seq;
     const u16* zeros;
@@ -61,138 +62,149 @@ __global__ __launch_bounds__(512) void k_conv_wgrad2(const CwArgs pa) {
     }
     const int cfirst = pa.conv_prefix[lo], ctiles = pa.conv_prefix[lo + 1] - cfirst;
     const int rel = work - cfirst * pa.splits;
-    const int split = rel / ctiles, tile0 = cfirst + (rel - split * ctiles);
-    const int64_t g0 = (int64_t)tile0 * pa.slabs + (int64_t)pa.slabs * split / pa.splits;
-    const int64_t g1 = (int64_t)tile0 * pa.slabs + (int64_t)pa.slabs * (split + 1) / pa.splits;
-    if (g0 >= g1) return;
+    const int split = rel / ctiles;
+    const int tile_u = __builtin_amdgcn_readfirstlane(cfirst + (rel - split * ctiles));
+    const int s0 = (int)((int64_t)pa.slabs * split / pa.splits), s1 = (int)((int64_t)pa.slabs * (split + 1) / pa.splits);
+    if (s0 >= s1) return;
+    const CwTile T = pa.tiles[tile_u];
 
     // ---- DMA side.  A 1-KiB piece = 2 rows of 512 B; lane -> row lane>>5, physical chunk lane&31, which holds
     // logical chunk (((p>>2) ^ (m&3)) << 2) | (p&3) (swz_w2).  Pieces 2*wid, 2*wid+1 of each operand per wave.
-    const int prow = lane >> 5, pch = lane & 31;
-    int ml[2], lc[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        ml[j] = 2 * (2 * wid + j) + prow;
-        lc[j] = ((((pch >> 2) ^ (ml[j] & 3)) << 2) | (pch & 3)) * 8;      // logical column inside the 256-wide tile
-    }
+    // Per-lane running state (pointers, level) advances by one 32-row slab per issue: the loop carries no
+    // division, no 64-bit multiply and no global load (whose vmcnt wait would drain the DMA ring).  Issues past
+    // the end of the range simply prefetch rows nobody reads (rows past the batch come from the zero page).
+    // The chunk right behind the last tap is a column of ONES (first element of the chunk): its row of the
+    // product is sum_m dZ[m][n], the bias gradient, computed by the MFMAs instead of ~120 VALU ops per slab.
     typedef u16 __attribute__((address_space(3))) * lds_p;
     const unsigned lds0 = (unsigned)(uintptr_t)((lds_p)cw_ring);
     const unsigned my_piece = __builtin_amdgcn_readfirstlane((unsigned)(2 * wid) * 1024u);
     const char* zpage = reinterpret_cast<const char*>(pa.zeros);
-
-    // issue-side tile state (runs 3 slabs ahead of the compute side)
-    int it_tile = -1;
-    const char* ih[2]; const char* iz[2]; int ish[2]; bool ihv[2]; int64_t ildh2 = 0, ildz2 = 0;
-    ih[0] = ih[1] = iz[0] = iz[1] = zpage; ish[0] = ish[1] = 0; ihv[0] = ihv[1] = false;
-#define CW2_ISSUE(gq)                                                                                  \
+    const char* opage = zpage + 64;                                   // {1.0, 0, 0, 0, 0, 0, 0, 0} bf16
+    const int prow = lane >> 5, pch = lane & 31;
+    const int64_t ldh2 = (int64_t)T.ldh * 2, ldz2 = (int64_t)T.ldz * 2;
+    const int linc = 32 % pa.seq;
+    const char *hp0, *hp1, *zp0, *zp1;       // source of row m + shift (H) / row m (Z) of the next slab to issue
+    int mi0, mi1, lv0, lv1;                  // that row m and its level + shift
+    int hk0, hk1;                            // 0 real channel chunk, 1 ones chunk, 2 beyond the taps (zero)
+#define CW2_INIT(j, hp, zp, mi, lv, hk)                                                                \
     {                                                                                                   \
-        const int64_t g_ = (gq) < g1 ? (gq) : g1 - 1;                                                   \
-        const int t_ = (int)(g_ / pa.slabs);                                                            \
-        const int s_ = (int)(g_ - (int64_t)t_ * pa.slabs);                                              \
-        if (t_ != it_tile) {                                                                            \
-            it_tile = t_;                                                                               \
-            const CwTile& T = pa.tiles[t_];                                                             \
-            ildh2 = (int64_t)T.ldh * 2; ildz2 = (int64_t)T.ldz * 2;                                     \
-            _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                             \
-                const int kk = T.k0 + lc[j];                                                            \
-                const int tap = kk / T.kpt, c = kk - tap * T.kpt;                                       \
-                ihv[j] = tap < T.taps;                                                                  \
-                ish[j] = T.taps == 3 ? tap - 1 : 0;                                                     \
-                ih[j] = reinterpret_cast<const char*>(T.H + c);                                         \
-                iz[j] = reinterpret_cast<const char*>(T.Z + T.n0 + lc[j]);                              \
-            }                                                                                           \
-        }                                                                                               \
-        const unsigned base_ = lds0 + (unsigned)((gq) & 3) * CW2_SLAB_BYTES + my_piece;                 \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                 \
-            const int64_t m_ = (int64_t)s_ * 32 + ml[j];                                                \
-            const int lev_ = (int)m_ % pa.seq + ish[j];                                                 \
-            const bool in_ = m_ < pa.m_rows;                                                            \
-            const char* hs_ = (in_ && ihv[j] && lev_ >= 0 && lev_ < pa.seq) ? ih[j] + (m_ + ish[j]) * ildh2 : zpage; \
-            const char* zs_ = in_ ? iz[j] + m_ * ildz2 : zpage;                                         \
-            dma16(hs_, base_ + j * 1024u);                                                              \
-            dma16(zs_, base_ + 16384u + j * 1024u);                                                     \
-        }                                                                                               \
+        const int ml_ = 2 * (2 * wid + (j)) + prow;                                                     \
+        const int lc_ = ((((pch >> 2) ^ (ml_ & 3)) << 2) | (pch & 3)) * 8;                              \
+        const int kk_ = T.k0 + lc_;                                                                     \
+        const int tap_ = kk_ / T.kpt, c_ = kk_ - tap_ * T.kpt;                                          \
+        const int sh_ = (T.taps == 3 && tap_ < 3) ? tap_ - 1 : 0;                                       \
+        hk = tap_ < T.taps ? 0 : (kk_ == T.taps * T.kpt ? 1 : 2);                                       \
+        mi = s0 * 32 + ml_;                                                                             \
+        lv = mi % pa.seq + sh_;                                                                         \
+        hp = reinterpret_cast<const char*>(T.H + c_) + (int64_t)(mi + sh_) * ldh2;                      \
+        zp = reinterpret_cast<const char*>(T.Z + T.n0 + lc_) + (int64_t)mi * ldz2;                      \
+        lvhi_##j = pa.seq + sh_;                                                                        \
+    }
+    int lvhi_0, lvhi_1;                      // lv = level + shift lives in [shift, seq + shift); valid iff 0 <= lv < seq
+    CW2_INIT(0, hp0, zp0, mi0, lv0, hk0)
+    CW2_INIT(1, hp1, zp1, mi1, lv1, hk1)
+#undef CW2_INIT
+#define CW2_PIECE(hp, zp, mi, lv, hk, lvhi, dst)                                                      \
+    {                                                                                                   \
+        const bool in_ = mi < (int)pa.m_rows;                                                           \
+        const char* hs_ = hk == 0 ? ((in_ && lv >= 0 && lv < pa.seq) ? hp : zpage) : ((hk == 1 && in_) ? opage : zpage); \
+        const char* zs_ = in_ ? zp : zpage;                                                             \
+        dma16(hs_, (dst));                                                                              \
+        dma16(zs_, (dst) + 16384u);                                                                     \
+        hp += 32 * ldh2; zp += 32 * ldz2; mi += 32;                                                     \
+        lv += linc; if (lv >= lvhi) lv -= pa.seq;                                                       \
+    }
+#define CW2_ISSUE(slot)                                                                                \
+    {                                                                                                   \
+        const unsigned base_ = lds0 + (unsigned)(slot) * CW2_SLAB_BYTES + my_piece;                     \
+        CW2_PIECE(hp0, zp0, mi0, lv0, hk0, lvhi_0, base_)                                               \
+        CW2_PIECE(hp1, zp1, mi1, lv1, hk1, lvhi_1, base_ + 1024u)                                     \
     }
 
     f32x4_t acc[4][7];
-    float bsum[7];
-#define CW2_ZERO()                                                                                     \
-    {                                                                                                   \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                   \
-            _Pragma("unroll") for (int j = 0; j < 7; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};    \
-        _Pragma("unroll") for (int j = 0; j < 7; ++j) bsum[j] = 0.f;                                    \
-    }
-    CW2_ZERO()
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 7; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-    // flush the partial sums of tile T: D[kk][n], lane owns column n = ..+(lane&15), rows kk = ..+4*(lane>>4)+r
-#define CW2_FLUSH(T)                                                                                   \
+    // fragment offsets inside a slab (elements): transposing read of X[8*(l>>4) + 0..7][cb + (l&15)], see frag_cw
+    int fo_h[4], fo_z[7];
+    {
+        const int mrow = 8 * (lane >> 4) + ((lane & 15) >> 2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fo_h[i] = swz_w2(mrow, wm * 64 + i * 16 + (lane & 3) * 4);
+#pragma unroll
+        for (int j = 0; j < 7; ++j) fo_z[j] = 32 * 256 + swz_w2(mrow, wn * 112 + j * 16 + (lane & 3) * 4);
+    }
+    typedef s16x4_t __attribute__((address_space(3))) * lds_v4;
+#define CW2_FRAG(dst, slab, off)                                                                       \
     {                                                                                                   \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                 \
-            const int kb_ = (T).k0 + wm * 64 + i * 16 + 4 * (lane >> 4);                                \
-            const int tap_ = kb_ / (T).kpt, c_ = kb_ - tap_ * (T).kpt;                                  \
-            if (tap_ < (T).taps) {                                                                      \
-                float* row_ = (T).dW + ((int64_t)tap_ * (T).cin + c_) * (T).cout;                       \
-                _Pragma("unroll") for (int j = 0; j < 7; ++j) {                                         \
-                    const int n_ = (T).n0 + wn * 112 + j * 16 + (lane & 15);                            \
-                    if (n_ < (T).cout) {                                                                \
-                        _Pragma("unroll") for (int r = 0; r < 4; ++r)                                   \
-                            if (c_ + r < (T).cin) atomicAdd(row_ + (int64_t)r * (T).cout + n_, acc[i][j][r]); \
-                    }                                                                                   \
-                }                                                                                       \
-            }                                                                                           \
-        }                                                                                               \
-        if ((T).db && (T).k0 == 0 && wm == 0) {                                                         \
-            _Pragma("unroll") for (int j = 0; j < 7; ++j) {                                             \
-                float v_ = bsum[j];                                                                     \
-                v_ += __shfl_xor(v_, 16, 64); v_ += __shfl_xor(v_, 32, 64);                             \
-                const int n_ = (T).n0 + wn * 112 + j * 16 + (lane & 15);                                \
-                if (lane < 16 && n_ < (T).cout) atomicAdd((T).db + n_, v_);                             \
-            }                                                                                           \
-        }                                                                                               \
-        CW2_ZERO()                                                                                      \
+        union { bf16x8_t v; s16x4_t h[2]; } u_;                                                         \
+        u_.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)((slab) + (off)));                    \
+        u_.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)((slab) + (off) + 4 * 256));          \
+        dst = u_.v;                                                                                     \
     }
 
-    CW2_ISSUE(g0)
-    CW2_ISSUE(g0 + 1)
-    CW2_ISSUE(g0 + 2)
-    int ct = (int)(g0 / pa.slabs);
-    CwTile T = pa.tiles[ct];
-    bool do_bias = T.db && T.k0 == 0 && wm == 0;
-    for (int64_t g = g0; g < g1; ++g) {
-        const int t = (int)(g / pa.slabs);
-        if (t != ct) {                                           // wave-uniform: finished a tile
-            CW2_FLUSH(T)
-            ct = t;
-            T = pa.tiles[ct];
-            do_bias = T.db && T.k0 == 0 && wm == 0;
-        }
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");        // this wave's 4 pieces of slab g have landed
-        __builtin_amdgcn_s_barrier();                           // ... and everyone's; slot (g-1)&3 is free
-        CW2_ISSUE(g + 3)
-        const u16* Hs = cw_ring + (g & 3) * (CW2_SLAB_BYTES / 2);
-        const u16* Zs = Hs + 32 * 256;
-        bf16x8_t fh[4], fz[7];
+    // Software pipeline: the fragments of slab s+1 are read from LDS between the MFMAs of slab s (each
+    // fragment register is reloaded in place right after its last use), and the DMA runs three slabs ahead.
+    CW2_ISSUE(0)
+    CW2_ISSUE(1)
+    CW2_ISSUE(2)
+    CW2_ISSUE(3)
+    bf16x8_t fh[4], fz[7];
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");           // first slab has landed (this wave's pieces)
+    __builtin_amdgcn_s_barrier();
 #pragma unroll
-        for (int i = 0; i < 4; ++i) fh[i] = frag_cw(Hs, 0, wm * 64 + i * 16, lane);
+    for (int i = 0; i < 4; ++i) CW2_FRAG(fh[i], cw_ring, fo_h[i])
 #pragma unroll
-        for (int j = 0; j < 7; ++j) fz[j] = frag_cw(Zs, 0, wn * 112 + j * 16, lane);
-        if (do_bias) {
+    for (int j = 0; j < 7; ++j) CW2_FRAG(fz[j], cw_ring, fo_z[j])
+    const int nsl = s1 - s0;
+    for (int s = 0; s < nsl; ++s) {
+        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");   // slab s+1 landed; my reads of slab s are done
+        __builtin_amdgcn_s_barrier();                                 // ... everyone's: slot s&3 is free
+        CW2_ISSUE(__builtin_amdgcn_readfirstlane(s & 3))
+        const u16* nx = cw_ring + ((s + 1) & 3) * (CW2_SLAB_BYTES / 2);
+        // every fragment register is reloaded (from slab s+1) right after its last MFMA of slab s
 #pragma unroll
-            for (int j = 0; j < 7; ++j) {
-                union { bf16x8_t v; u16 s[8]; } u;
-                u.v = fz[j];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) bsum[j] += bf2f(u.s[e]);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 7; ++j)
+        for (int j = 0; j < 6; ++j) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[i], fz[j], acc[i][j], 0, 0, 0);
+            CW2_FRAG(fz[j], nx, fo_z[j])
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            acc[i][6] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[i], fz[6], acc[i][6], 0, 0, 0);
+            CW2_FRAG(fh[i], nx, fo_h[i])
+        }
+        CW2_FRAG(fz[6], nx, fo_z[6])
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // clamped tail pieces
-    CW2_FLUSH(T)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the run-ahead pieces must not outlive the kernel
+
+    // ---- flush the partial sums: D[kk][n], lane owns column n = ..+(lane&15), rows kk = ..+4*(lane>>4)+r
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int kb = T.k0 + wm * 64 + i * 16 + 4 * (lane >> 4);
+        const int tap = kb / T.kpt, c = kb - tap * T.kpt;
+        if (tap < T.taps) {
+            float* row = T.dW + ((int64_t)tap * T.cin + c) * T.cout;
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                const int n = T.n0 + wn * 112 + j * 16 + (lane & 15);
+                if (n < T.cout) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (c + r < T.cin) atomicAdd(row + (int64_t)r * T.cout + n, acc[i][j][r]);
+                }
+            }
+        } else if (kb == T.taps * T.kpt && T.db) {              // the ones row: bias gradient
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                const int n = T.n0 + wn * 112 + j * 16 + (lane & 15);
+                if (n < T.cout) atomicAdd(T.db + n, acc[i][j][0]);
+            }
+        }
+    }
+#undef CW2_PIECE
 #undef CW2_ISSUE
-#undef CW2_ZERO
-#undef CW2_FLUSH
+#undef CW2_FRAG
 }
