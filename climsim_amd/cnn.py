@@ -56,7 +56,7 @@ class CNNEmulator:
     def __init__(self, depth: int = 12, channel_width: int = 406, kernel_width: int = 3, max_batch: int = 512,
                  device: Optional[int] = None, trainable: bool = False, optimizer: str = "Adam",
                  loss: str = "mean_absolute_error", dropout: float = 0.175, beta_1: float = 0.9, beta_2: float = 0.999,
-                 epsilon: float = 1e-7, seed: int = 0, init_seed: Optional[int] = None):
+                 epsilon: float = 1e-7, seed: int = 0, init_seed: Optional[int] = None, tile128: bool = False):
         import torch
         if not torch.cuda.is_available():
             raise _lib.EngineError("CNNEmulator needs a ROCm GPU (no CPU fallback)")
@@ -72,7 +72,7 @@ class CNNEmulator:
         self.trainable, self.loss_name, self.dropout = bool(trainable), loss, float(dropout)
         self.iterations = 0
         cfg = _lib.CsCnnCfg(depth=depth, channels=channel_width, kernel=kernel_width, seq=60, c_in=6, c_out=10, n_lin=2,
-                            max_batch=self.max_batch, device=self.device_index, flags=0, train=int(self.trainable),
+                            max_batch=self.max_batch, device=self.device_index, flags=int(bool(tile128)), train=int(self.trainable),
                             optimizer=OPTIMIZERS[optimizer], loss=LOSSES[loss], reserved=0, dropout=self.dropout,
                             beta1=beta_1, beta2=beta_2, eps=epsilon, seed=int(seed))
         self._h = C.c_void_p()

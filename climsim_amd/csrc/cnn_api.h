@@ -487,7 +487,6 @@ int cs_cnn_loss_grads(cs_cnn_t* h, const float* x_dev, int x3d, const float* y_d
         int splits = h->cw_splits > 0 ? h->cw_splits : (4 * h->n_cu + ca.n_tiles - 1) / ca.n_tiles;
         splits = std::max(1, std::min(splits, ca.slabs / 8 > 0 ? ca.slabs / 8 : 1));
         ca.splits = splits;
-        if (const char* e = getenv("CS_CW_ABLATE")) ca.ablate = atoi(e);
         const int grid = ca.n_tiles * splits;
         hipLaunchKernelGGL(k_conv_wgrad2, dim3((unsigned)grid), dim3(512), CW2_LDS_BYTES, st, ca);
     }

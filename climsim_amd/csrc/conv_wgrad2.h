@@ -28,7 +28,6 @@ struct CwArgs {
     const CwTile* tiles; int n_tiles;
     const int* conv_prefix; int n_convs;   // tiles of conv c: [conv_prefix[c], conv_prefix[c+1])
     int splits;                             // row ranges per tile
-    int ablate;                             // development: 1 no DMA in the loop, 2 no MFMA/LDS reads, 4 no flush
     int64_t m_rows; int slabs;   // 32-row slabs per tile (m_pad / 32)
     int seq;
     const u16* zeros;
