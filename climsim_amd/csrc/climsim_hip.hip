@@ -5,6 +5,7 @@
 #include "kernels.h"
 #include "chain.h"
 #include "wgrad2.h"
+#include "loader.h"
 
 #include <cmath>
 #include <cstdarg>
@@ -625,6 +626,32 @@ int cs_normalise_rows(const float* x_dev, const int64_t* row_idx_dev, int64_t n,
     const int64_t total = n * ((width + 3) / 4);
     hipLaunchKernelGGL(k_normalise_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x_dev,
                        row_idx_dev, n, width, sub_dev, div_dev, out_dev);
+    HIP_TRY(hipGetLastError());
+    return CS_OK;
+}
+
+int cs_loader_stack(const void* mli_dev, const void* mlo_dev, int32_t src_f64, int64_t n_steps, int32_t ncol, int32_t n_in,
+                    const double* in_sub_dev, const double* in_div_dev, int32_t n_out, const int32_t* tend_src_dev,
+                    const double* out_scale_dev, float* x_out_dev, float* y_out_dev, void* stream) {
+    if (!mli_dev) return fail(CS_ERR_INVALID, "null mli buffer");
+    if (!x_out_dev && !y_out_dev) return fail(CS_ERR_INVALID, "no output buffer");
+    if (x_out_dev && (!in_sub_dev || !in_div_dev)) return fail(CS_ERR_INVALID, "inputs need sub/div vectors");
+    if (y_out_dev && (!mlo_dev || !tend_src_dev || !out_scale_dev)) return fail(CS_ERR_INVALID, "targets need mlo, tend_src and scale");
+    if (n_steps <= 0 || n_steps > 65535 || ncol <= 0 || n_in <= 0 || n_out < 0) return fail(CS_ERR_INVALID, "bad sizes");
+    const int fmax = n_in > n_out ? n_in : n_out;
+    const size_t lds = (size_t)fmax * LD_PITCH * sizeof(float);
+    if (lds > 160 * 1024) return fail(CS_ERR_INVALID, "%d features exceed the LDS tile", fmax);
+    const dim3 grid((unsigned)((ncol + LD_COLS - 1) / LD_COLS), (unsigned)n_steps);
+    hipStream_t st = (hipStream_t)stream;
+    if (src_f64) {
+        if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_loader_stack<double>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_loader_stack<double>, grid, dim3(256), lds, st, (const double*)mli_dev, (const double*)mlo_dev, ncol, n_in,
+                           in_sub_dev, in_div_dev, n_out, tend_src_dev, out_scale_dev, x_out_dev, y_out_dev);
+    } else {
+        if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_loader_stack<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_loader_stack<float>, grid, dim3(256), lds, st, (const float*)mli_dev, (const float*)mlo_dev, ncol, n_in,
+                           in_sub_dev, in_div_dev, n_out, tend_src_dev, out_scale_dev, x_out_dev, y_out_dev);
+    }
     HIP_TRY(hipGetLastError());
     return CS_OK;
 }

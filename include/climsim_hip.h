@@ -142,6 +142,15 @@ int cs_normalise_rows(const float* x_dev, const int64_t* row_idx_dev, int64_t n,
  * (y3d = 0; reshape_target_for_cnn :1714-1738 applied on the fly) or (n,60,10) (y3d = 1). */
 typedef struct cs_cnn cs_cnn_t;
 typedef enum { CS_CNN_LOSS_MAE_ADJUSTED = 0, CS_CNN_LOSS_MSE_ADJUSTED = 1 } cs_cnn_loss_kind;   /* hpo_train.py:114-121 */
+/* Raw timestep fields -> normalised float32 training rows on the device: the per-file work of
+ * data_utils.load_ncdata_with_generator + save_as_npy (data_utils.py:698-711, 807-809, 815-820, 894-897, 906).
+ * mli_dev [n_steps][n_in][ncol], mlo_dev [n_steps][n_out][ncol] (float64 when src_f64 else float32), feature rows in
+ * stacking order; tend_src_dev[f] >= 0 marks a tendency target (mlo row f minus mli row tend_src[f], over 1200 s).
+ * x_out (n_steps*ncol, n_in), y_out (n_steps*ncol, n_out); either may be NULL.  Arithmetic in float64. */
+int cs_loader_stack(const void* mli_dev, const void* mlo_dev, int32_t src_f64, int64_t n_steps, int32_t ncol, int32_t n_in,
+                    const double* in_sub_dev, const double* in_div_dev, int32_t n_out, const int32_t* tend_src_dev,
+                    const double* out_scale_dev, float* x_out_dev, float* y_out_dev, void* stream);
+
 #define CS_CNN_FLAG_TILE128 1   /* development: run every conv on the 128x128-tile kernel (A/B runs, parity cross-check) */
 typedef struct cs_cnn_cfg {
     int32_t depth;       /* hp_depth = 12            */

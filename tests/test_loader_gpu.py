@@ -1,0 +1,74 @@
+"""Device loader (cs_loader_stack) against the host loader path of climsim_amd.data_utils on synthetic raw files:
+bit-identical float32 rows (float64 arithmetic on both sides), inf/nan rule, ragged column counts, float32 sources."""
+import copy
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from test_loader_cpu import make, raw_tree, NCOL  # noqa: E402,F401  (fixture + helpers)
+
+
+@pytest.fixture(scope="module")
+def L():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from climsim_amd import build
+    build.build()
+    from climsim_amd import loader
+    return loader
+
+
+def test_device_loader_matches_save_as_npy(L, raw_tree, lowres_assets, tmp_path):
+    root, _ = raw_tree
+    du = make(lowres_assets, "pytorch", root)
+    du.save_as_npy("train", save_path=str(tmp_path / "npy"))
+    xi = np.load(tmp_path / "npy" / "train_input.npy")
+    yi = np.load(tmp_path / "npy" / "train_target.npy")
+    ld = L.GpuColumnLoader(du)
+    x, y = ld.load_split("train")
+    assert x.dtype == torch.float32 and tuple(x.shape) == xi.shape and tuple(y.shape) == yi.shape
+    np.testing.assert_array_equal(x.cpu().numpy(), xi)
+    np.testing.assert_array_equal(y.cpu().numpy(), yi)
+
+
+def test_device_loader_edge_cases(L, raw_tree, lowres_assets):
+    root, _ = raw_tree
+    du = make(lowres_assets, "pytorch", root)
+    from climsim_amd.assets import AssetVar
+    mx = copy.copy(du.input_max)
+    mx["pbuf_SOLIN"] = AssetVar(np.asarray(du.input_min["pbuf_SOLIN"].values))      # max == min -> x/0
+    du.input_max = mx
+    ld = L.GpuColumnLoader(du)
+    rng = np.random.default_rng(3)
+    T, ncol = 3, 201                                                                 # ragged: 201 = 3*64 + 9 columns
+    a = rng.normal(0, 1, (T, 124, ncol)) * 50 + 100
+    b = rng.normal(0, 1, (T, 128, ncol))
+    a[1, 5, 7] = np.nan
+    x, y = ld.stack_raw(a, b)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        sub, div, scale = du.save_norm()
+        xr = (a.transpose(0, 2, 1).reshape(-1, 124) - sub) / div
+    xr[~np.isfinite(xr)] = 0
+    tend = ld._tend.cpu().numpy()
+    yr = b.copy()
+    m = tend >= 0
+    yr[:, m] = (b[:, m] - a[:, tend[m]]) / 1200
+    yr = yr.transpose(0, 2, 1).reshape(-1, 128) * scale
+    np.testing.assert_array_equal(x.cpu().numpy(), np.float32(xr))
+    np.testing.assert_array_equal(y.cpu().numpy(), np.float32(yr))
+    assert np.all(x.cpu().numpy()[:, 121] == 0)
+    # float32 sources: same formula evaluated on the float32 values
+    x32, y32 = ld.stack_raw(a.astype(np.float32), b.astype(np.float32))
+    a32, b32 = a.astype(np.float32).astype(np.float64), b.astype(np.float32).astype(np.float64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        xr = (a32.transpose(0, 2, 1).reshape(-1, 124) - sub) / div
+    xr[~np.isfinite(xr)] = 0
+    np.testing.assert_array_equal(x32.cpu().numpy(), np.float32(xr))
+    only_x, none_y = ld.stack_raw(a, None)
+    assert none_y is None
+    np.testing.assert_array_equal(only_x.cpu().numpy(), x.cpu().numpy())
+    with pytest.raises(ValueError):
+        ld.stack_raw(a[:, :100], b)
