@@ -63,6 +63,71 @@ def synth_on_device(torch, n, seed, device):
     return x.contiguous(), y.contiguous()
 
 
+def side_bench(fn):
+    try:
+        return fn()
+    except Exception as e:                       # a side figure must never take the headline line down
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
+def cnn_side_bench(batch=512, steps=10):
+    """Level-axis CNN (depth 12, width 406; hpo_train.py): training step and prediction, columns/s."""
+    import torch
+    from climsim_amd.cnn import CNNEmulator
+    m = CNNEmulator(depth=12, channel_width=406, max_batch=batch, trainable=True, init_seed=0, seed=1)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    x = (torch.rand((batch, 124), device="cuda", generator=g) - 0.5).contiguous()
+    y = (torch.rand((batch, 128), device="cuda", generator=g) * 0.1).contiguous()
+
+    def timed(fn, reps):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+    dt = timed(lambda: m.train_on_batch(x, y, 1e-4, x3d=0, y3d=0), steps)
+    dp = timed(lambda: m.predict(x, as_numpy=False), steps)
+    out = {"workload": "CNN depth 12 width 406, batch 512, dropout 0.175, mae_adjusted, Adam", "train_columns_per_s": round(batch / dt, 1),
+           "ms_per_step": round(dt * 1e3, 3), "train_tflops_algorithmic": round(3 * 1.584e9 * batch / dt / 1e12, 1),
+           "frac_of_bf16_peak": round(3 * 1.584e9 * batch / dt / 1e12 / PEAK_BF16_TFLOPS, 4),
+           "predict_columns_per_s": round(batch / dp, 1)}
+    m.close()
+    return out
+
+
+def loader_side_bench(steps=16, ncol=21600):
+    """Device loader on high-res-shaped timesteps (float64 raw fields in HBM -> normalised float32 rows)."""
+    import types
+    import numpy as np
+    import torch
+    from climsim_amd.loader import GpuColumnLoader
+    vin = ["state_t", "state_q0001", "state_ps", "pbuf_SOLIN", "pbuf_LHFLX", "pbuf_SHFLX"]
+    vout = ["ptend_t", "ptend_q0001", "cam_out_NETSW", "cam_out_FLWDS", "cam_out_PRECSC", "cam_out_PRECC", "cam_out_SOLS", "cam_out_SOLL",
+            "cam_out_SOLSD", "cam_out_SOLLD"]
+    lens = {v: 60 if v in ("state_t", "state_q0001", "ptend_t", "ptend_q0001") else 1 for v in vin + vout}
+    rng = np.random.default_rng(0)
+    du = types.SimpleNamespace(input_vars=vin, target_vars=vout, var_lens=lens, normalize=True, input_abbrev="mli", output_abbrev="mlo",
+                               save_norm=lambda: (rng.normal(0, 1, 124), rng.uniform(0.5, 2, 124), rng.uniform(0.5, 2, 128)))
+    ld = GpuColumnLoader(du)
+    a = torch.rand((steps, 124, ncol), device="cuda", dtype=torch.float64)
+    b = torch.rand((steps, 128, ncol), device="cuda", dtype=torch.float64)
+    for _ in range(3):
+        ld.stack_raw(a, b)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        ld.stack_raw(a, b)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 10
+    cols = steps * ncol
+    gbs = cols * 3024 / dt / 1e9
+    return {"workload": f"{steps} timesteps x {ncol} columns, float64 sources", "columns_per_s": round(cols / dt, 1),
+            "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 3)}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -72,6 +137,7 @@ def main():
     ap.add_argument("--rows", type=int, default=1 << 20, help="HBM-resident synthetic rows per GPU")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU-baseline timing (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event pass")
+    ap.add_argument("--no-extras", action="store_true", help="skip the CNN / loader side figures")
     args = ap.parse_args()
 
     import torch
@@ -193,6 +259,15 @@ def main():
         cpu = time_cpu_baseline(glorot_init(cfg, 0), cfg, xc, yc, batch=1024, budget_s=args.cpu_budget)
         cpu["value"] = round(cpu["value"], 1)
 
+    # ---- secondary figures of the other section-8 rows (untimed region, rank 0, single GPU): CNN step and device loader
+    extras = {}
+    n_params = model.count_params()
+    if rank == 0 and world == 1 and not args.no_extras:
+        model.close()
+        torch.cuda.empty_cache()
+        extras["cnn"] = side_bench(cnn_side_bench)
+        extras["loader"] = side_bench(loader_side_bench)
+
     if rank == 0:
         out = {"metric": "training columns/sec", "value": round(value, 1), "unit": "columns/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
@@ -200,10 +275,10 @@ def main():
                "config": {"workload": "cfg-MLP 124->5x512->128->(120||8) LeakyReLU(0.15), Adam(eps=1e-7) lr=1e-3, "
                                       "mse, synthetic low-res columns gathered from an HBM-resident split",
                           "per_gpu_batch": B, "global_batch": B * world, "rows_resident_per_gpu": args.rows,
-                          "parallelism": f"dp{world}", "params": model.count_params()},
+                          "parallelism": f"dp{world}", "params": n_params},
                "heldout": {"mse": held["mse"], "mae": held["mae"], "rows": 65536},
                "predict": {"columns_per_s": round(predict_cps, 1), "rows": n_pred, "batch": B},
-               "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu}
+               "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu, **extras}
         print(json.dumps(out), flush=True)
     if dist:
         dist.destroy_process_group()
