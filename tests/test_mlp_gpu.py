@@ -272,3 +272,67 @@ def test_full_size_training_reduces_loss(big):
     for _ in range(20):
         last = float(m.train_on_batch(xd, yd, 1e-3)[0])
     assert np.isfinite(last) and last < 0.5 * first
+
+
+def test_heldout_per_variable_mae_r2_match_cpu_training(M, lowres_assets):
+    """BASELINE acceptance ("MAE acceptance", synthetic form): the same model trained for the same 1600
+    steps on the same batches (Adam, lr 1e-3 then 1e-4 for the last quarter) by the HIP engine (bf16 operands) and by the
+    fp32 torch-CPU restatement of the reference step (oracle/mlp_torch_cpu.py), both scored on a held-out split through
+    the evaluation pipeline of data_utils (set_pressure_grid -> output_weighting -> calc_MAE / RMSE / R2 ->
+    create_metrics_df; golden-pinned on the CPU).
+    Tolerance: MAE and RMSE within 2 % relative for the two 60-level variables and 5 % for the eight single-output
+    variables (one output is noisier than the mean of 60), R2 within 0.02 absolute.  Measured (tests/accept_dbg.py):
+    aggregate MAE engine 0.01219 vs CPU 0.01210 (0.75 %), single outputs within 2.1 %, and the engine against itself with
+    another batch order 0.01219 - the bar is the run-to-run spread of a chaotic optimisation.  The learning-rate drop
+    matters: with a constant 1e-3 the final iterate of EITHER implementation moves by 10-35 % on single outputs from one
+    run to the next."""
+    import copy
+    from climsim_amd.data_utils import data_utils
+    from oracle.mlp_torch_cpu import TorchMLP
+    units, bs, steps = (256, 256), 1024, 1600
+    m, cfg, ws = make_model(M, units, bias_scale=0.0, max_batch=4608)
+    cpu = TorchMLP(ws, cfg)
+    def columns(n, seed):          # synth_columns inputs with a stronger signal in the targets (R2 ~ 0.9 attainable)
+        xx, _ = O.synth_columns(n, seed=seed)
+        A = np.random.default_rng(7).normal(0, 1 / np.sqrt(124), (124, 128)).astype(np.float32)
+        yy = np.tanh(3.0 * xx @ A) * 0.3 + np.random.default_rng(seed + 1000).normal(0, 0.01, (n, 128)).astype(np.float32)
+        yy[:, 120:] = np.maximum(yy[:, 120:], 0)
+        yy[:, 60:72] = 0
+        return xx, yy.astype(np.float32)
+    x, y = columns(32 * bs, 31)
+    xs, ys = columns(12 * 384, 32)                                  # 12 "timesteps" of the 384-column grid
+    xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    xt, yt = torch.from_numpy(x), torch.from_numpy(y)
+    for it in range(steps):
+        lo = (it % 32) * bs
+        lr = 1e-3 if it < steps * 3 // 4 else 1e-4
+        m.train_on_batch(xd[lo:lo + bs], yd[lo:lo + bs], lr)
+        _, g = cpu.loss_and_grads(xt[lo:lo + bs], yt[lo:lo + bs])
+        cpu.adam(g, lr)
+    p_gpu = m.predict(xs)
+    with torch.no_grad():
+        p_cpu = cpu.forward(torch.from_numpy(xs)).numpy()
+    grid, *sets = lowres_assets
+    d = data_utils(copy.copy(grid), *sets)
+    d.set_to_v1_vars()
+    d.input_scoring, d.target_scoring = xs, ys
+    d.set_pressure_grid("scoring")
+    d.model_names = ["engine", "cpu"]
+    d.preds_scoring = {"engine": p_gpu, "cpu": p_cpu}
+    d.reweight_target("scoring")
+    d.reweight_preds("scoring")
+    d.metrics_names = ["MAE", "RMSE", "R2"]
+    with np.errstate(all="ignore"):
+        d.create_metrics_df("scoring")
+    a, b = d.metrics_var_scoring["engine"], d.metrics_var_scoring["cpu"]
+    trained = float(np.mean((p_cpu - ys) ** 2)) < 0.5 * float(np.mean(ys ** 2))
+    assert trained, "the CPU restatement did not learn; the comparison would be vacuous"
+    for v in d.target_vars:
+        for name in ("MAE", "RMSE"):
+            ga, gb = float(a.loc[v, name]), float(b.loc[v, name])
+            assert abs(ga - gb) <= (2e-2 if d.var_lens[v] > 1 else 5e-2) * abs(gb), (v, name, ga, gb)
+        ra, rb = float(a.loc[v, "R2"]), float(b.loc[v, "R2"])
+        if np.isfinite(ra) and np.isfinite(rb):
+            assert abs(ra - rb) <= 2e-2, (v, ra, rb)
+        else:
+            assert np.isnan(ra) == np.isnan(rb) or np.isinf(ra) == np.isinf(rb), (v, ra, rb)
