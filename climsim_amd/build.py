@@ -12,8 +12,15 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "climsim_hip.hip")
-DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in ("kernels.h", "chain.h", "wgrad2.h", "cnn.h", "cnn_api.h")] + [
-    os.path.join(os.path.dirname(HERE), "include", "climsim_hip.h")]
+
+
+def _deps():
+    """Every source the .so is built from: the .hip file, all headers next to it and the public header."""
+    import glob
+    return [SRC] + sorted(glob.glob(os.path.join(HERE, "csrc", "*.h"))) + sorted(
+        glob.glob(os.path.join(os.path.dirname(HERE), "include", "*.h")))
+
+
 OUT = os.path.join(HERE, "libclimsim_hip.so")
 ARCH = "gfx950"
 
@@ -29,7 +36,7 @@ def needs_build() -> bool:
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    return any(os.path.getmtime(d) > t for d in DEPS)
+    return any(os.path.getmtime(d) > t for d in _deps())
 
 
 def build(force: bool = False, verbose: bool = False) -> str:

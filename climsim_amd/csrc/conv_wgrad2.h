@@ -36,14 +36,22 @@ struct CwArgs {
 #define CW2_SLAB_BYTES 32768     // H [32][256] + Z [32][256] bf16
 #define CW2_LDS_BYTES (4 * CW2_SLAB_BYTES)
 
+// [32][256] bf16 slab, 512-B rows.  A half-wave of ds_read_b64_tr_b16 in the 16x16x32 fragment form touches 8 rows
+// ({0-3} and {8-11}, or +4) x 32 B: the 64-B units are XOR-ed with (m & 3) as in swz_w2 and the 32-B half of the
+// unit with bit 3 of m, so the eight rows land on eight different 32-B bank groups (swz_w2 alone left rows m and m+8
+// on the same banks: SQ_LDS_BANK_CONFLICT was half of all LDS cycles).
+__device__ __forceinline__ int swz_cw(int m, int col) {
+    return m * 256 + ((((col >> 5) ^ (m & 3))) << 5) + ((col & 31) ^ (((m >> 3) & 1) << 4));
+}
+
 // transposed 16x16x32 fragment from a [32][256] swizzled tile: lane l -> X[mb + 8*(l>>4) + 0..7][cb + (l&15)]
 __device__ __forceinline__ bf16x8_t frag_cw(const u16* tile, int mb, int cb, int lane) {
     union { bf16x8_t v; s16x4_t h[2]; } u;
     const int col = cb + (lane & 3) * 4;
     const int m = mb + 8 * (lane >> 4) + ((lane & 15) >> 2);
     typedef s16x4_t __attribute__((address_space(3))) * lds_v4;
-    u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(tile + swz_w2(m, col)));
-    u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(tile + swz_w2(m + 4, col)));
+    u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(tile + swz_cw(m, col)));
+    u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(tile + swz_cw(m + 4, col)));
     return u.v;
 }
 
@@ -68,7 +76,7 @@ __global__ __launch_bounds__(512) void k_conv_wgrad2(const CwArgs pa) {
     const CwTile T = pa.tiles[tile_u];
 
     // ---- DMA side.  A 1-KiB piece = 2 rows of 512 B; lane -> row lane>>5, physical chunk lane&31, which holds
-    // logical chunk (((p>>2) ^ (m&3)) << 2) | (p&3) (swz_w2).  Pieces 2*wid, 2*wid+1 of each operand per wave.
+    // logical chunk (((p>>2) ^ (m&3)) << 2) | ((p&3) ^ 2*((m>>3)&1)) (swz_cw).  Pieces 2*wid, 2*wid+1 of each operand per wave.
     // Per-lane running state (pointers, level) advances by one 32-row slab per issue: the loop carries no
     // division, no 64-bit multiply and no global load (whose vmcnt wait would drain the DMA ring).  Issues past
     // the end of the range simply prefetch rows nobody reads (rows past the batch come from the zero page).
@@ -88,7 +96,7 @@ __global__ __launch_bounds__(512) void k_conv_wgrad2(const CwArgs pa) {
 #define CW2_INIT(j, hp, zp, mi, lv, hk)                                                                \
     {                                                                                                   \
         const int ml_ = 2 * (2 * wid + (j)) + prow;                                                     \
-        const int lc_ = ((((pch >> 2) ^ (ml_ & 3)) << 2) | (pch & 3)) * 8;                              \
+        const int lc_ = ((((pch >> 2) ^ (ml_ & 3)) << 2) | ((pch & 3) ^ (((ml_ >> 3) & 1) << 1))) * 8;  \
         const int kk_ = T.k0 + lc_;                                                                     \
         const int tap_ = kk_ / T.kpt, c_ = kk_ - tap_ * T.kpt;                                          \
         const int sh_ = (T.taps == 3 && tap_ < 3) ? tap_ - 1 : 0;                                       \
@@ -131,9 +139,9 @@ __global__ __launch_bounds__(512) void k_conv_wgrad2(const CwArgs pa) {
     {
         const int mrow = 8 * (lane >> 4) + ((lane & 15) >> 2);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) fo_h[i] = swz_w2(mrow, wm * 64 + i * 16 + (lane & 3) * 4);
+        for (int i = 0; i < 4; ++i) fo_h[i] = swz_cw(mrow, wm * 64 + i * 16 + (lane & 3) * 4);
 #pragma unroll
-        for (int j = 0; j < 7; ++j) fo_z[j] = 32 * 256 + swz_w2(mrow, wn * 112 + j * 16 + (lane & 3) * 4);
+        for (int j = 0; j < 7; ++j) fo_z[j] = 32 * 256 + swz_cw(mrow, wn * 112 + j * 16 + (lane & 3) * 4);
     }
     typedef s16x4_t __attribute__((address_space(3))) * lds_v4;
 #define CW2_FRAG(dst, slab, off)                                                                       \
