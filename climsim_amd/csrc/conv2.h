@@ -144,7 +144,7 @@ __global__ __launch_bounds__(512) void k_conv2(const ConvArgs p) {
     // ---- epilogue.  D[channel][row]: lane owns row ..+(lane&15), channels ..+4*(lane>>4)+{0..3}.
     // The accumulators are transformed in place; each output tensor then goes wave-tile by wave-tile through
     // a private LDS region (64 rows x 240-B pitch) so that the global stores are 16 B per lane along 224-B row
-    // segments (row-per-lane 8-B stores were store-issue bound: 13 us of a 58 us conv).
+    // segments instead of row-per-lane 8-B pieces.
     unsigned char* reg = cv2_ring + wid * (64 * 240);
     const int64_t mw = m0 + wm * 64;
     const int nw = n0 + wn * 112;

@@ -154,6 +154,7 @@ __global__ __launch_bounds__(512) void k_conv_wgrad2(const CwArgs pa) {
 
     // Software pipeline: the fragments of slab s+1 are read from LDS between the MFMAs of slab s (each
     // fragment register is reloaded in place right after its last use), and the DMA runs three slabs ahead.
+    // (With separate read and MFMA phases the eight waves leave the barrier together and run the phases serially.)
     CW2_ISSUE(0)
     CW2_ISSUE(1)
     CW2_ISSUE(2)
