@@ -6,8 +6,8 @@
 //     256 CUs.  8 waves of 64 x 112, v_mfma_f32_16x16x32_bf16: 4 x 7 tiles = 112 accumulator VGPRs,
 //     11 LDS fragment reads per 28 MFMAs (the 2x2 32x32 arrangement needed 16 per 16).
 //   * contraction in slabs of 32 (channel pad 416 instead of 448), operands stream global -> LDS with
-//     `global_load_lds_dwordx4` into a 4-slot ring (30 KiB per slot): two slabs are consumed per barrier
-//     while the next two stream in, `vmcnt` + raw `s_barrier`.  Rows that fall outside their column (tap shift at level 0 / 59) or past
+//     `global_load_lds_dwordx4` into a 4-slot ring (30 KiB per slot), three slabs in flight, counted `vmcnt` +
+//     raw `s_barrier`; the fragments of the next slab are read between the MFMAs of the current one.  Rows that fall outside their column (tap shift at level 0 / 59) or past
 //     the batch fetch from a zero page instead of being predicated, so every wave issues the same number
 //     of DMA pieces per slab.
 //   * LDS image is lane-linear per 1-KiB piece (16 rows x 64 B); the bank swizzle (16-B chunk ^ cv2_swz(row>>2))
@@ -75,8 +75,8 @@ __global__ __launch_bounds__(512) void k_conv2(const ConvArgs p) {
     const int nt = p.taps * kc;
     const char* zsrc = reinterpret_cast<const char*>(p.zeros);
 
-#define CV2_ISSUE(st)                                                                                  \
-    {                                                                                                   \
+    // sources of the four pieces of slab `st` (clamped past the end: identical bytes, uniform vmcnt count)
+#define CV2_SRC(st)                                                                                    \
         const int sc_ = min((st), nt - 1);                                                              \
         const int tap_ = sc_ / kc, c0_ = (sc_ - tap_ * kc) * 32;                                        \
         const int sh_ = tap_ == 0 ? p.sh0 : tap_ == 1 ? p.sh1 : tap_ == 2 ? p.sh2 : p.sh3;              \
@@ -84,11 +84,16 @@ __global__ __launch_bounds__(512) void k_conv2(const ConvArgs p) {
         const char* Sb_ = reinterpret_cast<const char*>(S_) + ((int64_t)sh_ * p.lda + c0_) * 2;         \
         const char* s0_ = ((ok0 >> tap_) & 1u) ? Sb_ + arow0 : zsrc;                                    \
         const char* s1_ = ((ok1 >> tap_) & 1u) ? Sb_ + arow1 : zsrc;                                    \
-        const unsigned base_ = lds0 + (unsigned)((st) & (CV2_STAGES - 1)) * CV2_STAGE_BYTES;            \
-        dma16(s0_, base_ + a_piece0);                                                                   \
-        dma16(s1_, base_ + a_piece0 + 8192u);                                                           \
-        dma16(bsrc0 + sc_ * 64, base_ + CV2_A_BYTES + a_piece0);                                        \
-        dma16(bsrc1 + sc_ * 64, base_ + CV2_A_BYTES + b_piece1);                                        \
+        const char* s2_ = bsrc0 + sc_ * 64;                                                             \
+        const char* s3_ = bsrc1 + sc_ * 64;                                                             \
+        const unsigned base_ = lds0 + (unsigned)((st) & (CV2_STAGES - 1)) * CV2_STAGE_BYTES;
+#define CV2_PIECE(k)                                                                                   \
+        dma16((k) == 0 ? s0_ : (k) == 1 ? s1_ : (k) == 2 ? s2_ : s3_,                                   \
+              base_ + ((k) == 0 ? a_piece0 : (k) == 1 ? a_piece0 + 8192u : (k) == 2 ? CV2_A_BYTES + a_piece0 : CV2_A_BYTES + b_piece1));
+#define CV2_ISSUE(st)                                                                                  \
+    {                                                                                                   \
+        CV2_SRC(st)                                                                                     \
+        CV2_PIECE(0) CV2_PIECE(1) CV2_PIECE(2) CV2_PIECE(3)                                             \
     }
 
     f32x4_t acc[4][7];
@@ -102,20 +107,12 @@ __global__ __launch_bounds__(512) void k_conv2(const ConvArgs p) {
     const unsigned a_off = (unsigned)((wm * 64 + (lane & 15)) * 64) + sw;
     const unsigned b_off = (unsigned)(CV2_A_BYTES + (wn * 112 + (lane & 15)) * 64) + sw;
 
-#define CV2_COMPUTE(slab)                                                                              \
-    {                                                                                                   \
-        const unsigned char* st_ = cv2_ring + ((slab) & (CV2_STAGES - 1)) * CV2_STAGE_BYTES;            \
-        bf16x8_t fa[4], fw[7];                                                                          \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(st_ + a_off + i * 1024); \
-        _Pragma("unroll") for (int j = 0; j < 7; ++j) fw[j] = *reinterpret_cast<const bf16x8_t*>(st_ + b_off + j * 1024); \
-        _Pragma("unroll") for (int j = 0; j < 7; ++j)                                                   \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                               \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0);  \
-    }
-
-    // two slabs per barrier: slabs s, s+1 are consumed while s+2, s+3 stream into the other half of the ring
+    // Software pipeline: DMA three slabs ahead; the fragments of slab s+1 are read from LDS between the MFMAs of
+    // slab s, each fragment register reloaded in place right after its last use (no second fragment buffer).
     CV2_ISSUE(0)
     CV2_ISSUE(1)
+    CV2_ISSUE(2)
+    CV2_ISSUE(3)
     // bias of this lane's 7 channel quads, fetched now: a load issued in the epilogue costs a full L2 round
     // trip per dependent use, and there is nothing left to hide it behind
     float4 bq[7];
@@ -123,22 +120,42 @@ __global__ __launch_bounds__(512) void k_conv2(const ConvArgs p) {
     for (int j = 0; j < 7; ++j)
         bq[j] = MODE != CONV_BWD ? *reinterpret_cast<const float4*>(p.bias + n0 + wn * 112 + j * 16 + 4 * (lane >> 4))
                                  : make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int s = 0; s < nt; s += 2) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's pieces of slabs s, s+1 have landed
-        __builtin_amdgcn_s_barrier();                       // ... everyone's; slots of s-2, s-1 are free again
-        if (!(p.ablate & 1)) {
-            CV2_ISSUE(s + 2)
-            CV2_ISSUE(s + 3)
+    bf16x8_t fa[4], fw[7];
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");       // slab 0 has landed (the bias loads are older still)
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(cv2_ring + a_off + i * 1024);
+#pragma unroll
+    for (int j = 0; j < 7; ++j) fw[j] = *reinterpret_cast<const bf16x8_t*>(cv2_ring + b_off + j * 1024);
+    for (int s = 0; s < nt; ++s) {
+        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");   // slab s+1 landed; my reads of slab s are done
+        __builtin_amdgcn_s_barrier();                                 // ... everyone's: slot s&3 is free
+        // the four DMA pieces of slab s+4 are issued one at a time between MFMA groups: all eight waves leave the
+        // barrier together, and a wave that issues its pieces back to back stalls while its SIMD partner does the same
+        CV2_SRC(s + 4)
+        const unsigned char* nx = cv2_ring + ((s + 1) & (CV2_STAGES - 1)) * CV2_STAGE_BYTES;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0);
+            fw[j] = *reinterpret_cast<const bf16x8_t*>(nx + b_off + j * 1024);
+            if (j == 0) CV2_PIECE(0)
+            if (j == 1) CV2_PIECE(1)
+            if (j == 2) CV2_PIECE(2)
+            if (j == 3) CV2_PIECE(3)
         }
-        if (!(p.ablate & 2)) {
-            CV2_COMPUTE(s)
-            if (s + 1 < nt) CV2_COMPUTE(s + 1)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            acc[i][6] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[6], fa[i], acc[i][6], 0, 0, 0);
+            fa[i] = *reinterpret_cast<const bf16x8_t*>(nx + a_off + i * 1024);
         }
+        fw[6] = *reinterpret_cast<const bf16x8_t*>(nx + b_off + 6 * 1024);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the clamped tail pieces have landed ...
     __builtin_amdgcn_s_barrier();                           // ... and nobody reads the ring any more
 #undef CV2_ISSUE
-#undef CV2_COMPUTE
+#undef CV2_SRC
+#undef CV2_PIECE
 
     if (p.ablate & 4) return;
     // ---- epilogue.  D[channel][row]: lane owns row ..+(lane&15), channels ..+4*(lane>>4)+{0..3}.
