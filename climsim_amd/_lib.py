@@ -63,6 +63,7 @@ SIGNATURES = {
     "cs_mlp_profile_step": (C.c_int, [_P, _P, _P, _P, _I64, C.c_int, _F, _P, _P, C.POINTER(CsKernelTimes)]),
     "cs_mlp_debug_stamps": (C.c_int, [_P, _P, _I64]),
     "cs_normalise_rows": (C.c_int, [_P, _P, _I64, _I32, _P, _P, _P, _P]),
+    "cs_metrics_columns": (C.c_int, [_P, _P, _I64, _I32, _I32, _P, _P, _P, _P, _P, _P]),
     "cs_loader_stack": (C.c_int, [_P, _P, _I32, _I64, _I32, _I32, _P, _P, _I32, _P, _P, _P, _P, _P]),
     "cs_cnn_create": (C.c_int, [C.POINTER(_P), C.POINTER(CsCnnCfg)]),
     "cs_cnn_destroy": (None, [_P]),

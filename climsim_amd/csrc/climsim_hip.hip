@@ -6,6 +6,7 @@
 #include "chain.h"
 #include "wgrad2.h"
 #include "loader.h"
+#include "metrics.h"
 
 #include <cmath>
 #include <cstdarg>
@@ -652,6 +653,17 @@ int cs_loader_stack(const void* mli_dev, const void* mlo_dev, int32_t src_f64, i
         hipLaunchKernelGGL(k_loader_stack<float>, grid, dim3(256), lds, st, (const float*)mli_dev, (const float*)mlo_dev, ncol, n_in,
                            in_sub_dev, in_div_dev, n_out, tend_src_dev, out_scale_dev, x_out_dev, y_out_dev);
     }
+    HIP_TRY(hipGetLastError());
+    return CS_OK;
+}
+
+int cs_metrics_columns(const float* pred_dev, const float* target_dev, int64_t n_steps, int32_t ncol, int32_t n_out,
+                       const double* ps_dev, const double* wa_dev, const double* wb_dev, const double* area_dev,
+                       double* stats_dev, void* stream) {
+    if (!pred_dev || !target_dev || !ps_dev || !wa_dev || !wb_dev || !area_dev || !stats_dev) return fail(CS_ERR_INVALID, "null argument");
+    if (n_steps <= 0 || n_steps > 0x7fffffff || ncol <= 0 || n_out <= 0) return fail(CS_ERR_INVALID, "bad sizes");
+    hipLaunchKernelGGL(k_metrics_columns, dim3((unsigned)ncol, (unsigned)((n_out + 127) / 128)), dim3(256), 0, (hipStream_t)stream,
+                       pred_dev, target_dev, (int)n_steps, ncol, n_out, ps_dev, wa_dev, wb_dev, area_dev, stats_dev);
     HIP_TRY(hipGetLastError());
     return CS_OK;
 }

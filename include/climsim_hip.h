@@ -151,6 +151,14 @@ int cs_loader_stack(const void* mli_dev, const void* mlo_dev, int32_t src_f64, i
                     const double* in_sub_dev, const double* in_div_dev, int32_t n_out, const int32_t* tend_src_dev,
                     const double* out_scale_dev, float* x_out_dev, float* y_out_dev, void* stream);
 
+/* Evaluation metrics on the device: data_utils.output_weighting + calc_MAE / calc_RMSE / calc_R2 / calc_bias with
+ * avg_grid=False (data_utils.py:1112-1362, 1432-1497).  pred/target (n_steps*ncol, n_out) float32 rows, row = t*ncol + c;
+ * weight(row, f) = (wa[f] + wb[f]*ps[row]) * area[c]  (constants folded on the host, see climsim_amd/metrics.py).
+ * stats_dev [ncol][n_out][4] float64 = MAE, RMSE, R2, bias per grid column and output. */
+int cs_metrics_columns(const float* pred_dev, const float* target_dev, int64_t n_steps, int32_t ncol, int32_t n_out,
+                       const double* ps_dev, const double* wa_dev, const double* wb_dev, const double* area_dev,
+                       double* stats_dev, void* stream);
+
 #define CS_CNN_FLAG_TILE128 1   /* development: run every conv on the 128x128-tile kernel (A/B runs, parity cross-check) */
 typedef struct cs_cnn_cfg {
     int32_t depth;       /* hp_depth = 12            */
