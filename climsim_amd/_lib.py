@@ -58,6 +58,7 @@ SIGNATURES = {
     "cs_mlp_loss_grads": (C.c_int, [_P, _P, _P, _P, _I64, C.c_int, _P, C.c_int, _P]),
     "cs_mlp_grad_buffer": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_I64)]),
     "cs_mlp_set_grad_buffer": (C.c_int, [_P, _P]),
+    "cs_mlp_get_grads": (C.c_int, [_P, _P, _I64, _P]),
     "cs_mlp_apply": (C.c_int, [_P, _F, _F, _P]),
     "cs_mlp_train_step": (C.c_int, [_P, _P, _P, _P, _I64, C.c_int, _F, _P, _P]),
     "cs_mlp_profile_step": (C.c_int, [_P, _P, _P, _P, _I64, C.c_int, _F, _P, _P, C.POINTER(CsKernelTimes)]),

@@ -64,7 +64,8 @@ struct ProfScope {
 };
 
 struct Layer {
-    int K, Kp, N;
+    int K, Kp, N;              // real contraction length, padded (x128), output width padded (x128)
+    int Nr = 0;                // real output width (N == Nr except for the two output layers of a non-128 model)
     int64_t w_off, b_off;      // offsets (floats) in the flat parameter buffer
     u16 *Wt = nullptr, *Wn = nullptr;   // bf16 operand copies [N][Kp], [Kp][N] (per-layer kernels)
     u16 *Wf = nullptr, *Wb = nullptr;   // fragment-major copies for the chain kernels
@@ -80,7 +81,9 @@ struct cs_mlp {
     cs_mlp_cfg cfg;
     int L = 0;
     std::vector<Layer> layers;
-    int64_t n_params = 0;
+    int64_t n_params = 0;      // floats of the internal (padded) flat buffers P, M, V, G
+    int64_t n_params_keras = 0;  // floats of the Keras-ordered weight list (what set/get_weights exchange)
+    int n_out = 128, n_outp = 128;
     int64_t m_pad_max = 0;
     float *P = nullptr, *M = nullptr, *V = nullptr, *G = nullptr;
     bool own_G = true;
@@ -102,14 +105,21 @@ struct cs_mlp {
 
 namespace {
 
-// Keras order <-> internal order differ only in the last layer: heads [W_lin(128,120), b_lin,
-// W_relu(128,8), b_relu] are stored as one fused [128][128] matrix + one [128] bias.
+// Keras order <-> internal order: every layer is stored [K][N] with N padded to a multiple of 128 (zero columns;
+// only the two output layers of a model whose output width is not a multiple of 128 are actually padded), and the
+// heads [W_lin(n_out,n_lin), b_lin, W_relu(n_out,n_relu), b_relu] are one fused [n_out][N] matrix + one [N] bias.
 void keras_to_internal(const cs_mlp* h, const float* src, float* dst) {
+    memset(dst, 0, sizeof(float) * h->n_params);
+    for (int l = 0; l + 1 < h->L; ++l) {
+        const Layer& ly = h->layers[l];
+        for (int k = 0; k < ly.K; ++k) memcpy(dst + ly.w_off + (int64_t)k * ly.N, src + (int64_t)k * ly.Nr, sizeof(float) * ly.Nr);
+        src += (int64_t)ly.K * ly.Nr;
+        memcpy(dst + ly.b_off, src, sizeof(float) * ly.Nr);
+        src += ly.Nr;
+    }
     const Layer& last = h->layers[h->L - 1];
-    const int64_t head = last.w_off;
-    memcpy(dst, src, sizeof(float) * head);
     const int nl = h->cfg.n_out_lin, nr = h->cfg.n_out_relu, K = last.K, N = last.N;
-    const float* wl = src + head;
+    const float* wl = src;
     const float* bl = wl + (int64_t)K * nl;
     const float* wr = bl + nl;
     const float* br = wr + (int64_t)K * nr;
@@ -122,11 +132,16 @@ void keras_to_internal(const cs_mlp* h, const float* src, float* dst) {
 }
 
 void internal_to_keras(const cs_mlp* h, const float* src, float* dst) {
+    for (int l = 0; l + 1 < h->L; ++l) {
+        const Layer& ly = h->layers[l];
+        for (int k = 0; k < ly.K; ++k) memcpy(dst + (int64_t)k * ly.Nr, src + ly.w_off + (int64_t)k * ly.N, sizeof(float) * ly.Nr);
+        dst += (int64_t)ly.K * ly.Nr;
+        memcpy(dst, src + ly.b_off, sizeof(float) * ly.Nr);
+        dst += ly.Nr;
+    }
     const Layer& last = h->layers[h->L - 1];
-    const int64_t head = last.w_off;
-    memcpy(dst, src, sizeof(float) * head);
     const int nl = h->cfg.n_out_lin, nr = h->cfg.n_out_relu, K = last.K, N = last.N;
-    float* wl = dst + head;
+    float* wl = dst;
     float* bl = wl + (int64_t)K * nl;
     float* wr = bl + nl;
     float* br = wr + (int64_t)K * nr;
@@ -248,7 +263,7 @@ int run_forward(cs_mlp* h, const float* x, const int64_t* row_idx, int64_t n, in
             p.out = h->layers[l + 1].H; p.ldo = h->layers[l + 1].Kp;
             hipLaunchKernelGGL(k_gemm_nt<EPI_HIDDEN>, grid, dim3(256), 0, st, p);
         } else {
-            p.n_lin = h->cfg.n_out_lin; p.yhat = yhat; p.y = y; p.row_idx = row_idx; p.n_rows = n; p.loss = loss;
+            p.n_lin = h->cfg.n_out_lin; p.n_real = h->n_out; p.yhat = yhat; p.y = y; p.row_idx = row_idx; p.n_rows = n; p.loss = loss;
             p.out = want_dz ? ly.dZ : nullptr; p.ldo = ly.N;
             hipLaunchKernelGGL(k_gemm_nt<EPI_OUT>, grid, dim3(256), 0, st, p);
         }
@@ -347,8 +362,9 @@ int cs_mlp_create(cs_mlp_t** out, const cs_mlp_cfg* cfg) {
     if (cfg->n_hidden < 1 || cfg->n_hidden > CS_MAX_HIDDEN) return fail(CS_ERR_INVALID, "n_hidden=%d not in 1..%d", cfg->n_hidden, CS_MAX_HIDDEN);
     for (int i = 0; i < cfg->n_hidden; ++i)
         if (cfg->hidden[i] <= 0 || cfg->hidden[i] % 128) return fail(CS_ERR_INVALID, "hidden[%d]=%d must be a positive multiple of 128", i, cfg->hidden[i]);
-    if (cfg->n_out_lin + cfg->n_out_relu != 128 || cfg->n_out_lin % 4 || cfg->n_out_lin < 0 || cfg->n_out_relu < 0)
-        return fail(CS_ERR_INVALID, "heads must total 128 outputs with n_out_lin a multiple of 4 (got %d+%d)", cfg->n_out_lin, cfg->n_out_relu);
+    if (cfg->n_out_lin < 0 || cfg->n_out_relu < 0 || cfg->n_out_lin % 4 || cfg->n_out_relu % 4 || cfg->n_out_lin + cfg->n_out_relu < 4 ||
+        cfg->n_out_lin + cfg->n_out_relu > 1024)
+        return fail(CS_ERR_INVALID, "heads must total 4..1024 outputs, both counts multiples of 4 (got %d+%d)", cfg->n_out_lin, cfg->n_out_relu);
     if (cfg->act < 0 || cfg->act > 2) return fail(CS_ERR_INVALID, "unknown activation %d", cfg->act);
     if (cfg->optimizer < 0 || cfg->optimizer > 3) return fail(CS_ERR_INVALID, "unknown optimizer %d", cfg->optimizer);
     if (cfg->max_batch <= 0) return fail(CS_ERR_INVALID, "max_batch must be positive");
@@ -364,23 +380,29 @@ int cs_mlp_create(cs_mlp_t** out, const cs_mlp_cfg* cfg) {
     std::vector<int> dims;
     dims.push_back(cfg->n_in);
     for (int i = 0; i < cfg->n_hidden; ++i) dims.push_back(cfg->hidden[i]);
-    dims.push_back(128);
-    dims.push_back(128);
-    int64_t off = 0;
+    // the "upper output" Dense(output_length) and the fused heads: output_length wide (step2_retrain.py:113-122;
+    // 368 for the v2 variable set, hpo_baseline_v2.py:89-101), padded to a multiple of 128 with zero columns
+    h->n_out = cfg->n_out_lin + cfg->n_out_relu;
+    h->n_outp = (int)round_up(h->n_out, 128);
+    dims.push_back(h->n_out);
+    dims.push_back(h->n_out);
+    int64_t off = 0, off_keras = 0;
     h->layers.resize(h->L);
     for (int l = 0; l < h->L; ++l) {
         Layer& ly = h->layers[l];
-        ly.K = dims[l]; ly.N = dims[l + 1]; ly.Kp = (int)round_up(ly.K, 128);
+        ly.K = dims[l]; ly.Nr = dims[l + 1]; ly.N = (int)round_up(ly.Nr, 128); ly.Kp = (int)round_up(ly.K, 128);
         ly.w_off = off; off += (int64_t)ly.K * ly.N;
         ly.b_off = off; off += ly.N;
+        off_keras += (int64_t)ly.K * ly.Nr + ly.Nr;
     }
     h->n_params = off;
+    h->n_params_keras = off_keras;
     h->use_chain = !(cfg->flags & CS_FLAG_NO_CHAIN);
     for (int l = 0; l < h->L; ++l) {
         const Layer& ly = h->layers[l];
         if (!(ly.N == 128 || ly.N == 256 || ly.N == 512) || ly.Kp > CHAIN_PITCH || ly.Kp % 64) h->use_chain = false;
     }
-    if (2 * h->L > CHAIN_MAX_STAGES) h->use_chain = false;
+    if (2 * h->L > CHAIN_MAX_STAGES || h->n_out != 128) h->use_chain = false;
     {
         int boff = 0;
         for (int l = 0; l < h->L; ++l) { h->layers[l].bias_off = boff; boff += h->layers[l].N; }
@@ -461,7 +483,7 @@ void cs_mlp_destroy(cs_mlp_t* h) {
     delete h;
 }
 
-int64_t cs_mlp_num_params(const cs_mlp_t* h) { return h ? h->n_params : 0; }
+int64_t cs_mlp_num_params(const cs_mlp_t* h) { return h ? h->n_params_keras : 0; }
 int64_t cs_mlp_device_bytes(const cs_mlp_t* h) { return h ? h->bytes : 0; }
 
 int cs_mlp_set_norm(cs_mlp_t* h, const float* input_sub, const float* input_div) {
@@ -474,21 +496,32 @@ int cs_mlp_set_norm(cs_mlp_t* h, const float* input_sub, const float* input_div)
 
 int cs_mlp_set_weights(cs_mlp_t* h, const float* host, int64_t n, void* stream) {
     if (!h || !host) return fail(CS_ERR_INVALID, "null argument");
-    if (n != h->n_params) return fail(CS_ERR_INVALID, "expected %lld floats, got %lld", (long long)h->n_params, (long long)n);
-    std::vector<float> tmp((size_t)n);
+    if (n != h->n_params_keras) return fail(CS_ERR_INVALID, "expected %lld floats, got %lld", (long long)h->n_params_keras, (long long)n);
+    std::vector<float> tmp((size_t)h->n_params);
     keras_to_internal(h, host, tmp.data());
     hipStream_t st = (hipStream_t)stream;
-    HIP_TRY(hipMemcpyAsync(h->P, tmp.data(), sizeof(float) * n, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(h->P, tmp.data(), sizeof(float) * h->n_params, hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));
     return launch_optimizer(h, 0.f, 0.f, true, st);
 }
 
 int cs_mlp_get_weights(cs_mlp_t* h, float* host, int64_t n, void* stream) {
     if (!h || !host) return fail(CS_ERR_INVALID, "null argument");
-    if (n != h->n_params) return fail(CS_ERR_INVALID, "expected %lld floats, got %lld", (long long)h->n_params, (long long)n);
-    std::vector<float> tmp((size_t)n);
+    if (n != h->n_params_keras) return fail(CS_ERR_INVALID, "expected %lld floats, got %lld", (long long)h->n_params_keras, (long long)n);
+    std::vector<float> tmp((size_t)h->n_params);
     hipStream_t st = (hipStream_t)stream;
-    HIP_TRY(hipMemcpyAsync(tmp.data(), h->P, sizeof(float) * n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(tmp.data(), h->P, sizeof(float) * h->n_params, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    internal_to_keras(h, tmp.data(), host);
+    return CS_OK;
+}
+
+int cs_mlp_get_grads(cs_mlp_t* h, float* host, int64_t n, void* stream) {
+    if (!h || !host) return fail(CS_ERR_INVALID, "null argument");
+    if (n != h->n_params_keras) return fail(CS_ERR_INVALID, "expected %lld floats, got %lld", (long long)h->n_params_keras, (long long)n);
+    std::vector<float> tmp((size_t)h->n_params);
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(tmp.data(), h->G, sizeof(float) * h->n_params, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     internal_to_keras(h, tmp.data(), host);
     return CS_OK;
@@ -496,13 +529,13 @@ int cs_mlp_get_weights(cs_mlp_t* h, float* host, int64_t n, void* stream) {
 
 int cs_mlp_get_opt_state(cs_mlp_t* h, float* host_m, float* host_v, int64_t n, int64_t* iterations, void* stream) {
     if (!h || !host_m || !host_v) return fail(CS_ERR_INVALID, "null argument");
-    if (n != h->n_params) return fail(CS_ERR_INVALID, "expected %lld floats, got %lld", (long long)h->n_params, (long long)n);
-    std::vector<float> tmp((size_t)n);
+    if (n != h->n_params_keras) return fail(CS_ERR_INVALID, "expected %lld floats, got %lld", (long long)h->n_params_keras, (long long)n);
+    std::vector<float> tmp((size_t)h->n_params);
     hipStream_t st = (hipStream_t)stream;
-    HIP_TRY(hipMemcpyAsync(tmp.data(), h->M, sizeof(float) * n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(tmp.data(), h->M, sizeof(float) * h->n_params, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     internal_to_keras(h, tmp.data(), host_m);
-    HIP_TRY(hipMemcpyAsync(tmp.data(), h->V, sizeof(float) * n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(tmp.data(), h->V, sizeof(float) * h->n_params, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     internal_to_keras(h, tmp.data(), host_v);
     if (iterations) *iterations = h->iterations;
@@ -511,15 +544,15 @@ int cs_mlp_get_opt_state(cs_mlp_t* h, float* host_m, float* host_v, int64_t n, i
 
 int cs_mlp_set_opt_state(cs_mlp_t* h, const float* host_m, const float* host_v, int64_t n, int64_t iterations, void* stream) {
     if (!h || !host_m || !host_v) return fail(CS_ERR_INVALID, "null argument");
-    if (n != h->n_params) return fail(CS_ERR_INVALID, "expected %lld floats, got %lld", (long long)h->n_params, (long long)n);
+    if (n != h->n_params_keras) return fail(CS_ERR_INVALID, "expected %lld floats, got %lld", (long long)h->n_params_keras, (long long)n);
     if (iterations < 0) return fail(CS_ERR_INVALID, "negative iteration count");
-    std::vector<float> tmp((size_t)n);
+    std::vector<float> tmp((size_t)h->n_params);
     hipStream_t st = (hipStream_t)stream;
     keras_to_internal(h, host_m, tmp.data());
-    HIP_TRY(hipMemcpyAsync(h->M, tmp.data(), sizeof(float) * n, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(h->M, tmp.data(), sizeof(float) * h->n_params, hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));
     keras_to_internal(h, host_v, tmp.data());
-    HIP_TRY(hipMemcpyAsync(h->V, tmp.data(), sizeof(float) * n, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(h->V, tmp.data(), sizeof(float) * h->n_params, hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));
     h->iterations = iterations;
     return CS_OK;
@@ -584,7 +617,7 @@ int cs_mlp_train_step(cs_mlp_t* h, const float* x_dev, const float* y_dev, const
                       int normalise, float lr, float* loss_dev, void* stream) {
     int rc = cs_mlp_loss_grads(h, x_dev, y_dev, row_idx_dev, n, normalise, loss_dev, 0, stream);
     if (rc) return rc;
-    return cs_mlp_apply(h, lr, 1.0f / (128.0f * (float)n), stream);
+    return cs_mlp_apply(h, lr, 1.0f / ((float)h->n_out * (float)n), stream);
 }
 
 int cs_mlp_profile_step(cs_mlp_t* h, const float* x_dev, const float* y_dev, const int64_t* row_idx_dev, int64_t n,

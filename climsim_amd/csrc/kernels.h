@@ -119,6 +119,7 @@ struct GemmNT {
     u16* out;  int ldo;          // bf16 output [m_pad][ldo] (hidden activation, or dz of the heads / prev layer)
     // EPI_OUT
     int n_lin;                   // columns < n_lin are linear, the rest relu
+    int n_real;                  // real output width (row pitch of yhat / y); columns >= n_real are padding
     float* yhat;                 // [n][N] fp32 or null
     const float* y;              // targets (row-gathered) or null
     const int64_t* row_idx;
@@ -223,17 +224,17 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const GemmNT p) {
                     *reinterpret_cast<uint2*>(p.out + m * p.ldo + n) = pack4(v[0], v[1], v[2], v[3]);
                 } else {  // EPI_OUT
                     v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
-                    const bool valid = m < p.n_rows;
                     float d[4] = {0.f, 0.f, 0.f, 0.f};
                     if (n >= p.n_lin) {  // relu head (n_lin is a multiple of 4)
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
                     }
+                    const bool valid = m < p.n_rows && n < p.n_real;
                     if (valid && p.yhat)
-                        *reinterpret_cast<float4*>(p.yhat + m * p.N + n) = make_float4(v[0], v[1], v[2], v[3]);
+                        *reinterpret_cast<float4*>(p.yhat + m * p.n_real + n) = make_float4(v[0], v[1], v[2], v[3]);
                     if (p.y && valid) {
                         const int64_t src = p.row_idx ? p.row_idx[m] : m;
-                        const float4 t4 = *reinterpret_cast<const float4*>(p.y + src * p.N + n);
+                        const float4 t4 = *reinterpret_cast<const float4*>(p.y + src * p.n_real + n);
                         const float e4[4] = {v[0] - t4.x, v[1] - t4.y, v[2] - t4.z, v[3] - t4.w};
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {

@@ -73,7 +73,9 @@ def _ptr(t):
 
 # ------------------------------------------------------------------------------- the model
 class MLPEmulator:
-    """ClimSim baseline MLP (124 -> units... -> 128 -> [120 linear || 8 relu]) on one MI355X."""
+    """ClimSim baseline MLP (input_length -> units... -> output_length -> [lin || relu]) on one MI355X:
+    124 -> ... -> 128 -> [120 || 8] for the v1 variable set (layer-chain kernels), e.g. 425 -> ... -> 368 -> [360 || 8]
+    for v2 (hpo_baseline_v2.py:58-101; one GEMM launch per layer)."""
 
     def __init__(self, units: Sequence[int] = (512, 512, 512, 512, 512), activation: str = "leakyrelu",
                  optimizer: str = "Adam", input_length: int = 124, output_length_lin: int = 120,
@@ -268,25 +270,22 @@ class MLPEmulator:
 
     def gradient_tensor(self):
         """Flat float32 gradient buffer as a torch tensor (allocated by torch and bound into the
-        engine) - the payload of the one-per-step RCCL all-reduce."""
+        engine) - the payload of the one-per-step RCCL all-reduce.  Internal parameter order (heads fused,
+        output layers padded to a multiple of 128 columns), so it may be longer than count_params()."""
         if self._grad_tensor is None:
             torch = _torch()
-            self._grad_tensor = torch.zeros(self._n_params, dtype=torch.float32, device=self.device)
+            ptr, n = C.c_void_p(), C.c_int64(0)
+            _lib.check(self.lib.cs_mlp_grad_buffer(self._h, C.byref(ptr), C.byref(n)))
+            self._grad_tensor = torch.zeros(int(n.value), dtype=torch.float32, device=self.device)
             _lib.check(self.lib.cs_mlp_set_grad_buffer(self._h, _ptr(self._grad_tensor)))
         return self._grad_tensor
 
     def get_gradients(self, grad_scale: float = 1.0) -> List[np.ndarray]:
         """Gradients of the last loss_grads call, Keras order (testing / inspection)."""
-        g = self.gradient_tensor().detach().cpu().numpy() * np.float32(grad_scale)
-        dims = [self.input_length, *self.units, self.output_length, self.output_length]
-        out, at = [], 0
-        for i in range(len(dims) - 1):
-            k, n = dims[i], dims[i + 1]
-            out += [g[at:at + k * n].reshape(k, n).copy(), g[at + k * n:at + k * n + n].copy()]
-            at += k * n + n
-        w, b = out[-2], out[-1]
-        nl = self.output_length_lin
-        return out[:-2] + [w[:, :nl].copy(), b[:nl].copy(), w[:, nl:].copy(), b[nl:].copy()]
+        self.gradient_tensor()
+        flat = np.empty(self._n_params, np.float32)
+        _lib.check(self.lib.cs_mlp_get_grads(self._h, flat.ctypes.data_as(C.c_void_p), flat.size, self._stream()))
+        return self._split(flat * np.float32(grad_scale))
 
     # ---- Keras-like API
     def predict(self, x, batch_size: Optional[int] = None, normalise: bool = False, as_numpy: bool = True):

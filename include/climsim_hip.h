@@ -44,7 +44,8 @@ typedef struct cs_mlp_cfg {
     int32_t n_hidden;             /* hp num_layers (2..12 in the HPO space)                      */
     int32_t hidden[CS_MAX_HIDDEN];/* hp units_k, multiples of 128 (128..1024 in the HPO space)   */
     int32_t n_out_lin;            /* output_length_lin  = 120 (linear head)                      */
-    int32_t n_out_relu;           /* output_length_relu = 8   (relu head); lin+relu must be 128  */
+    int32_t n_out_relu;           /* output_length_relu = 8   (relu head); both multiples of 4, lin+relu <= 1024;
+                                     128 (v1) runs on the layer-chain kernels, other widths (368 = v2) per layer */
     int32_t act;                  /* cs_act                                                       */
     float   alpha;                /* LeakyReLU slope (0.15)                                       */
     int32_t optimizer;            /* cs_opt                                                       */
@@ -91,16 +92,19 @@ int cs_mlp_forward(cs_mlp_t* h, const float* x_dev, const int64_t* row_idx_dev, 
                    float* yhat_dev, const float* y_dev, float* loss_dev, int accumulate, void* stream);
 
 /* Forward + backward of one batch (the autodiff half of Model.train_step): fills the flat float32
- * gradient buffer with d(sum of squared errors)/d(param) = UNSCALED sums; the 1/(128 n) of the
+ * gradient buffer with d(sum of squared errors)/d(param) = UNSCALED sums; the 1/(n_out n) of the
  * 'mse' mean (and 1/world for data parallel) is applied by cs_mlp_apply's grad_scale.
  * accumulate != 0 adds to the existing gradient/loss (micro-batching). */
 int cs_mlp_loss_grads(cs_mlp_t* h, const float* x_dev, const float* y_dev, const int64_t* row_idx_dev,
                       int64_t n, int normalise, float* loss_dev, int accumulate, void* stream);
 
-/* Flat gradient buffer (internal parameter order, n = num_params floats) for an external
- * all-reduce (RCCL via torch.distributed on a tensor aliasing it), or rebind it to caller memory. */
+/* Flat gradient buffer (internal parameter order: Keras order with the heads fused and the two output layers padded
+ * to a multiple of 128 columns; *n_floats >= num_params) for an external all-reduce (RCCL via torch.distributed on a
+ * tensor aliasing it), or rebind it to caller memory of that many floats.  cs_mlp_get_grads copies it out in Keras
+ * order (n = num_params) for inspection. */
 int cs_mlp_grad_buffer(cs_mlp_t* h, void** dev_ptr, int64_t* n_floats);
 int cs_mlp_set_grad_buffer(cs_mlp_t* h, void* dev_ptr);
+int cs_mlp_get_grads(cs_mlp_t* h, float* host, int64_t n, void* stream);
 
 /* optimizer.apply_gradients: g = grad * grad_scale; Keras-2.11 Adam / RMSprop / SGD or tfa-0.19
  * RectifiedAdam update with learning rate `lr`; increments optimizer.iterations; re-casts bf16

@@ -336,3 +336,51 @@ def test_heldout_per_variable_mae_r2_match_cpu_training(M, lowres_assets):
             assert abs(ra - rb) <= 2e-2, (v, ra, rb)
         else:
             assert np.isnan(ra) == np.isnan(rb) or np.isinf(ra) == np.isinf(rb), (v, ra, rb)
+
+
+@pytest.mark.parametrize("n_in,n_lin,n_relu,units,n", [(425, 360, 8, (256, 384), 300), (557, 360, 8, (128,), 129), (124, 60, 4, (128, 128), 77)])
+def test_v2_shapes_forward_gradients_and_training(M, n_in, n_lin, n_relu, units, n):
+    """Other variable sets (hpo_baseline_v2.py:58-101: 425 -> ... -> 368 -> [360 || 8]; v2 full inputs 557): the
+    "upper output" layer and the heads are output_length wide, padded to 384 columns inside the engine.  Same tolerances
+    as the v1 tests; the padding must stay exactly zero through Adam steps (checked through the weight round trip)."""
+    n_out = n_lin + n_relu
+    m = M.MLPEmulator(units=units, activation="leakyrelu", optimizer="Adam", input_length=n_in, output_length_lin=n_lin,
+                      output_length_relu=n_relu, max_batch=512, seed=None)
+    cfg = O.MLPConfig(n_in=n_in, hidden=tuple(units), n_out_lin=n_lin, n_out_relu=n_relu, act="leakyrelu")
+    ws = O.glorot_init(cfg, 5)
+    rng = np.random.default_rng(9)
+    for i in range(1, len(ws), 2):
+        ws[i] = rng.normal(0, 0.05, ws[i].shape).astype(np.float32)
+    assert m.count_params() == cfg.n_params() == sum(w.size for w in ws)
+    m.set_weights(ws)
+    for a, b in zip(m.get_weights(), ws):
+        np.testing.assert_array_equal(a, b)
+    x, y = O.synth_columns(n, seed=3, n_in=n_in, n_out=n_out)
+    got = m.predict(x)
+    ref16 = O.forward(ws, x, cfg, bf16=True)
+    assert got.shape == (n, n_out)
+    assert np.max(np.abs(got - ref16)) <= 2e-3 * np.max(np.abs(ref16))
+    assert np.all(got[:, n_lin:] >= 0)
+    xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    loss = m.loss_grads(xd, yd).cpu().numpy().astype(np.float64)
+    ref_loss, ref_mae, ref_g, _ = O.loss_and_grads(ws, x, y, cfg, bf16=True)
+    assert loss[0] / (n_out * n) == pytest.approx(ref_loss, rel=2e-3)
+    assert loss[1] / (n_out * n) == pytest.approx(ref_mae, rel=2e-3)
+    grads = m.get_gradients(1.0 / (n_out * n))
+    for i, (g, r) in enumerate(zip(grads, ref_g)):
+        assert g.shape == r.shape and rel(g, r) <= 5e-3, (i, rel(g, r))
+    ev = m.evaluate(x, y)
+    assert ev["mse"] == pytest.approx(ref_loss, rel=2e-3)
+    # training: losses track the oracle, padding stays zero (weights round-trip through the padded layout)
+    opt = O.Optimizer("Adam")
+    w = ws
+    lg, lr_ = [], []
+    for it in range(8):
+        lg.append(m.train_on_batch(xd, yd, 1e-3).cpu().numpy()[0] / (n_out * n))
+        w, l, _ = O.train_step(w, opt, x, y, cfg, 1e-3, bf16=True)
+        lr_.append(l)
+    np.testing.assert_allclose(lg, lr_, rtol=2e-2)
+    assert lg[-1] < lg[0]
+    after = m.get_weights()
+    m.set_weights(after)
+    np.testing.assert_allclose(m.predict(x), O.forward(after, x, cfg, bf16=True), atol=2e-3 * np.max(np.abs(ref16)))
