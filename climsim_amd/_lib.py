@@ -12,6 +12,7 @@ CS_FLAG_NO_TR_READ = 1
 CS_FLAG_NO_CHAIN = 2
 CS_FLAG_CHAIN_BM64 = 4
 CS_FLAG_CHAIN_BM128 = 8
+CS_FLAG_CHAIN_BM32 = 16
 
 ACT = {"relu": 0, "elu": 1, "leakyrelu": 2}
 OPT = {"Adam": 0, "RAdam": 1, "RMSprop": 2, "SGD": 3}

@@ -439,9 +439,14 @@ __global__ __launch_bounds__(512) void k_chain(const ChainArgs p) {
         } else if (S.Nc == 256) {   // wave = all BM rows x 32 columns
             chain_stage<BM, BM / 32, 1, E, ELU>(X, bias_lds, rows_lds, p, S, last, m0, wid, 0, tid, sq, ab, slot, pend);
         } else if (!BWD && S.epi == EPI_OUT) {   // heads: 128 wide, wave = half the rows x 32 columns
-            chain_stage<BM, BM / 64, 1, EPI_OUT, ELU>(X, bias_lds, rows_lds, p, S, last, m0, wid & 3, (wid >> 2) * (BM / 2), tid, sq, ab, slot, pend);
+            // (32-row tiles: four column waves cover the tile; waves 4-7 repeat their work - identical values to
+            //  identical places - and are dropped from the loss sums)
+            chain_stage<BM, (BM >= 64 ? BM / 64 : 1), 1, EPI_OUT, ELU>(X, bias_lds, rows_lds, p, S, last, m0, wid & 3,
+                                                                      BM >= 64 ? (wid >> 2) * (BM / 2) : 0, tid, sq, ab, slot, pend);
+            if (BM < 64 && wid >= 4) { sq = 0.f; ab = 0.f; }
         } else {                    // 128: wave = half the rows x 32 columns
-            chain_stage<BM, BM / 64, 1, E, ELU>(X, bias_lds, rows_lds, p, S, last, m0, wid & 3, (wid >> 2) * (BM / 2), tid, sq, ab, slot, pend);
+            chain_stage<BM, (BM >= 64 ? BM / 64 : 1), 1, E, ELU>(X, bias_lds, rows_lds, p, S, last, m0, wid & 3,
+                                                                BM >= 64 ? (wid >> 2) * (BM / 2) : 0, tid, sq, ab, slot, pend);
         }
     }
     if (!BWD && p.y) {

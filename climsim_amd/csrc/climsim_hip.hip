@@ -202,19 +202,28 @@ void launch_chain(const cs_mlp* h, int bm, int64_t m_pad, const ChainArgs& c, hi
         const dim3 g((unsigned)(m_pad / 128));
         if (elu) hipLaunchKernelGGL((k_chain<128, BWD, true>), g, dim3(512), chain_lds_bytes<128>(), st, c);
         else hipLaunchKernelGGL((k_chain<128, BWD, false>), g, dim3(512), chain_lds_bytes<128>(), st, c);
-    } else {
+    } else if (bm == 64) {
         const dim3 g((unsigned)(m_pad / 64));
         if (elu) hipLaunchKernelGGL((k_chain<64, BWD, true>), g, dim3(512), chain_lds_bytes<64>(), st, c);
         else hipLaunchKernelGGL((k_chain<64, BWD, false>), g, dim3(512), chain_lds_bytes<64>(), st, c);
+    } else {
+        const dim3 g((unsigned)(m_pad / 32));
+        if (elu) hipLaunchKernelGGL((k_chain<32, BWD, true>), g, dim3(512), chain_lds_bytes<32>(), st, c);
+        else hipLaunchKernelGGL((k_chain<32, BWD, false>), g, dim3(512), chain_lds_bytes<32>(), st, c);
     }
 }
 
 int chain_bm(const cs_mlp* h, int64_t n) {
+    if (h->cfg.flags & CS_FLAG_CHAIN_BM32) return 32;
     if (h->cfg.flags & CS_FLAG_CHAIN_BM64) return 64;
     if (h->cfg.flags & CS_FLAG_CHAIN_BM128) return 128;
-    // 128-row tiles halve the weight bytes per FLOP (the per-CU vector-memory path tops out near
-    // 64 B/clk, which is exactly the MFMA rate at 64 rows) but need >= 256 tiles to fill the chip.
-    return n >= 32768 ? 128 : 64;
+    // Every workgroup streams ALL weights once, whatever its row count.  128-row tiles halve the weight bytes per FLOP
+    // (the per-CU vector-memory path tops out near 64 B/clk, which is exactly the MFMA rate at 64 rows) but need >= 256
+    // tiles to fill the chip.  32-row tiles put a workgroup on every CU from 8192 rows down, but 256 workgroups then pull
+    // 612 MB of weights through the L2s per launch: measured forward 103 us vs 85 us (64 rows) at 8192 rows, while at
+    // 1024 / 3072 rows they win (58 vs 72 us, 67 vs 71 us; backward 40 vs 54 us).  Forward and backward share the tile
+    // (the sign masks are stored per workgroup and lane).
+    return n >= 32768 ? 128 : (n > 4096 ? 64 : 32);
 }
 
 int run_forward(cs_mlp* h, const float* x, const int64_t* row_idx, int64_t n, int normalise, float* yhat,
@@ -286,7 +295,7 @@ int run_backward(cs_mlp* h, int64_t n, bool atomics_needed, hipStream_t st) {
             S.out = h->layers[l - 1].dZ; S.ldo = h->layers[l - 1].N;
             S.hprev = ly.H; S.ldh = ly.Kp; S.epi = EPI_DGRAD;
         }
-        c.ablate = h->chain_ablate; c.dbg = h->dbg ? h->dbg + (h->m_pad_max / 64) * 64 : nullptr;
+        c.ablate = h->chain_ablate; c.dbg = h->dbg ? h->dbg + (h->m_pad_max / 32) * 64 : nullptr;
         c.dz_in = h->layers[h->L - 1].dZ; c.ld_dz_in = 128; c.w_in = 128;
         c.n_rows = n; c.act = h->cfg.act; c.slope = (h->cfg.act == CS_ACT_RELU) ? 0.f : h->cfg.alpha;
         const int bm = chain_bm(h, n);
@@ -418,6 +427,7 @@ int cs_mlp_create(cs_mlp_t** out, const cs_mlp_cfg* cfg) {
     if (h->use_chain) {
         for (const void* f : chain_kernels<128>()) HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, chain_lds_bytes<128>()));
         for (const void* f : chain_kernels<64>()) HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, chain_lds_bytes<64>()));
+        for (const void* f : chain_kernels<32>()) HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, chain_lds_bytes<32>()));
     }
     // ONE arena for every device buffer of the handle: a single large hipMalloc gets 2-MiB-aligned
     // virtual memory backed by large page fragments.  (Many small hipMallocs measured ~2 us effective
@@ -441,9 +451,9 @@ int cs_mlp_create(cs_mlp_t** out, const cs_mlp_cfg* cfg) {
         }
     }
     A((void**)&h->seg_dev, sizeof(Segment) * 2 * h->L);
-    if (getenv("CS_CHAIN_DBG")) A((void**)&h->dbg, (size_t)2 * (h->m_pad_max / 64) * 64 * 8);
+    if (getenv("CS_CHAIN_DBG")) A((void**)&h->dbg, (size_t)2 * (h->m_pad_max / 32) * 64 * 8);
     if (h->use_chain)
-        for (int l = 0; l + 1 < h->L; ++l) A((void**)&h->layers[l].mask, (size_t)(h->m_pad_max / 64) * 512 * 16);
+        for (int l = 0; l + 1 < h->L; ++l) A((void**)&h->layers[l].mask, (size_t)(h->m_pad_max / 32) * 512 * 16);
     for (int l = 0; l < h->L; ++l) {       // activations last: the big, streamed part
         Layer& ly = h->layers[l];
         A((void**)&ly.H, sizeof(u16) * h->m_pad_max * ly.Kp);
@@ -647,7 +657,7 @@ int cs_mlp_profile_step(cs_mlp_t* h, const float* x_dev, const float* y_dev, con
 int cs_mlp_debug_stamps(cs_mlp_t* h, unsigned long long* host, int64_t n_words) {
     if (!h || !host) return fail(CS_ERR_INVALID, "null argument");
     if (!h->dbg) return fail(CS_ERR_STATE, "set CS_CHAIN_DBG=1 before cs_mlp_create");
-    const int64_t have = 2 * (h->m_pad_max / 64) * 64;
+    const int64_t have = 2 * (h->m_pad_max / 32) * 64;
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(host, h->dbg, sizeof(unsigned long long) * (n_words < have ? n_words : have), hipMemcpyDeviceToHost));
     return CS_OK;

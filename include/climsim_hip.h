@@ -61,6 +61,7 @@ typedef struct cs_mlp_cfg {
 #define CS_FLAG_NO_CHAIN   2      /* one GEMM launch per layer instead of the fused layer-chain kernels    */
 #define CS_FLAG_CHAIN_BM64  4     /* force 64-row chain tiles  (default: by batch size)                    */
 #define CS_FLAG_CHAIN_BM128 8     /* force 128-row chain tiles                                             */
+#define CS_FLAG_CHAIN_BM32  16    /* force 32-row chain tiles                                              */
 
 /* keras.Model(...) + compile(): allocates weights (zero), optimiser state, workspace. */
 int  cs_mlp_create(cs_mlp_t** out, const cs_mlp_cfg* cfg);
