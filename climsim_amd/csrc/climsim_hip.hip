@@ -89,6 +89,9 @@ struct cs_mlp {
     bool own_G = true;
     float *sub = nullptr, *div = nullptr;
     bool have_norm = false;
+    float* loss_ring = nullptr;   // [2][2]: train_step accumulates the loss sums here; the optimiser kernel hands them over
+    int loss_cur = 0;
+    const float* opt_loss_src = nullptr; float* opt_loss_dst = nullptr; float* opt_loss_zero = nullptr;   // next optimiser launch
     Segment* seg_dev = nullptr;
     int n_seg = 0;
     int64_t iterations = 0;
@@ -160,6 +163,8 @@ int launch_optimizer(cs_mlp* h, float lr, float grad_scale, bool recast_only, hi
     a.n_seg = h->n_seg; a.seg = h->seg_dev;
     a.kind = h->cfg.optimizer; a.lr = lr; a.grad_scale = grad_scale;
     a.recast_only = recast_only ? 1 : 0;
+    a.loss_src = h->opt_loss_src; a.loss_dst = h->opt_loss_dst; a.loss_zero = h->opt_loss_zero;
+    h->opt_loss_dst = nullptr;
     // float32 scalars, cast where TensorFlow casts (variable dtype float32)
     const float b1 = (float)h->cfg.beta1, b2 = (float)h->cfg.beta2;
     const float t = (float)(h->iterations + 1);
@@ -438,6 +443,7 @@ int cs_mlp_create(cs_mlp_t** out, const cs_mlp_cfg* cfg) {
     A((void**)&h->M, sizeof(float) * off);
     A((void**)&h->V, sizeof(float) * off);
     A((void**)&h->G, sizeof(float) * off);
+    A((void**)&h->loss_ring, sizeof(float) * 4);
     A((void**)&h->sub, sizeof(float) * cfg->n_in);
     A((void**)&h->div, sizeof(float) * cfg->n_in);
     for (int l = 0; l < h->L; ++l) {
@@ -625,8 +631,25 @@ int cs_mlp_apply(cs_mlp_t* h, float lr, float grad_scale, void* stream) {
 
 int cs_mlp_train_step(cs_mlp_t* h, const float* x_dev, const float* y_dev, const int64_t* row_idx_dev, int64_t n,
                       int normalise, float lr, float* loss_dev, void* stream) {
-    int rc = cs_mlp_loss_grads(h, x_dev, y_dev, row_idx_dev, n, normalise, loss_dev, 0, stream);
+    int rc = check_batch(h, n);
     if (rc) return rc;
+    if (!x_dev || !y_dev || !loss_dev) return fail(CS_ERR_INVALID, "x_dev, y_dev and loss_dev are required");
+    if (normalise && !h->have_norm) return fail(CS_ERR_STATE, "normalise requested before cs_mlp_set_norm");
+    hipStream_t st = (hipStream_t)stream;
+    // No memset launch in the steady state: the loss sums accumulate in an internal slot that the PREVIOUS step's
+    // optimiser kernel zeroed; this step's optimiser kernel copies them to loss_dev and zeroes the other slot.
+    if (h->grads_dirty) {
+        ProfScope ps(CS_K_MEMSET, st);
+        HIP_TRY(hipMemsetAsync(h->G, 0, sizeof(float) * h->n_params, st));
+    }
+    h->grads_dirty = true;
+    float* slot = h->loss_ring + 2 * h->loss_cur;
+    rc = run_forward(h, x_dev, row_idx_dev, n, normalise, nullptr, y_dev, slot, true, st);
+    if (rc) return rc;
+    rc = run_backward(h, n, false, st);
+    if (rc) return rc;
+    h->opt_loss_src = slot; h->opt_loss_dst = loss_dev; h->opt_loss_zero = h->loss_ring + 2 * (h->loss_cur ^ 1);
+    h->loss_cur ^= 1;
     return cs_mlp_apply(h, lr, 1.0f / ((float)h->n_out * (float)n), stream);
 }
 

@@ -441,6 +441,8 @@ struct OptArgs {
     float bc1, bc2;       // RAdam: 1 - beta^t
     float radam_r; int radam_rect;
     int recast_only;      // set_weights: only refresh the bf16 copies
+    // train_step hands the step's loss sums over without a memset launch: copy loss_src -> loss_dst, zero loss_zero
+    const float* loss_src; float* loss_dst; float* loss_zero;
 };
 
 // Update rules (float32, one thread = 4 parameters):
@@ -452,6 +454,10 @@ struct OptArgs {
 //   SGD     : w -= lr*g
 __global__ __launch_bounds__(256) void k_optimizer(const OptArgs a) {
     const int64_t g4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g4 == 0 && a.loss_dst) {
+        a.loss_dst[0] = a.loss_src[0]; a.loss_dst[1] = a.loss_src[1];
+        a.loss_zero[0] = 0.f; a.loss_zero[1] = 0.f;
+    }
     if (g4 >= a.n4) return;
     const int64_t i0 = g4 * 4;
     float4 w = *reinterpret_cast<const float4*>(a.P + i0);
