@@ -15,8 +15,8 @@ d=json.loads(open('gpurun_out/bench.log').read().strip().splitlines()[-1])
 print({k:d[k] for k in ('value','ms_per_step')}, d['roofline'], {k:(round(v['ms_per_step'],4),v['launches_per_step']) for k,v in d['kernels'].items()}, d['cpu_baseline'])
 PY
 echo "== sweep"; rm -f gpurun_out/bench_sweep.log
-for b in 1024 3072 8192 32768 65536; do
-  timeout 600 python bench.py --batch $b --steps 100 --warmup 10 --cpu-budget 0 2>&1 | tail -1 >> gpurun_out/bench_sweep.log
+for b in 1024 3072 4096 8192 16384 32768 65536; do
+  timeout 600 python bench.py --batch $b --steps 100 --warmup 10 --cpu-budget 0 --no-extras 2>&1 | tail -1 >> gpurun_out/bench_sweep.log
 done
 python - <<'PY'
 import json
@@ -27,7 +27,7 @@ for line in open('gpurun_out/bench_sweep.log'):
 PY
 if [ "${1:-}" != "noprof" ]; then
 echo "== rocprof stats"
-cd /tmp && rm -rf /tmp/prof && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -- python3 $REPO/bench.py --steps 100 --warmup 10 --cpu-budget 0 --no-profile > $REPO/gpurun_out/rocprof_run.log 2>&1
+cd /tmp && rm -rf /tmp/prof && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -- python3 $REPO/bench.py --steps 100 --warmup 10 --cpu-budget 0 --no-profile --no-extras > $REPO/gpurun_out/rocprof_run.log 2>&1
 cd $REPO
 find /tmp/prof -name "*kernel_stats*" -exec cp {} gpurun_out/rocprof_kernel_stats.csv \;
 grep -E "k_|rocclr" gpurun_out/rocprof_kernel_stats.csv | cut -c1-160
