@@ -94,6 +94,7 @@ struct cs_mlp {
     const float* opt_loss_src = nullptr; float* opt_loss_dst = nullptr; float* opt_loss_zero = nullptr;   // next optimiser launch
     Segment* seg_dev = nullptr;
     int n_seg = 0;
+    int opt_blocks = 0;        // workgroups of the optimiser launch (32x32 weight tiles + 1024-float bias slices)
     int64_t iterations = 0;
     int64_t bytes = 0;
     bool use_chain = false;
@@ -159,7 +160,6 @@ void internal_to_keras(const cs_mlp* h, const float* src, float* dst) {
 int launch_optimizer(cs_mlp* h, float lr, float grad_scale, bool recast_only, hipStream_t st) {
     OptArgs a{};
     a.P = h->P; a.M = h->M; a.V = h->V; a.G = h->G;
-    a.n4 = h->n_params / 4;
     a.n_seg = h->n_seg; a.seg = h->seg_dev;
     a.kind = h->cfg.optimizer; a.lr = lr; a.grad_scale = grad_scale;
     a.recast_only = recast_only ? 1 : 0;
@@ -184,11 +184,9 @@ int launch_optimizer(cs_mlp* h, float lr, float grad_scale, bool recast_only, hi
         a.radam_r = a.radam_rect
             ? sqrtf((sma_t - 4.f) / (sma_inf - 4.f) * (sma_t - 2.f) / (sma_inf - 2.f) * sma_inf / sma_t) : 0.f;
     }
-    const int threads = 256;
-    const int64_t blocks = (a.n4 + threads - 1) / threads;
     {
         ProfScope ps(CS_K_OPTIMIZER, st);
-        hipLaunchKernelGGL(k_optimizer, dim3((unsigned)blocks), dim3(threads), 0, st, a);
+        hipLaunchKernelGGL(k_optimizer, dim3((unsigned)h->opt_blocks), dim3(256), 0, st, a);
     }
     HIP_TRY(hipGetLastError());
     return CS_OK;
@@ -480,8 +478,10 @@ int cs_mlp_create(cs_mlp_t** out, const cs_mlp_cfg* cfg) {
     std::vector<Segment> segs;
     for (int l = 0; l < h->L && rc == CS_OK; ++l) {
         Layer& ly = h->layers[l];
-        Segment sw{ly.w_off, (int64_t)ly.K * ly.N, ly.K, ly.N, ly.Kp, ly.Wt, ly.Wn, ly.Wf, ly.Wb};
-        Segment sb{ly.b_off, (int64_t)ly.N, 1, ly.N, 0, nullptr, nullptr, nullptr, nullptr};
+        Segment sw{ly.w_off, (int64_t)ly.K * ly.N, ly.K, ly.N, ly.Kp, ly.Wt, ly.Wn, ly.Wf, ly.Wb, h->opt_blocks};
+        h->opt_blocks += ((ly.K + 31) / 32) * (ly.N / 32);
+        Segment sb{ly.b_off, (int64_t)ly.N, 1, ly.N, 0, nullptr, nullptr, nullptr, nullptr, h->opt_blocks};
+        h->opt_blocks += (ly.N + 1023) / 1024;
         segs.push_back(sw);
         segs.push_back(sb);
     }
