@@ -25,7 +25,7 @@ struct cs_cnn {
     int conv_ablate = 0;                 // CS_CONV_ABLATE (development)
     int cpw = 0;                         // contraction pad of the trunk channels (32- or 64-granular)
     float *P = nullptr, *M = nullptr, *V = nullptr, *G = nullptr, *G_own = nullptr;
-    CnnSeg* seg_dev = nullptr; int n_seg = 0;
+    CnnSeg* seg_dev = nullptr; int n_seg = 0, opt_blocks = 0;
     ConvWgradItem* items_dev = nullptr; int n_items = 0, total_tiles = 0;
     CwTile* cw_tiles_dev = nullptr; int n_cw_tiles = 0, n_cu = 256;      // conv_wgrad2.h
     int* cw_prefix_dev = nullptr; int n_cw_convs = 0, cw_splits = 0;
@@ -104,7 +104,7 @@ int cnn_upload_items(cs_cnn* h) {
 
 int cnn_launch_optimizer(cs_cnn* h, float lr, float grad_scale, bool recast_only, hipStream_t st) {
     CnnOptArgs a{};
-    a.P = h->P; a.M = h->M; a.V = h->V; a.G = h->G; a.n = h->n_params; a.seg = h->seg_dev; a.n_seg = h->n_seg;
+    a.P = h->P; a.M = h->M; a.V = h->V; a.G = h->G; a.seg = h->seg_dev; a.n_seg = h->n_seg;
     a.kind = h->cfg.optimizer; a.lr = lr; a.grad_scale = grad_scale; a.recast_only = recast_only ? 1 : 0;
     // float32 scalars cast where TensorFlow casts them (see launch_optimizer of the MLP engine)
     const float b1 = (float)h->cfg.beta1, b2 = (float)h->cfg.beta2;
@@ -112,7 +112,7 @@ int cnn_launch_optimizer(cs_cnn* h, float lr, float grad_scale, bool recast_only
     a.omb1 = (float)(1.0 - h->cfg.beta1); a.omb2 = (float)(1.0 - h->cfg.beta2);
     a.alpha = lr * sqrtf(1.f - powf(b2, t)) / (1.f - powf(b1, t));
     a.eps = (float)h->cfg.eps;
-    hipLaunchKernelGGL(k_cnn_optimizer, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_cnn_optimizer, dim3((unsigned)h->opt_blocks), dim3(256), 0, st, a);
     HIP_TRY(hipGetLastError());
     return CS_OK;
 }
@@ -339,6 +339,10 @@ int cs_cnn_create(cs_cnn_t** out, const cs_cnn_cfg* cfg) {
         s.off = h->off_bl; s.size = nl; s.kind = 3; s.dst = h->bd; s.dst_off = 0; s.ncols = nl; segs.push_back(s);
         s.off = h->off_wr; s.size = 10 * nr; s.kind = 2; s.dst = h->wd; s.dst_off = nl; s.ncols = nr; segs.push_back(s);
         s.off = h->off_br; s.size = nr; s.kind = 3; s.dst = h->bd; s.dst_off = nl; s.ncols = nr; segs.push_back(s);
+    }
+    for (auto& sg : segs) {
+        sg.blk_begin = h->opt_blocks;
+        h->opt_blocks += sg.kind == 0 ? sg.taps * ((sg.cin + 31) / 32) * ((sg.cout + 31) / 32) : (int)((sg.size + 255) / 256);
     }
     if (hipMemcpy(h->seg_dev, segs.data(), segs.size() * sizeof(CnnSeg), hipMemcpyHostToDevice) != hipSuccess) {
         cs_cnn_destroy(h);

@@ -252,55 +252,112 @@ struct CnnSeg {
     u16* Wf; int ldf, kpf;
     u16* Wd; int ldd, kpd, slot0, flip;
     float* dst; int dst_off, ncols;     // kind 1: dst[i]; kind 2: dst[c*10 + dst_off + j]; kind 3: dst[dst_off + j]
+    int blk_begin;            // first workgroup of this tensor: 32(c_in) x 32(c_out) tiles per tap, or 256-element slices
 };
 struct CnnOptArgs {
     float *P, *M, *V, *G;
-    int64_t n;
     const CnnSeg* seg; int n_seg;
     int kind;                 // CS_OPT_ADAM (0) | CS_OPT_SGD (3)
     float lr, grad_scale, omb1, omb2, alpha, eps;
     int recast_only;
 };
 
-__global__ __launch_bounds__(256) void k_cnn_optimizer(const CnnOptArgs a) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.n) return;
-    float w = a.P[i];
+// two consecutive parameters at an even offset (8-byte accesses)
+__device__ __forceinline__ void cnn_opt_update2(const CnnOptArgs& a, int64_t i, float& w0, float& w1) {
+    float2 w = *reinterpret_cast<const float2*>(a.P + i);
     if (!a.recast_only) {
-        const float g = a.G[i] * a.grad_scale;
+        float2 g = *reinterpret_cast<const float2*>(a.G + i);
+        g.x *= a.grad_scale; g.y *= a.grad_scale;
         if (a.kind == 3) {
-            w -= a.lr * g;
+            w.x -= a.lr * g.x; w.y -= a.lr * g.y;
         } else {
-            float m = a.M[i], v = a.V[i];
-            m += (g - m) * a.omb1;
-            v += (g * g - v) * a.omb2;
-            w -= (m * a.alpha) / (sqrtf(v) + a.eps);
-            a.M[i] = m; a.V[i] = v;
+            float2 m = *reinterpret_cast<const float2*>(a.M + i), v = *reinterpret_cast<const float2*>(a.V + i);
+            m.x += (g.x - m.x) * a.omb1; m.y += (g.y - m.y) * a.omb1;
+            v.x += (g.x * g.x - v.x) * a.omb2; v.y += (g.y * g.y - v.y) * a.omb2;
+            w.x -= (m.x * a.alpha) / (sqrtf(v.x) + a.eps); w.y -= (m.y * a.alpha) / (sqrtf(v.y) + a.eps);
+            *reinterpret_cast<float2*>(a.M + i) = m; *reinterpret_cast<float2*>(a.V + i) = v;
         }
-        a.P[i] = w;
-        a.G[i] = 0.f;
+        *reinterpret_cast<float2*>(a.P + i) = w;
+        *reinterpret_cast<float2*>(a.G + i) = make_float2(0.f, 0.f);
     }
+    w0 = w.x; w1 = w.y;
+}
+
+__device__ __forceinline__ float cnn_opt_update(const CnnOptArgs& a, int64_t i) {
+    float w = a.P[i];
+    if (a.recast_only) return w;
+    const float g = a.G[i] * a.grad_scale;
+    if (a.kind == 3) {
+        w -= a.lr * g;
+    } else {
+        float m = a.M[i], v = a.V[i];
+        m += (g - m) * a.omb1;
+        v += (g * g - v) * a.omb2;
+        w -= (m * a.alpha) / (sqrtf(v) + a.eps);
+        a.M[i] = m; a.V[i] = v;
+    }
+    a.P[i] = w;
+    a.G[i] = 0.f;
+    return w;
+}
+
+// Conv kernels: one workgroup = one 32(c_in) x 32(c_out) tile of one tap; the updated tile goes through LDS so that both
+// bf16 operand packs are written along their contiguous axis (the data-gradient pack along c_out straight from the
+// registers, the forward pack along c_in after the transpose).  One thread per parameter wrote the forward pack as
+// 13 M scattered 2-byte stores: 0.235 ms per step.
+__global__ __launch_bounds__(256) void k_cnn_optimizer(const CnnOptArgs a) {
+    __shared__ u16 tile[32][34];
+    const int tid = threadIdx.x;
     int lo = 0, hi = a.n_seg - 1;
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
-        if (a.seg[mid].off <= i) lo = mid; else hi = mid - 1;
+        if (a.seg[mid].blk_begin <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
     }
-    const CnnSeg& s = a.seg[lo];
-    const int64_t rel = i - s.off;
-    if (s.kind == 0) {
-        const int per_tap = s.cin * s.cout;
-        const int t = (int)(rel / per_tap);
-        const int r2 = (int)(rel - (int64_t)t * per_tap);
-        const int ci = r2 / s.cout, co = r2 - ci * s.cout;
-        const u16 wb = f2bf(w);
-        s.Wf[(int64_t)co * s.ldf + t * s.kpf + ci] = wb;
-        if (s.Wd) s.Wd[(int64_t)ci * s.ldd + (s.slot0 + (s.flip ? s.taps - 1 - t : t)) * s.kpd + co] = wb;
-    } else if (s.kind == 1) {
-        s.dst[rel] = w;
-    } else if (s.kind == 2) {
-        const int c = (int)(rel / s.ncols), j = (int)(rel - (int64_t)c * s.ncols);
-        s.dst[c * 10 + s.dst_off + j] = w;
-    } else {
-        s.dst[s.dst_off + rel] = w;
+    const CnnSeg s = a.seg[lo];
+    const int rel = blockIdx.x - s.blk_begin;
+    if (s.kind != 0) {
+        const int64_t r = (int64_t)rel * 256 + tid;
+        if (r >= s.size) return;
+        const float w = cnn_opt_update(a, s.off + r);
+        if (s.kind == 1) s.dst[r] = w;
+        else if (s.kind == 2) { const int c = (int)(r / s.ncols), j = (int)(r - (int64_t)c * s.ncols); s.dst[c * 10 + s.dst_off + j] = w; }
+        else s.dst[s.dst_off + r] = w;
+        return;
+    }
+    const int tiles_i = (s.cin + 31) >> 5, tiles_o = (s.cout + 31) >> 5;
+    const int t = rel / (tiles_i * tiles_o), r2 = rel - t * tiles_i * tiles_o;
+    const int it = r2 / tiles_o, ot = r2 - it * tiles_o;
+    const int il = tid >> 3, oq = (tid & 7) * 4;                  // this thread: c_in = 32*it + il, 4 consecutive c_out
+    const int ci = it * 32 + il, co0 = ot * 32 + oq;
+    float w[4] = {0.f, 0.f, 0.f, 0.f};
+    if (ci < s.cin) {
+        const int64_t base = s.off + ((int64_t)t * s.cin + ci) * s.cout + co0;
+        if (!(base & 1) && co0 + 3 < s.cout) {
+            cnn_opt_update2(a, base, w[0], w[1]);
+            cnn_opt_update2(a, base + 2, w[2], w[3]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (co0 + e < s.cout) w[e] = cnn_opt_update(a, base + e);
+        }
+    }
+    const unsigned p01 = cvt_pk_bf16(w[0], w[1]), p23 = cvt_pk_bf16(w[2], w[3]);
+    tile[il][oq] = (u16)(p01 & 0xffff); tile[il][oq + 1] = (u16)(p01 >> 16);
+    tile[il][oq + 2] = (u16)(p23 & 0xffff); tile[il][oq + 3] = (u16)(p23 >> 16);
+    if (s.Wd && ci < s.cin) {                                     // data-gradient pack [c_in][slot*kpd + c_out]: 8 B along c_out
+        u16* d = s.Wd + (int64_t)ci * s.ldd + (s.slot0 + (s.flip ? s.taps - 1 - t : t)) * s.kpd + co0;
+        if (co0 + 3 < s.kpd) *reinterpret_cast<uint2*>(d) = make_uint2(p01, p23);      // pad columns (>= c_out) get zeros
+        else { for (int e = 0; e < 4; ++e) if (co0 + e < s.kpd) d[e] = tile[il][oq + e]; }
+    }
+    __syncthreads();
+    {                                                             // forward pack [c_out][t*kpf + c_in]: 8 B along c_in
+        const int ol = tid >> 3, iq = (tid & 7) * 4;
+        const int co = ot * 32 + ol, ci0 = it * 32 + iq;
+        if (co < s.cout && ci0 < s.kpf) {
+            u16* d = s.Wf + (int64_t)co * s.ldf + t * s.kpf + ci0;
+            if (ci0 + 3 < s.kpf)
+                *reinterpret_cast<uint2*>(d) = make_uint2((unsigned)tile[iq][ol] | ((unsigned)tile[iq + 1][ol] << 16),
+                                                          (unsigned)tile[iq + 2][ol] | ((unsigned)tile[iq + 3][ol] << 16));
+            else { for (int e = 0; e < 4; ++e) if (ci0 + e < s.kpf) d[e] = tile[iq + e][ol]; }
+        }
     }
 }
