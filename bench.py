@@ -70,6 +70,32 @@ def side_bench(fn):
         return {"error": f"{type(e).__name__}: {e}"}
 
 
+def heldout_per_variable(model, xv, yv):
+    """Per-variable MAE / R2 of the just-trained model on the held-out split, through the evaluation pipeline of the
+    reference (pressure-thickness, area and energy-unit weighting; data_utils.py:1112-1362, 1432-1497) on the device
+    (climsim_amd.metrics).  Grid and normalisation constants: the committed low-res bundles under tests/golden/."""
+    import os
+    from climsim_amd.assets import load_grid_info, load_npz_assets
+    from climsim_amd.data_utils import data_utils
+    from climsim_amd.metrics import GpuMetrics
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden")
+    grid = load_grid_info(os.path.join(gold, "grid_lowres.npz"))
+    sets = [load_npz_assets(os.path.join(gold, "norm_lowres.npz"), k) for k in ("input_mean", "input_max", "input_min", "output_scale")]
+    du = data_utils(grid, *sets)
+    du.set_to_v1_vars()
+    n = (xv.shape[0] // 384) * 384                       # whole "time steps" of the 384-column grid
+    pred = model.predict(xv[:n], as_numpy=False)
+    df_var, _ = GpuMetrics(du).metrics_tables(pred, yv[:n], xv[:n])
+    import math
+
+    def num(x, nd):                                      # strict JSON: no inf/nan (zero-variance levels give R2 = -inf)
+        x = float(x)
+        return round(x, nd) if math.isfinite(x) else None
+    return {"rows": n, "MAE": {v: num(df_var.loc[v, "MAE"], 6) for v in df_var.index},
+            "R2": {v: num(df_var.loc[v, "R2"], 4) for v in df_var.index},
+            "note": "energy-weighted units (W/m2) as in the reference's evaluation; R2 is null where a level has zero target variance"}
+
+
 def cnn_side_bench(batch=512, steps=10):
     """Level-axis CNN (depth 12, width 406; hpo_train.py): training step and prediction, columns/s."""
     import torch
@@ -215,6 +241,9 @@ def main():
 
     # ---- untimed: held-out error of the model that was just trained, per-kernel timing, CPU baseline
     held = model.evaluate(xv, yv)
+    per_var = None
+    if rank == 0:
+        per_var = side_bench(lambda: heldout_per_variable(model, xv, yv))
     # model.predict throughput (reference: 36.6k-46.7k columns/s on an A100, step3_inference.ipynb) - secondary figure
     n_pred = min(args.rows, 1_681_920)
     torch.cuda.synchronize()
@@ -276,10 +305,10 @@ def main():
                                       "mse, synthetic low-res columns gathered from an HBM-resident split",
                           "per_gpu_batch": B, "global_batch": B * world, "rows_resident_per_gpu": args.rows,
                           "parallelism": f"dp{world}", "params": n_params},
-               "heldout": {"mse": held["mse"], "mae": held["mae"], "rows": 65536},
+               "heldout": {"mse": held["mse"], "mae": held["mae"], "rows": 65536, "per_variable": per_var},
                "predict": {"columns_per_s": round(predict_cps, 1), "rows": n_pred, "batch": B},
                "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu, **extras}
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out, allow_nan=False), flush=True)
     if dist:
         dist.destroy_process_group()
 
