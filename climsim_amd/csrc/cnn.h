@@ -29,6 +29,9 @@ struct ConvArgs {
     u16* out2; int ldo2;         // TRAIN_FWD: value before the residual add (may be null) ; BWD: masked gradient
     const u16* mask; int ldmask; float mscale;       // BWD: out2 = acc * (mask != 0) * mscale
     const u16* zeros; int n_tiles;                   // k_conv2 only: zero page for out-of-column rows, channel tiles
+    // k_conv2 only, forward modes: second pass accumulated on top of the activated first one -
+    // out = [dropout](act(conv(A) + bias)) + (A2nd * B2nd + bias2)   (conv b + the block's 1-tap projection in one launch)
+    const u16* A2nd; int lda2; const u16* B2nd; int ldb2, kpt2; const float* bias2;
     int ablate;                                      // development (CS_CONV_ABLATE): 1 no DMA in the loop, 2 no MFMA, 4 no epilogue
 };
 

@@ -136,20 +136,29 @@ void cnn_dispatch(const cs_cnn* h, ConvArgs& p, bool wide, int n_pad, int64_t m_
     }
 }
 
-// inference-mode conv (dropout is identity): out = act(conv(in)) (+ add)
+void cnn_second_pass(ConvArgs& p, const CnnConv* c2, const u16* in2, int ld_in2) {
+    if (!c2) return;
+    p.A2nd = in2; p.lda2 = ld_in2; p.B2nd = c2->W; p.ldb2 = c2->taps * c2->cin_p; p.kpt2 = c2->cin_p; p.bias2 = c2->bias;
+}
+
+// inference-mode conv (dropout is identity): out = act(conv(in)) (+ add | + conv2nd(in2))
 void launch_conv(const cs_cnn* h, const CnnConv& c, const u16* in, int ld_in, int act, const u16* add, u16* out,
-                 int ld_out, int64_t m_rows, int64_t m_pad, hipStream_t st) {
+                 int ld_out, int64_t m_rows, int64_t m_pad, hipStream_t st, const CnnConv* c2 = nullptr, const u16* in2 = nullptr,
+                 int ld_in2 = 0) {
     ConvArgs p{};
     cnn_fill_conv(h, p, c, in, ld_in, m_rows);
+    cnn_second_pass(p, c2, in2, ld_in2);
     p.act = act; p.add = add; p.ldadd = CNN_CP; p.out = out; p.ldo = ld_out;
     cnn_dispatch<CONV_PREDICT>(h, p, c.n_pad == CNN_CP, c.n_pad, m_pad, st);
 }
 
 // training-mode conv: out2 = dropout(act(conv(in))), out = out2 + add
 void launch_conv_train(const cs_cnn* h, const CnnConv& c, const u16* in, int ld_in, int layer, unsigned seed, const u16* add,
-                       u16* out, u16* out2, int64_t m_rows, int64_t m_pad, hipStream_t st) {
+                       u16* out, u16* out2, int64_t m_rows, int64_t m_pad, hipStream_t st, const CnnConv* c2 = nullptr,
+                       const u16* in2 = nullptr, int ld_in2 = 0) {
     ConvArgs p{};
     cnn_fill_conv(h, p, c, in, ld_in, m_rows);
+    cnn_second_pass(p, c2, in2, ld_in2);
     p.act = CACT_RELU; p.add = add; p.ldadd = CNN_CP; p.out = out; p.ldo = CNN_CP; p.out2 = out2; p.ldo2 = CNN_CP;
     p.drop_key = host_lowbias32(seed + 0x9e3779b9u * (unsigned)(layer + 1));
     p.drop_thr = (unsigned)(h->cfg.dropout * 65536.0);
@@ -187,8 +196,12 @@ void cnn_trunk_predict(cs_cnn* h, const float* x_dev, const int64_t* row_idx, in
     for (int b = 0; b < h->cfg.depth; ++b) {
         const CnnConv &ca = h->convs[3 * b], &cb = h->convs[3 * b + 1], &cr = h->convs[3 * b + 2];
         launch_conv(h, ca, x, ldx, CACT_RELU, nullptr, h->A1, CNN_CP, m_rows, m_pad, st);
-        launch_conv(h, cr, x, ldx, CACT_NONE, nullptr, h->R, CNN_CP, m_rows, m_pad, st);
-        launch_conv(h, cb, h->A1, CNN_CP, CACT_RELU, h->R, XN, CNN_CP, m_rows, m_pad, st);
+        if (h->tile128) {
+            launch_conv(h, cr, x, ldx, CACT_NONE, nullptr, h->R, CNN_CP, m_rows, m_pad, st);
+            launch_conv(h, cb, h->A1, CNN_CP, CACT_RELU, h->R, XN, CNN_CP, m_rows, m_pad, st);
+        } else {            // conv b and the projection of the block input in one launch
+            launch_conv(h, cb, h->A1, CNN_CP, CACT_RELU, nullptr, XN, CNN_CP, m_rows, m_pad, st, &cr, x, ldx);
+        }
         x = XN; ldx = CNN_CP;
         std::swap(X, XN);
     }
@@ -461,8 +474,12 @@ int cs_cnn_loss_grads(cs_cnn_t* h, const float* x_dev, int x3d, const float* y_d
         const CnnConv &ca = h->convs[3 * b], &cb = h->convs[3 * b + 1], &cr = h->convs[3 * b + 2];
         CnnBlockBufs& B = h->blk[b];
         launch_conv_train(h, ca, x, ldx, 2 * b, seed, nullptr, B.A1, nullptr, m_rows, m_pad, st);
-        launch_conv(h, cr, x, ldx, CACT_NONE, nullptr, h->R, CNN_CP, m_rows, m_pad, st);
-        launch_conv_train(h, cb, B.A1, CNN_CP, 2 * b + 1, seed, h->R, B.XS, B.A2, m_rows, m_pad, st);
+        if (h->tile128) {
+            launch_conv(h, cr, x, ldx, CACT_NONE, nullptr, h->R, CNN_CP, m_rows, m_pad, st);
+            launch_conv_train(h, cb, B.A1, CNN_CP, 2 * b + 1, seed, h->R, B.XS, B.A2, m_rows, m_pad, st);
+        } else {
+            launch_conv_train(h, cb, B.A1, CNN_CP, 2 * b + 1, seed, nullptr, B.XS, B.A2, m_rows, m_pad, st, &cr, x, ldx);
+        }
         x = B.XS; ldx = CNN_CP;
     }
     launch_conv(h, h->convs.back(), x, ldx, CACT_ELU, nullptr, h->O10, 128, m_rows, m_pad, st);

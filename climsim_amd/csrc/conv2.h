@@ -47,41 +47,47 @@ __global__ __launch_bounds__(512) void k_conv2(const ConvArgs p) {
     const int n0 = (work % p.n_tiles) * CV2_BN;
 
     // ---- DMA geometry: lane -> (row prow, physical chunk pos) of a 16-row piece; it fetches logical chunk
-    // pos ^ ((prow>>2)&3).  Pieces wid, wid+8 of the row operand and wid, min(wid+8,13) of the weights
+    // pos ^ cv2_swz(prow>>2).  Pieces wid, wid+8 of the row operand and wid, min(wid+8,13) of the weights
     // belong to this wave (waves 6,7 re-fetch piece 13: identical bytes, keeps the vmcnt count uniform).
     const int prow = lane >> 2, pos = lane & 3;
     const int cl = (pos ^ cv2_swz((prow >> 2) & 3)) * 8;
     const int64_t am0 = m0 + wid * 16 + prow, am1 = am0 + 128;
     const int pb1 = wid + 8 < 14 ? wid + 8 : 13;
-    const char* bsrc0 = reinterpret_cast<const char*>(p.B + (int64_t)(n0 + wid * 16 + prow) * p.ldb + cl);
-    const char* bsrc1 = reinterpret_cast<const char*>(p.B + (int64_t)(n0 + pb1 * 16 + prow) * p.ldb + cl);
-    // per-lane byte offset of its two rows, and which of the 4 tap shifts keep them inside their column
-    const int64_t arow0 = (am0 * p.lda + cl) * 2, arow1 = (am1 * p.lda + cl) * 2;
-    unsigned ok0 = 0u, ok1 = 0u;
-    {
-        const int l0 = (int)(am0 % p.seq), l1 = (int)(am1 % p.seq);
-        const int shs[4] = {p.sh0, p.sh1, p.sh2, p.sh3};
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            if (am0 < p.m_rows && l0 + shs[t] >= 0 && l0 + shs[t] < p.seq) ok0 |= 1u << t;
-            if (am1 < p.m_rows && l1 + shs[t] >= 0 && l1 + shs[t] < p.seq) ok1 |= 1u << t;
-        }
-    }
     typedef unsigned char __attribute__((address_space(3))) * lds_b;
     const unsigned lds0 = (unsigned)(uintptr_t)((lds_b)cv2_ring);
     const unsigned a_piece0 = __builtin_amdgcn_readfirstlane((unsigned)wid * 1024u);
     const unsigned b_piece1 = __builtin_amdgcn_readfirstlane((unsigned)pb1 * 1024u);
-    const int kc = p.kpt >> 5;
-    const int nt = p.taps * kc;
     const char* zsrc = reinterpret_cast<const char*>(p.zeros);
+    const int lev0 = (int)(am0 % p.seq), lev1 = (int)(am1 % p.seq);
+
+    // The operands of the running pass (a kernel runs one pass, or two for "conv b + projection", see below).
+    const u16 *qA0 = p.A0, *qA1 = p.A1, *qA2 = p.A2, *qA3 = p.A3, *qB = p.B;
+    int qs0 = p.sh0, qs1 = p.sh1, qs2 = p.sh2, qs3 = p.sh3, qlda = p.lda, qldb = p.ldb, qkpt = p.kpt, qtaps = p.taps;
+    const char *bsrc0, *bsrc1;
+    int64_t arow0, arow1;          // per-lane byte offset of its two rows
+    unsigned ok0, ok1;             // which of the 4 tap shifts keep them inside their column
+    int kc, nt;
+#define CV2_SETUP()                                                                                    \
+    {                                                                                                   \
+        bsrc0 = reinterpret_cast<const char*>(qB + (int64_t)(n0 + wid * 16 + prow) * qldb + cl);        \
+        bsrc1 = reinterpret_cast<const char*>(qB + (int64_t)(n0 + pb1 * 16 + prow) * qldb + cl);        \
+        arow0 = (am0 * qlda + cl) * 2; arow1 = (am1 * qlda + cl) * 2;                                   \
+        ok0 = 0u; ok1 = 0u;                                                                             \
+        const int shs_[4] = {qs0, qs1, qs2, qs3};                                                       \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                 \
+            if (am0 < p.m_rows && lev0 + shs_[t] >= 0 && lev0 + shs_[t] < p.seq) ok0 |= 1u << t;        \
+            if (am1 < p.m_rows && lev1 + shs_[t] >= 0 && lev1 + shs_[t] < p.seq) ok1 |= 1u << t;        \
+        }                                                                                               \
+        kc = qkpt >> 5; nt = qtaps * kc;                                                                \
+    }
 
     // sources of the four pieces of slab `st` (clamped past the end: identical bytes, uniform vmcnt count)
 #define CV2_SRC(st)                                                                                    \
         const int sc_ = min((st), nt - 1);                                                              \
         const int tap_ = sc_ / kc, c0_ = (sc_ - tap_ * kc) * 32;                                        \
-        const int sh_ = tap_ == 0 ? p.sh0 : tap_ == 1 ? p.sh1 : tap_ == 2 ? p.sh2 : p.sh3;              \
-        const u16* S_ = tap_ == 0 ? p.A0 : tap_ == 1 ? p.A1 : tap_ == 2 ? p.A2 : p.A3;                  \
-        const char* Sb_ = reinterpret_cast<const char*>(S_) + ((int64_t)sh_ * p.lda + c0_) * 2;         \
+        const int sh_ = tap_ == 0 ? qs0 : tap_ == 1 ? qs1 : tap_ == 2 ? qs2 : qs3;                      \
+        const u16* S_ = tap_ == 0 ? qA0 : tap_ == 1 ? qA1 : tap_ == 2 ? qA2 : qA3;                      \
+        const char* Sb_ = reinterpret_cast<const char*>(S_) + ((int64_t)sh_ * qlda + c0_) * 2;          \
         const char* s0_ = ((ok0 >> tap_) & 1u) ? Sb_ + arow0 : zsrc;                                    \
         const char* s1_ = ((ok1 >> tap_) & 1u) ? Sb_ + arow1 : zsrc;                                    \
         const char* s2_ = bsrc0 + sc_ * 64;                                                             \
@@ -102,60 +108,57 @@ __global__ __launch_bounds__(512) void k_conv2(const ConvArgs p) {
 #pragma unroll
         for (int j = 0; j < 7; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-    // fragment addresses: row (..+(lane&15)), chunk lane>>4, swizzled by ((row>>2)&3) = (lane&15)>>2
+    // fragment addresses: row (..+(lane&15)), chunk lane>>4, swizzled by cv2_swz((row>>2)&3)
     const unsigned sw = (unsigned)(((lane >> 4) ^ cv2_swz((lane & 15) >> 2)) << 4);
     const unsigned a_off = (unsigned)((wm * 64 + (lane & 15)) * 64) + sw;
     const unsigned b_off = (unsigned)(CV2_A_BYTES + (wn * 112 + (lane & 15)) * 64) + sw;
 
-    // Software pipeline: DMA three slabs ahead; the fragments of slab s+1 are read from LDS between the MFMAs of
-    // slab s, each fragment register reloaded in place right after its last use (no second fragment buffer).
-    CV2_ISSUE(0)
-    CV2_ISSUE(1)
-    CV2_ISSUE(2)
-    CV2_ISSUE(3)
-    // bias of this lane's 7 channel quads, fetched now: a load issued in the epilogue costs a full L2 round
-    // trip per dependent use, and there is nothing left to hide it behind
+    // One pass of the software pipeline over the current operands, accumulating into acc: DMA three slabs ahead; the
+    // fragments of slab s+1 are read from LDS between the MFMAs of slab s, each fragment register reloaded in place
+    // right after its last use; the four DMA pieces of slab s+4 are issued one at a time between MFMA groups (all
+    // eight waves leave the barrier together, and a wave that issues its pieces back to back stalls while its SIMD
+    // partner does the same).  Ends with the ring drained and free.
+#define CV2_PIPELINE(NOLDR)                                                                            \
+    {                                                                                                   \
+        CV2_ISSUE(0) CV2_ISSUE(1) CV2_ISSUE(2) CV2_ISSUE(3)                                             \
+        bf16x8_t fa[4], fw[7];                                                                          \
+        asm volatile("s_waitcnt vmcnt(" #NOLDR ")" ::: "memory");   /* slab 0 has landed */               \
+        __builtin_amdgcn_s_barrier();                                                                   \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(cv2_ring + a_off + i * 1024); \
+        _Pragma("unroll") for (int j = 0; j < 7; ++j) fw[j] = *reinterpret_cast<const bf16x8_t*>(cv2_ring + b_off + j * 1024); \
+        for (int s = 0; s < nt; ++s) {                                                                  \
+            asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");   /* slab s+1 landed; my reads of slab s done */ \
+            __builtin_amdgcn_s_barrier();                                 /* ... everyone's: slot s&3 is free */ \
+            CV2_SRC(s + 4)                                                                              \
+            const unsigned char* nx = cv2_ring + ((s + 1) & (CV2_STAGES - 1)) * CV2_STAGE_BYTES;        \
+            _Pragma("unroll") for (int j = 0; j < 6; ++j) {                                             \
+                _Pragma("unroll") for (int i = 0; i < 4; ++i)                                           \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0); \
+                fw[j] = *reinterpret_cast<const bf16x8_t*>(nx + b_off + j * 1024);                      \
+                if (j == 0) CV2_PIECE(0)                                                                \
+                if (j == 1) CV2_PIECE(1)                                                                \
+                if (j == 2) CV2_PIECE(2)                                                                \
+                if (j == 3) CV2_PIECE(3)                                                                \
+            }                                                                                           \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                             \
+                acc[i][6] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[6], fa[i], acc[i][6], 0, 0, 0);  \
+                fa[i] = *reinterpret_cast<const bf16x8_t*>(nx + a_off + i * 1024);                      \
+            }                                                                                           \
+            fw[6] = *reinterpret_cast<const bf16x8_t*>(nx + b_off + 6 * 1024);                          \
+        }                                                                                               \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   /* the clamped tail pieces have landed ... */ \
+        __builtin_amdgcn_s_barrier();                                  /* ... and nobody reads the ring any more */ \
+    }
+
+    // bias of this lane's 7 channel quads, fetched before the pipeline: a load issued in the epilogue costs a full L2
+    // round trip per dependent use, and there is nothing left to hide it behind
     float4 bq[7];
 #pragma unroll
     for (int j = 0; j < 7; ++j)
         bq[j] = MODE != CONV_BWD ? *reinterpret_cast<const float4*>(p.bias + n0 + wn * 112 + j * 16 + 4 * (lane >> 4))
                                  : make_float4(0.f, 0.f, 0.f, 0.f);
-    bf16x8_t fa[4], fw[7];
-    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");       // slab 0 has landed (the bias loads are older still)
-    __builtin_amdgcn_s_barrier();
-#pragma unroll
-    for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(cv2_ring + a_off + i * 1024);
-#pragma unroll
-    for (int j = 0; j < 7; ++j) fw[j] = *reinterpret_cast<const bf16x8_t*>(cv2_ring + b_off + j * 1024);
-    for (int s = 0; s < nt; ++s) {
-        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");   // slab s+1 landed; my reads of slab s are done
-        __builtin_amdgcn_s_barrier();                                 // ... everyone's: slot s&3 is free
-        // the four DMA pieces of slab s+4 are issued one at a time between MFMA groups: all eight waves leave the
-        // barrier together, and a wave that issues its pieces back to back stalls while its SIMD partner does the same
-        CV2_SRC(s + 4)
-        const unsigned char* nx = cv2_ring + ((s + 1) & (CV2_STAGES - 1)) * CV2_STAGE_BYTES;
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0);
-            fw[j] = *reinterpret_cast<const bf16x8_t*>(nx + b_off + j * 1024);
-            if (j == 0) CV2_PIECE(0)
-            if (j == 1) CV2_PIECE(1)
-            if (j == 2) CV2_PIECE(2)
-            if (j == 3) CV2_PIECE(3)
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            acc[i][6] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[6], fa[i], acc[i][6], 0, 0, 0);
-            fa[i] = *reinterpret_cast<const bf16x8_t*>(nx + a_off + i * 1024);
-        }
-        fw[6] = *reinterpret_cast<const bf16x8_t*>(nx + b_off + 6 * 1024);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the clamped tail pieces have landed ...
-    __builtin_amdgcn_s_barrier();                           // ... and nobody reads the ring any more
-#undef CV2_ISSUE
-#undef CV2_SRC
-#undef CV2_PIECE
+    CV2_SETUP()
+    CV2_PIPELINE(12)
 
     if (p.ablate & 4) return;
     // ---- epilogue.  D[channel][row]: lane owns row ..+(lane&15), channels ..+4*(lane>>4)+{0..3}.
@@ -230,7 +233,22 @@ __global__ __launch_bounds__(512) void k_conv2(const ConvArgs p) {
             }
         }
         if (MODE == CONV_TRAIN_FWD && p.out2) CV2_STORE_TILE(p.out2, p.ldo2)
-        if (p.add) {
+        if (p.A2nd) {
+            // second pass: the block's projection of its input, accumulated on top of the activated conv output
+            // (x_next = dropout(relu(conv_b(a1))) + conv_r(x): one launch, no R tensor, no extra epilogue)
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                const float4 b4 = *reinterpret_cast<const float4*>(p.bias2 + nw + j * 16 + 4 * (lane >> 4));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { acc[i][j][0] += b4.x; acc[i][j][1] += b4.y; acc[i][j][2] += b4.z; acc[i][j][3] += b4.w; }
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                   // every wave is done with its LDS staging region
+            qA0 = qA1 = qA2 = qA3 = p.A2nd; qs0 = qs1 = qs2 = qs3 = 0; qlda = p.lda2;
+            qB = p.B2nd; qldb = p.ldb2; qkpt = p.kpt2; qtaps = 1;
+            CV2_SETUP()
+            CV2_PIPELINE(12)
+        } else if (p.add) {
 #pragma unroll
             for (int jh = 0; jh < 7; jh += 4) {
                 uint2 r2[4][4];
@@ -252,4 +270,9 @@ __global__ __launch_bounds__(512) void k_conv2(const ConvArgs p) {
         CV2_STORE_TILE(p.out, p.ldo)
     }
 #undef CV2_STORE_TILE
+#undef CV2_PIPELINE
+#undef CV2_ISSUE
+#undef CV2_SRC
+#undef CV2_PIECE
+#undef CV2_SETUP
 }

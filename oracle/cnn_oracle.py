@@ -10,7 +10,8 @@ holds no test or golden vector for the CNN (saved_model.pb has no variables); th
 exists - 13,215,420 parameters for depth 12 / width 406 - is asserted in tests.
 
 `bf16=True` mirrors the engine's rounding points: weights, and every stored activation tensor
-(conv outputs after activation, the residual projection, the block sum) rounded to bfloat16.
+(conv outputs after activation, the block sum) rounded to bfloat16; the residual projection is accumulated
+in fp32 on top of the activated second conv inside one kernel and is never stored.
 """
 from __future__ import annotations
 
@@ -63,7 +64,7 @@ def forward(ws, x3, depth=12, n_lin=2, bf16=False):
         wa, ba, wb, bb, wr, br = ws[i:i + 6]
         i += 6
         a1 = _q(torch.relu(_conv(x, wa, ba, bf16)), bf16)
-        r = _q(_conv(x, wr, br, bf16), bf16)
+        r = _conv(x, wr, br, bf16)                      # accumulated in fp32 on top of the activated conv b (same launch)
         x = _q(torch.relu(_conv(a1, wb, bb, bf16)) + r, bf16)
     wo, bo, wl, bl, wrel, brel = ws[i:i + 6]
     o = _q(F.elu(_conv(x, wo, bo, bf16)), bf16)
@@ -168,7 +169,7 @@ def loss_and_grads(ws, x3, y3, depth=12, n_lin=2, loss="mae", rate=0.0, seed=0, 
         i += 6
         za = _rg(_tconv(x, wa, ba, bf16), bf16)                       # dz1 is stored bf16
         a1 = _st(drop(torch.relu(za), 2 * blk), bf16)
-        r = _rg(_st(_tconv(x, wr, br, bf16), bf16), bf16)             # projection branch sees the stored bf16 g
+        r = _rg(_tconv(x, wr, br, bf16), bf16)                        # projection branch sees the stored bf16 g
         zb = _rg(_tconv(a1, wb, bb, bf16), bf16)                      # dz2 = round(g_fp32 * mask / keep)
         x = _st(drop(torch.relu(zb), 2 * blk + 1) + r, bf16)
     wo, bo, wl, bl, wrel, brel = P[i:i + 6]

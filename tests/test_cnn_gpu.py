@@ -227,7 +227,9 @@ def test_cnn_full_depth_gradients(CNN):
 def test_cnn_kernel_families_agree(CNN):
     """The 256x224 LDS-DMA kernels (default) against the 128x128 register-staged kernels (CS_CNN_FLAG_TILE128):
     two independent implementations of the same tap-GEMMs (different tiling, MFMA shape, contraction padding,
-    weight-gradient decomposition) must agree to bf16 accumulation-order noise."""
+    weight-gradient decomposition).  They differ by accumulation order and by ONE rounding point: the 128-tile family
+    stores the block's projection as a bf16 tensor before adding it, the default family accumulates it in fp32 on top
+    of the activated conv inside the same kernel - hence 1e-2 on the predictions rather than bf16 flip noise."""
     depth, width, n = 3, 406, 9
     ws = CO.glorot_cnn(seed=4, bias_scale=0.05, depth=depth, channels=width)
     x3, y3 = make_xy(n, 6)
@@ -239,8 +241,8 @@ def test_cnn_kernel_families_agree(CNN):
         pred = m.predict(x3)
         sums = m.loss_grads(x3, y3).cpu().numpy()
         res.append((pred, sums, m.get_gradients(1.0 / (n * 60))))
-    assert rms_rel(res[0][0], res[1][0]) <= 2e-3
-    np.testing.assert_allclose(res[0][1], res[1][1], rtol=5e-3)
+    assert rms_rel(res[0][0], res[1][0]) <= 1e-2
+    np.testing.assert_allclose(res[0][1], res[1][1], rtol=2e-2)
     for i, (a, b) in enumerate(zip(res[0][2], res[1][2])):
         c, ratio = cos_rel(a, b)
         assert c >= 0.999 and abs(ratio - 1) <= 1e-2, (i, c, ratio)
