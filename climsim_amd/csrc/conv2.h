@@ -81,20 +81,21 @@ __global__ __launch_bounds__(512) void k_conv2(const ConvArgs p) {
         kc = qkpt >> 5; nt = qtaps * kc;                                                                \
     }
 
-    // sources of the four pieces of slab `st` (clamped past the end: identical bytes, uniform vmcnt count)
+    // Slab `st` (clamped past the end: identical bytes, uniform vmcnt count): CV2_SRC derives the wave-uniform part of
+    // the four piece sources (SGPRs), CV2_PIECE(k) forms the per-lane address right where the piece is issued - holding
+    // four 64-bit lane addresses across the MFMA groups cost 22-31 spilled VGPRs in the two-pass kernels.
 #define CV2_SRC(st)                                                                                    \
         const int sc_ = min((st), nt - 1);                                                              \
         const int tap_ = sc_ / kc, c0_ = (sc_ - tap_ * kc) * 32;                                        \
         const int sh_ = tap_ == 0 ? qs0 : tap_ == 1 ? qs1 : tap_ == 2 ? qs2 : qs3;                      \
         const u16* S_ = tap_ == 0 ? qA0 : tap_ == 1 ? qA1 : tap_ == 2 ? qA2 : qA3;                      \
         const char* Sb_ = reinterpret_cast<const char*>(S_) + ((int64_t)sh_ * qlda + c0_) * 2;          \
-        const char* s0_ = ((ok0 >> tap_) & 1u) ? Sb_ + arow0 : zsrc;                                    \
-        const char* s1_ = ((ok1 >> tap_) & 1u) ? Sb_ + arow1 : zsrc;                                    \
-        const char* s2_ = bsrc0 + sc_ * 64;                                                             \
-        const char* s3_ = bsrc1 + sc_ * 64;                                                             \
+        const int boff_ = sc_ * 64;                                                                     \
         const unsigned base_ = lds0 + (unsigned)((st) & (CV2_STAGES - 1)) * CV2_STAGE_BYTES;
 #define CV2_PIECE(k)                                                                                   \
-        dma16((k) == 0 ? s0_ : (k) == 1 ? s1_ : (k) == 2 ? s2_ : s3_,                                   \
+        dma16((k) == 0 ? (((ok0 >> tap_) & 1u) ? Sb_ + arow0 : zsrc)                                    \
+              : (k) == 1 ? (((ok1 >> tap_) & 1u) ? Sb_ + arow1 : zsrc)                                  \
+              : (k) == 2 ? bsrc0 + boff_ : bsrc1 + boff_,                                               \
               base_ + ((k) == 0 ? a_piece0 : (k) == 1 ? a_piece0 + 8192u : (k) == 2 ? CV2_A_BYTES + a_piece0 : CV2_A_BYTES + b_piece1));
 #define CV2_ISSUE(st)                                                                                  \
     {                                                                                                   \
