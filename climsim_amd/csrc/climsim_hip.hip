@@ -705,20 +705,14 @@ int cs_loader_stack(const void* mli_dev, const void* mlo_dev, int32_t src_f64, i
     if (x_out_dev && (!in_sub_dev || !in_div_dev)) return fail(CS_ERR_INVALID, "inputs need sub/div vectors");
     if (y_out_dev && (!mlo_dev || !tend_src_dev || !out_scale_dev)) return fail(CS_ERR_INVALID, "targets need mlo, tend_src and scale");
     if (n_steps <= 0 || n_steps > 65535 || ncol <= 0 || n_in <= 0 || n_out < 0) return fail(CS_ERR_INVALID, "bad sizes");
-    const int fmax = n_in > n_out ? n_in : n_out;
-    const size_t lds = (size_t)fmax * LD_PITCH * sizeof(float);
-    if (lds > 160 * 1024) return fail(CS_ERR_INVALID, "%d features exceed the LDS tile", fmax);
-    const dim3 grid((unsigned)((ncol + LD_COLS - 1) / LD_COLS), (unsigned)n_steps);
+    const dim3 grid((unsigned)((ncol + 64 * LD_CPL - 1) / (64 * LD_CPL)), (unsigned)n_steps);
     hipStream_t st = (hipStream_t)stream;
-    if (src_f64) {
-        if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_loader_stack<double>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_loader_stack<double>, grid, dim3(256), lds, st, (const double*)mli_dev, (const double*)mlo_dev, ncol, n_in,
-                           in_sub_dev, in_div_dev, n_out, tend_src_dev, out_scale_dev, x_out_dev, y_out_dev);
-    } else {
-        if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_loader_stack<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_loader_stack<float>, grid, dim3(256), lds, st, (const float*)mli_dev, (const float*)mlo_dev, ncol, n_in,
-                           in_sub_dev, in_div_dev, n_out, tend_src_dev, out_scale_dev, x_out_dev, y_out_dev);
-    }
+    if (src_f64)
+        hipLaunchKernelGGL((k_loader_stack2<double, LD_CPL, LD_FCH, LD_U>), grid, dim3(256), 0, st, (const double*)mli_dev,
+                           (const double*)mlo_dev, ncol, n_in, in_sub_dev, in_div_dev, n_out, tend_src_dev, out_scale_dev, x_out_dev, y_out_dev);
+    else
+        hipLaunchKernelGGL((k_loader_stack2<float, LD_CPL, LD_FCH, LD_U>), grid, dim3(256), 0, st, (const float*)mli_dev,
+                           (const float*)mlo_dev, ncol, n_in, in_sub_dev, in_div_dev, n_out, tend_src_dev, out_scale_dev, x_out_dev, y_out_dev);
     HIP_TRY(hipGetLastError());
     return CS_OK;
 }

@@ -8,16 +8,10 @@
 //   y[t*ncol + c][f] = float32( v * scale[f] ),  v = tend_src[f] >= 0 ? (mlo[t][f][c] - mli[t][tend_src[f]][c]) / 1200
 //                                                                     : mlo[t][f][c]
 // Arithmetic in float64 like numpy on the host (bit-identical results), one pass over HBM: a workgroup owns 64
-// columns of one timestep, reads feature rows coalesced along the column axis, transposes through LDS (pitch 65)
-// and writes 496/512-byte training rows.  HBM-bound: 3,024 B per column with f64 sources (2,016 with f32).
+// columns of one timestep, reads feature rows coalesced along the column axis, transposes through LDS in chunks of 64
+// features and writes the training rows in 256-byte pieces.  HBM-bound: 3,024 B per column with f64 sources (2,016 with f32).
 #pragma once
 #include "kernels.h"
-
-// tile: 64 columns of one timestep (33 KB of LDS: 4 workgroups per CU keep enough loads in flight; a 128-column
-// tile halved the occupancy and ran 40 % slower).  Pitch 65 floats: the transposed read (feature varies over the lanes) and the
-// row-wise write (column varies) are both bank-conflict free.
-#define LD_COLS 64
-#define LD_PITCH 65
 
 template <typename T, bool TARGET>
 __device__ __forceinline__ float loader_value(const T* __restrict__ src, const T* __restrict__ mli, int64_t off, int f, int ncol,
@@ -32,48 +26,62 @@ __device__ __forceinline__ float loader_value(const T* __restrict__ src, const T
     return (fabs(v) <= 1.79769313486231570e308) ? (float)v : 0.f;      // inf / nan -> 0, decided on the float64 value
 }
 
-// one pass (inputs or targets) of a tile: feature rows in, training rows out
-template <typename T, bool TARGET>
-__device__ __forceinline__ void loader_pass(float* tile, const T* __restrict__ src, const T* __restrict__ mli, int nf, int ncol, int c0,
-                                            const double* __restrict__ p0, const double* __restrict__ p1,
-                                            const int* __restrict__ tend_src, float* __restrict__ out_rows) {
+// Tile = 64*CPL columns of one timestep, features in chunks of FCH, U feature rows in flight per wave: CPL consecutive
+// columns per lane (read segments of 64*CPL*sizeof(T) bytes per feature row), LDS tile [FCH][64*CPL+1] floats (the
+// odd pitch keeps both the row-wise fill and the transposed read conflict-free), output written as FCH*4-byte row
+// pieces.  Same-box sweep on 64 x 21,600 float64 columns (ms per call): (CPL,FCH,U) = (1,128,8) 1.65 [first version],
+// (1,64,2) 1.21, (1,64,4) 1.22, (1,64,8) 1.28, (1,32,4) 1.30, (1,16,4) 1.49, (2,64,4) 1.63, (2,32,4) 1.43, (2,128,2)
+// 2.16: small LDS footprints (more workgroups per CU) and 256-B output pieces win; (1,64,4) is built.
+#define LD_CPL 1
+#define LD_FCH 64
+#define LD_U 4
+template <typename T, bool TARGET, int CPL, int FCH, int U>
+__device__ __forceinline__ void loader_pass2(float* tile, const T* __restrict__ src, const T* __restrict__ mli, int nf, int ncol, int c0,
+                                             const double* __restrict__ p0, const double* __restrict__ p1,
+                                             const int* __restrict__ tend_src, float* __restrict__ out_rows) {
+    constexpr int COLS = 64 * CPL, PITCH = COLS + 1;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    // read: wave w takes features w, w+4, ...; a lane owns column c0+lane; 8 features in flight per lane
-    const int c = c0 + lane;
-    for (int f0 = w; f0 < nf; f0 += 32) {
-        float r[8];
+    const int c = c0 + CPL * lane;
+    const int ncols = min(COLS, ncol - c0);
+    for (int fc = 0; fc < nf; fc += FCH) {
+        const int nfc = min(FCH, nf - fc);
+        for (int fl0 = w; fl0 < nfc; fl0 += 4 * U) {
+            float r[U][CPL];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int f = f0 + 4 * u;
-            r[u] = (f < nf && c < ncol) ? loader_value<T, TARGET>(src, mli, (int64_t)f * ncol + c, f, ncol, p0, p1, tend_src) : 0.f;
-        }
+            for (int u = 0; u < U; ++u) {
+                const int fl = fl0 + 4 * u, f = fc + fl;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int f = f0 + 4 * u;
-            if (f < nf) tile[f * LD_PITCH + lane] = r[u];
+                for (int q = 0; q < CPL; ++q)
+                    r[u][q] = (fl < nfc && c + q < ncol) ? loader_value<T, TARGET>(src, mli, (int64_t)f * ncol + c + q, f, ncol, p0, p1, tend_src) : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int fl = fl0 + 4 * u;
+                if (fl < nfc) {
+#pragma unroll
+                    for (int q = 0; q < CPL; ++q) tile[fl * PITCH + CPL * lane + q] = r[u][q];
+                }
+            }
         }
+        __syncthreads();
+        for (int cc = w; cc < ncols; cc += 4) {
+            float* row = out_rows + (int64_t)cc * nf + fc;
+            for (int f = lane; f < nfc; f += 64) row[f] = tile[f * PITCH + cc];
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    // write: a wave emits whole rows; lanes run over the features (rows are nf*4 bytes, contiguous)
-    const int ncols = min(LD_COLS, ncol - c0);
-    for (int cc = w; cc < ncols; cc += 4) {
-        float* row = out_rows + (int64_t)cc * nf;
-        for (int f = lane; f < nf; f += 64) row[f] = tile[f * LD_PITCH + cc];
-    }
-    __syncthreads();
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void k_loader_stack(const T* __restrict__ mli, const T* __restrict__ mlo, int ncol, int n_in,
-                                                      const double* __restrict__ sub, const double* __restrict__ div, int n_out,
-                                                      const int* __restrict__ tend_src, const double* __restrict__ scale,
-                                                      float* __restrict__ x_out, float* __restrict__ y_out) {
-    extern __shared__ float tile[];                       // [max(n_in, n_out)][LD_PITCH]
-    const int c0 = blockIdx.x * LD_COLS;
+template <typename T, int CPL, int FCH, int U>
+__global__ __launch_bounds__(256) void k_loader_stack2(const T* __restrict__ mli, const T* __restrict__ mlo, int ncol, int n_in,
+                                                       const double* __restrict__ sub, const double* __restrict__ div, int n_out,
+                                                       const int* __restrict__ tend_src, const double* __restrict__ scale,
+                                                       float* __restrict__ x_out, float* __restrict__ y_out) {
+    __shared__ float tile[FCH * (64 * CPL + 1)];
+    const int c0 = blockIdx.x * 64 * CPL;
     const int64_t t = blockIdx.y;
     const T* a = mli + t * (int64_t)n_in * ncol;
-    if (x_out) loader_pass<T, false>(tile, a, a, n_in, ncol, c0, sub, div, nullptr, x_out + (t * ncol + c0) * (int64_t)n_in);
-    if (y_out) loader_pass<T, true>(tile, mlo + t * (int64_t)n_out * ncol, a, n_out, ncol, c0, scale, nullptr, tend_src,
-                                    y_out + (t * ncol + c0) * (int64_t)n_out);
+    if (x_out) loader_pass2<T, false, CPL, FCH, U>(tile, a, a, n_in, ncol, c0, sub, div, nullptr, x_out + (t * ncol + c0) * (int64_t)n_in);
+    if (y_out) loader_pass2<T, true, CPL, FCH, U>(tile, mlo + t * (int64_t)n_out * ncol, a, n_out, ncol, c0, scale, nullptr, tend_src,
+                                               y_out + (t * ncol + c0) * (int64_t)n_out);
 }
-
