@@ -64,11 +64,11 @@ class GpuMetrics:
         if tuple(t.shape) != (n, self.n_out) or tuple(p.shape) != (n, self.n_out) or x.shape[0] != n or n % self.ncol:
             raise ValueError(f"expected (T*{self.ncol}, {self.n_out}) predictions and targets and matching inputs")
         ps = (x[:, self.du.ps_index].double() * self._ps_mul + self._ps_add).contiguous()
-        out = torch.empty((self.ncol, self.n_out, 4), dtype=torch.float64, device=self.device)
+        out = torch.empty((self.ncol, self.n_out, 6), dtype=torch.float64, device=self.device)
         st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         _lib.check(self.lib.cs_metrics_columns(_ptr(p), _ptr(t), n // self.ncol, self.ncol, self.n_out, _ptr(ps), _ptr(self._wa),
                                                _ptr(self._wb), _ptr(self._area), _ptr(out), st))
-        return out
+        return out[:, :, :4]
 
     def metrics_tables(self, preds, target, inputs):
         """(df_var, df_idx) like data_utils.create_metrics_df: per-variable means and per-output values, grid-averaged."""

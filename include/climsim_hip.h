@@ -159,7 +159,7 @@ int cs_loader_stack(const void* mli_dev, const void* mlo_dev, int32_t src_f64, i
 /* Evaluation metrics on the device: data_utils.output_weighting + calc_MAE / calc_RMSE / calc_R2 / calc_bias with
  * avg_grid=False (data_utils.py:1112-1362, 1432-1497).  pred/target (n_steps*ncol, n_out) float32 rows, row = t*ncol + c;
  * weight(row, f) = (wa[f] + wb[f]*ps[row]) * area[c]  (constants folded on the host, see climsim_amd/metrics.py).
- * stats_dev [ncol][n_out][4] float64 = MAE, RMSE, R2, bias per grid column and output. */
+ * stats_dev [ncol][n_out][6] float64: slots 0..3 = MAE, RMSE, R2, bias per grid column and output (4, 5: scratch). */
 int cs_metrics_columns(const float* pred_dev, const float* target_dev, int64_t n_steps, int32_t ncol, int32_t n_out,
                        const double* ps_dev, const double* wa_dev, const double* wb_dev, const double* area_dev,
                        double* stats_dev, void* stream);

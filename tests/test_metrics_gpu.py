@@ -12,7 +12,8 @@ pytestmark = pytest.mark.gpu
 from golden_inputs import make_metric_inputs  # noqa: E402
 
 
-def test_device_metrics_match_host_pipeline(lowres_assets):
+@pytest.mark.parametrize("T", [9, 70])          # 70 time steps: five slices of the time axis, combined with float64 atomics
+def test_device_metrics_match_host_pipeline(lowres_assets, T):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from climsim_amd import build
@@ -22,7 +23,7 @@ def test_device_metrics_match_host_pipeline(lowres_assets):
     grid, *sets = lowres_assets
     d = data_utils(copy.copy(grid), *sets)
     d.set_to_v1_vars()
-    x, y, p = make_metric_inputs(9)
+    x, y, p = make_metric_inputs(T)
     d.input_scoring, d.target_scoring = x, y
     d.set_pressure_grid("scoring")
     d.model_names = ["m"]
