@@ -54,6 +54,7 @@ struct ChainArgs {
     int act; float slope;
     // heads (EPI_OUT)
     int n_lin; float* yhat; const float* y; float* loss; u16* dz_out; int ld_dz_out;
+    int mask_bm64;           // backward with 32-row tiles over sign masks written by a 64-row forward (see chain_stage)
     int ablate;              // timing experiments only (CS_CHAIN_ABLATE): 4 no global stores, 8 no warm-up
     unsigned long long* dbg; // optional [grid][64] s_memtime stamps (CS_CHAIN_DBG), null in production
 };
@@ -309,7 +310,19 @@ __device__ __forceinline__ void chain_stage(u16* X, const float* bias_lds, const
     }
     u32x4_t msk = u32x4_t{0u, 0u, 0u, 0u};
     u32x4_t* mptr = S.mask ? S.mask + (int64_t)blockIdx.x * 512 + tid : nullptr;
-    if (EPI == EPI_DGRAD && !ELU) msk = *mptr;                 // lands during the k-loop
+    if (EPI == EPI_DGRAD && !ELU) {
+        if (BMROWS == 32 && p.mask_bm64) {
+            // The forward pass ran 64-row tiles (fewer weight bytes through the L2s), this pass 32-row tiles (a workgroup
+            // on every CU): workgroup 2i+a0 covers row tile a0 of forward workgroup i.  Forward layout: tile t = a*NT+b in
+            // dword t>>1, half t&1; 128-wide stages put rows 32..63 on waves 4..7 (threads 256..511).
+            const int a0 = blockIdx.x & 1;
+            const int ft = S.Nc == 128 ? (tid & 255) + 256 * a0 : tid;
+            const u32x4_t m = S.mask[(int64_t)(blockIdx.x >> 1) * 512 + ft];
+            msk[0] = S.Nc == 512 ? (a0 ? m[1] : m[0]) : (S.Nc == 256 ? m[0] >> (16 * a0) : m[0]);
+        } else {
+            msk = *mptr;                                       // lands during the k-loop
+        }
+    }
     // deep prefetch (8 steps = 16 KiB per wave in flight) where registers allow and the contraction is long enough
     if (MT <= 2 && (S.Kc & 127) == 0) chain_mma<BMROWS, MT, NT, 8>(X, S.wfrag, S.Kc >> 4, S.Nc >> 5, jt0, mrow0, tid, acc, pend, m0);
     else chain_mma<BMROWS, MT, NT, 4>(X, S.wfrag, S.Kc >> 4, S.Nc >> 5, jt0, mrow0, tid, acc, pend, m0);

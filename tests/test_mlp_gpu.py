@@ -60,7 +60,7 @@ def test_forward_matches_oracle(M, act, n, flags):
     assert np.all(got[:, 120:] >= 0)                      # relu head
 
 
-@pytest.mark.parametrize("flags", [0, 1, 2, 3, 4, 8])     # +1 = CS_FLAG_NO_TR_READ
+@pytest.mark.parametrize("flags", [0, 1, 2, 3, 4, 8, 36])  # +1 = CS_FLAG_NO_TR_READ; 36 = 64-row forward + 32-row backward
 @pytest.mark.parametrize("act,n,units", [("leakyrelu", 300, (256, 128, 512)), ("relu", 128, (512, 512)),
                                          ("elu", 1000, (256, 128, 384))])   # 384: per-layer fallback
 def test_loss_and_gradients_match_oracle(M, act, n, units, flags):
