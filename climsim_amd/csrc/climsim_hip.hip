@@ -733,7 +733,7 @@ int cs_metrics_columns(const float* pred_dev, const float* target_dev, int64_t n
     const int64_t items = (int64_t)ncol * n_out;
     HIP_TRY(hipMemsetAsync(stats_dev, 0, sizeof(double) * 6 * items, st));
     int tsplit = (int)((4096 + (int64_t)ncol * ((n_out + 127) / 128) - 1) / ((int64_t)ncol * ((n_out + 127) / 128)));   // ~4096 workgroups
-    tsplit = std::max(1, std::min<int>(tsplit, (int)((n_steps + 15) / 16)));
+    tsplit = std::max(1, std::min<int>(tsplit, (int)(n_steps / 64)));     // >= 64 time steps per slice: 6 float64 atomics per (column, output, slice)
     hipLaunchKernelGGL(k_metrics_partial, dim3((unsigned)ncol, (unsigned)((n_out + 127) / 128), (unsigned)tsplit), dim3(256), 0, st,
                        pred_dev, target_dev, (int)n_steps, ncol, n_out, ps_dev, wa_dev, wb_dev, area_dev, stats_dev);
     hipLaunchKernelGGL(k_metrics_finish, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, stats_dev, items, (int)n_steps);
