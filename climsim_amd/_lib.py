@@ -14,6 +14,7 @@ CS_FLAG_CHAIN_BM64 = 4
 CS_FLAG_CHAIN_BM128 = 8
 CS_FLAG_CHAIN_BM32 = 16
 CS_FLAG_CHAIN_BWD32_ON_FWD64 = 32
+CS_FLAG_GEMM_V1 = 64
 
 ACT = {"relu": 0, "elu": 1, "leakyrelu": 2}
 OPT = {"Adam": 0, "RAdam": 1, "RMSprop": 2, "SGD": 3}

@@ -6,6 +6,7 @@
 #include "chain.h"
 #include "wgrad2.h"
 #include "loader.h"
+#include "gemm2.h"
 #include "metrics.h"
 
 #include <cmath>
@@ -271,13 +272,16 @@ int run_forward(cs_mlp* h, const float* x, const int64_t* row_idx, int64_t n, in
         p.bias = h->P + ly.b_off;
         const dim3 grid((unsigned)(m_pad / 128), (unsigned)(ly.N / 128));
         ProfScope ps(CS_K_GEMM_FWD, st);
+        const bool v1 = (h->cfg.flags & CS_FLAG_GEMM_V1) != 0;     // register-staged 128x128x64 kernels (A/B and parity runs)
         if (l + 1 < h->L) {
             p.out = h->layers[l + 1].H; p.ldo = h->layers[l + 1].Kp;
-            hipLaunchKernelGGL(k_gemm_nt<EPI_HIDDEN>, grid, dim3(256), 0, st, p);
+            if (v1) hipLaunchKernelGGL(k_gemm_nt<EPI_HIDDEN>, grid, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL(k_gemm_nt2<EPI_HIDDEN>, grid, dim3(256), G2_LDS_BYTES, st, p);
         } else {
             p.n_lin = h->cfg.n_out_lin; p.n_real = h->n_out; p.yhat = yhat; p.y = y; p.row_idx = row_idx; p.n_rows = n; p.loss = loss;
             p.out = want_dz ? ly.dZ : nullptr; p.ldo = ly.N;
-            hipLaunchKernelGGL(k_gemm_nt<EPI_OUT>, grid, dim3(256), 0, st, p);
+            if (v1) hipLaunchKernelGGL(k_gemm_nt<EPI_OUT>, grid, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL(k_gemm_nt2<EPI_OUT>, grid, dim3(256), G2_LDS_BYTES, st, p);
         }
     }
     HIP_TRY(hipGetLastError());
@@ -322,7 +326,8 @@ int run_backward(cs_mlp* h, int64_t n, bool atomics_needed, hipStream_t st) {
             p.hprev = ly.H; p.ldh = ly.Kp;
             const dim3 g2((unsigned)(m_pad / 128), (unsigned)(ly.Kp / 128));
             ProfScope ps(CS_K_GEMM_DGRAD, st);
-            hipLaunchKernelGGL(k_gemm_nt<EPI_DGRAD>, g2, dim3(256), 0, st, p);
+            if (h->cfg.flags & CS_FLAG_GEMM_V1) hipLaunchKernelGGL(k_gemm_nt<EPI_DGRAD>, g2, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL(k_gemm_nt2<EPI_DGRAD>, g2, dim3(256), G2_LDS_BYTES, st, p);
         }
     }
     {   // weight/bias gradients of ALL layers in one grouped launch

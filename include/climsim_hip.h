@@ -62,6 +62,7 @@ typedef struct cs_mlp_cfg {
 #define CS_FLAG_CHAIN_BM64  4     /* force 64-row chain tiles  (default: by batch size)                    */
 #define CS_FLAG_CHAIN_BM128 8     /* force 128-row chain tiles                                             */
 #define CS_FLAG_CHAIN_BM32  16    /* force 32-row chain tiles                                              */
+#define CS_FLAG_GEMM_V1 64         /* per-layer path on the first (register-staged) GEMM kernels: A/B and parity runs */
 #define CS_FLAG_CHAIN_BWD32_ON_FWD64 32   /* tests: 64-row forward tiles (with CHAIN_BM64), 32-row backward tiles    */
 
 /* keras.Model(...) + compile(): allocates weights (zero), optimiser state, workspace. */

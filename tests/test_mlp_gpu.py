@@ -45,7 +45,7 @@ def make_model(M, units, act="leakyrelu", opt="Adam", max_batch=1024, seed=3, fl
 
 # engine flags: 0 = layer-chain kernels (tile by batch: 32 rows at these sizes), 2 = one GEMM per layer,
 # 4/8/16 = chain with 64/128/32-row tiles
-@pytest.mark.parametrize("flags", [0, 2, 4, 8])
+@pytest.mark.parametrize("flags", [0, 2, 4, 8, 66])      # 66 = per-layer path on the first GEMM kernels
 @pytest.mark.parametrize("act", ["relu", "elu", "leakyrelu"])
 @pytest.mark.parametrize("n", [1, 200, 384])
 def test_forward_matches_oracle(M, act, n, flags):
@@ -60,7 +60,7 @@ def test_forward_matches_oracle(M, act, n, flags):
     assert np.all(got[:, 120:] >= 0)                      # relu head
 
 
-@pytest.mark.parametrize("flags", [0, 1, 2, 3, 4, 8, 36])  # +1 = CS_FLAG_NO_TR_READ; 36 = 64-row forward + 32-row backward
+@pytest.mark.parametrize("flags", [0, 1, 2, 3, 4, 8, 36, 66])  # +1 = CS_FLAG_NO_TR_READ; 36 = 64-row forward + 32-row backward; 66 = first GEMM kernels
 @pytest.mark.parametrize("act,n,units", [("leakyrelu", 300, (256, 128, 512)), ("relu", 128, (512, 512)),
                                          ("elu", 1000, (256, 128, 384))])   # 384: per-layer fallback
 def test_loss_and_gradients_match_oracle(M, act, n, units, flags):
