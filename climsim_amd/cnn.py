@@ -70,6 +70,7 @@ class CNNEmulator:
         self.device = torch.device("cuda", self.device_index)
         self.max_batch = int(max_batch)
         self.trainable, self.loss_name, self.dropout = bool(trainable), loss, float(dropout)
+        self._seed = int(seed)
         self.iterations = 0
         cfg = _lib.CsCnnCfg(depth=depth, channels=channel_width, kernel=kernel_width, seq=60, c_in=6, c_out=10, n_lin=2,
                             max_batch=self.max_batch, device=self.device_index, flags=int(bool(tile128)), train=int(self.trainable),
@@ -285,6 +286,8 @@ class CNNEmulator:
         rank, world = dp.rank, dp.world
         if distributed:
             dp.broadcast_weights()
+            # every rank draws its own dropout masks (same weights, different rows AND different masks)
+            _lib.check(self.lib.cs_cnn_set_seed(self._h, C.c_uint64((self._seed + 1000003 * rank) & 0xFFFFFFFFFFFFFFFF)))
         if batch_size % world or batch_size // world > self.max_batch:
             raise ValueError("global batch must be divisible by the world size and fit max_batch per GPU")
         n = x.shape[0]

@@ -523,6 +523,13 @@ int cs_cnn_loss_grads(cs_cnn_t* h, const float* x_dev, int x3d, const float* y_d
     return CS_OK;
 }
 
+int cs_cnn_set_seed(cs_cnn_t* h, uint64_t seed) {
+    if (!h) return fail(CS_ERR_INVALID, "null handle");
+    h->cfg.seed = seed;
+    h->drop_calls = 0;
+    return CS_OK;
+}
+
 int cs_cnn_grad_buffer(cs_cnn_t* h, void** grad_dev, int64_t* n_floats) {
     if (!h || !grad_dev || !n_floats) return fail(CS_ERR_INVALID, "null argument");
     if (!h->cfg.train) return fail(CS_ERR_STATE, "handle was created without training state");

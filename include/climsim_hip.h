@@ -206,6 +206,9 @@ int  cs_cnn_evaluate(cs_cnn_t* h, const float* x_dev, int x3d, const float* y_de
  * the flat gradient buffer; loss_dev[4] as above. */
 int  cs_cnn_loss_grads(cs_cnn_t* h, const float* x_dev, int x3d, const float* y_dev, int y3d, const int64_t* row_idx_dev,
                        int64_t n, float* loss_dev, void* stream);
+/* Restart the dropout stream: call k of cs_cnn_loss_grads uses seed + k.  Under data parallelism every rank takes its
+ * own stream (climsim_amd.cnn.CNNEmulator.fit: seed + 1000003 * rank). */
+int  cs_cnn_set_seed(cs_cnn_t* h, uint64_t seed);
 int  cs_cnn_grad_buffer(cs_cnn_t* h, void** grad_dev, int64_t* n_floats);     /* payload of the DP all-reduce */
 int  cs_cnn_set_grad_buffer(cs_cnn_t* h, float* grad_dev, int64_t n_floats);  /* bind a caller-owned buffer (NULL: own) */
 /* optimizer.apply_gradients: w -= update(grad_scale * G); grad_scale = 1/(n*seq*world_size); zeroes G. */
