@@ -1,0 +1,179 @@
+// Layer chain for WIDE models: hidden widths that are any multiple of 128 up to 1024 (the reference's search space,
+// hpo_baseline_v1.py:78; e.g. the published 768-640-512-640-640 model), which the tuned chain kernels of chain.h
+// (widths 128/256/512, 512-element LDS rows) do not take.  Same idea - the whole Dense stack of a row tile in ONE
+// launch, activations in LDS, weights streamed fragment-major from L2 - in a plainer form:
+//
+//   * 32-row tiles, two LDS activation buffers of [32][1024] bf16 (ping-pong: a stage reads one and writes the other, so
+//     a wide stage can be produced in several column passes without clobbering its input);
+//   * a wave owns the 32-column tiles w, w+8, w+16, w+24 of a stage and produces them two per pass (v_mfma 32x32x16,
+//     one row tile x two column tiles), weights prefetched four k16-steps ahead;
+//   * backward reads act'(h) from the global activation copies (no sign masks).
+// Against 13 separate GEMM launches of ~11 us each this removes the per-launch latency, which is what bounds the
+// per-layer path at the reference's batch sizes.
+#pragma once
+#include "chain.h"
+
+#define CWD_PITCH 1024
+#define CWD_BM 32
+constexpr int chainw_lds_bytes() { return 2 * CWD_BM * CWD_PITCH * 2 + CHAIN_MAX_BIAS * 4 + CWD_BM * 8; }
+
+__device__ __forceinline__ int cwd_off(int row, int col) {        // element offset of (row, col): 16-B chunks XOR (row & 15)
+    return row * CWD_PITCH + ((((col >> 3) ^ (row & 15))) << 3) + (col & 7);
+}
+
+// acc0/acc1 = Xin[32 rows][Kc] x W[:, tile0*32 .. +32) (and tile1): one wave, weights fragment-major.
+__device__ __forceinline__ void cwd_mma(const u16* __restrict__ Xin, const u16* __restrict__ wfrag, int ks_total, int ntiles, int tile0,
+                                        int tile1, bool two, int lane, f32x16_t& acc0, f32x16_t& acc1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    const uint4* w0 = reinterpret_cast<const uint4*>(wfrag) + tile0 * 64 + lane;
+    const uint4* w1 = reinterpret_cast<const uint4*>(wfrag) + tile1 * 64 + lane;
+    const int sstride = ntiles * 64;
+    const int arow = lane & 31, ahalf = lane >> 5;
+    uint4 qa0, qa1, qa2, qa3, qb0, qb1, qb2, qb3;               // prefetch ring, four k16-steps deep (named: see kernels.h)
+    qa0 = w0[0 * sstride]; qa1 = w0[min(1, ks_total - 1) * sstride]; qa2 = w0[min(2, ks_total - 1) * sstride]; qa3 = w0[min(3, ks_total - 1) * sstride];
+    qb0 = qa0; qb1 = qa1; qb2 = qa2; qb3 = qa3;
+    if (two) { qb0 = w1[0 * sstride]; qb1 = w1[min(1, ks_total - 1) * sstride]; qb2 = w1[min(2, ks_total - 1) * sstride]; qb3 = w1[min(3, ks_total - 1) * sstride]; }
+#define CWD_STEP(QA, QB, u)                                                                             \
+    {                                                                                                    \
+        const int s = s0 + (u);                                                                          \
+        const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(Xin + cwd_off(arow, (2 * s + ahalf) * 8)); \
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, QA), a, acc0, 0, 0, 0); \
+        if (two) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, QB), a, acc1, 0, 0, 0); \
+        const int sn = min(s + 4, ks_total - 1);                                                         \
+        QA = w0[sn * sstride];                                                                           \
+        if (two) QB = w1[sn * sstride];                                                                  \
+    }
+    for (int s0 = 0; s0 < ks_total; s0 += 4) {                   // contraction lengths are multiples of 64 = 4 steps
+        CWD_STEP(qa0, qb0, 0)
+        CWD_STEP(qa1, qb1, 1)
+        CWD_STEP(qa2, qb2, 2)
+        CWD_STEP(qa3, qb3, 3)
+    }
+#undef CWD_STEP
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(512) void k_chainw(const ChainArgs p) {
+    extern __shared__ __attribute__((aligned(16))) u16 XW[];
+    u16* Xin = XW;
+    u16* Xout = XW + CWD_BM * CWD_PITCH;
+    float* bias_lds = reinterpret_cast<float*>(XW + 2 * CWD_BM * CWD_PITCH);
+    int64_t* rows_lds = reinterpret_cast<int64_t*>(bias_lds + CHAIN_MAX_BIAS);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int64_t m0 = (int64_t)blockIdx.x * CWD_BM;
+
+    if (!BWD) {
+        for (int i = 0; i < p.n_stages; ++i)
+            for (int t = tid; t < p.bias_len[i]; t += 512) bias_lds[p.st[i].bias_off + t] = p.bias_src[i][t];
+        if (tid < CWD_BM) rows_lds[tid] = (m0 + tid < p.n_rows) ? (p.row_idx ? p.row_idx[m0 + tid] : m0 + tid) : -1;
+        __syncthreads();
+        const int groups = p.kp0 >> 2;                           // 4 features per item
+        for (int g = tid; g < CWD_BM * groups; g += 512) {
+            const int ml = g / groups, c = (g - ml * groups) * 4;
+            const int64_t src = rows_lds[ml];
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (src >= 0) {
+                for (int j = 0; j < 4 && c + j < p.n_in; ++j) {
+                    float t = p.x[src * p.n_in + c + j];
+                    if (p.normalise) { t = (t - p.sub[c + j]) / p.div[c + j]; t = (fabsf(t) <= 3.402823466e38f) ? t : 0.f; }
+                    v[j] = t;
+                }
+            }
+            const uint2 pk = pack4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<uint2*>(Xin + cwd_off(ml, c)) = pk;
+            if (p.h0) *reinterpret_cast<uint2*>(p.h0 + (m0 + ml) * p.ldh0 + c) = pk;
+        }
+    } else {
+        const int chunks = p.w_in >> 3;                          // 16-B chunks per row
+        for (int g = tid; g < CWD_BM * chunks; g += 512) {
+            const int ml = g / chunks, c = (g - ml * chunks) * 8;
+            *reinterpret_cast<uint4*>(Xin + cwd_off(ml, c)) = *reinterpret_cast<const uint4*>(p.dz_in + (m0 + ml) * p.ld_dz_in + c);
+        }
+    }
+    __syncthreads();
+
+    float sq = 0.f, ab = 0.f;
+    const int mrow = lane & 31, hi4 = 4 * (lane >> 5);
+    for (int i = 0; i < p.n_stages; ++i) {
+        const ChainStage& S = p.st[i];
+        const int ntiles = S.Nc >> 5, ks = S.Kc >> 4;
+        if (!BWD && S.epi == EPI_OUT) {                          // heads: 128 wide, one column tile per wave 0..3
+            if (wid < 4) {
+                f32x16_t acc, dummy;
+                cwd_mma(Xin, S.wfrag, ks, ntiles, wid, wid, false, lane, acc, dummy);
+                const int64_t m = m0 + mrow;
+                const bool valid = m < p.n_rows;
+                const int64_t yrow = valid ? rows_lds[mrow] : 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = wid * 32 + 8 * q + hi4;
+                    const float4 b4 = *reinterpret_cast<const float4*>(bias_lds + S.bias_off + n);
+                    float v[4] = {acc[4 * q + 0] + b4.x, acc[4 * q + 1] + b4.y, acc[4 * q + 2] + b4.z, acc[4 * q + 3] + b4.w};
+                    float d[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (n >= p.n_lin) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    }
+                    if (valid && p.yhat) *reinterpret_cast<float4*>(p.yhat + m * S.Nc + n) = make_float4(v[0], v[1], v[2], v[3]);
+                    if (p.y && valid) {
+                        const float4 t4 = *reinterpret_cast<const float4*>(p.y + yrow * S.Nc + n);
+                        const float e4[4] = {v[0] - t4.x, v[1] - t4.y, v[2] - t4.z, v[3] - t4.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            sq += e4[e] * e4[e];
+                            ab += fabsf(e4[e]);
+                            d[e] = 2.f * e4[e];
+                            if (n >= p.n_lin && !(v[e] > 0.f)) d[e] = 0.f;
+                        }
+                    }
+                    if (p.dz_out) *reinterpret_cast<uint2*>(p.dz_out + m * p.ld_dz_out + n) = make_uint2(cvt_pk_bf16(d[0], d[1]), cvt_pk_bf16(d[2], d[3]));
+                }
+            }
+            continue;                                            // last stage of the forward pass
+        }
+        for (int tile0 = wid; tile0 < ntiles; tile0 += 16) {     // a pass: column tiles tile0 and tile0 + 8
+            const int tile1 = tile0 + 8;
+            const bool two = tile1 < ntiles;
+            f32x16_t acc0, acc1;
+            cwd_mma(Xin, S.wfrag, ks, ntiles, tile0, two ? tile1 : tile0, two, lane, acc0, acc1);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                if (b == 1 && !two) break;
+                const int tile = b == 0 ? tile0 : tile1;
+                const f32x16_t& acc = b == 0 ? acc0 : acc1;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = tile * 32 + 8 * q + hi4;
+                    float v[4] = {acc[4 * q + 0], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+                    if (!BWD) {
+                        const float4 b4 = *reinterpret_cast<const float4*>(bias_lds + S.bias_off + n);
+                        v[0] = act_fwd(v[0] + b4.x, p.act, p.slope); v[1] = act_fwd(v[1] + b4.y, p.act, p.slope);
+                        v[2] = act_fwd(v[2] + b4.z, p.act, p.slope); v[3] = act_fwd(v[3] + b4.w, p.act, p.slope);
+                    } else {
+                        const uint2 hh = *reinterpret_cast<const uint2*>(S.hprev + (m0 + mrow) * S.ldh + n);
+                        v[0] *= act_bwd_from_h(bf2f((u16)(hh.x & 0xffff)), p.act, p.slope);
+                        v[1] *= act_bwd_from_h(bf2f((u16)(hh.x >> 16)), p.act, p.slope);
+                        v[2] *= act_bwd_from_h(bf2f((u16)(hh.y & 0xffff)), p.act, p.slope);
+                        v[3] *= act_bwd_from_h(bf2f((u16)(hh.y >> 16)), p.act, p.slope);
+                    }
+                    *reinterpret_cast<uint2*>(Xout + cwd_off(mrow, n)) = make_uint2(cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3]));
+                }
+            }
+        }
+        __syncthreads();                                         // Xout complete, nobody reads Xin any more
+        if (S.out) {                                             // global copy (next layer's wgrad / the backward pass), coalesced
+            const int cpr = S.Nc >> 3;
+            for (int g = tid; g < CWD_BM * cpr; g += 512) {
+                const int r = g / cpr, c = g - r * cpr;
+                *reinterpret_cast<uint4*>(S.out + (m0 + r) * S.ldo + c * 8) = *reinterpret_cast<const uint4*>(Xout + cwd_off(r, c * 8));
+            }
+        }
+        u16* t = Xin; Xin = Xout; Xout = t;
+    }
+    if (!BWD && p.y) {
+        sq = wave_sum(sq);
+        ab = wave_sum(ab);
+        if (lane == 0 && wid < 4) { atomicAdd(p.loss, sq); atomicAdd(p.loss + 1, ab); }
+    }
+}

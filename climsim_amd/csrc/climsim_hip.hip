@@ -7,6 +7,7 @@
 #include "wgrad2.h"
 #include "loader.h"
 #include "gemm2.h"
+#include "chainw.h"
 #include "metrics.h"
 
 #include <cmath>
@@ -99,6 +100,8 @@ struct cs_mlp {
     int64_t iterations = 0;
     int64_t bytes = 0;
     bool use_chain = false;
+    bool use_chainw = false;   // wide-model chain (chainw.h): widths any multiple of 128 up to 1024, batches up to chainw_max_n
+    int64_t chainw_max_n = 8192;
     bool grads_dirty = true;   // G may hold non-zero values (cleared by cs_mlp_apply)
     unsigned long long* dbg = nullptr;   // CS_CHAIN_DBG: [2][grid_max][64] stamps (fwd, bwd)
     int chain_ablate = 0;      // CS_CHAIN_ABLATE env, timing experiments only
@@ -258,6 +261,27 @@ int run_forward(cs_mlp* h, const float* x, const int64_t* row_idx, int64_t n, in
         HIP_TRY(hipGetLastError());
         return CS_OK;
     }
+    if (h->use_chainw && n <= h->chainw_max_n) {
+        ChainArgs c{};
+        c.n_stages = h->L;
+        for (int l = 0; l < h->L; ++l) {
+            const Layer& ly = h->layers[l];
+            ChainStage& S = c.st[l];
+            S.wfrag = ly.Wf; S.bias_off = ly.bias_off; S.Kc = ly.Kp; S.Nc = ly.N;
+            c.bias_src[l] = h->P + ly.b_off; c.bias_len[l] = ly.N;
+            if (l + 1 < h->L) { S.out = want_dz ? h->layers[l + 1].H : nullptr; S.ldo = h->layers[l + 1].Kp; S.epi = EPI_HIDDEN; }
+            else { S.out = nullptr; S.ldo = 0; S.epi = EPI_OUT; }
+        }
+        c.x = x; c.row_idx = row_idx; c.n_in = h->cfg.n_in; c.kp0 = l0.Kp; c.sub = h->sub; c.div = h->div;
+        c.normalise = normalise; c.h0 = want_dz ? l0.H : nullptr; c.ldh0 = l0.Kp; c.n_rows = n;
+        c.act = h->cfg.act; c.slope = (h->cfg.act == CS_ACT_RELU) ? 0.f : h->cfg.alpha;
+        c.n_lin = h->cfg.n_out_lin; c.yhat = yhat; c.y = y; c.loss = loss;
+        c.dz_out = want_dz ? h->layers[h->L - 1].dZ : nullptr; c.ld_dz_out = 128;
+        ProfScope ps(CS_K_CHAIN_FWD, st);
+        hipLaunchKernelGGL(k_chainw<false>, dim3((unsigned)(m_pad / CWD_BM)), dim3(512), chainw_lds_bytes(), st, c);
+        HIP_TRY(hipGetLastError());
+        return CS_OK;
+    }
     {
         const int64_t total = m_pad * (l0.Kp / 4);
         ProfScope ps(CS_K_PREPARE, st);
@@ -316,7 +340,23 @@ int run_backward(cs_mlp* h, int64_t n, bool atomics_needed, hipStream_t st) {
         ProfScope ps(CS_K_CHAIN_BWD, st);
         launch_chain<true>(h, bm, m_pad, c, st);
     }
-    if (!h->use_chain) {
+    const bool wide = h->use_chainw && n <= h->chainw_max_n;
+    if (wide && h->L > 1) {
+        ChainArgs c{};
+        c.n_stages = h->L - 1;
+        for (int l = h->L - 1, i = 0; l >= 1; --l, ++i) {
+            const Layer& ly = h->layers[l];
+            ChainStage& S = c.st[i];
+            S.wfrag = ly.Wb; S.bias_off = 0; S.Kc = ly.N; S.Nc = ly.Kp;
+            S.out = h->layers[l - 1].dZ; S.ldo = h->layers[l - 1].N;
+            S.hprev = ly.H; S.ldh = ly.Kp; S.epi = EPI_DGRAD;
+        }
+        c.dz_in = h->layers[h->L - 1].dZ; c.ld_dz_in = 128; c.w_in = 128;
+        c.n_rows = n; c.act = h->cfg.act; c.slope = (h->cfg.act == CS_ACT_RELU) ? 0.f : h->cfg.alpha;
+        ProfScope ps(CS_K_CHAIN_BWD, st);
+        hipLaunchKernelGGL(k_chainw<true>, dim3((unsigned)(m_pad / CWD_BM)), dim3(512), chainw_lds_bytes(), st, c);
+    }
+    if (!h->use_chain && !wide) {
         for (int l = h->L - 1; l >= 1; --l) {
             const Layer& ly = h->layers[l];
             GemmNT p{};
@@ -427,10 +467,19 @@ int cs_mlp_create(cs_mlp_t** out, const cs_mlp_cfg* cfg) {
         if (!(ly.N == 128 || ly.N == 256 || ly.N == 512) || ly.Kp > CHAIN_PITCH || ly.Kp % 64) h->use_chain = false;
     }
     if (2 * h->L > CHAIN_MAX_STAGES || h->n_out != 128) h->use_chain = false;
+    h->use_chainw = !(cfg->flags & CS_FLAG_NO_CHAIN) && h->n_out == 128 && 2 * h->L <= CHAIN_MAX_STAGES;
+    for (int l = 0; l < h->L; ++l)
+        if (h->layers[l].N > CWD_PITCH || h->layers[l].Kp > CWD_PITCH) h->use_chainw = false;
     {
         int boff = 0;
         for (int l = 0; l < h->L; ++l) { h->layers[l].bias_off = boff; boff += h->layers[l].N; }
-        if (boff > CHAIN_MAX_BIAS) h->use_chain = false;
+        if (boff > CHAIN_MAX_BIAS) { h->use_chain = false; h->use_chainw = false; }
+    }
+    if (h->use_chain) h->use_chainw = false;               // the tuned kernels take the 128/256/512 models
+    if (const char* e = getenv("CS_CHAINW_MAX_N")) h->chainw_max_n = atoll(e);
+    if (h->use_chainw) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chainw<false>), hipFuncAttributeMaxDynamicSharedMemorySize, chainw_lds_bytes()));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chainw<true>), hipFuncAttributeMaxDynamicSharedMemorySize, chainw_lds_bytes()));
     }
     if (h->L > WGRAD_MAX_LAYERS) { delete h; return fail(CS_ERR_INVALID, "too many layers"); }
     if (const char* e = getenv("CS_WGRAD_SPLITK")) h->wgrad_splitk = atoi(e);
@@ -461,7 +510,8 @@ int cs_mlp_create(cs_mlp_t** out, const cs_mlp_cfg* cfg) {
         if (!h->use_chain) {
             A((void**)&ly.Wt, sizeof(u16) * ly.N * ly.Kp);
             A((void**)&ly.Wn, sizeof(u16) * ly.Kp * ly.N);
-        } else {
+        }
+        if (h->use_chain || h->use_chainw) {                  // the wide chain keeps both sets: big batches fall back to the per-layer path
             A((void**)&ly.Wf, sizeof(u16) * ly.N * ly.Kp);
             if (l > 0) A((void**)&ly.Wb, sizeof(u16) * ly.Kp * ly.N);
         }
