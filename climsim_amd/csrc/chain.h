@@ -59,9 +59,11 @@ struct ChainArgs {
     unsigned long long* dbg; // optional [grid][64] s_memtime stamps (CS_CHAIN_DBG), null in production
 };
 
-__device__ __forceinline__ int chain_lds_off(int row, int col) {   // element offset of (row, col)
-    return row * CHAIN_PITCH + ((((col >> 3) ^ (row & 15))) << 3) + (col & 7);
+template <int PITCH>
+__device__ __forceinline__ int chain_lds_off_p(int row, int col) {   // element offset of (row, col)
+    return row * PITCH + ((((col >> 3) ^ (row & 15))) << 3) + (col & 7);
 }
+__device__ __forceinline__ int chain_lds_off(int row, int col) { return chain_lds_off_p<CHAIN_PITCH>(row, col); }
 __device__ __forceinline__ unsigned bf_pos(unsigned h16) { return (unsigned)((h16 & 0xffffu) - 1u) < 0x7fffu; }   // bf16 > 0
 
 // Stage output rows LDS -> global, fully coalesced (one wave-instruction = 1 KiB of one row).  The MFMA
@@ -85,7 +87,7 @@ struct ChainPending {          // stage output still to be copied LDS -> global 
 
 // One stage for one wave: acc[MT][NT] 32x32 tiles over contraction length Kc.
 // D = weight prefetch depth in k16-steps (4 or 8; 8 needs 32 more VGPRs).
-template <int BMROWS, int MT, int NT, int D>
+template <int BMROWS, int MT, int NT, int D, int PITCH = CHAIN_PITCH>
 __device__ __forceinline__ void chain_mma(const u16* __restrict__ X, const u16* __restrict__ wfrag, int ks_total, int ntiles,
                                           int jt0, int mrow0, int tid, f32x16_t (&acc)[MT][NT], ChainPending& pend, int64_t m0) {
     const int lane = tid & 63;
@@ -116,7 +118,7 @@ __device__ __forceinline__ void chain_mma(const u16* __restrict__ X, const u16* 
     }
 #define CHAIN_AF(dst, step)                                                                                    \
     _Pragma("unroll") for (int a = 0; a < MT; ++a)                                                             \
-        dst[a] = *reinterpret_cast<const bf16x8_t*>(X + chain_lds_off(arow + a * 32, (2 * min((step), ks_total - 1) + ahalf) * 8));
+        dst[a] = *reinterpret_cast<const bf16x8_t*>(X + chain_lds_off_p<PITCH>(arow + a * 32, (2 * min((step), ks_total - 1) + ahalf) * 8));
 // A fragments of step s+1 are read from LDS while the MFMAs of step s run (AC = current, AN = next).
 #define CHAIN_STEP(d, Q0, Q1, AC, AN)                                                                          \
     {                                                                                                          \

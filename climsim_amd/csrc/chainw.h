@@ -5,8 +5,8 @@
 //
 //   * 32-row tiles, two LDS activation buffers of [32][1024] bf16 (ping-pong: a stage reads one and writes the other, so
 //     a wide stage can be produced in several column passes without clobbering its input);
-//   * a wave owns the 32-column tiles w, w+8, w+16, w+24 of a stage and produces them two per pass (v_mfma 32x32x16,
-//     one row tile x two column tiles), weights prefetched four k16-steps ahead;
+//   * a wave owns the 32-column tile pairs (2w, 2w+1), (2w+16, 2w+17) of a stage, one pair per pass, through chain_mma
+//     (v_mfma 32x32x16, one row tile x two column tiles, inline-asm weight stream with counted vmcnt);
 //   * backward reads act'(h) from the global activation copies (no sign masks).
 // Against 13 separate GEMM launches of ~11 us each this removes the per-launch latency, which is what bounds the
 // per-layer path at the reference's batch sizes.
@@ -19,38 +19,6 @@ constexpr int chainw_lds_bytes() { return 2 * CWD_BM * CWD_PITCH * 2 + CHAIN_MAX
 
 __device__ __forceinline__ int cwd_off(int row, int col) {        // element offset of (row, col): 16-B chunks XOR (row & 15)
     return row * CWD_PITCH + ((((col >> 3) ^ (row & 15))) << 3) + (col & 7);
-}
-
-// acc0/acc1 = Xin[32 rows][Kc] x W[:, tile0*32 .. +32) (and tile1): one wave, weights fragment-major.
-__device__ __forceinline__ void cwd_mma(const u16* __restrict__ Xin, const u16* __restrict__ wfrag, int ks_total, int ntiles, int tile0,
-                                        int tile1, bool two, int lane, f32x16_t& acc0, f32x16_t& acc1) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-    const uint4* w0 = reinterpret_cast<const uint4*>(wfrag) + tile0 * 64 + lane;
-    const uint4* w1 = reinterpret_cast<const uint4*>(wfrag) + tile1 * 64 + lane;
-    const int sstride = ntiles * 64;
-    const int arow = lane & 31, ahalf = lane >> 5;
-    uint4 qa0, qa1, qa2, qa3, qb0, qb1, qb2, qb3;               // prefetch ring, four k16-steps deep (named: see kernels.h)
-    qa0 = w0[0 * sstride]; qa1 = w0[min(1, ks_total - 1) * sstride]; qa2 = w0[min(2, ks_total - 1) * sstride]; qa3 = w0[min(3, ks_total - 1) * sstride];
-    qb0 = qa0; qb1 = qa1; qb2 = qa2; qb3 = qa3;
-    if (two) { qb0 = w1[0 * sstride]; qb1 = w1[min(1, ks_total - 1) * sstride]; qb2 = w1[min(2, ks_total - 1) * sstride]; qb3 = w1[min(3, ks_total - 1) * sstride]; }
-#define CWD_STEP(QA, QB, u)                                                                             \
-    {                                                                                                    \
-        const int s = s0 + (u);                                                                          \
-        const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(Xin + cwd_off(arow, (2 * s + ahalf) * 8)); \
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, QA), a, acc0, 0, 0, 0); \
-        if (two) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, QB), a, acc1, 0, 0, 0); \
-        const int sn = min(s + 4, ks_total - 1);                                                         \
-        QA = w0[sn * sstride];                                                                           \
-        if (two) QB = w1[sn * sstride];                                                                  \
-    }
-    for (int s0 = 0; s0 < ks_total; s0 += 4) {                   // contraction lengths are multiples of 64 = 4 steps
-        CWD_STEP(qa0, qb0, 0)
-        CWD_STEP(qa1, qb1, 1)
-        CWD_STEP(qa2, qb2, 2)
-        CWD_STEP(qa3, qb3, 3)
-    }
-#undef CWD_STEP
 }
 
 template <bool BWD>
@@ -100,8 +68,10 @@ __global__ __launch_bounds__(512) void k_chainw(const ChainArgs p) {
         const int ntiles = S.Nc >> 5, ks = S.Kc >> 4;
         if (!BWD && S.epi == EPI_OUT) {                          // heads: 128 wide, one column tile per wave 0..3
             if (wid < 4) {
-                f32x16_t acc, dummy;
-                cwd_mma(Xin, S.wfrag, ks, ntiles, wid, wid, false, lane, acc, dummy);
+                f32x16_t acc1[1][1];
+                ChainPending none{nullptr, 0, 0};
+                chain_mma<CWD_BM, 1, 1, 4, CWD_PITCH>(Xin, S.wfrag, ks, ntiles, wid, 0, tid, acc1, none, m0);
+                const f32x16_t& acc = acc1[0][0];
                 const int64_t m = m0 + mrow;
                 const bool valid = m < p.n_rows;
                 const int64_t yrow = valid ? rows_lds[mrow] : 0;
@@ -132,16 +102,24 @@ __global__ __launch_bounds__(512) void k_chainw(const ChainArgs p) {
             }
             continue;                                            // last stage of the forward pass
         }
-        for (int tile0 = wid; tile0 < ntiles; tile0 += 16) {     // a pass: column tiles tile0 and tile0 + 8
-            const int tile1 = tile0 + 8;
-            const bool two = tile1 < ntiles;
-            f32x16_t acc0, acc1;
-            cwd_mma(Xin, S.wfrag, ks, ntiles, tile0, two ? tile1 : tile0, two, lane, acc0, acc1);
+        for (int tile0 = 2 * wid; tile0 < ntiles; tile0 += 16) { // a pass: column tiles tile0, tile0 + 1 (widths are multiples of 128)
+            f32x16_t acc2[1][2];
+            ChainPending none{nullptr, 0, 0};
+            uint2 hh[2][4];                                      // backward: the activations to differentiate through, in flight during the k-loop
+            if (BWD) {
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        hh[b][q] = *reinterpret_cast<const uint2*>(S.hprev + (m0 + mrow) * S.ldh + (tile0 + b) * 32 + 8 * q + hi4);
+            }
+            // the weight stream of chain.h: inline-asm loads, counted vmcnt, 8 (or 4) k16-steps in flight
+            if ((S.Kc & 127) == 0) chain_mma<CWD_BM, 1, 2, 8, CWD_PITCH>(Xin, S.wfrag, ks, ntiles, tile0, 0, tid, acc2, none, m0);
+            else chain_mma<CWD_BM, 1, 2, 4, CWD_PITCH>(Xin, S.wfrag, ks, ntiles, tile0, 0, tid, acc2, none, m0);
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
-                if (b == 1 && !two) break;
-                const int tile = b == 0 ? tile0 : tile1;
-                const f32x16_t& acc = b == 0 ? acc0 : acc1;
+                const int tile = tile0 + b;
+                const f32x16_t& acc = acc2[0][b];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int n = tile * 32 + 8 * q + hi4;
@@ -151,11 +129,11 @@ __global__ __launch_bounds__(512) void k_chainw(const ChainArgs p) {
                         v[0] = act_fwd(v[0] + b4.x, p.act, p.slope); v[1] = act_fwd(v[1] + b4.y, p.act, p.slope);
                         v[2] = act_fwd(v[2] + b4.z, p.act, p.slope); v[3] = act_fwd(v[3] + b4.w, p.act, p.slope);
                     } else {
-                        const uint2 hh = *reinterpret_cast<const uint2*>(S.hprev + (m0 + mrow) * S.ldh + n);
-                        v[0] *= act_bwd_from_h(bf2f((u16)(hh.x & 0xffff)), p.act, p.slope);
-                        v[1] *= act_bwd_from_h(bf2f((u16)(hh.x >> 16)), p.act, p.slope);
-                        v[2] *= act_bwd_from_h(bf2f((u16)(hh.y & 0xffff)), p.act, p.slope);
-                        v[3] *= act_bwd_from_h(bf2f((u16)(hh.y >> 16)), p.act, p.slope);
+                        const uint2 h2 = hh[b][q];
+                        v[0] *= act_bwd_from_h(bf2f((u16)(h2.x & 0xffff)), p.act, p.slope);
+                        v[1] *= act_bwd_from_h(bf2f((u16)(h2.x >> 16)), p.act, p.slope);
+                        v[2] *= act_bwd_from_h(bf2f((u16)(h2.y & 0xffff)), p.act, p.slope);
+                        v[3] *= act_bwd_from_h(bf2f((u16)(h2.y >> 16)), p.act, p.slope);
                     }
                     *reinterpret_cast<uint2*>(Xout + cwd_off(mrow, n)) = make_uint2(cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3]));
                 }
