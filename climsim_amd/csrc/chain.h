@@ -54,6 +54,7 @@ struct ChainArgs {
     int act; float slope;
     // heads (EPI_OUT)
     int n_lin; float* yhat; const float* y; float* loss; u16* dz_out; int ld_dz_out;
+    int n_real;              // k_chainw: real output width (row pitch of yhat / y); the tuned chain is 128-wide only
     int mask_bm64;           // backward with 32-row tiles over sign masks written by a 64-row forward (see chain_stage)
     int ablate;              // timing experiments only (CS_CHAIN_ABLATE): 4 no global stores, 8 no warm-up
     unsigned long long* dbg; // optional [grid][64] s_memtime stamps (CS_CHAIN_DBG), null in production

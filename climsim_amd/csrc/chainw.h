@@ -66,18 +66,19 @@ __global__ __launch_bounds__(512) void k_chainw(const ChainArgs p) {
     for (int i = 0; i < p.n_stages; ++i) {
         const ChainStage& S = p.st[i];
         const int ntiles = S.Nc >> 5, ks = S.Kc >> 4;
-        if (!BWD && S.epi == EPI_OUT) {                          // heads: 128 wide, one column tile per wave 0..3
-            if (wid < 4) {
+        if (!BWD && S.epi == EPI_OUT) {                          // heads: one column tile per wave and pass (128 wide: waves 0..3)
+            for (int tile = wid; tile < ntiles; tile += 8) {
                 f32x16_t acc1[1][1];
                 ChainPending none{nullptr, 0, 0};
-                chain_mma<CWD_BM, 1, 1, 4, CWD_PITCH>(Xin, S.wfrag, ks, ntiles, wid, 0, tid, acc1, none, m0);
+                chain_mma<CWD_BM, 1, 1, 4, CWD_PITCH>(Xin, S.wfrag, ks, ntiles, tile, 0, tid, acc1, none, m0);
                 const f32x16_t& acc = acc1[0][0];
                 const int64_t m = m0 + mrow;
-                const bool valid = m < p.n_rows;
-                const int64_t yrow = valid ? rows_lds[mrow] : 0;
+                const bool row_ok = m < p.n_rows;
+                const int64_t yrow = row_ok ? rows_lds[mrow] : 0;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int n = wid * 32 + 8 * q + hi4;
+                    const int n = tile * 32 + 8 * q + hi4;
+                    const bool valid = row_ok && n < p.n_real;
                     const float4 b4 = *reinterpret_cast<const float4*>(bias_lds + S.bias_off + n);
                     float v[4] = {acc[4 * q + 0] + b4.x, acc[4 * q + 1] + b4.y, acc[4 * q + 2] + b4.z, acc[4 * q + 3] + b4.w};
                     float d[4] = {0.f, 0.f, 0.f, 0.f};
@@ -85,9 +86,9 @@ __global__ __launch_bounds__(512) void k_chainw(const ChainArgs p) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
                     }
-                    if (valid && p.yhat) *reinterpret_cast<float4*>(p.yhat + m * S.Nc + n) = make_float4(v[0], v[1], v[2], v[3]);
+                    if (valid && p.yhat) *reinterpret_cast<float4*>(p.yhat + m * p.n_real + n) = make_float4(v[0], v[1], v[2], v[3]);
                     if (p.y && valid) {
-                        const float4 t4 = *reinterpret_cast<const float4*>(p.y + yrow * S.Nc + n);
+                        const float4 t4 = *reinterpret_cast<const float4*>(p.y + yrow * p.n_real + n);
                         const float e4[4] = {v[0] - t4.x, v[1] - t4.y, v[2] - t4.z, v[3] - t4.w};
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
@@ -152,6 +153,6 @@ __global__ __launch_bounds__(512) void k_chainw(const ChainArgs p) {
     if (!BWD && p.y) {
         sq = wave_sum(sq);
         ab = wave_sum(ab);
-        if (lane == 0 && wid < 4) { atomicAdd(p.loss, sq); atomicAdd(p.loss + 1, ab); }
+        if (lane == 0) { atomicAdd(p.loss, sq); atomicAdd(p.loss + 1, ab); }
     }
 }

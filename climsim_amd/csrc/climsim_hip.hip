@@ -276,7 +276,7 @@ int run_forward(cs_mlp* h, const float* x, const int64_t* row_idx, int64_t n, in
         c.normalise = normalise; c.h0 = want_dz ? l0.H : nullptr; c.ldh0 = l0.Kp; c.n_rows = n;
         c.act = h->cfg.act; c.slope = (h->cfg.act == CS_ACT_RELU) ? 0.f : h->cfg.alpha;
         c.n_lin = h->cfg.n_out_lin; c.yhat = yhat; c.y = y; c.loss = loss;
-        c.dz_out = want_dz ? h->layers[h->L - 1].dZ : nullptr; c.ld_dz_out = 128;
+        c.dz_out = want_dz ? h->layers[h->L - 1].dZ : nullptr; c.ld_dz_out = h->n_outp; c.n_real = h->n_out;
         ProfScope ps(CS_K_CHAIN_FWD, st);
         hipLaunchKernelGGL(k_chainw<false>, dim3((unsigned)(m_pad / CWD_BM)), dim3(512), chainw_lds_bytes(), st, c);
         HIP_TRY(hipGetLastError());
@@ -351,7 +351,7 @@ int run_backward(cs_mlp* h, int64_t n, bool atomics_needed, hipStream_t st) {
             S.out = h->layers[l - 1].dZ; S.ldo = h->layers[l - 1].N;
             S.hprev = ly.H; S.ldh = ly.Kp; S.epi = EPI_DGRAD;
         }
-        c.dz_in = h->layers[h->L - 1].dZ; c.ld_dz_in = 128; c.w_in = 128;
+        c.dz_in = h->layers[h->L - 1].dZ; c.ld_dz_in = h->n_outp; c.w_in = h->n_outp;
         c.n_rows = n; c.act = h->cfg.act; c.slope = (h->cfg.act == CS_ACT_RELU) ? 0.f : h->cfg.alpha;
         ProfScope ps(CS_K_CHAIN_BWD, st);
         hipLaunchKernelGGL(k_chainw<true>, dim3((unsigned)(m_pad / CWD_BM)), dim3(512), chainw_lds_bytes(), st, c);
@@ -467,7 +467,7 @@ int cs_mlp_create(cs_mlp_t** out, const cs_mlp_cfg* cfg) {
         if (!(ly.N == 128 || ly.N == 256 || ly.N == 512) || ly.Kp > CHAIN_PITCH || ly.Kp % 64) h->use_chain = false;
     }
     if (2 * h->L > CHAIN_MAX_STAGES || h->n_out != 128) h->use_chain = false;
-    h->use_chainw = !(cfg->flags & CS_FLAG_NO_CHAIN) && h->n_out == 128 && 2 * h->L <= CHAIN_MAX_STAGES;
+    h->use_chainw = !(cfg->flags & CS_FLAG_NO_CHAIN) && 2 * h->L <= CHAIN_MAX_STAGES;
     for (int l = 0; l < h->L; ++l)
         if (h->layers[l].N > CWD_PITCH || h->layers[l].Kp > CWD_PITCH) h->use_chainw = false;
     {

@@ -342,14 +342,15 @@ def test_heldout_per_variable_mae_r2_match_cpu_training(M, lowres_assets):
             assert np.isnan(ra) == np.isnan(rb) or np.isinf(ra) == np.isinf(rb), (v, ra, rb)
 
 
+@pytest.mark.parametrize("flags", [0, 2, 66])             # wide chain | one GEMM per layer (k_gemm_nt2 | k_gemm_nt)
 @pytest.mark.parametrize("n_in,n_lin,n_relu,units,n", [(425, 360, 8, (256, 384), 300), (557, 360, 8, (128,), 129), (124, 60, 4, (128, 128), 77)])
-def test_v2_shapes_forward_gradients_and_training(M, n_in, n_lin, n_relu, units, n):
+def test_v2_shapes_forward_gradients_and_training(M, n_in, n_lin, n_relu, units, n, flags):
     """Other variable sets (hpo_baseline_v2.py:58-101: 425 -> ... -> 368 -> [360 || 8]; v2 full inputs 557): the
     "upper output" layer and the heads are output_length wide, padded to 384 columns inside the engine.  Same tolerances
     as the v1 tests; the padding must stay exactly zero through Adam steps (checked through the weight round trip)."""
     n_out = n_lin + n_relu
     m = M.MLPEmulator(units=units, activation="leakyrelu", optimizer="Adam", input_length=n_in, output_length_lin=n_lin,
-                      output_length_relu=n_relu, max_batch=512, seed=None)
+                      output_length_relu=n_relu, max_batch=512, seed=None, flags=flags)
     cfg = O.MLPConfig(n_in=n_in, hidden=tuple(units), n_out_lin=n_lin, n_out_relu=n_relu, act="leakyrelu")
     ws = O.glorot_init(cfg, 5)
     rng = np.random.default_rng(9)
