@@ -383,6 +383,10 @@ int run_backward(cs_mlp* h, int64_t n, bool atomics_needed, hipStream_t st) {
             tiles += ((h->layers[l].Kp + tdim - 1) / tdim) * ((h->layers[l].N + tdim - 1) / tdim);
         const int target = big ? 256 : 365;               // workgroups: ~1 per CU (128 KiB LDS) or ~1.4 (atomics grow with splits)
         int splitk = h->wgrad_splitk > 0 ? h->wgrad_splitk : (target + tiles / 2) / tiles;
+        // small batches: every split re-fills the LDS-DMA ring and adds a round of atomics for a handful of slabs -
+        // measured (cfg-MLP, k_wgrad3): 1024 columns 26.6 us with 5 splits, 18.2 with 2; 3072: 31.9 / 27.3 with 3;
+        // 4096: 34.3 / 30.3 with 3; 8192: 44.9 with 5 (best)
+        if (h->wgrad_splitk <= 0 && !big) { if (n < 2048) splitk = std::min(splitk, 2); else if (n < 6144) splitk = std::min(splitk, 3); }
         if (splitk < 1) splitk = 1;
         if (splitk > msteps) splitk = msteps;
         w.splitk = splitk;
