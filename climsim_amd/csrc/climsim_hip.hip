@@ -471,7 +471,7 @@ int cs_mlp_create(cs_mlp_t** out, const cs_mlp_cfg* cfg) {
         if (!(ly.N == 128 || ly.N == 256 || ly.N == 512) || ly.Kp > CHAIN_PITCH || ly.Kp % 64) h->use_chain = false;
     }
     if (2 * h->L > CHAIN_MAX_STAGES || h->n_out != 128) h->use_chain = false;
-    h->use_chainw = !(cfg->flags & CS_FLAG_NO_CHAIN) && 2 * h->L <= CHAIN_MAX_STAGES;
+    h->use_chainw = !(cfg->flags & CS_FLAG_NO_CHAIN) && h->L <= CHAIN_MAX_STAGES;   // (the tuned chain stages only 9 biases at once)
     for (int l = 0; l < h->L; ++l)
         if (h->layers[l].N > CWD_PITCH || h->layers[l].Kp > CWD_PITCH) h->use_chainw = false;
     {

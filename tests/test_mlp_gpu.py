@@ -64,7 +64,8 @@ def test_forward_matches_oracle(M, act, n, flags):
 @pytest.mark.parametrize("act,n,units", [("leakyrelu", 300, (256, 128, 512)), ("relu", 128, (512, 512)),
                                          ("elu", 1000, (256, 128, 384)),    # 384: wide chain (chainw.h), or per-layer with flag 2
                                          ("leakyrelu", 200, (768, 640, 512, 640, 640)),   # the published lot-147/trial_0027 widths
-                                         ("relu", 77, (1024, 896))])
+                                         ("relu", 77, (1024, 896)),
+                                         ("relu", 90, (256, 128, 384, 128, 256, 128, 128, 384, 256, 128))])   # 10 hidden layers
 def test_loss_and_gradients_match_oracle(M, act, n, units, flags):
     m, cfg, ws = make_model(M, units, act=act, flags=flags)
     x, y = O.synth_columns(n, seed=7)
@@ -81,7 +82,9 @@ def test_loss_and_gradients_match_oracle(M, act, n, units, flags):
         assert rel(g, r) <= 5e-3, (i, rel(g, r))
     l32, _, g32, _ = O.loss_and_grads(ws, x, y, cfg, bf16=False)
     assert loss[0] / (128 * n) == pytest.approx(l32, rel=2e-2)
-    tol32 = 6e-2 if len(units) <= 3 else 9e-2            # bf16 operand rounding accumulates with depth (7 layers: measured 6.6e-2)
+    # bf16 operand rounding accumulates with depth (5 hidden layers: measured 6.6e-2; 10: 1.03e-1, identical for the
+    # chain and the per-layer kernels - the bf16-aware oracle above is the parity check, this one bounds the precision)
+    tol32 = 6e-2 if len(units) <= 3 else 9e-2 if len(units) <= 7 else 1.4e-1
     for g, r in zip(got, g32):
         assert rel(g, r) <= tol32
 
