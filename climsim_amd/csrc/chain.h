@@ -54,6 +54,7 @@ struct ChainArgs {
     int act; float slope;
     // heads (EPI_OUT)
     int n_lin; float* yhat; const float* y; float* loss; u16* dz_out; int ld_dz_out;
+    int loss_stripes;        // > 1: `loss` is a striped internal accumulator (loss_flush, kernels.h)
     int n_real;              // k_chainw: real output width (row pitch of yhat / y); the tuned chain is 128-wide only
     int mask_bm64;           // backward with 32-row tiles over sign masks written by a 64-row forward (see chain_stage)
     int ablate;              // timing experiments only (CS_CHAIN_ABLATE): 4 no global stores, 8 no warm-up
@@ -360,6 +361,11 @@ __global__ __launch_bounds__(512) void k_chain(const ChainArgs p) {
     const int64_t m0 = (int64_t)blockIdx.x * BM;
     int slot = 0;
     chain_stamp(p, tid, slot);
+    if (p.dbg && tid == 0) {                 // development: 100 MHz wall clock + placement (HW_ID, XCC_ID) of this workgroup
+        p.dbg[(int64_t)blockIdx.x * 64 + 61] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) |
+                                               (unsigned)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+        p.dbg[(int64_t)blockIdx.x * 64 + 62] = __builtin_amdgcn_s_memrealtime();
+    }
 
     // ---- L2 warm-up.  The bf16 weights were written by the optimiser kernel on other XCDs, so at
     // launch they sit in HBM / Infinity Cache, not in this XCD's L2.  The workgroups that share an XCD
@@ -465,10 +471,7 @@ __global__ __launch_bounds__(512) void k_chain(const ChainArgs p) {
                                                                 BM >= 64 ? (wid >> 2) * (BM / 2) : 0, tid, sq, ab, slot, pend);
         }
     }
-    if (!BWD && p.y) {
-        sq = wave_sum(sq);
-        ab = wave_sum(ab);
-        if ((tid & 63) == 0) { atomicAdd(p.loss, sq); atomicAdd(p.loss + 1, ab); }
-    }
+    if (!BWD && p.y) loss_flush(p.loss, p.loss_stripes, blockIdx.x, sq, ab, reinterpret_cast<float*>(X), tid, 8);   // (X is free: the heads stage ended with a barrier)
     chain_stamp(p, tid, slot);
+    if (p.dbg && tid == 0) p.dbg[(int64_t)blockIdx.x * 64 + 63] = __builtin_amdgcn_s_memrealtime();
 }

@@ -151,8 +151,7 @@ __global__ __launch_bounds__(512) void k_chainw(const ChainArgs p) {
         u16* t = Xin; Xin = Xout; Xout = t;
     }
     if (!BWD && p.y) {
-        sq = wave_sum(sq);
-        ab = wave_sum(ab);
-        if (lane == 0) { atomicAdd(p.loss, sq); atomicAdd(p.loss + 1, ab); }
+        __syncthreads();                                         // the heads stage has no trailing barrier: XW still being read
+        loss_flush(p.loss, p.loss_stripes, blockIdx.x, sq, ab, reinterpret_cast<float*>(XW), tid, 8);
     }
 }

@@ -91,8 +91,9 @@ struct cs_mlp {
     bool own_G = true;
     float *sub = nullptr, *div = nullptr;
     bool have_norm = false;
-    float* loss_ring = nullptr;   // [2][2]: train_step accumulates the loss sums here; the optimiser kernel hands them over
+    float* loss_ring = nullptr;   // [2][LOSS_STRIPES * LOSS_STRIPE_FLOATS]: train_step accumulates the loss sums here; the optimiser kernel hands them over
     int loss_cur = 0;
+    bool loss_striped = false;    // run_forward: `loss` is a slot of loss_ring
     const float* opt_loss_src = nullptr; float* opt_loss_dst = nullptr; float* opt_loss_zero = nullptr;   // next optimiser launch
     Segment* seg_dev = nullptr;
     int n_seg = 0;
@@ -227,10 +228,12 @@ int chain_bm(const cs_mlp* h, int64_t n) {
     // Every workgroup streams ALL weights once, whatever its row count.  128-row tiles halve the weight bytes per FLOP
     // (the per-CU vector-memory path tops out near 64 B/clk, which is exactly the MFMA rate at 64 rows) but need >= 256
     // tiles to fill the chip.  32-row tiles put a workgroup on every CU from 8192 rows down, but 256 workgroups then pull
-    // 612 MB of weights through the L2s per launch: measured forward 103 us vs 85 us (64 rows) at 8192 rows, while at
-    // 1024 / 3072 rows they win (58 vs 72 us, 67 vs 71 us; backward 40 vs 54 us).  Forward and backward share the tile
-    // (the sign masks are stored per workgroup and lane).
-    return n >= 32768 ? 128 : (n > 4096 ? 64 : 32);
+    // 612 MB of weights through the L2s per launch.  Measured step at 8192 rows: 0.154 ms with 32-row tiles vs 0.159 ms
+    // with 64 (forward 51 vs 59 us); at 16384 rows 0.279 vs 0.232 ms.  (An earlier measurement had 64 rows ahead at 8192:
+    // that was the loss atomics of 256 workgroups finishing together, see loss_flush.)  Forward and backward share the
+    // tile (the sign masks are stored per workgroup and lane) except in the hybrid range of run_backward.
+    static const int64_t bm32_max = getenv("CS_CHAIN_BM32_MAX") ? atoll(getenv("CS_CHAIN_BM32_MAX")) : 8192;
+    return n >= 32768 ? 128 : (n > bm32_max ? 64 : 32);
 }
 
 int run_forward(cs_mlp* h, const float* x, const int64_t* row_idx, int64_t n, int normalise, float* yhat,
@@ -254,6 +257,7 @@ int run_forward(cs_mlp* h, const float* x, const int64_t* row_idx, int64_t n, in
         c.normalise = normalise; c.h0 = want_dz ? l0.H : nullptr; c.ldh0 = l0.Kp; c.n_rows = n;
         c.act = h->cfg.act; c.slope = (h->cfg.act == CS_ACT_RELU) ? 0.f : h->cfg.alpha;
         c.n_lin = h->cfg.n_out_lin; c.yhat = yhat; c.y = y; c.loss = loss;
+        c.loss_stripes = h->loss_striped ? LOSS_STRIPES : 1;
         c.dz_out = want_dz ? h->layers[h->L - 1].dZ : nullptr; c.ld_dz_out = 128;
         const int bm = chain_bm(h, n);
         ProfScope ps(CS_K_CHAIN_FWD, st);
@@ -276,6 +280,7 @@ int run_forward(cs_mlp* h, const float* x, const int64_t* row_idx, int64_t n, in
         c.normalise = normalise; c.h0 = want_dz ? l0.H : nullptr; c.ldh0 = l0.Kp; c.n_rows = n;
         c.act = h->cfg.act; c.slope = (h->cfg.act == CS_ACT_RELU) ? 0.f : h->cfg.alpha;
         c.n_lin = h->cfg.n_out_lin; c.yhat = yhat; c.y = y; c.loss = loss;
+        c.loss_stripes = h->loss_striped ? LOSS_STRIPES : 1;
         c.dz_out = want_dz ? h->layers[h->L - 1].dZ : nullptr; c.ld_dz_out = h->n_outp; c.n_real = h->n_out;
         ProfScope ps(CS_K_CHAIN_FWD, st);
         hipLaunchKernelGGL(k_chainw<false>, dim3((unsigned)(m_pad / CWD_BM)), dim3(512), chainw_lds_bytes(), st, c);
@@ -302,7 +307,7 @@ int run_forward(cs_mlp* h, const float* x, const int64_t* row_idx, int64_t n, in
             if (v1) hipLaunchKernelGGL(k_gemm_nt<EPI_HIDDEN>, grid, dim3(256), 0, st, p);
             else hipLaunchKernelGGL(k_gemm_nt2<EPI_HIDDEN>, grid, dim3(256), G2_LDS_BYTES, st, p);
         } else {
-            p.n_lin = h->cfg.n_out_lin; p.n_real = h->n_out; p.yhat = yhat; p.y = y; p.row_idx = row_idx; p.n_rows = n; p.loss = loss;
+            p.n_lin = h->cfg.n_out_lin; p.n_real = h->n_out; p.yhat = yhat; p.y = y; p.row_idx = row_idx; p.n_rows = n; p.loss = loss; p.loss_stripes = h->loss_striped ? LOSS_STRIPES : 1;
             p.out = want_dz ? ly.dZ : nullptr; p.ldo = ly.N;
             if (v1) hipLaunchKernelGGL(k_gemm_nt<EPI_OUT>, grid, dim3(256), 0, st, p);
             else hipLaunchKernelGGL(k_gemm_nt2<EPI_OUT>, grid, dim3(256), G2_LDS_BYTES, st, p);
@@ -506,7 +511,7 @@ int cs_mlp_create(cs_mlp_t** out, const cs_mlp_cfg* cfg) {
     A((void**)&h->M, sizeof(float) * off);
     A((void**)&h->V, sizeof(float) * off);
     A((void**)&h->G, sizeof(float) * off);
-    A((void**)&h->loss_ring, sizeof(float) * 4);
+    A((void**)&h->loss_ring, sizeof(float) * 2 * LOSS_STRIPES * LOSS_STRIPE_FLOATS);
     A((void**)&h->sub, sizeof(float) * cfg->n_in);
     A((void**)&h->div, sizeof(float) * cfg->n_in);
     for (int l = 0; l < h->L; ++l) {
@@ -709,12 +714,14 @@ int cs_mlp_train_step(cs_mlp_t* h, const float* x_dev, const float* y_dev, const
         HIP_TRY(hipMemsetAsync(h->G, 0, sizeof(float) * h->n_params, st));
     }
     h->grads_dirty = true;
-    float* slot = h->loss_ring + 2 * h->loss_cur;
+    float* slot = h->loss_ring + LOSS_STRIPES * LOSS_STRIPE_FLOATS * h->loss_cur;
+    h->loss_striped = true;
     rc = run_forward(h, x_dev, row_idx_dev, n, normalise, nullptr, y_dev, slot, true, st);
+    h->loss_striped = false;
     if (rc) return rc;
     rc = run_backward(h, n, false, st);
     if (rc) return rc;
-    h->opt_loss_src = slot; h->opt_loss_dst = loss_dev; h->opt_loss_zero = h->loss_ring + 2 * (h->loss_cur ^ 1);
+    h->opt_loss_src = slot; h->opt_loss_dst = loss_dev; h->opt_loss_zero = h->loss_ring + LOSS_STRIPES * LOSS_STRIPE_FLOATS * (h->loss_cur ^ 1);
     h->loss_cur ^= 1;
     return cs_mlp_apply(h, lr, 1.0f / ((float)h->n_out * (float)n), stream);
 }

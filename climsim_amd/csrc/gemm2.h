@@ -131,8 +131,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt2(const GemmNT p) {
         }
     }
     if (EPI == EPI_OUT && p.y) {
-        sq = wave_sum(sq);
-        ab = wave_sum(ab);
-        if (lane == 0) { atomicAdd(p.loss, sq); atomicAdd(p.loss + 1, ab); }
+        __syncthreads();                                        // every wave is out of the ring
+        loss_flush(p.loss, p.loss_stripes, blockIdx.x + blockIdx.y, sq, ab, reinterpret_cast<float*>(g2_ring), tid, 4);
     }
 }

@@ -56,6 +56,27 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// Loss sums of a workgroup -> global memory.  Device-scope float atomics on ONE address retire at ~12.5 ns each on this
+// part (measured: 256 workgroups x 8 waves x 2 sums finishing together kept the forward kernel open for 51 us after its
+// last workgroup had ended), so: one pair of atomics per WORKGROUP (LDS reduction over the waves), and - where the
+// caller owns the accumulator (train_step) - spread over LOSS_STRIPES cache lines that the optimiser kernel adds up.
+#define LOSS_STRIPES 16
+#define LOSS_STRIPE_FLOATS 32            // 128 B apart
+__device__ __forceinline__ void loss_flush(float* __restrict__ loss, int stripes, unsigned wg_index, float sq, float ab,
+                                           float* red /* LDS, 2 floats per wave, not in use by any wave */, int tid, int nwaves) {
+    sq = wave_sum(sq);
+    ab = wave_sum(ab);
+    if ((tid & 63) == 0) { red[2 * (tid >> 6)] = sq; red[2 * (tid >> 6) + 1] = ab; }
+    __syncthreads();
+    if (tid == 0) {
+        float s = 0.f, a = 0.f;
+        for (int w = 0; w < nwaves; ++w) { s += red[2 * w]; a += red[2 * w + 1]; }
+        float* dst = loss + (stripes > 1 ? (wg_index & (unsigned)(stripes - 1)) * LOSS_STRIPE_FLOATS : 0u);
+        atomicAdd(dst, s);
+        atomicAdd(dst + 1, a);
+    }
+}
+
 // ---------------------------------------------------------------- input staging
 // h0[m][0..127] = bf16( normalise ? (x-sub)/div with inf/nan->0 : x ), zero for cols >= n_in and
 // rows >= n (rows up to m_pad are written so that later tiles read finite data).
@@ -125,6 +146,7 @@ struct GemmNT {
     const int64_t* row_idx;
     int64_t n_rows;              // valid rows
     float* loss;                 // [2] sum sq err, sum abs err
+    int loss_stripes;            // > 1: `loss` is a striped internal accumulator (loss_flush)
     // EPI_DGRAD
     const u16* hprev; int ldh;   // activation output of the previous layer (same shape as out)
 };
@@ -250,9 +272,8 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const GemmNT p) {
         }
     }
     if (EPI == EPI_OUT && p.y) {
-        sq = wave_sum(sq);
-        ab = wave_sum(ab);
-        if (lane == 0) { atomicAdd(p.loss, sq); atomicAdd(p.loss + 1, ab); }
+        __shared__ float red[8];
+        loss_flush(p.loss, p.loss_stripes, blockIdx.x + blockIdx.y, sq, ab, red, tid, 4);
     }
 }
 
@@ -442,6 +463,7 @@ struct OptArgs {
     float radam_r; int radam_rect;
     int recast_only;      // set_weights: only refresh the bf16 copies
     // train_step hands the step's loss sums over without a memset launch: copy loss_src -> loss_dst, zero loss_zero
+    // (both internal accumulators are LOSS_STRIPES x LOSS_STRIPE_FLOATS floats, see loss_flush)
     const float* loss_src; float* loss_dst; float* loss_zero;
 };
 
@@ -504,8 +526,12 @@ __global__ __launch_bounds__(256) void k_optimizer(const OptArgs a) {
     __shared__ __attribute__((aligned(16))) u16 tile[32][40];
     const int tid = threadIdx.x;
     if (blockIdx.x == 0 && tid == 0 && a.loss_dst) {
-        a.loss_dst[0] = a.loss_src[0]; a.loss_dst[1] = a.loss_src[1];
-        a.loss_zero[0] = 0.f; a.loss_zero[1] = 0.f;
+        float s0 = 0.f, s1 = 0.f;
+        for (int i = 0; i < LOSS_STRIPES; ++i) {
+            s0 += a.loss_src[i * LOSS_STRIPE_FLOATS]; s1 += a.loss_src[i * LOSS_STRIPE_FLOATS + 1];
+            a.loss_zero[i * LOSS_STRIPE_FLOATS] = 0.f; a.loss_zero[i * LOSS_STRIPE_FLOATS + 1] = 0.f;
+        }
+        a.loss_dst[0] = s0; a.loss_dst[1] = s1;
     }
     int s = 0;
     while (s + 1 < a.n_seg && (int)blockIdx.x >= a.seg[s + 1].blk_begin) ++s;
