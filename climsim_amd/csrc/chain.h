@@ -87,12 +87,47 @@ struct ChainPending {          // stage output still to be copied LDS -> global 
     u16* out; int ldo; int width;
 };
 
+// The weight queue of a wave: 8 (or 4) k16-steps x up to 2 column tiles of 1 KiB wave-loads in flight.  Named scalars
+// (tied asm operands cannot be array elements).
+struct ChainQ { u32x4_t q00, q01, q10, q11, q20, q21, q30, q31, q40, q41, q50, q51, q60, q61, q70, q71; };
+
+#ifndef CHAIN_LOAD_MOD
+#define CHAIN_LOAD_MOD ""                 // cache-policy bits of the weight stream (A/B builds; " nt" measured 50 % slower)
+#endif
+#define CHAIN_LD1(QR, ptr) asm volatile("global_load_dwordx4 %0, %1, off" CHAIN_LOAD_MOD : "=v"(QR) : "v"(ptr) : "memory")
+
+// Issue the loads of k16-steps 0..D-1 of a stage (column tiles jt0 .. jt0+NT-1) into queue slots 0..D-1.
+template <int NT, int D>
+__device__ __forceinline__ void chain_prime_t(ChainQ& Q, const u16* __restrict__ wfrag, int ks_total, int ntiles, int jt0, int lane) {
+    const uint4* wp0 = reinterpret_cast<const uint4*>(wfrag) + jt0 * 64 + lane;
+    const int sstride = ntiles * 64;             // uint4 per k16 step
+#define CHAIN_PRIME(Q0, Q1, step)                                                 \
+    {                                                                              \
+        const uint4* a_ = wp0 + min((step), ks_total - 1) * sstride;               \
+        CHAIN_LD1(Q0, a_);                                                         \
+        if (NT == 2) CHAIN_LD1(Q1, a_ + 64);                                       \
+    }
+    CHAIN_PRIME(Q.q00, Q.q01, 0)
+    CHAIN_PRIME(Q.q10, Q.q11, 1)
+    CHAIN_PRIME(Q.q20, Q.q21, 2)
+    CHAIN_PRIME(Q.q30, Q.q31, 3)
+    if (D == 8) {
+        CHAIN_PRIME(Q.q40, Q.q41, 4)
+        CHAIN_PRIME(Q.q50, Q.q51, 5)
+        CHAIN_PRIME(Q.q60, Q.q61, 6)
+        CHAIN_PRIME(Q.q70, Q.q71, 7)
+    }
+#undef CHAIN_PRIME
+}
+
 // One stage for one wave: acc[MT][NT] 32x32 tiles over contraction length Kc.
 // D = weight prefetch depth in k16-steps (4 or 8; 8 needs 32 more VGPRs).
-template <int BMROWS, int MT, int NT, int D, int PITCH = CHAIN_PITCH>
+// (SELF_PRIME is always true: see the note in chain_stage.)
+template <int BMROWS, int MT, int NT, int D, bool SELF_PRIME, int PITCH = CHAIN_PITCH>
 __device__ __forceinline__ void chain_mma(const u16* __restrict__ X, const u16* __restrict__ wfrag, int ks_total, int ntiles,
                                           int jt0, int mrow0, int tid, f32x16_t (&acc)[MT][NT], ChainPending& pend, int64_t m0) {
     const int lane = tid & 63;
+    ChainQ Q;
     static_assert(D == 4 || D == 8, "queue slots are written out for depth 4 and 8");
 #pragma unroll
     for (int a = 0; a < MT; ++a)
@@ -100,54 +135,63 @@ __device__ __forceinline__ void chain_mma(const u16* __restrict__ X, const u16* 
         for (int b = 0; b < NT; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-    const uint4* wp[NT];
-#pragma unroll
-    for (int b = 0; b < NT; ++b) wp[b] = reinterpret_cast<const uint4*>(wfrag) + (jt0 + b) * 64 + lane;
+    const uint4* wp0 = reinterpret_cast<const uint4*>(wfrag) + jt0 * 64 + lane;
     const int sstride = ntiles * 64;             // uint4 per k16 step
     // The weight stream is issued with inline-asm loads and waited for with COUNTED vmcnt: hipcc's own
     // bookkeeping falls back to vmcnt(0) at the loop header (and rotates the queue through v_mov's that
     // need the data).  Protocol: slot d is refilled right after its last use; before its next use
     // exactly NT*(D-1) younger loads have been issued by this wave, so vmcnt(NT*(D-1)) means "slot d
-    // has landed".  Loads are issued unconditionally (address clamped at the tail) to keep that count
-    // exact.  Queue slots are named scalars (tied asm operands cannot be array elements).
-    u32x4_t q00, q01, q10, q11, q20, q21, q30, q31, q40, q41, q50, q51, q60, q61, q70, q71;
-#define CHAIN_LOAD(Q0, Q1, step)                                                                              \
-    {                                                                                                          \
-        const int sn_ = min((step), ks_total - 1);                                                             \
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(Q0) : "v"(wp[0] + sn_ * sstride) : "memory");    \
-        if (NT == 2)                                                                                           \
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(Q1) : "v"(wp[NT - 1] + sn_ * sstride) : "memory"); \
-    }
+    // has landed".  The last D steps refill nothing and count down instead (re-loading clamped addresses there, as
+    // the first version did, cost 25 % more bytes on the path that bounds the kernel: the per-CU vector-memory pipe).
 #define CHAIN_AF(dst, step)                                                                                    \
     _Pragma("unroll") for (int a = 0; a < MT; ++a)                                                             \
         dst[a] = *reinterpret_cast<const bf16x8_t*>(X + chain_lds_off_p<PITCH>(arow + a * 32, (2 * min((step), ks_total - 1) + ahalf) * 8));
 // A fragments of step s+1 are read from LDS while the MFMAs of step s run (AC = current, AN = next).
-#define CHAIN_STEP(d, Q0, Q1, AC, AN)                                                                          \
+#define CHAIN_STEP(d, Q0, Q1, AC, AN, TAIL)                                                                    \
     {                                                                                                          \
         const int s = s0 + (d);                                                                                \
         if (MT <= 2) { CHAIN_AF(AN, s + 1) } else { CHAIN_AF(AC, s) }                                          \
-        if (NT == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(Q0), "+v"(Q1) : "i"(NT * (D - 1)) : "memory");  \
-        else asm volatile("s_waitcnt vmcnt(%1)" : "+v"(Q0) : "i"(NT * (D - 1)) : "memory");                    \
+        if (NT == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(Q0), "+v"(Q1) : "i"((TAIL) ? NT * (D - 1 - (d)) : NT * (D - 1)) : "memory"); \
+        else asm volatile("s_waitcnt vmcnt(%1)" : "+v"(Q0) : "i"((TAIL) ? NT * (D - 1 - (d)) : NT * (D - 1)) : "memory"); \
         _Pragma("unroll") for (int a = 0; a < MT; ++a) {                                                       \
             acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, Q0), AC[a], acc[a][0], 0, 0, 0); \
             if (NT == 2)                                                                                       \
                 acc[a][NT - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, Q1), AC[a], acc[a][NT - 1], 0, 0, 0); \
         }                                                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
-        CHAIN_LOAD(Q0, Q1, s + D)                                                                              \
+        if (!(TAIL)) {                                                                                         \
+            const uint4* a_ = wp0 + (s + D) * sstride;                                                         \
+            CHAIN_LD1(Q0, a_);                                                                                 \
+            if (NT == 2) CHAIN_LD1(Q1, a_ + 64);                                                               \
+        }                                                                                                      \
+    }
+#define CHAIN_BLOCK(TAIL)                                                                                      \
+    if (MT <= 2) {                                                                                             \
+        CHAIN_STEP(0, Q.q00, Q.q01, afA, afB, TAIL)                                                            \
+        CHAIN_STEP(1, Q.q10, Q.q11, afB, afA, TAIL)                                                            \
+        CHAIN_STEP(2, Q.q20, Q.q21, afA, afB, TAIL)                                                            \
+        CHAIN_STEP(3, Q.q30, Q.q31, afB, afA, TAIL)                                                            \
+        if (D == 8) {                                                                                          \
+            CHAIN_STEP(4, Q.q40, Q.q41, afA, afB, TAIL)                                                        \
+            CHAIN_STEP(5, Q.q50, Q.q51, afB, afA, TAIL)                                                        \
+            CHAIN_STEP(6, Q.q60, Q.q61, afA, afB, TAIL)                                                        \
+            CHAIN_STEP(7, Q.q70, Q.q71, afB, afA, TAIL)                                                        \
+        }                                                                                                      \
+    } else {                                                                                                   \
+        CHAIN_STEP(0, Q.q00, Q.q01, afA, afA, TAIL)                                                            \
+        CHAIN_STEP(1, Q.q10, Q.q11, afA, afA, TAIL)                                                            \
+        CHAIN_STEP(2, Q.q20, Q.q21, afA, afA, TAIL)                                                            \
+        CHAIN_STEP(3, Q.q30, Q.q31, afA, afA, TAIL)                                                            \
+        if (D == 8) {                                                                                          \
+            CHAIN_STEP(4, Q.q40, Q.q41, afA, afA, TAIL)                                                        \
+            CHAIN_STEP(5, Q.q50, Q.q51, afA, afA, TAIL)                                                        \
+            CHAIN_STEP(6, Q.q60, Q.q61, afA, afA, TAIL)                                                        \
+            CHAIN_STEP(7, Q.q70, Q.q71, afA, afA, TAIL)                                                        \
+        }                                                                                                      \
     }
     // Older compiler-issued memory ops need no explicit drain: completion is in order, so the first counted
     // wait below also covers them.
-    CHAIN_LOAD(q00, q01, 0)
-    CHAIN_LOAD(q10, q11, 1)
-    CHAIN_LOAD(q20, q21, 2)
-    CHAIN_LOAD(q30, q31, 3)
-    if (D == 8) {
-        CHAIN_LOAD(q40, q41, 4)
-        CHAIN_LOAD(q50, q51, 5)
-        CHAIN_LOAD(q60, q61, 6)
-        CHAIN_LOAD(q70, q71, 7)
-    }
+    if (SELF_PRIME) chain_prime_t<NT, D>(Q, wfrag, ks_total, ntiles, jt0, lane);
     // The previous stage's output (= this stage's input, still intact in X) goes to global memory NOW, behind
     // the queue-priming loads: its stores are younger than every primed slot, so the counted waits never
     // wait for a store acknowledgement (waiting vmcnt(0) for them before priming cost ~1 us per stage).
@@ -159,36 +203,14 @@ __device__ __forceinline__ void chain_mma(const u16* __restrict__ X, const u16* 
     // (double-buffered only for <= 2 row tiles per wave; with 4 the second buffer would spill)
     bf16x8_t afA[MT], afB[MT <= 2 ? MT : 1];
     if (MT <= 2) { CHAIN_AF(afA, 0) }
-    for (int s0 = 0; s0 < ks_total; s0 += D) {     // contraction lengths are multiples of 64 = 4 steps; D=8 needs 128
-        if (MT <= 2) {
-            CHAIN_STEP(0, q00, q01, afA, afB)
-            CHAIN_STEP(1, q10, q11, afB, afA)
-            CHAIN_STEP(2, q20, q21, afA, afB)
-            CHAIN_STEP(3, q30, q31, afB, afA)
-            if (D == 8) {
-                CHAIN_STEP(4, q40, q41, afA, afB)
-                CHAIN_STEP(5, q50, q51, afB, afA)
-                CHAIN_STEP(6, q60, q61, afA, afB)
-                CHAIN_STEP(7, q70, q71, afB, afA)
-            }
-        } else {
-            CHAIN_STEP(0, q00, q01, afA, afA)
-            CHAIN_STEP(1, q10, q11, afA, afA)
-            CHAIN_STEP(2, q20, q21, afA, afA)
-            CHAIN_STEP(3, q30, q31, afA, afA)
-            if (D == 8) {
-                CHAIN_STEP(4, q40, q41, afA, afA)
-                CHAIN_STEP(5, q50, q51, afA, afA)
-                CHAIN_STEP(6, q60, q61, afA, afA)
-                CHAIN_STEP(7, q70, q71, afA, afA)
-            }
-        }
+    int s0 = 0;
+    for (; s0 + D < ks_total; s0 += D) {     // contraction lengths are multiples of 64 = 4 steps; D=8 needs 128
+        CHAIN_BLOCK(false)
     }
+    CHAIN_BLOCK(true)                        // last D steps: the final wait is vmcnt(0), every slot is consumed
 #undef CHAIN_AF
 #undef CHAIN_STEP
-#undef CHAIN_LOAD
-    // drain: the tail re-loads are still in flight and their destination registers are about to be reused
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef CHAIN_BLOCK
 }
 
 
@@ -314,22 +336,25 @@ __device__ __forceinline__ void chain_stage(u16* X, const float* bias_lds, const
     }
     u32x4_t msk = u32x4_t{0u, 0u, 0u, 0u};
     u32x4_t* mptr = S.mask ? S.mask + (int64_t)blockIdx.x * 512 + tid : nullptr;
+    const bool remap = BMROWS == 32 && p.mask_bm64;            // 32-row tiles over the sign masks of a 64-row forward pass
     if (EPI == EPI_DGRAD && !ELU) {
-        if (BMROWS == 32 && p.mask_bm64) {
-            // The forward pass ran 64-row tiles (fewer weight bytes through the L2s), this pass 32-row tiles (a workgroup
-            // on every CU): workgroup 2i+a0 covers row tile a0 of forward workgroup i.  Forward layout: tile t = a*NT+b in
-            // dword t>>1, half t&1; 128-wide stages put rows 32..63 on waves 4..7 (threads 256..511).
-            const int a0 = blockIdx.x & 1;
-            const int ft = S.Nc == 128 ? (tid & 255) + 256 * a0 : tid;
-            const u32x4_t m = S.mask[(int64_t)(blockIdx.x >> 1) * 512 + ft];
-            msk[0] = S.Nc == 512 ? (a0 ? m[1] : m[0]) : (S.Nc == 256 ? m[0] >> (16 * a0) : m[0]);
-        } else {
-            msk = *mptr;                                       // lands during the k-loop
-        }
+        // The forward pass ran 64-row tiles, this pass 32-row tiles: workgroup 2i+a0 covers row tile a0 of forward
+        // workgroup i.  Forward layout: tile t = a*NT+b in dword t>>1, half t&1; 128-wide stages put rows 32..63 on
+        // waves 4..7 (threads 256..511).  (The dword is picked AFTER the k-loop: a use here would make hipcc wait for
+        // the load before the weight queue is primed.)
+        if (remap) msk = S.mask[(int64_t)(blockIdx.x >> 1) * 512 + (S.Nc == 128 ? (tid & 255) + 256 * (blockIdx.x & 1) : tid)];
+        else msk = *mptr;                                      // lands during the k-loop
     }
     // deep prefetch (8 steps = 16 KiB per wave in flight) where registers allow and the contraction is long enough
-    if (MT <= 2 && (S.Kc & 127) == 0) chain_mma<BMROWS, MT, NT, 8>(X, S.wfrag, S.Kc >> 4, S.Nc >> 5, jt0, mrow0, tid, acc, pend, m0);
-    else chain_mma<BMROWS, MT, NT, 4>(X, S.wfrag, S.Kc >> 4, S.Nc >> 5, jt0, mrow0, tid, acc, pend, m0);
+    // (Priming the NEXT stage's queue here, so that its first loads fly during this epilogue, was tried: the queue
+    //  registers then live across the stage dispatch, hipcc copies / spills them - 140-300 B of scratch per lane - and a
+    //  copy of a register whose asm load has not landed yet is garbage.  The queue stays local to chain_mma.)
+    if (MT <= 2 && (S.Kc & 127) == 0) chain_mma<BMROWS, MT, NT, 8, true>(X, S.wfrag, S.Kc >> 4, S.Nc >> 5, jt0, mrow0, tid, acc, pend, m0);
+    else chain_mma<BMROWS, MT, NT, 4, true>(X, S.wfrag, S.Kc >> 4, S.Nc >> 5, jt0, mrow0, tid, acc, pend, m0);
+    if (EPI == EPI_DGRAD && !ELU && remap) {
+        const int a0 = blockIdx.x & 1;
+        msk[0] = S.Nc == 512 ? (a0 ? msk[1] : msk[0]) : (S.Nc == 256 ? msk[0] >> (16 * a0) : msk[0]);
+    }
     __syncthreads();                         // every wave has finished reading X for this stage
     chain_stamp(p, tid, slot);
     if (p.ablate & 16) {                     // timing experiment: no epilogue at all

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(512) void k_chainw(const ChainArgs p) {
             for (int tile = wid; tile < ntiles; tile += 8) {
                 f32x16_t acc1[1][1];
                 ChainPending none{nullptr, 0, 0};
-                chain_mma<CWD_BM, 1, 1, 4, CWD_PITCH>(Xin, S.wfrag, ks, ntiles, tile, 0, tid, acc1, none, m0);
+                chain_mma<CWD_BM, 1, 1, 4, true, CWD_PITCH>(Xin, S.wfrag, ks, ntiles, tile, 0, tid, acc1, none, m0);
                 const f32x16_t& acc = acc1[0][0];
                 const int64_t m = m0 + mrow;
                 const bool row_ok = m < p.n_rows;
@@ -115,8 +115,8 @@ __global__ __launch_bounds__(512) void k_chainw(const ChainArgs p) {
                         hh[b][q] = *reinterpret_cast<const uint2*>(S.hprev + (m0 + mrow) * S.ldh + (tile0 + b) * 32 + 8 * q + hi4);
             }
             // the weight stream of chain.h: inline-asm loads, counted vmcnt, 8 (or 4) k16-steps in flight
-            if ((S.Kc & 127) == 0) chain_mma<CWD_BM, 1, 2, 8, CWD_PITCH>(Xin, S.wfrag, ks, ntiles, tile0, 0, tid, acc2, none, m0);
-            else chain_mma<CWD_BM, 1, 2, 4, CWD_PITCH>(Xin, S.wfrag, ks, ntiles, tile0, 0, tid, acc2, none, m0);
+            if ((S.Kc & 127) == 0) chain_mma<CWD_BM, 1, 2, 8, true, CWD_PITCH>(Xin, S.wfrag, ks, ntiles, tile0, 0, tid, acc2, none, m0);
+            else chain_mma<CWD_BM, 1, 2, 4, true, CWD_PITCH>(Xin, S.wfrag, ks, ntiles, tile0, 0, tid, acc2, none, m0);
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
                 const int tile = tile0 + b;

@@ -335,11 +335,12 @@ int run_backward(cs_mlp* h, int64_t n, bool atomics_needed, hipStream_t st) {
         c.dz_in = h->layers[h->L - 1].dZ; c.ld_dz_in = 128; c.w_in = 128;
         c.n_rows = n; c.act = h->cfg.act; c.slope = (h->cfg.act == CS_ACT_RELU) ? 0.f : h->cfg.alpha;
         int bm = chain_bm(h, n);
-        // 64-row forward + 32-row backward between 4096 and ~12k rows: measured backward 49 -> 42 us at 8192 rows (a
-        // workgroup on every CU), while the forward pass is faster with 64 rows there (85 vs 103 us); the backward
-        // workgroups read the sign masks in the forward layout.
+        // 64-row forward + 32-row backward (the backward workgroups read the sign masks in the forward layout): only on
+        // request (CS_FLAG_CHAIN_BWD32_ON_FWD64 / CS_CHAIN_HYBRID_MAX).  It paid while the forward pass ran 64-row tiles
+        // at 8192 columns; above 8192 columns 32-row tiles need a second round of workgroups (12288: 0.198 vs 0.180 ms).
         const bool forced = h->cfg.flags & (CS_FLAG_CHAIN_BM32 | CS_FLAG_CHAIN_BM64 | CS_FLAG_CHAIN_BM128);
-        if ((bm == 64 && !forced && n <= 12288 && h->cfg.act != CS_ACT_ELU) || (h->cfg.flags & CS_FLAG_CHAIN_BWD32_ON_FWD64)) {
+        static const int64_t hybrid_max = getenv("CS_CHAIN_HYBRID_MAX") ? atoll(getenv("CS_CHAIN_HYBRID_MAX")) : 0;
+        if ((bm == 64 && !forced && n <= hybrid_max && h->cfg.act != CS_ACT_ELU) || (h->cfg.flags & CS_FLAG_CHAIN_BWD32_ON_FWD64)) {
             bm = 32; c.mask_bm64 = 1;
         }
         ProfScope ps(CS_K_CHAIN_BWD, st);
@@ -383,6 +384,7 @@ int run_backward(cs_mlp* h, int64_t n, bool atomics_needed, hipStream_t st) {
         const int msteps = (big || dma_small) ? (int)(m_pad / WG2_ROWS) : steps;
         WgradArgs w{};
         w.n_layers = h->L; w.m_pad = m_pad;
+        { static const int ab = getenv("CS_WGRAD_ABLATE") ? atoi(getenv("CS_WGRAD_ABLATE")) : 0; w.ablate = ab; }
         int tiles = 0;
         for (int l = 0; l < h->L; ++l)
             tiles += ((h->layers[l].Kp + tdim - 1) / tdim) * ((h->layers[l].N + tdim - 1) / tdim);

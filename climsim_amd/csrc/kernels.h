@@ -294,6 +294,7 @@ struct WgradArgs {               // ALL layers of the step in one launch: grid.x
     int64_t m_pad;               // multiple of 128; rows >= n hold zeros in Z
     int splitk;                  // row-range splits per tile (same for every layer)
     int use_atomics;             // splitk > 1 or accumulate
+    int ablate;                  // timing experiments only (CS_WGRAD_ABLATE): 1 no result flush, 2 no contraction loop
 };
 
 // LDS tile [64 m][128 cols] bf16 (256-B rows).  The four 64-B units of a row are XOR-swizzled with

@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void k_wgrad3(const WgradArgs pa) {
     const int steps = (int)(pa.m_pad / WG2_ROWS);
     const int s_begin = (int)((int64_t)steps * split / pa.splitk);
     const int s_end = (int)((int64_t)steps * (split + 1) / pa.splitk);
-    const int nst = s_end - s_begin;
+    const int nst = (pa.ablate & 2) ? 0 : s_end - s_begin;
 
     // a 1-KiB DMA piece = 4 rows of 256 B; lane i -> row i>>4, physical chunk i&15, which holds logical
     // chunk (((p>>2) ^ (m&3)) << 2) | (p&3)  (swz_tn).  Pieces 2*wid, 2*wid+1 of each operand per wave.
@@ -262,6 +262,13 @@ __global__ __launch_bounds__(256) void k_wgrad3(const WgradArgs pa) {
         }
 #undef WG3_ISSUE
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if (pa.ablate & 1) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) asm volatile("" :: "v"(acc[i][j]));
+        return;
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
