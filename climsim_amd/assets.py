@@ -10,6 +10,8 @@ this package, so this module provides
 * ``AssetVar`` / ``AssetSet`` - a tiny mapping that quacks like the slice of ``xarray.Dataset``
                        the data_utils API touches (``ds[var].values``, ``.mean(dim=)``, ``/``,
                        ``*``, ``len``);
+* ``read_netcdf`` / ``load_nc_assets`` - either NetCDF flavour (NetCDF-4 = HDF5 through
+                       ``climsim_amd.hdf5``), e.g. the reference's normalisation files;
 * ``load_npz_assets`` - rebuild AssetSets from the ``.npz`` bundles under ``tests/golden``.
 
 Real xarray Datasets can be passed to ``climsim_amd.data_utils.data_utils`` as well.
@@ -187,6 +189,26 @@ def load_grid_info(path: str) -> AssetSet:
         raw = read_cdf5(path)
         dims = raw.pop("__dims__")
     return AssetSet.from_arrays(raw, dims)
+
+
+def read_netcdf(path: str) -> Dict[str, np.ndarray]:
+    """Every variable of a NetCDF file, classic (CDF-1/2/5) or NetCDF-4 (= HDF5), as native ndarrays."""
+    with open(path, "rb") as f:
+        magic = f.read(8)
+    if magic[:3] == b"CDF":
+        raw = read_cdf5(path)
+        raw.pop("__dims__", None)
+        return raw
+    from .hdf5 import read_hdf5
+    return read_hdf5(path)
+
+
+def load_nc_assets(path: str) -> AssetSet:
+    """One of the reference's normalisation files (``preprocessing/normalizations/{inputs,outputs}/*.nc``, HDF5) or
+    any NetCDF file of scalars / per-level profiles as the mapping the ``data_utils`` ctor takes
+    (the reference passes ``xr.open_dataset(path)``, ``step2_retrain.py:187-190``)."""
+    raw = read_netcdf(path)
+    return AssetSet.from_arrays(raw, {k: (("lev",) if np.ndim(v) == 1 else ()) for k, v in raw.items()})
 
 
 def load_npz_assets(path: str, prefix: str) -> AssetSet:

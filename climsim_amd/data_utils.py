@@ -347,9 +347,8 @@ class data_utils:  # noqa: N801  (name fixed by the reference API)
             with open(stem + ".npy", "wb") as f:
                 np.save(f, arr)
         if self.save_h5:
-            import h5py
-            with h5py.File(stem + ".h5", "w") as hdf:
-                hdf.create_dataset("data", data=arr, dtype=arr.dtype)
+            from .hdf5 import write_hdf5_dataset                  # h5py is not a dependency
+            write_hdf5_dataset(stem + ".h5", "data", arr)
 
     def reshape_npy(self, var_arr, var_arr_dim):
         return var_arr.reshape((int(var_arr.shape[0] / self.num_latlon), self.num_latlon, var_arr_dim))
@@ -378,9 +377,10 @@ class data_utils:  # noqa: N801  (name fixed by the reference API)
 
     @staticmethod
     def load_h5_file(load_path=""):
-        import h5py
-        with h5py.File(load_path, "r") as hf:
-            return np.array(hf.get("pred"))
+        """Predictions saved as HDF5 dataset 'pred' (data_utils.py:1029-1035), read without h5py."""
+        from .hdf5 import Hdf5File
+        with Hdf5File(load_path) as hf:
+            return hf["pred"]
 
     # ------------------------------------------------------------------ evaluation
     def set_pressure_grid(self, data_split):
@@ -572,19 +572,9 @@ def _values(v):
 
 
 def _open_columns(path) -> Dict[str, np.ndarray]:
-    """All variables of one E3SM-MMF timestep file as ndarrays.  NetCDF-4/HDF5 files need
-    xarray or netCDF4 (lazy import); classic CDF-1/2/5 files are read natively."""
-    with open(path, "rb") as f:
-        magic = f.read(4)
-    if magic[:3] == b"CDF":
-        from .assets import read_cdf5
-        raw = read_cdf5(path)
-        raw.pop("__dims__", None)
-        return {k: np.asarray(v, dtype=np.float64) for k, v in raw.items()}
-    try:
-        import xarray as xr
-    except ImportError as e:  # pragma: no cover - depends on the user's environment
-        raise ImportError(f"{path} is NetCDF-4/HDF5; reading it needs xarray+netCDF4 (not a dependency "
-                          "of climsim_amd). Use the pre-materialised .npy splits instead.") from e
-    with xr.open_dataset(path, engine="netcdf4") as ds:
-        return {k: np.asarray(ds[k].values, dtype=np.float64) for k in ds.data_vars}
+    """All numeric variables of one E3SM-MMF timestep file as float64 ndarrays: classic CDF-1/2/5 and
+    NetCDF-4/HDF5 files are both read natively (`climsim_amd.assets.read_netcdf`; the reference goes through
+    xarray, data_utils.py:619-640)."""
+    from .assets import read_netcdf
+    raw = read_netcdf(path)
+    return {k: np.asarray(v, dtype=np.float64) for k, v in raw.items() if np.asarray(v).dtype.kind in "iuf"}

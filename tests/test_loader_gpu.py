@@ -72,3 +72,15 @@ def test_device_loader_edge_cases(L, raw_tree, lowres_assets):
     np.testing.assert_array_equal(only_x.cpu().numpy(), x.cpu().numpy())
     with pytest.raises(ValueError):
         ld.stack_raw(a[:, :100], b)
+
+
+def test_device_loader_from_netcdf4_files(L, lowres_assets, tmp_path):
+    """NetCDF-4 (= HDF5) timestep files, read by the native reader (climsim_amd/hdf5.py), through the device loader:
+    the rows are bit-identical to what the host path writes from the same files."""
+    from test_hdf5_cpu import nc4_tree
+    du = make(lowres_assets, "pytorch", nc4_tree(tmp_path))
+    du.save_as_npy("train", save_path=str(tmp_path / "npy"))
+    ld = L.GpuColumnLoader(du)
+    x, y = ld.load_split("train")
+    np.testing.assert_array_equal(x.cpu().numpy(), np.load(tmp_path / "npy" / "train_input.npy"))
+    np.testing.assert_array_equal(y.cpu().numpy(), np.load(tmp_path / "npy" / "train_target.npy"))
