@@ -17,7 +17,9 @@ CS_FLAG_CHAIN_BWD32_ON_FWD64 = 32
 CS_FLAG_GEMM_V1 = 64
 
 ACT = {"relu": 0, "elu": 1, "leakyrelu": 2}
-OPT = {"Adam": 0, "RAdam": 1, "RMSprop": 2, "SGD": 3}
+OPT = {"Adam": 0, "RAdam": 1, "RMSprop": 2, "SGD": 3, "AdamTorch": 4}
+LOSS = {"mse": 0, "mae": 1, "huber": 2}
+FLAG_DIRECT_HEAD = 128
 
 
 class CsMlpCfg(C.Structure):
@@ -53,6 +55,7 @@ SIGNATURES = {
     "cs_mlp_num_params": (_I64, [_P]),
     "cs_mlp_device_bytes": (_I64, [_P]),
     "cs_mlp_set_norm": (C.c_int, [_P, _P, _P]),
+    "cs_mlp_set_head_options": (C.c_int, [_P, C.c_int, _P, C.c_int64]),
     "cs_mlp_set_weights": (C.c_int, [_P, _P, _I64, _P]),
     "cs_mlp_get_weights": (C.c_int, [_P, _P, _I64, _P]),
     "cs_mlp_get_opt_state": (C.c_int, [_P, _P, _P, _I64, C.POINTER(_I64), _P]),

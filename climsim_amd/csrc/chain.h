@@ -55,6 +55,8 @@ struct ChainArgs {
     // heads (EPI_OUT)
     int n_lin; float* yhat; const float* y; float* loss; u16* dz_out; int ld_dz_out;
     int loss_stripes;        // > 1: `loss` is a striped internal accumulator (loss_flush, kernels.h)
+    int loss_kind;           // cs_loss (head4, kernels.h)
+    const float* keep;       // [output width] 1/0 per column (output pruning) or null
     int n_real;              // k_chainw: real output width (row pitch of yhat / y); the tuned chain is 128-wide only
     int mask_bm64;           // backward with 32-row tiles over sign masks written by a 64-row forward (see chain_stage)
     int ablate;              // timing experiments only (CS_CHAIN_ABLATE): 4 no global stores, 8 no warm-up
@@ -289,23 +291,9 @@ __device__ __forceinline__ void chain_heads(const float* __restrict__ bias_lds, 
             float v[4] = {acc[a][0][4 * q + 0] + b4.x, acc[a][0][4 * q + 1] + b4.y, acc[a][0][4 * q + 2] + b4.z,
                           acc[a][0][4 * q + 3] + b4.w};
             const bool valid = m < p.n_rows;
-            float d[4] = {0.f, 0.f, 0.f, 0.f};
-            if (n >= p.n_lin) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-            }
+            float d[4];
+            head4(v, d, n >= p.n_lin, p.keep, n, (have_y && valid) ? &tgt[a][q] : nullptr, p.loss_kind, sq, ab);
             if (valid && p.yhat) *reinterpret_cast<float4*>(p.yhat + m * S.Nc + n) = make_float4(v[0], v[1], v[2], v[3]);
-            if (have_y && valid) {
-                const float4 t4 = tgt[a][q];
-                const float e4[4] = {v[0] - t4.x, v[1] - t4.y, v[2] - t4.z, v[3] - t4.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    sq += e4[e] * e4[e];
-                    ab += fabsf(e4[e]);
-                    d[e] = 2.f * e4[e];
-                    if (n >= p.n_lin && !(v[e] > 0.f)) d[e] = 0.f;
-                }
-            }
             if (p.dz_out) *reinterpret_cast<uint2*>(p.dz_out + m * p.ld_dz_out + n) = make_uint2(cvt_pk_bf16(d[0], d[1]), cvt_pk_bf16(d[2], d[3]));
         }
     }

@@ -81,23 +81,11 @@ __global__ __launch_bounds__(512) void k_chainw(const ChainArgs p) {
                     const bool valid = row_ok && n < p.n_real;
                     const float4 b4 = *reinterpret_cast<const float4*>(bias_lds + S.bias_off + n);
                     float v[4] = {acc[4 * q + 0] + b4.x, acc[4 * q + 1] + b4.y, acc[4 * q + 2] + b4.z, acc[4 * q + 3] + b4.w};
-                    float d[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (n >= p.n_lin) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                    }
+                    float d[4];
+                    float4 t4;
+                    if (p.y && valid) t4 = *reinterpret_cast<const float4*>(p.y + yrow * p.n_real + n);
+                    head4(v, d, n >= p.n_lin, p.keep, n, (p.y && valid) ? &t4 : nullptr, p.loss_kind, sq, ab);
                     if (valid && p.yhat) *reinterpret_cast<float4*>(p.yhat + m * p.n_real + n) = make_float4(v[0], v[1], v[2], v[3]);
-                    if (p.y && valid) {
-                        const float4 t4 = *reinterpret_cast<const float4*>(p.y + yrow * p.n_real + n);
-                        const float e4[4] = {v[0] - t4.x, v[1] - t4.y, v[2] - t4.z, v[3] - t4.w};
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            sq += e4[e] * e4[e];
-                            ab += fabsf(e4[e]);
-                            d[e] = 2.f * e4[e];
-                            if (n >= p.n_lin && !(v[e] > 0.f)) d[e] = 0.f;
-                        }
-                    }
                     if (p.dz_out) *reinterpret_cast<uint2*>(p.dz_out + m * p.ld_dz_out + n) = make_uint2(cvt_pk_bf16(d[0], d[1]), cvt_pk_bf16(d[2], d[3]));
                 }
             }

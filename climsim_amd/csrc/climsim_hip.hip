@@ -86,6 +86,9 @@ struct cs_mlp {
     int64_t n_params = 0;      // floats of the internal (padded) flat buffers P, M, V, G
     int64_t n_params_keras = 0;  // floats of the Keras-ordered weight list (what set/get_weights exchange)
     int n_out = 128, n_outp = 128;
+    int loss_kind = CS_LOSS_MSE;   // cs_mlp_set_head_options
+    float* keep = nullptr;         // [n_outp] 1/0 per output column, or null (no output pruning)
+    float* keep_store = nullptr;   // the arena slot `keep` points to when pruning is on
     int64_t m_pad_max = 0;
     float *P = nullptr, *M = nullptr, *V = nullptr, *G = nullptr;
     bool own_G = true;
@@ -181,6 +184,12 @@ int launch_optimizer(cs_mlp* h, float lr, float grad_scale, bool recast_only, hi
     if (a.kind == CS_OPT_ADAM) {
         a.omb1 = (float)(1.0 - h->cfg.beta1); a.omb2 = (float)(1.0 - h->cfg.beta2);
         a.alpha = lr * sqrtf(1.f - p2) / (1.f - p1);
+    } else if (a.kind == CS_OPT_ADAM_TORCH) {
+        // torch keeps these scalars as Python floats (doubles) and casts them when they meet a float32 tensor
+        const double td = (double)(h->iterations + 1);
+        a.omb1 = (float)(1.0 - h->cfg.beta1); a.omb2 = (float)(1.0 - h->cfg.beta2);
+        a.alpha = (float)((double)lr / (1.0 - pow(h->cfg.beta1, td)));
+        a.bc2 = (float)sqrt(1.0 - pow(h->cfg.beta2, td));
     } else {
         a.omb1 = 1.f - b1; a.omb2 = 1.f - b2;
         const float sma_inf = 2.f / (1.f - b2) - 1.f;
@@ -258,6 +267,7 @@ int run_forward(cs_mlp* h, const float* x, const int64_t* row_idx, int64_t n, in
         c.act = h->cfg.act; c.slope = (h->cfg.act == CS_ACT_RELU) ? 0.f : h->cfg.alpha;
         c.n_lin = h->cfg.n_out_lin; c.yhat = yhat; c.y = y; c.loss = loss;
         c.loss_stripes = h->loss_striped ? LOSS_STRIPES : 1;
+        c.loss_kind = h->loss_kind; c.keep = h->keep;
         c.dz_out = want_dz ? h->layers[h->L - 1].dZ : nullptr; c.ld_dz_out = 128;
         const int bm = chain_bm(h, n);
         ProfScope ps(CS_K_CHAIN_FWD, st);
@@ -281,6 +291,7 @@ int run_forward(cs_mlp* h, const float* x, const int64_t* row_idx, int64_t n, in
         c.act = h->cfg.act; c.slope = (h->cfg.act == CS_ACT_RELU) ? 0.f : h->cfg.alpha;
         c.n_lin = h->cfg.n_out_lin; c.yhat = yhat; c.y = y; c.loss = loss;
         c.loss_stripes = h->loss_striped ? LOSS_STRIPES : 1;
+        c.loss_kind = h->loss_kind; c.keep = h->keep;
         c.dz_out = want_dz ? h->layers[h->L - 1].dZ : nullptr; c.ld_dz_out = h->n_outp; c.n_real = h->n_out;
         ProfScope ps(CS_K_CHAIN_FWD, st);
         hipLaunchKernelGGL(k_chainw<false>, dim3((unsigned)(m_pad / CWD_BM)), dim3(512), chainw_lds_bytes(), st, c);
@@ -308,6 +319,7 @@ int run_forward(cs_mlp* h, const float* x, const int64_t* row_idx, int64_t n, in
             else hipLaunchKernelGGL(k_gemm_nt2<EPI_HIDDEN>, grid, dim3(256), G2_LDS_BYTES, st, p);
         } else {
             p.n_lin = h->cfg.n_out_lin; p.n_real = h->n_out; p.yhat = yhat; p.y = y; p.row_idx = row_idx; p.n_rows = n; p.loss = loss; p.loss_stripes = h->loss_striped ? LOSS_STRIPES : 1;
+            p.loss_kind = h->loss_kind; p.keep = h->keep;
             p.out = want_dz ? ly.dZ : nullptr; p.ldo = ly.N;
             if (v1) hipLaunchKernelGGL(k_gemm_nt<EPI_OUT>, grid, dim3(256), 0, st, p);
             else hipLaunchKernelGGL(k_gemm_nt2<EPI_OUT>, grid, dim3(256), G2_LDS_BYTES, st, p);
@@ -441,7 +453,7 @@ int cs_mlp_create(cs_mlp_t** out, const cs_mlp_cfg* cfg) {
         cfg->n_out_lin + cfg->n_out_relu > 1024)
         return fail(CS_ERR_INVALID, "heads must total 4..1024 outputs, both counts multiples of 4 (got %d+%d)", cfg->n_out_lin, cfg->n_out_relu);
     if (cfg->act < 0 || cfg->act > 2) return fail(CS_ERR_INVALID, "unknown activation %d", cfg->act);
-    if (cfg->optimizer < 0 || cfg->optimizer > 3) return fail(CS_ERR_INVALID, "unknown optimizer %d", cfg->optimizer);
+    if (cfg->optimizer < 0 || cfg->optimizer > 4) return fail(CS_ERR_INVALID, "unknown optimizer %d", cfg->optimizer);
     if (cfg->max_batch <= 0) return fail(CS_ERR_INVALID, "max_batch must be positive");
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
@@ -450,7 +462,8 @@ int cs_mlp_create(cs_mlp_t** out, const cs_mlp_cfg* cfg) {
 
     cs_mlp* h = new cs_mlp();
     h->cfg = *cfg;
-    h->L = cfg->n_hidden + 2;
+    const bool direct = (cfg->flags & CS_FLAG_DIRECT_HEAD) != 0;   // online_testing MLP: final Linear on the last hidden layer
+    h->L = cfg->n_hidden + (direct ? 1 : 2);
     h->m_pad_max = round_up(cfg->max_batch, 128);
     std::vector<int> dims;
     dims.push_back(cfg->n_in);
@@ -459,7 +472,7 @@ int cs_mlp_create(cs_mlp_t** out, const cs_mlp_cfg* cfg) {
     // 368 for the v2 variable set, hpo_baseline_v2.py:89-101), padded to a multiple of 128 with zero columns
     h->n_out = cfg->n_out_lin + cfg->n_out_relu;
     h->n_outp = (int)round_up(h->n_out, 128);
-    dims.push_back(h->n_out);
+    if (!direct) dims.push_back(h->n_out);
     dims.push_back(h->n_out);
     int64_t off = 0, off_keras = 0;
     h->layers.resize(h->L);
@@ -514,6 +527,7 @@ int cs_mlp_create(cs_mlp_t** out, const cs_mlp_cfg* cfg) {
     A((void**)&h->V, sizeof(float) * off);
     A((void**)&h->G, sizeof(float) * off);
     A((void**)&h->loss_ring, sizeof(float) * 2 * LOSS_STRIPES * LOSS_STRIPE_FLOATS);
+    A((void**)&h->keep_store, sizeof(float) * h->n_outp);
     A((void**)&h->sub, sizeof(float) * cfg->n_in);
     A((void**)&h->div, sizeof(float) * cfg->n_in);
     for (int l = 0; l < h->L; ++l) {
@@ -580,6 +594,22 @@ int cs_mlp_set_norm(cs_mlp_t* h, const float* input_sub, const float* input_div)
     HIP_TRY(hipMemcpy(h->sub, input_sub, sizeof(float) * h->cfg.n_in, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->div, input_div, sizeof(float) * h->cfg.n_in, hipMemcpyHostToDevice));
     h->have_norm = true;
+    return CS_OK;
+}
+
+int cs_mlp_set_head_options(cs_mlp_t* h, int loss_kind, const float* keep_host, int64_t n) {
+    if (!h) return fail(CS_ERR_INVALID, "null argument");
+    if (loss_kind < CS_LOSS_MSE || loss_kind > CS_LOSS_HUBER) return fail(CS_ERR_INVALID, "unknown loss %d", loss_kind);
+    if (keep_host) {
+        if (n != h->n_out) return fail(CS_ERR_INVALID, "keep mask has %lld entries, the model %d outputs", (long long)n, h->n_out);
+        std::vector<float> tmp((size_t)h->n_outp, 1.f);
+        for (int i = 0; i < h->n_out; ++i) tmp[(size_t)i] = keep_host[i] != 0.f ? 1.f : 0.f;
+        HIP_TRY(hipMemcpy(h->keep_store, tmp.data(), sizeof(float) * h->n_outp, hipMemcpyHostToDevice));
+        h->keep = h->keep_store;
+    } else {
+        h->keep = nullptr;
+    }
+    h->loss_kind = loss_kind;
     return CS_OK;
 }
 

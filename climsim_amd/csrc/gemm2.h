@@ -107,25 +107,12 @@ __global__ __launch_bounds__(256) void k_gemm_nt2(const GemmNT p) {
                 *reinterpret_cast<uint2*>(p.out + m * p.ldo + n) = pack4_hw(v[0], v[1], v[2], v[3]);
             } else {  // EPI_OUT
                 v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
-                float d[4] = {0.f, 0.f, 0.f, 0.f};
-                if (n >= p.n_lin) {  // relu head (n_lin is a multiple of 4)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                }
+                float d[4];
                 const bool valid = m < p.n_rows && n < p.n_real;
+                float4 t4;
+                if (p.y && valid) t4 = *reinterpret_cast<const float4*>(p.y + (p.row_idx ? p.row_idx[m] : m) * p.n_real + n);
+                head4(v, d, n >= p.n_lin, p.keep, n, (p.y && valid) ? &t4 : nullptr, p.loss_kind, sq, ab);   // (n_lin is a multiple of 4)
                 if (valid && p.yhat) *reinterpret_cast<float4*>(p.yhat + m * p.n_real + n) = make_float4(v[0], v[1], v[2], v[3]);
-                if (p.y && valid) {
-                    const int64_t src = p.row_idx ? p.row_idx[m] : m;
-                    const float4 t4 = *reinterpret_cast<const float4*>(p.y + src * p.n_real + n);
-                    const float e4[4] = {v[0] - t4.x, v[1] - t4.y, v[2] - t4.z, v[3] - t4.w};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        sq += e4[e] * e4[e];
-                        ab += fabsf(e4[e]);
-                        d[e] = 2.f * e4[e];
-                        if (n >= p.n_lin && !(v[e] > 0.f)) d[e] = 0.f;
-                    }
-                }
                 if (p.out) *reinterpret_cast<uint2*>(p.out + m * p.ldo + n) = pack4_hw(d[0], d[1], d[2], d[3]);
             }
         }

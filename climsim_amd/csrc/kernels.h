@@ -128,6 +128,37 @@ __global__ __launch_bounds__(256) void k_normalise_rows(const float* __restrict_
     }
 }
 
+// Heads, four consecutive output columns n..n+3 of one row: per-column output activation (relu on the last head),
+// optional output pruning (online_testing/baseline_models/MLP_v2rh/training/mlp.py:56-61: pruned columns are set to 0
+// after the final Linear, so they also pass no gradient), error sums and d loss / d z (the 1/(B*n_out) of the mean is
+// applied by the optimiser kernel).
+//   kind 0  mse   (keras 'mse' / nn.MSELoss):       d = 2e            s0 += e^2
+//   kind 1  mae   (nn.L1Loss):                      d = sign(e)       s0 += e^2
+//   kind 2  huber (nn.SmoothL1Loss, beta = 1):      d = clamp(e,-1,1) s0 += |e| < 1 ? e^2/2 : |e| - 1/2
+//   s1 += |e| always.  t4 == nullptr: prediction only.
+__device__ __forceinline__ void head4(float (&v)[4], float (&d)[4], bool relu_cols, const float* __restrict__ keep, int n,
+                                      const float4* t4, int kind, float& s0, float& s1) {
+    float kp[4] = {1.f, 1.f, 1.f, 1.f};
+    if (keep) { const float4 k4 = *reinterpret_cast<const float4*>(keep + n); kp[0] = k4.x; kp[1] = k4.y; kp[2] = k4.z; kp[3] = k4.w; }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (relu_cols) v[e] = fmaxf(v[e], 0.f);
+        if (keep && kp[e] == 0.f) v[e] = 0.f;
+        d[e] = 0.f;
+    }
+    if (!t4) return;
+    const float e4[4] = {v[0] - t4->x, v[1] - t4->y, v[2] - t4->z, v[3] - t4->w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float a = fabsf(e4[e]);
+        s1 += a;
+        if (kind == 2) { s0 += a < 1.f ? 0.5f * e4[e] * e4[e] : a - 0.5f; d[e] = fminf(fmaxf(e4[e], -1.f), 1.f); }
+        else { s0 += e4[e] * e4[e]; d[e] = kind == 1 ? (e4[e] > 0.f ? 1.f : (e4[e] < 0.f ? -1.f : 0.f)) : 2.f * e4[e]; }
+        if (relu_cols && !(v[e] > 0.f)) d[e] = 0.f;
+        if (keep && kp[e] == 0.f) d[e] = 0.f;
+    }
+}
+
 // ---------------------------------------------------------------- NT GEMM (forward, dgrad)
 struct GemmNT {
     const u16* A;  int lda;      // [m_pad][lda]  activations / dz, K-contiguous
@@ -145,8 +176,10 @@ struct GemmNT {
     const float* y;              // targets (row-gathered) or null
     const int64_t* row_idx;
     int64_t n_rows;              // valid rows
-    float* loss;                 // [2] sum sq err, sum abs err
+    float* loss;                 // [2] sum sq err (huber: sum of SmoothL1 terms), sum abs err
     int loss_stripes;            // > 1: `loss` is a striped internal accumulator (loss_flush)
+    int loss_kind;               // cs_loss: what d loss / d z is formed from (head4)
+    const float* keep;           // [N] 1/0 per output column (output pruning) or null
     // EPI_DGRAD
     const u16* hprev; int ldh;   // activation output of the previous layer (same shape as out)
 };
@@ -246,26 +279,13 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const GemmNT p) {
                     *reinterpret_cast<uint2*>(p.out + m * p.ldo + n) = pack4(v[0], v[1], v[2], v[3]);
                 } else {  // EPI_OUT
                     v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
-                    float d[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (n >= p.n_lin) {  // relu head (n_lin is a multiple of 4)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                    }
+                    float d[4];
                     const bool valid = m < p.n_rows && n < p.n_real;
+                    float4 t4;
+                    if (p.y && valid) t4 = *reinterpret_cast<const float4*>(p.y + (p.row_idx ? p.row_idx[m] : m) * p.n_real + n);
+                    head4(v, d, n >= p.n_lin, p.keep, n, (p.y && valid) ? &t4 : nullptr, p.loss_kind, sq, ab);   // (n_lin is a multiple of 4)
                     if (valid && p.yhat)
                         *reinterpret_cast<float4*>(p.yhat + m * p.n_real + n) = make_float4(v[0], v[1], v[2], v[3]);
-                    if (p.y && valid) {
-                        const int64_t src = p.row_idx ? p.row_idx[m] : m;
-                        const float4 t4 = *reinterpret_cast<const float4*>(p.y + src * p.n_real + n);
-                        const float e4[4] = {v[0] - t4.x, v[1] - t4.y, v[2] - t4.z, v[3] - t4.w};
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            sq += e4[e] * e4[e];
-                            ab += fabsf(e4[e]);
-                            d[e] = 2.f * e4[e];
-                            if (n >= p.n_lin && !(v[e] > 0.f)) d[e] = 0.f;
-                        }
-                    }
                     if (p.out) *reinterpret_cast<uint2*>(p.out + m * p.ldo + n) = pack4(d[0], d[1], d[2], d[3]);
                 }
             }
@@ -475,6 +495,8 @@ struct OptArgs {
 //            w -= lr * (rect ? r*(m/bc1)/(sqrt(v/bc2)+eps) : m/bc1)
 //   RMSprop (keras 2.11 optimizers/rmsprop.py): v = rho v + (1-rho) g^2; w -= lr*g*rsqrt(v+eps)
 //   SGD     : w -= lr*g
+//   torch Adam (torch.optim.Adam, torch 2.x _single_tensor_adam; online_testing/.../train_mlp_h5loader.py:210-211):
+//            m.lerp_(g, 1-b1); v = v*b2 + (1-b2) g g; w -= (lr/(1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
 __device__ __forceinline__ void opt_update4(const OptArgs& a, int64_t i0, float (&wv)[4]) {
     const float4 w = *reinterpret_cast<const float4*>(a.P + i0);
     wv[0] = w.x; wv[1] = w.y; wv[2] = w.z; wv[3] = w.w;
@@ -503,6 +525,10 @@ __device__ __forceinline__ void opt_update4(const OptArgs& a, int64_t i0, float 
                 mv[e] += (gv[e] - mv[e]) * a.omb1;
                 vv[e] += (gv[e] * gv[e] - vv[e]) * a.omb2;
                 wv[e] -= (mv[e] * a.alpha) / (sqrtf(vv[e]) + a.eps);
+            } else if (a.kind == 4) {   // torch.optim.Adam: alpha = lr / (1 - b1^t), bc2 = sqrt(1 - b2^t)
+                mv[e] += a.omb1 * (gv[e] - mv[e]);
+                vv[e] = vv[e] * a.beta2 + (a.omb2 * gv[e]) * gv[e];
+                wv[e] -= (a.alpha * mv[e]) / (sqrtf(vv[e]) / a.bc2 + a.eps);
             } else {
                 mv[e] = a.beta1 * mv[e] + a.omb1 * gv[e];
                 vv[e] = a.beta2 * vv[e] + a.omb2 * (gv[e] * gv[e]);

@@ -48,10 +48,10 @@ class ConstantLearningRate:
         return self.learning_rate
 
 
-def glorot_uniform_weights(n_in, units, n_out_lin, n_out_relu, seed):
+def glorot_uniform_weights(n_in, units, n_out_lin, n_out_relu, seed, direct_head=False):
     """Keras-ordered initial weights: glorot_uniform kernels, zero biases (Dense defaults)."""
     rng = np.random.default_rng(seed)
-    dims = [n_in, *units, n_out_lin + n_out_relu]
+    dims = [n_in, *units] + ([] if direct_head else [n_out_lin + n_out_relu])
     shapes = [(dims[i], dims[i + 1]) for i in range(len(dims) - 1)]
     shapes += [(dims[-1], n_out_lin), (dims[-1], n_out_relu)]
     ws = []
@@ -81,7 +81,11 @@ class MLPEmulator:
                  optimizer: str = "Adam", input_length: int = 124, output_length_lin: int = 120,
                  output_length_relu: int = 8, alpha: float = 0.15, max_batch: int = 8192,
                  device: Optional[int] = None, seed: Optional[int] = 0, beta_1: float = 0.9,
-                 beta_2: float = 0.999, epsilon: float = 1e-7, rho: float = 0.9, flags: int = 0):
+                 beta_2: float = 0.999, epsilon: float = 1e-7, rho: float = 0.9, flags: int = 0,
+                 direct_head: bool = False, loss: str = "mse", output_keep=None):
+        """`direct_head`, `loss` ('mse' | 'mae' | 'huber'), `output_keep` (1/0 per output column) and optimizer
+        'AdamTorch' are the pieces of the online-testing MLP (climsim_amd/online_mlp.py); the baseline models leave
+        them at their defaults."""
         torch = _torch()
         if not torch.cuda.is_available():
             raise _lib.EngineError("MLPEmulator needs a ROCm GPU (no CPU fallback)")
@@ -89,7 +93,12 @@ class MLPEmulator:
             raise ValueError(f"activation must be one of {list(_lib.ACT)}")
         if optimizer not in _lib.OPT:
             raise ValueError(f"optimizer must be one of {list(_lib.OPT)}")
+        if loss not in _lib.LOSS:
+            raise ValueError(f"loss must be one of {list(_lib.LOSS)}")
         self.lib = _lib.load()
+        self.direct_head, self.loss_name = bool(direct_head), loss
+        if self.direct_head:
+            flags |= _lib.FLAG_DIRECT_HEAD
         self.units = tuple(int(u) for u in units)
         self.activation, self.optimizer_name = activation, optimizer
         self.input_length, self.output_length = input_length, output_length_lin + output_length_relu
@@ -109,6 +118,7 @@ class MLPEmulator:
         with torch.cuda.device(self.device):
             _lib.check(self.lib.cs_mlp_create(C.byref(self._h), C.byref(cfg)))
         self._n_params = int(self.lib.cs_mlp_num_params(self._h))
+        self.set_head_options(loss, output_keep)
         self._loss = torch.zeros(2, dtype=torch.float32, device=self.device)
         self._grad_tensor = None
         self.gradient_tensor()          # gradients always live in a torch tensor (all-reduce payload)
@@ -116,7 +126,7 @@ class MLPEmulator:
         self.stop_training = False
         if seed is not None:
             self.set_weights(glorot_uniform_weights(input_length, self.units, output_length_lin,
-                                                    output_length_relu, seed))
+                                                    output_length_relu, seed, self.direct_head))
 
     # ---- lifetime
     def close(self):
@@ -137,13 +147,27 @@ class MLPEmulator:
     def count_params(self) -> int:
         return self._n_params
 
+    def set_head_options(self, loss: str = "mse", output_keep=None):
+        """Training loss and output pruning (cs_mlp_set_head_options): `output_keep` holds 1 for the output columns
+        the model produces and 0 for the ones forced to zero (MLP_v2rh/training/mlp.py:56-61)."""
+        if loss not in _lib.LOSS:
+            raise ValueError(f"loss must be one of {list(_lib.LOSS)}")
+        keep = None
+        if output_keep is not None:
+            keep = np.ascontiguousarray(output_keep, dtype=np.float32)
+            if keep.shape != (self.output_length,):
+                raise ValueError(f"output_keep must have {self.output_length} entries")
+        _lib.check(self.lib.cs_mlp_set_head_options(self._h, _lib.LOSS[loss], keep.ctypes.data_as(C.c_void_p) if keep is not None else None,
+                                                    0 if keep is None else keep.size))
+        self.loss_name, self.output_keep = loss, keep
+
     def _shapes(self):
-        dims = [self.input_length, *self.units, self.output_length]
+        dims = [self.input_length, *self.units] + ([] if self.direct_head else [self.output_length])
         sh = []
         for i in range(len(dims) - 1):
             sh += [(dims[i], dims[i + 1]), (dims[i + 1],)]
-        sh += [(self.output_length, self.output_length_lin), (self.output_length_lin,),
-               (self.output_length, self.output_length_relu), (self.output_length_relu,)]
+        sh += [(dims[-1], self.output_length_lin), (self.output_length_lin,),
+               (dims[-1], self.output_length_relu), (self.output_length_relu,)]
         return sh
 
     def _split(self, flat):

@@ -34,7 +34,13 @@ typedef enum { CS_OK = 0, CS_ERR_INVALID = -1, CS_ERR_HIP = -2, CS_ERR_NOMEM = -
 /* keras.layers.ReLU / ELU / LeakyReLU(alpha) - step2_retrain.py:104-110 */
 typedef enum { CS_ACT_RELU = 0, CS_ACT_ELU = 1, CS_ACT_LEAKYRELU = 2 } cs_act;
 /* keras.optimizers.Adam / tfa RectifiedAdam / keras RMSprop / SGD - step2_retrain.py:150-157 */
-typedef enum { CS_OPT_ADAM = 0, CS_OPT_RADAM = 1, CS_OPT_RMSPROP = 2, CS_OPT_SGD = 3 } cs_opt;
+typedef enum { CS_OPT_ADAM = 0, CS_OPT_RADAM = 1, CS_OPT_RMSPROP = 2, CS_OPT_SGD = 3,
+               /* torch.optim.Adam(lr) - online_testing/baseline_models/MLP_v2rh/training/train_mlp_h5loader.py:210-211
+                * (bias corrections as Python doubles, eps added to sqrt(v)/sqrt(1-b2^t); default eps 1e-8) */
+               CS_OPT_ADAM_TORCH = 4 } cs_opt;
+/* compile(loss='mse') step2_retrain.py:160-162 | nn.MSELoss / nn.L1Loss / nn.SmoothL1Loss
+ * (train_mlp_h5loader.py:226-236); every one is a mean over batch x outputs */
+typedef enum { CS_LOSS_MSE = 0, CS_LOSS_MAE = 1, CS_LOSS_HUBER = 2 } cs_loss;
 
 #define CS_MAX_HIDDEN 16
 
@@ -63,6 +69,9 @@ typedef struct cs_mlp_cfg {
 #define CS_FLAG_CHAIN_BM128 8     /* force 128-row chain tiles                                             */
 #define CS_FLAG_CHAIN_BM32  16    /* force 32-row chain tiles                                              */
 #define CS_FLAG_GEMM_V1 64         /* per-layer path on the first (register-staged) GEMM kernels: A/B and parity runs */
+#define CS_FLAG_DIRECT_HEAD 128   /* online_testing MLP (MLP_v2rh/training/mlp.py:41-67): no Dense(output_length)+act between the
+                                     hidden stack and the heads - the output layer [n_out_lin linear || n_out_relu relu] sits on
+                                     the last hidden layer (torch `final_linear` + relu on the last 8 columns)              */
 #define CS_FLAG_CHAIN_BWD32_ON_FWD64 32   /* tests: 64-row forward tiles (with CHAIN_BM64), 32-row backward tiles    */
 
 /* keras.Model(...) + compile(): allocates weights (zero), optimiser state, workspace. */
@@ -75,6 +84,13 @@ int64_t cs_mlp_num_params(const cs_mlp_t* h);
  * (data_utils.py:807-809, :894-897).  Host pointers, copied.  Only used when a call passes
  * normalise != 0; the .npy splits of save_as_npy are already normalised. */
 int cs_mlp_set_norm(cs_mlp_t* h, const float* input_sub, const float* input_div);
+
+/* Loss the gradients are taken of (default CS_LOSS_MSE) and output pruning: keep_host[n_out] (n = n_out) holds 1 for
+ * the output columns the model produces and 0 for the ones it forces to zero - `x[:, 60:60+strato_lev_out] = 0` ... in
+ * MLP.forward (online_testing/baseline_models/MLP_v2rh/training/mlp.py:56-61); pruned columns stay in the loss mean
+ * with prediction 0 and pass no gradient.  keep_host == NULL: no pruning.  With CS_LOSS_HUBER the first loss sum
+ * (loss_sums[0]) is the sum of SmoothL1 terms instead of squared errors; loss_sums[1] is always the sum of |e|. */
+int cs_mlp_set_head_options(cs_mlp_t* h, int loss_kind, const float* keep_host, int64_t n);
 
 /* model.set_weights / model.get_weights: one flat float32 host buffer in Keras order
  * [W0(in,out), b0, ..., W_up(.,128), b_up, W_lin(128,120), b_lin, W_relu(128,8), b_relu].
