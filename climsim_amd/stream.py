@@ -1,0 +1,126 @@
+"""Streamed training from raw timestep fields (BASELINE config 5: high-res 21,600-column grids).
+
+The reference trains from files through `data_utils.load_ncdata_with_generator` -> `tf.data` `shuffle(buffer)` ->
+`batch` -> `prefetch` (baseline_models/MLP/training/HPO/baseline_v1/step2_retrain/step2_retrain.py:266-277; generator
+`climsim_utils/data_utils.py:791-881`): a producer fills a buffer of loaded timesteps while the model consumes batches
+drawn from it.  Here the producer is the device loader (`cs_loader_stack`, one HBM-bound kernel that does tendencies,
+normalisation, inf/nan -> 0, stacking and the float32 cast for a CHUNK of timesteps) on a side HIP stream, the consumer
+is the training step on the main stream, and the buffer is a ring of `slots` chunks in HBM: while the engine trains on
+chunk k (batches drawn from a permutation of its rows, gathered inside the first kernel), chunk k+1 is being produced.
+Raw chunks may be host arrays (pinned staging + asynchronous copy on the side stream) or device tensors (a raw shard
+resident in HBM, the high-res layout of SURVEY section 8d).  Under data parallelism every rank streams its own
+timesteps; the step is `DataParallel.train_step`'s (one all-reduce of the flat gradient).
+
+PyTorch provides streams, events and memory only; there is no CPU execution path.
+"""
+from __future__ import annotations
+
+from typing import Callable, Iterable, Optional
+
+import numpy as np
+
+
+class StreamedTrainer:
+    def __init__(self, model, loader, batch_size: int, slots: int = 2, dist=None):
+        import torch
+        if slots < 2:
+            raise ValueError("need at least two chunk slots (one being produced while one is consumed)")
+        if batch_size > model.max_batch:
+            raise ValueError(f"batch {batch_size} exceeds the engine's max_batch {model.max_batch}")
+        self.torch, self.model, self.loader, self.batch, self.slots = torch, model, loader, int(batch_size), int(slots)
+        self.device = model.device
+        self.side = torch.cuda.Stream(device=self.device)
+        self.dist = dist
+        self.world = dist.get_world_size() if dist is not None else 1
+        self.rows_seen = 0
+
+    # ---- producer (side stream)
+    def _produce(self, raw, free_event):
+        torch = self.torch
+        mli, mlo = raw
+        with torch.cuda.stream(self.side):
+            if free_event is not None:
+                self.side.wait_event(free_event)             # the slot's previous chunk has been consumed
+            def dev(a):
+                if isinstance(a, np.ndarray):
+                    a = torch.from_numpy(np.ascontiguousarray(a)).pin_memory()
+                    return a.to(self.device, non_blocking=True)
+                return a
+            x, y = self.loader.stack_raw(dev(mli), dev(mlo))
+            ready = torch.cuda.Event()
+            ready.record(self.side)
+        main = torch.cuda.current_stream(self.device)
+        x.record_stream(main)
+        y.record_stream(main)
+        return x, y, ready
+
+    # ---- consumer (main stream)
+    def _consume(self, x, y, ready, lr_of_step: Callable[[int], float], gen, passes: int, step0: int):
+        torch = self.torch
+        main = torch.cuda.current_stream(self.device)
+        main.wait_event(ready)
+        n = x.shape[0]
+        step = step0
+        # one [sum sq err, sum abs err] slot per step: the engine writes them, nothing is launched to add them up
+        sums = torch.zeros((passes * ((n + self.batch - 1) // self.batch), 2), dtype=torch.float32, device=self.device)
+        self._sums.append(sums)
+        k = 0
+        for _ in range(passes):
+            perm = torch.randperm(n, device=self.device, generator=gen)
+            for lo in range(0, n, self.batch):
+                idx = perm[lo:lo + self.batch]
+                lr = lr_of_step(step)
+                if self.dist is None:
+                    self.model.train_on_batch(x, y, lr, row_idx=idx, loss=sums[k])
+                else:
+                    self.model.loss_grads(x, y, row_idx=idx, loss=sums[k])
+                    self.dist.all_reduce(self.model.gradient_tensor())            # the ONE collective of the step
+                    self.model.apply_gradients(lr, 1.0 / (self.model.output_length * idx.numel() * self.world))
+                step += 1
+                k += 1
+        done = torch.cuda.Event()
+        done.record(main)
+        self.rows_seen += n * passes
+        return done, step
+
+    def fit_chunks(self, chunks: Iterable, learning_rate=1e-3, passes_per_chunk: int = 1, seed: int = 0):
+        """Train on a stream of raw chunks `(mli_raw (T, n_in, ncol), mlo_raw (T, n_out, ncol))`.
+        `learning_rate`: float or callable(step).  Returns {'loss', 'mae', 'rows', 'steps'} of the pass (means over the
+        rows seen; one host synchronisation at the end)."""
+        torch = self.torch
+        lr_of_step = learning_rate if callable(learning_rate) else (lambda s, v=float(learning_rate): v)
+        gen = torch.Generator(device=self.device)
+        gen.manual_seed(seed)
+        self._sums = []
+        self.rows_seen = 0
+        it = iter(chunks)
+        ring = []                                  # [(x, y, ready)] produced, not yet consumed
+        free = []                                  # `done` events of consumed chunks, oldest first
+        step = step_start = self.model.iterations
+        produced = 0
+
+        def produce_one():
+            nonlocal produced
+            raw = next(it, None)
+            if raw is None:
+                return False
+            ev = free.pop(0) if produced >= self.slots else None
+            ring.append(self._produce(raw, ev))
+            produced += 1
+            return True
+
+        for _ in range(self.slots - 1):            # fill the ring but one slot
+            if not produce_one():
+                break
+        while True:
+            produce_one()                          # next chunk goes out on the side stream ...
+            if not ring:
+                break
+            x, y, ready = ring.pop(0)
+            done, step = self._consume(x, y, ready, lr_of_step, gen, passes_per_chunk, step)   # ... while this one trains
+            free.append(done)
+            del x, y
+        s = np.sum([t.cpu().numpy().astype(np.float64).sum(axis=0) for t in self._sums], axis=0) if self._sums else np.zeros(2)
+        self._sums = []
+        denom = max(self.rows_seen, 1) * self.model.output_length
+        return {"loss": float(s[0]) / denom, "mae": float(s[1]) / denom, "rows": self.rows_seen, "steps": step - step_start}

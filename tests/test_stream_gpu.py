@@ -1,0 +1,56 @@
+"""Streamed training (climsim_amd/stream.py): raw timestep chunks -> device loader on a side stream -> training steps
+on the main stream, double-buffered.  The result must be the training you get by materialising every chunk first and
+stepping through the same permutations (float atomics in the weight gradients: 1e-3)."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from test_loader_cpu import make, raw_tree  # noqa: E402,F401
+
+
+def test_streamed_training_equals_materialised_training(raw_tree, lowres_assets):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from climsim_amd import build
+    build.build()
+    from climsim_amd.loader import GpuColumnLoader
+    from climsim_amd.mlp import MLPEmulator
+    from climsim_amd.stream import StreamedTrainer
+    root, _ = raw_tree
+    du = make(lowres_assets, "pytorch", root)
+    ld = GpuColumnLoader(du)
+    files = du.get_filelist("train")
+    raws = [ld.read_raw(f) for f in files]
+    # four chunks: host arrays (pinned staging path) and device tensors (HBM-resident raw shard), T = 1 or 2 timesteps
+    chunks = [(raws[0][0][None], raws[0][1][None]),
+              (torch.from_numpy(raws[1][0][None]).cuda(), torch.from_numpy(raws[1][1][None]).cuda()),
+              (np.stack([raws[2][0], raws[0][0]]), np.stack([raws[2][1], raws[0][1]])),
+              (raws[1][0][None], raws[1][1][None])]
+    B, LR = 128, 1e-3
+
+    a = MLPEmulator(units=(128, 128), max_batch=B, seed=3)
+    st = StreamedTrainer(a, ld, batch_size=B, slots=2)
+    out = st.fit_chunks(iter(chunks), learning_rate=LR, passes_per_chunk=2, seed=11)
+    rows = sum(c[0].shape[0] * c[0].shape[2] for c in chunks)
+    assert out["rows"] == 2 * rows and out["steps"] == 2 * sum(-(-c[0].shape[0] * 384 // B) for c in chunks) == a.iterations
+
+    b = MLPEmulator(units=(128, 128), max_batch=B, seed=3)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(11)
+    tot = np.zeros(2)
+    for mli, mlo in chunks:
+        x, y = ld.stack_raw(mli, mlo)
+        for _ in range(2):
+            perm = torch.randperm(x.shape[0], device="cuda", generator=gen)
+            for lo in range(0, x.shape[0], B):
+                tot += b.train_on_batch(x, y, LR, row_idx=perm[lo:lo + B]).cpu().numpy()
+    for wa, wb in zip(a.get_weights(), b.get_weights()):
+        np.testing.assert_allclose(wa, wb, rtol=0, atol=1e-3 * max(1.0, float(np.abs(wb).max())))
+    assert abs(out["loss"] - tot[0] / (2 * rows * 128)) <= 1e-3 * tot[0] / (2 * rows * 128)
+
+    with pytest.raises(ValueError):
+        StreamedTrainer(a, ld, batch_size=B, slots=1)
+    with pytest.raises(ValueError):
+        StreamedTrainer(a, ld, batch_size=4 * B)
