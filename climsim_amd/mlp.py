@@ -389,22 +389,21 @@ class MLPEmulator:
             writer = csv.writer(f)
             if new:
                 writer.writerow(["epoch", *history.keys()])
-        epoch_sum = torch.zeros(2, dtype=torch.float32, device=self.device)
-        step_loss = torch.zeros(2, dtype=torch.float32, device=self.device)
         self.stop_training = False
         for epoch in range(epochs):
             gen.manual_seed(seed + epoch)            # identical permutation on every rank
             perm = torch.randperm(n, device=self.device, generator=gen) if shuffle else torch.arange(n, device=self.device)
-            epoch_sum.zero_()
             lr = sched(self.iterations)
+            # one [sum sq err, sum abs err] slot per step, written by the engine: nothing is launched to add them up
+            step_loss = torch.zeros((steps, 2), dtype=torch.float32, device=self.device)
             for s in range(steps):
                 lr = sched(self.iterations)
                 if distributed:
-                    dp.train_step(x, y, perm, s, batch_size, lr, loss=step_loss, normalise=normalise)
+                    dp.train_step(x, y, perm, s, batch_size, lr, loss=step_loss[s], normalise=normalise)
                 else:
                     idx = shard_of_batch(perm, s, batch_size, 0, 1)
-                    self.train_on_batch(x, y, lr, row_idx=idx, normalise=normalise, loss=step_loss)
-                epoch_sum += step_loss
+                    self.train_on_batch(x, y, lr, row_idx=idx, normalise=normalise, loss=step_loss[s])
+            epoch_sum = step_loss.sum(dim=0)
             if distributed:
                 dist.all_reduce(epoch_sum)
             tr = epoch_sum.cpu().numpy().astype(np.float64) / (self.output_length * batch_size * steps)

@@ -180,11 +180,11 @@ class MLP:
         lr = learning_rate
         for ep in range(epochs):
             perm = torch.randperm(x.shape[0], device=self.engine.device, generator=gen)
-            acc = torch.zeros(2, dtype=torch.float32, device=self.engine.device)
-            for lo in range(0, x.shape[0], batch_size):
-                idx = perm[lo:lo + batch_size]
-                acc += self.engine.train_on_batch(x, y, lr, row_idx=idx)
-            hist["loss"].append(self._loss_from_sums(acc, x.shape[0]))
+            nsteps = (x.shape[0] + batch_size - 1) // batch_size
+            sums = torch.zeros((nsteps, 2), dtype=torch.float32, device=self.engine.device)   # one slot per step, written by the engine
+            for k, lo in enumerate(range(0, x.shape[0], batch_size)):
+                self.engine.train_on_batch(x, y, lr, row_idx=perm[lo:lo + batch_size], loss=sums[k])
+            hist["loss"].append(self._loss_from_sums(sums.sum(dim=0), x.shape[0]))
             hist["lr"].append(lr)
             vl = self.evaluate(*validation_data) if validation_data is not None else None
             hist["val_loss"].append(vl)
