@@ -124,6 +124,13 @@ def cnn_side_bench(batch=512, steps=10):
     return out
 
 
+def stream_side_bench():
+    """BASELINE config 5 on one GPU: cfg-MLP trained from raw high-res-shaped fields through the device loader (bench_stream.py)."""
+    import bench_stream
+    r = bench_stream.run(4, 8, 8192)
+    return {k: r[k] for k in ("workload", "value", "unit", "train_only_columns_per_s", "loader_only_columns_per_s", "serial_sum_columns_per_s")}
+
+
 def loader_side_bench(steps=16, ncol=21600):
     """Device loader on high-res-shaped timesteps (float64 raw fields in HBM -> normalised float32 rows)."""
     import types
@@ -296,6 +303,7 @@ def main():
         torch.cuda.empty_cache()
         extras["cnn"] = side_bench(cnn_side_bench)
         extras["loader"] = side_bench(loader_side_bench)
+        extras["stream"] = side_bench(stream_side_bench)
 
     if rank == 0:
         out = {"metric": "training columns/sec", "value": round(value, 1), "unit": "columns/s",

@@ -17,67 +17,71 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tes
 from climsim_amd import build  # noqa: E402
 
 build.build()
+
 from climsim_amd.assets import load_grid_info, load_npz_assets  # noqa: E402
 from climsim_amd.data_utils import data_utils  # noqa: E402
 from climsim_amd.loader import GpuColumnLoader  # noqa: E402
 from climsim_amd.mlp import MLPEmulator  # noqa: E402
 from climsim_amd.stream import StreamedTrainer  # noqa: E402
 
-NCH = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-T = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-B = int(sys.argv[3]) if len(sys.argv) > 3 else 8192
 NCOL = 21600
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden")
-grid = load_grid_info(os.path.join(G, "grid_lowres.npz"))
-sets = [load_npz_assets(os.path.join(G, "norm_lowres.npz"), k) for k in ("input_mean", "input_max", "input_min", "output_scale")]
-du = data_utils(grid, *sets, ml_backend="pytorch")
-du.set_to_v1_vars()
-ld = GpuColumnLoader(du)
-dev = torch.device("cuda")
-g = torch.Generator(device=dev).manual_seed(0)
-sub, div = ld._sub, ld._div
-# raw fields whose normalised values look like training data: x = sub + div * N(0, 0.15); next-step state close to it
-chunks = []
-for c in range(NCH):
-    mli = (sub[None, :, None] + div[None, :, None] * 0.15 * torch.randn((T, ld.n_in, NCOL), device=dev, dtype=torch.float64, generator=g))
-    # targets of size ~0.05 after scaling: state(t+1) = state(t) + 1200 s * tendency, surface fields = value / scale
-    mlo = 0.05 * torch.randn((T, ld.n_out, NCOL), device=dev, dtype=torch.float64, generator=g) / ld._scale[None, :, None]
-    mlo[:, :120] = mli[:, :120] + 1200.0 * mlo[:, :120]
-    mlo[:, 120:] = mlo[:, 120:].abs()
-    chunks.append((mli.contiguous(), mlo.contiguous()))
-rows = NCH * T * NCOL
 
 
-def timed(fn):
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    fn()
-    torch.cuda.synchronize()
-    return time.perf_counter() - t0
+def run(nch=8, T=8, B=8192):
+    grid = load_grid_info(os.path.join(G, "grid_lowres.npz"))
+    sets = [load_npz_assets(os.path.join(G, "norm_lowres.npz"), k) for k in ("input_mean", "input_max", "input_min", "output_scale")]
+    du = data_utils(grid, *sets, ml_backend="pytorch")
+    du.set_to_v1_vars()
+    ld = GpuColumnLoader(du)
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(0)
+    sub, div = ld._sub, ld._div
+    # raw fields whose normalised values look like training data: x = sub + div * N(0, 0.15); next-step state close to it
+    chunks = []
+    for c in range(nch):
+        mli = (sub[None, :, None] + div[None, :, None] * 0.15 * torch.randn((T, ld.n_in, NCOL), device=dev, dtype=torch.float64, generator=g))
+        # targets of size ~0.05 after scaling: state(t+1) = state(t) + 1200 s * tendency, surface fields = value / scale
+        mlo = 0.05 * torch.randn((T, ld.n_out, NCOL), device=dev, dtype=torch.float64, generator=g) / ld._scale[None, :, None]
+        mlo[:, :120] = mli[:, :120] + 1200.0 * mlo[:, :120]
+        mlo[:, 120:] = mlo[:, 120:].abs()
+        chunks.append((mli.contiguous(), mlo.contiguous()))
+    rows = nch * T * NCOL
+
+    def timed(fn):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    model = MLPEmulator(units=(512,) * 5, max_batch=B, seed=0)
+    st = StreamedTrainer(model, ld, batch_size=B, slots=2)
+    st.fit_chunks(iter(chunks[:2]), learning_rate=1e-3)                       # warm-up
+    res = {}
+    t_stream = timed(lambda: res.update(st.fit_chunks(iter(chunks), learning_rate=1e-3, seed=1)))
+    # the two halves alone, same rows
+    xs = []
+    t_load = timed(lambda: xs.extend(ld.stack_raw(a, b) for a, b in chunks))
+    gen = torch.Generator(device=dev).manual_seed(1)
+
+    def train_only():
+        for x, y in xs:
+            perm = torch.randperm(x.shape[0], device=dev, generator=gen)
+            for lo in range(0, x.shape[0], B):
+                model.train_on_batch(x, y, 1e-3, row_idx=perm[lo:lo + B])
+
+    t_train = timed(train_only)
+    model.close()
+    return {"metric": "training columns/sec",
+            "workload": f"cfg-MLP streamed from raw high-res timesteps: {nch} chunks x {T} timesteps x {NCOL} columns, float64 raw fields in HBM, batch {B}",
+            "value": round(rows / t_stream, 1), "unit": "columns/s", "n_gpus": 1, "dtype": "bf16", "data": "synthetic",
+            "rows": rows, "steps": res["steps"], "loss": res["loss"],
+            "train_only_columns_per_s": round(rows / t_train, 1), "loader_only_columns_per_s": round(rows / t_load, 1),
+            "serial_sum_columns_per_s": round(rows / (t_train + t_load), 1),
+            "loader_share_hidden": round(1.0 - (t_stream - t_train) / t_load, 3)}
 
 
-model = MLPEmulator(units=(512,) * 5, max_batch=B, seed=0)
-st = StreamedTrainer(model, ld, batch_size=B, slots=2)
-st.fit_chunks(iter(chunks[:2]), learning_rate=1e-3)                       # warm-up
-res = {}
-t_stream = timed(lambda: res.update(st.fit_chunks(iter(chunks), learning_rate=1e-3, seed=1)))
-# the two halves alone, same rows
-xs = []
-t_load = timed(lambda: xs.extend(ld.stack_raw(a, b) for a, b in chunks))
-gen = torch.Generator(device=dev).manual_seed(1)
-
-
-def train_only():
-    for x, y in xs:
-        perm = torch.randperm(x.shape[0], device=dev, generator=gen)
-        for lo in range(0, x.shape[0], B):
-            model.train_on_batch(x, y, 1e-3, row_idx=perm[lo:lo + B])
-
-
-t_train = timed(train_only)
-print(json.dumps({"metric": "training columns/sec", "workload": f"cfg-MLP streamed from raw high-res timesteps: {NCH} chunks x {T} timesteps x {NCOL} columns, float64 raw fields in HBM, batch {B}",
-                  "value": round(rows / t_stream, 1), "unit": "columns/s", "n_gpus": 1, "dtype": "bf16", "data": "synthetic",
-                  "rows": rows, "steps": res["steps"], "loss": res["loss"],
-                  "train_only_columns_per_s": round(rows / t_train, 1), "loader_only_columns_per_s": round(rows / t_load, 1),
-                  "serial_sum_columns_per_s": round(rows / (t_train + t_load), 1),
-                  "loader_share_hidden": round(1.0 - (t_stream - t_train) / t_load, 3)}))
+if __name__ == "__main__":
+    a = [int(v) for v in sys.argv[1:4]]
+    print(json.dumps(run(*a)))
