@@ -21,6 +21,7 @@ struct cs_cnn {
     u16 *A0 = nullptr, *X = nullptr, *A1 = nullptr, *R = nullptr, *XN = nullptr, *O10 = nullptr, *DZO = nullptr;
     float *wd = nullptr, *bd = nullptr;  // fused heads: [10][10], [10]
     u16* zeros = nullptr;                // zero page (k_conv2 fetches out-of-column rows from it)
+    int cw_waves = 8;                    // waves per workgroup of k_conv_wgrad2 (CS_CW2_WAVES=4: 128 x 112 wave tiles, measured slower)
     bool tile128 = false;                // CS_CNN_FLAG_TILE128: the 128x128 kernels everywhere (A/B and parity runs)
     int conv_ablate = 0;                 // CS_CONV_ABLATE (development)
     int cpw = 0;                         // contraction pad of the trunk channels (32- or 64-granular)
@@ -249,7 +250,9 @@ int cs_cnn_create(cs_cnn_t** out, const cs_cnn_cfg* cfg) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv2<CONV_PREDICT>), hipFuncAttributeMaxDynamicSharedMemorySize, CV2_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv2<CONV_TRAIN_FWD>), hipFuncAttributeMaxDynamicSharedMemorySize, CV2_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv2<CONV_BWD>), hipFuncAttributeMaxDynamicSharedMemorySize, CV2_LDS_BYTES));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wgrad2), hipFuncAttributeMaxDynamicSharedMemorySize, CW2_LDS_BYTES));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wgrad2<8>), hipFuncAttributeMaxDynamicSharedMemorySize, CW2_LDS_BYTES));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wgrad2<4>), hipFuncAttributeMaxDynamicSharedMemorySize, CW2_LDS_BYTES));
+    if (const char* e = getenv("CS_CW2_WAVES")) h->cw_waves = atoi(e) == 4 ? 4 : 8;
     {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, cfg->device));
@@ -509,7 +512,8 @@ int cs_cnn_loss_grads(cs_cnn_t* h, const float* x_dev, int x3d, const float* y_d
         splits = std::max(1, std::min(splits, ca.slabs / 8 > 0 ? ca.slabs / 8 : 1));
         ca.splits = splits;
         const int grid = ca.n_tiles * splits;
-        hipLaunchKernelGGL(k_conv_wgrad2, dim3((unsigned)grid), dim3(512), CW2_LDS_BYTES, st, ca);
+        if (h->cw_waves == 8) hipLaunchKernelGGL(k_conv_wgrad2<8>, dim3((unsigned)grid), dim3(512), CW2_LDS_BYTES, st, ca);
+        else hipLaunchKernelGGL(k_conv_wgrad2<4>, dim3((unsigned)grid), dim3(256), CW2_LDS_BYTES, st, ca);
     }
     ConvWgradArgs wa{};
     wa.items = h->items_dev; wa.n_items = h->n_items; wa.m_rows = m_rows; wa.m_pad = m_pad; wa.seq = seq;

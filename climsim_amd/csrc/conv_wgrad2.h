@@ -55,7 +55,15 @@ __device__ __forceinline__ bf16x8_t frag_cw(const u16* tile, int mb, int cb, int
     return u.v;
 }
 
-__global__ __launch_bounds__(512) void k_conv_wgrad2(const CwArgs pa) {
+// NW = 8 (built in): waves of 64(kk) x 112(n), 112 accumulator registers, two waves per SIMD.  NW = 4 (CS_CW2_WAVES=4):
+// waves of 128 x 112, 224 accumulators in AGPRs, one wave per SIMD.  The wide tiling reads 60 KiB of fragments out of
+// LDS per 32-row slab instead of 88 KiB (next to the 32 KiB the DMA writes; 736 vs 960 clocks of LDS time against 896
+// clocks of MFMA), which looked like the bound - but it measured SLOWER (step 4.50 vs 4.24 ms at batch 512): with one
+// wave per SIMD nothing covers the LDS latency between a fragment reload and its next MFMA.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void k_conv_wgrad2(const CwArgs pa) {
+    constexpr int IT = 32 / NW;              // 16-row kk tiles per wave (256 / (NW/2) rows)
+    constexpr int PP = 16 / NW;              // 1-KiB DMA pieces per operand, wave and slab
     extern __shared__ __attribute__((aligned(16))) u16 cw_ring[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -76,7 +84,7 @@ __global__ __launch_bounds__(512) void k_conv_wgrad2(const CwArgs pa) {
     const CwTile T = pa.tiles[tile_u];
 
     // ---- DMA side.  A 1-KiB piece = 2 rows of 512 B; lane -> row lane>>5, physical chunk lane&31, which holds
-    // logical chunk (((p>>2) ^ (m&3)) << 2) | ((p&3) ^ 2*((m>>3)&1)) (swz_cw).  Pieces 2*wid, 2*wid+1 of each operand per wave.
+    // logical chunk (((p>>2) ^ (m&3)) << 2) | ((p&3) ^ 2*((m>>3)&1)) (swz_cw).  Pieces PP*wid .. PP*wid+PP-1 of each operand per wave.
     // Per-lane running state (pointers, level) advances by one 32-row slab per issue: the loop carries no
     // division, no 64-bit multiply and no global load (whose vmcnt wait would drain the DMA ring).  Issues past
     // the end of the range simply prefetch rows nobody reads (rows past the batch come from the zero page).
@@ -84,62 +92,61 @@ __global__ __launch_bounds__(512) void k_conv_wgrad2(const CwArgs pa) {
     // product is sum_m dZ[m][n], the bias gradient, computed by the MFMAs instead of ~120 VALU ops per slab.
     typedef u16 __attribute__((address_space(3))) * lds_p;
     const unsigned lds0 = (unsigned)(uintptr_t)((lds_p)cw_ring);
-    const unsigned my_piece = __builtin_amdgcn_readfirstlane((unsigned)(2 * wid) * 1024u);
+    const unsigned my_piece = __builtin_amdgcn_readfirstlane((unsigned)(PP * wid) * 1024u);
     const char* zpage = reinterpret_cast<const char*>(pa.zeros);
     const char* opage = zpage + 64;                                   // {1.0, 0, 0, 0, 0, 0, 0, 0} bf16
     const int prow = lane >> 5, pch = lane & 31;
     const int64_t ldh2 = (int64_t)T.ldh * 2, ldz2 = (int64_t)T.ldz * 2;
     const int linc = 32 % pa.seq;
-    const char *hp0, *hp1, *zp0, *zp1;       // source of row m + shift (H) / row m (Z) of the next slab to issue
-    int mi0, mi1, lv0, lv1;                  // that row m and its level + shift
-    int hk0, hk1;                            // 0 real channel chunk, 1 ones chunk, 2 beyond the taps (zero)
-#define CW2_INIT(j, hp, zp, mi, lv, hk)                                                                \
-    {                                                                                                   \
-        const int ml_ = 2 * (2 * wid + (j)) + prow;                                                     \
-        const int lc_ = ((((pch >> 2) ^ (ml_ & 3)) << 2) | ((pch & 3) ^ (((ml_ >> 3) & 1) << 1))) * 8;  \
-        const int kk_ = T.k0 + lc_;                                                                     \
-        const int tap_ = kk_ / T.kpt, c_ = kk_ - tap_ * T.kpt;                                          \
-        const int sh_ = (T.taps == 3 && tap_ < 3) ? tap_ - 1 : 0;                                       \
-        hk = tap_ < T.taps ? 0 : (kk_ == T.taps * T.kpt ? 1 : 2);                                       \
-        mi = s0 * 32 + ml_;                                                                             \
-        lv = mi % pa.seq + sh_;                                                                         \
-        hp = reinterpret_cast<const char*>(T.H + c_) + (int64_t)(mi + sh_) * ldh2;                      \
-        zp = reinterpret_cast<const char*>(T.Z + T.n0 + lc_) + (int64_t)mi * ldz2;                      \
-        lvhi_##j = pa.seq + sh_;                                                                        \
+    const char *hp[PP], *zp[PP];             // source of row m + shift (H) / row m (Z) of the next slab to issue
+    int mi[PP], lv[PP];                      // that row m and its level + shift; lv lives in [shift, seq + shift), valid iff 0 <= lv < seq
+    int hk[PP], lvhi[PP];                    // 0 real channel chunk, 1 ones chunk, 2 beyond the taps (zero)
+#pragma unroll
+    for (int j = 0; j < PP; ++j) {
+        const int ml_ = 2 * (PP * wid + j) + prow;
+        const int lc_ = ((((pch >> 2) ^ (ml_ & 3)) << 2) | ((pch & 3) ^ (((ml_ >> 3) & 1) << 1))) * 8;
+        const int kk_ = T.k0 + lc_;
+        const int tap_ = kk_ / T.kpt, c_ = kk_ - tap_ * T.kpt;
+        const int sh_ = (T.taps == 3 && tap_ < 3) ? tap_ - 1 : 0;
+        hk[j] = tap_ < T.taps ? 0 : (kk_ == T.taps * T.kpt ? 1 : 2);
+        mi[j] = s0 * 32 + ml_;
+        lv[j] = mi[j] % pa.seq + sh_;
+        hp[j] = reinterpret_cast<const char*>(T.H + c_) + (int64_t)(mi[j] + sh_) * ldh2;
+        zp[j] = reinterpret_cast<const char*>(T.Z + T.n0 + lc_) + (int64_t)mi[j] * ldz2;
+        lvhi[j] = pa.seq + sh_;
     }
-    int lvhi_0, lvhi_1;                      // lv = level + shift lives in [shift, seq + shift); valid iff 0 <= lv < seq
-    CW2_INIT(0, hp0, zp0, mi0, lv0, hk0)
-    CW2_INIT(1, hp1, zp1, mi1, lv1, hk1)
-#undef CW2_INIT
-#define CW2_PIECE(hp, zp, mi, lv, hk, lvhi, dst)                                                      \
+    // sources of piece j of the next slab to issue (hs, zs), then advance the running state by one slab
+#define CW2_SRC(j, hs, zs)                                                                             \
     {                                                                                                   \
-        const bool in_ = mi < (int)pa.m_rows;                                                           \
-        const char* hs_ = hk == 0 ? ((in_ && lv >= 0 && lv < pa.seq) ? hp : zpage) : ((hk == 1 && in_) ? opage : zpage); \
-        const char* zs_ = in_ ? zp : zpage;                                                             \
-        dma16(hs_, (dst));                                                                              \
-        dma16(zs_, (dst) + 16384u);                                                                     \
-        hp += 32 * ldh2; zp += 32 * ldz2; mi += 32;                                                     \
-        lv += linc; if (lv >= lvhi) lv -= pa.seq;                                                       \
+        const bool in_ = mi[j] < (int)pa.m_rows;                                                        \
+        hs = hk[j] == 0 ? ((in_ && lv[j] >= 0 && lv[j] < pa.seq) ? hp[j] : zpage) : ((hk[j] == 1 && in_) ? opage : zpage); \
+        zs = in_ ? zp[j] : zpage;                                                                       \
+        hp[j] += 32 * ldh2; zp[j] += 32 * ldz2; mi[j] += 32;                                            \
+        lv[j] += linc; if (lv[j] >= lvhi[j]) lv[j] -= pa.seq;                                           \
     }
 #define CW2_ISSUE(slot)                                                                                \
     {                                                                                                   \
         const unsigned base_ = lds0 + (unsigned)(slot) * CW2_SLAB_BYTES + my_piece;                     \
-        CW2_PIECE(hp0, zp0, mi0, lv0, hk0, lvhi_0, base_)                                               \
-        CW2_PIECE(hp1, zp1, mi1, lv1, hk1, lvhi_1, base_ + 1024u)                                     \
+        _Pragma("unroll") for (int j = 0; j < PP; ++j) {                                                \
+            const char *hs_, *zs_;                                                                      \
+            CW2_SRC(j, hs_, zs_)                                                                        \
+            dma16(hs_, base_ + 1024u * j);                                                              \
+            dma16(zs_, base_ + 1024u * j + 16384u);                                                     \
+        }                                                                                               \
     }
 
-    f32x4_t acc[4][7];
+    f32x4_t acc[IT][7];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < IT; ++i)
 #pragma unroll
         for (int j = 0; j < 7; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
     // fragment offsets inside a slab (elements): transposing read of X[8*(l>>4) + 0..7][cb + (l&15)], see frag_cw
-    int fo_h[4], fo_z[7];
+    int fo_h[IT], fo_z[7];
     {
         const int mrow = 8 * (lane >> 4) + ((lane & 15) >> 2);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) fo_h[i] = swz_cw(mrow, wm * 64 + i * 16 + (lane & 3) * 4);
+        for (int i = 0; i < IT; ++i) fo_h[i] = swz_cw(mrow, wm * (16 * IT) + i * 16 + (lane & 3) * 4);
 #pragma unroll
         for (int j = 0; j < 7; ++j) fo_z[j] = 32 * 256 + swz_cw(mrow, wn * 112 + j * 16 + (lane & 3) * 4);
     }
@@ -159,28 +166,37 @@ __global__ __launch_bounds__(512) void k_conv_wgrad2(const CwArgs pa) {
     CW2_ISSUE(1)
     CW2_ISSUE(2)
     CW2_ISSUE(3)
-    bf16x8_t fh[4], fz[7];
-    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");           // first slab has landed (this wave's pieces)
+    bf16x8_t fh[IT], fz[7];
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * PP) : "memory");  // first slab has landed (this wave's pieces)
     __builtin_amdgcn_s_barrier();
 #pragma unroll
-    for (int i = 0; i < 4; ++i) CW2_FRAG(fh[i], cw_ring, fo_h[i])
+    for (int i = 0; i < IT; ++i) CW2_FRAG(fh[i], cw_ring, fo_h[i])
 #pragma unroll
     for (int j = 0; j < 7; ++j) CW2_FRAG(fz[j], cw_ring, fo_z[j])
     const int nsl = s1 - s0;
     for (int s = 0; s < nsl; ++s) {
-        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");   // slab s+1 landed; my reads of slab s are done
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(4 * PP) : "memory");   // slab s+1 landed; my reads of slab s are done
         __builtin_amdgcn_s_barrier();                                 // ... everyone's: slot s&3 is free
-        CW2_ISSUE(__builtin_amdgcn_readfirstlane(s & 3))
+        // The 2*PP 1-KiB DMA pieces of slab s+4 go out one at a time between the MFMA groups: issued together right
+        // after the barrier, the 32 pieces of the workgroup queue up in the CU's vector-memory pipe (16 clk each) and
+        // every wave sits in the issue of its last piece while its MFMAs wait.
+        const unsigned base_ = lds0 + (unsigned)__builtin_amdgcn_readfirstlane(s & 3) * CW2_SLAB_BYTES + my_piece;
+        const char *hs_[PP], *zs_[PP];
+#pragma unroll
+        for (int j = 0; j < PP; ++j) CW2_SRC(j, hs_[j], zs_[j])
         const u16* nx = cw_ring + ((s + 1) & 3) * (CW2_SLAB_BYTES / 2);
         // every fragment register is reloaded (from slab s+1) right after its last MFMA of slab s
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[i], fz[j], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < IT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[i], fz[j], acc[i][j], 0, 0, 0);
             CW2_FRAG(fz[j], nx, fo_z[j])
+#pragma unroll
+            for (int d = 0; d < 2 * PP; ++d)                          // piece d>>1, operand d&1, after MFMA group d*6/(2*PP)
+                if ((d * 6) / (2 * PP) == j) dma16((d & 1) ? zs_[d >> 1] : hs_[d >> 1], base_ + 1024u * (d >> 1) + ((d & 1) ? 16384u : 0u));
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < IT; ++i) {
             acc[i][6] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[i], fz[6], acc[i][6], 0, 0, 0);
             CW2_FRAG(fh[i], nx, fo_h[i])
         }
@@ -190,8 +206,8 @@ __global__ __launch_bounds__(512) void k_conv_wgrad2(const CwArgs pa) {
 
     // ---- flush the partial sums: D[kk][n], lane owns column n = ..+(lane&15), rows kk = ..+4*(lane>>4)+r
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int kb = T.k0 + wm * 64 + i * 16 + 4 * (lane >> 4);
+    for (int i = 0; i < IT; ++i) {
+        const int kb = T.k0 + wm * (16 * IT) + i * 16 + 4 * (lane >> 4);
         const int tap = kb / T.kpt, c = kb - tap * T.kpt;
         if (tap < T.taps) {
             float* row = T.dW + ((int64_t)tap * T.cin + c) * T.cout;
@@ -212,7 +228,7 @@ __global__ __launch_bounds__(512) void k_conv_wgrad2(const CwArgs pa) {
             }
         }
     }
-#undef CW2_PIECE
+#undef CW2_SRC
 #undef CW2_ISSUE
 #undef CW2_FRAG
 }
