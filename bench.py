@@ -186,10 +186,15 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    force_dist = os.environ.get("CS_BENCH_FORCE_DIST") == "1"     # development: run the N > 1 code path with a one-rank RCCL group
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if force_dist and world == 1:
+            os.environ.setdefault("MASTER_PORT", "29517")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     from climsim_amd import build
     if rank == 0:
@@ -213,14 +218,14 @@ def main():
     nb = args.rows // B
 
     from climsim_amd.dp import DataParallel
-    dp = DataParallel(model, dist if world > 1 else None)
+    dp = DataParallel(model, dist if (world > 1 or force_dist) else None)
     dp.broadcast_weights()
 
     def step(i):
         # every rank owns its own HBM-resident shard of the split, so its local batch is a slice of
         # its own permutation (equivalent to the round-robin deal of a global permutation)
         idx = perm[(i % nb) * B:(i % nb + 1) * B]
-        if world > 1:
+        if world > 1 or force_dist:
             model.loss_grads(x, y, row_idx=idx, loss=loss)
             dist.all_reduce(grad)                                   # ONE RCCL all-reduce per step
             model.apply_gradients(lr, scale)
@@ -316,9 +321,24 @@ def main():
                "heldout": {"mse": held["mse"], "mae": held["mae"], "rows": 65536, "per_variable": per_var},
                "predict": {"columns_per_s": round(predict_cps, 1), "rows": n_pred, "batch": B},
                "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu, **extras}
-        print(json.dumps(out, allow_nan=False), flush=True)
+        line = json.dumps(out, allow_nan=False)
+
+    def flush_c_stdio():
+        # RCCL writes a version banner through C stdio; on a pipe it would otherwise come out at exit, BEHIND the result
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+
     if dist:
+        flush_c_stdio()                  # every rank empties its buffers before rank 0 prints
+        dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        flush_c_stdio()
+        print(line, flush=True)          # the JSON line is the last line of stdout
 
 
 if __name__ == "__main__":
