@@ -227,7 +227,7 @@ def main():
         idx = perm[(i % nb) * B:(i % nb + 1) * B]
         if world > 1 or force_dist:
             model.loss_grads(x, y, row_idx=idx, loss=loss)
-            dist.all_reduce(grad)                                   # ONE RCCL all-reduce per step
+            dp.all_reduce_grads()                                   # ONE RCCL all-reduce per step (cs_dp_allreduce, compute stream)
             model.apply_gradients(lr, scale)
         else:
             model.train_on_batch(x, y, lr, row_idx=idx, loss=loss)

@@ -54,6 +54,10 @@ SIGNATURES = {
     "cs_mlp_destroy": (None, [_P]),
     "cs_mlp_num_params": (_I64, [_P]),
     "cs_mlp_device_bytes": (_I64, [_P]),
+    "cs_dp_unique_id": (C.c_int, [C.c_char_p, _P]),
+    "cs_dp_init": (C.c_int, [C.POINTER(_P), C.c_char_p, _P, C.c_int, C.c_int, C.c_int]),
+    "cs_dp_allreduce": (C.c_int, [_P, _P, C.c_int64, _P]),
+    "cs_dp_destroy": (None, [_P]),
     "cs_mlp_set_norm": (C.c_int, [_P, _P, _P]),
     "cs_mlp_set_head_options": (C.c_int, [_P, C.c_int, _P, C.c_int64]),
     "cs_mlp_set_weights": (C.c_int, [_P, _P, _I64, _P]),

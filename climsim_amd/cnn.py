@@ -313,7 +313,7 @@ class CNNEmulator:
                 if distributed:
                     idx = shard_of_batch(perm, s, batch_size, rank, world)
                     self.loss_grads(x, y, row_idx=idx, loss=step_loss, x3d=x3d, y3d=y3d)
-                    dist.all_reduce(dp.grad)
+                    dp.all_reduce_grads()
                     self.apply_gradients(lr, 1.0 / (60 * batch_size))
                 else:
                     idx = shard_of_batch(perm, s, batch_size, 0, 1)

@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <string>
 #include <utility>
 #include <vector>
@@ -842,3 +843,81 @@ int cs_metrics_columns(const float* pred_dev, const float* target_dev, int64_t n
 }  // extern "C"
 
 #include "cnn_api.h"
+
+// ---------------------------------------------------------------------------------------------- data parallel (RCCL)
+namespace {
+struct RcclId { char internal[CS_DP_UNIQUE_ID_BYTES]; };          // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES = 128)
+struct RcclApi {
+    void* lib = nullptr;
+    int (*GetUniqueId)(RcclId*) = nullptr;                                            // ncclGetUniqueId
+    int (*CommInitRank)(void**, int, RcclId, int) = nullptr;                          // ncclCommInitRank (id by value)
+    int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;   // ncclAllReduce
+    int (*CommDestroy)(void*) = nullptr;                                              // ncclCommDestroy
+    const char* (*GetErrorString)(int) = nullptr;                                     // ncclGetErrorString
+};
+RcclApi g_rccl;
+
+int rccl_bind(const char* path) {
+    if (g_rccl.lib) return CS_OK;
+    const char* name = (path && *path) ? path : "librccl.so.1";
+    void* lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) return fail(CS_ERR_STATE, "cannot load RCCL (%s): %s", name, dlerror());
+    RcclApi a;
+    a.lib = lib;
+    a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
+    a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(lib, "ncclCommInitRank"));
+    a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(dlsym(lib, "ncclAllReduce"));
+    a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+    a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+    if (!a.GetUniqueId || !a.CommInitRank || !a.AllReduce || !a.CommDestroy)
+        return fail(CS_ERR_STATE, "%s does not export the RCCL entry points", name);
+    g_rccl = a;
+    return CS_OK;
+}
+int rccl_fail(const char* what, int rc) {
+    return fail(CS_ERR_HIP, "%s: RCCL error %d (%s)", what, rc, g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
+}
+}  // namespace
+
+struct cs_dp { void* comm = nullptr; int world = 1, rank = 0, device = 0; };
+
+extern "C" {
+
+int cs_dp_unique_id(const char* rccl_path, void* id_out) {
+    if (!id_out) return fail(CS_ERR_INVALID, "null argument");
+    if (int rc = rccl_bind(rccl_path)) return rc;
+    RcclId id;
+    if (int rc = g_rccl.GetUniqueId(&id)) return rccl_fail("ncclGetUniqueId", rc);
+    memcpy(id_out, id.internal, CS_DP_UNIQUE_ID_BYTES);
+    return CS_OK;
+}
+
+int cs_dp_init(cs_dp_t** out, const char* rccl_path, const void* id_bytes, int world, int rank, int device) {
+    if (!out || !id_bytes) return fail(CS_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (world < 1 || rank < 0 || rank >= world) return fail(CS_ERR_INVALID, "rank %d of %d", rank, world);
+    if (int rc = rccl_bind(rccl_path)) return rc;
+    HIP_TRY(hipSetDevice(device));
+    RcclId id;
+    memcpy(id.internal, id_bytes, CS_DP_UNIQUE_ID_BYTES);
+    cs_dp* c = new cs_dp();
+    c->world = world; c->rank = rank; c->device = device;
+    if (int rc = g_rccl.CommInitRank(&c->comm, world, id, rank)) { delete c; return rccl_fail("ncclCommInitRank", rc); }
+    *out = c;
+    return CS_OK;
+}
+
+int cs_dp_allreduce(cs_dp_t* c, float* buf, int64_t n, void* stream) {
+    if (!c || !c->comm || !buf || n <= 0) return fail(CS_ERR_INVALID, "bad argument");
+    if (int rc = g_rccl.AllReduce(buf, buf, (size_t)n, /*ncclFloat32*/ 7, /*ncclSum*/ 0, c->comm, (hipStream_t)stream))
+        return rccl_fail("ncclAllReduce", rc);
+    return CS_OK;
+}
+
+void cs_dp_destroy(cs_dp_t* c) {
+    if (!c) return;
+    if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
+    delete c;
+}
+
+}  // extern "C"

@@ -15,6 +15,49 @@ buffer, same deterministic update), so no parameter broadcast is needed after th
 """
 from __future__ import annotations
 
+import os
+
+
+class RcclComm:
+    """The native collective of the C ABI (`cs_dp_*`, include/climsim_hip.h): an RCCL communicator of the engine's own,
+    bootstrapped through the torch.distributed rendezvous (rank 0's unique id is broadcast), whose all-reduce is
+    issued on the stream the step's kernels run on - ordered with them without events or a second stream."""
+
+    def __init__(self, dist, device):
+        import ctypes as C
+        import numpy as np
+        import torch
+        from . import _lib
+        self._lib, self._check, self._C, self._torch = _lib.load(), _lib.check, C, torch
+        self.device = device
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        self._path = path.encode() if os.path.exists(path) else None          # the RCCL torch already loaded
+        idbuf = C.create_string_buffer(128)
+        if dist.get_rank() == 0:
+            self._check(self._lib.cs_dp_unique_id(self._path, idbuf))
+        t = torch.from_numpy(np.frombuffer(idbuf.raw, dtype=np.uint8).copy()).to(device)
+        dist.broadcast(t, src=0)
+        ident = C.create_string_buffer(t.cpu().numpy().tobytes(), 128)
+        self._c = C.c_void_p()
+        with torch.cuda.device(device):
+            self._check(self._lib.cs_dp_init(C.byref(self._c), self._path, ident, dist.get_world_size(), dist.get_rank(),
+                                             device.index if device.index is not None else torch.cuda.current_device()))
+
+    def all_reduce(self, tensor):
+        st = self._C.c_void_p(self._torch.cuda.current_stream(tensor.device).cuda_stream)
+        self._check(self._lib.cs_dp_allreduce(self._c, self._C.c_void_p(tensor.data_ptr()), tensor.numel(), st))
+
+    def close(self):
+        if getattr(self, "_c", None) is not None and self._c.value:
+            self._lib.cs_dp_destroy(self._c)
+            self._c = self._C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
 
 def shard_of_batch(perm, step: int, global_batch: int, rank: int, world: int):
     """Rows of global batch `step` owned by `rank`: a strided view of the epoch permutation."""
@@ -29,6 +72,22 @@ class DataParallel:
         self.rank = dist.get_rank() if dist is not None else 0
         self.output_length = output_length
         self.grad = engine.gradient_tensor()
+        # GPU runs take the engine's own RCCL communicator (collective on the compute stream); torch.distributed's
+        # all_reduce remains for CPU tensors (gloo tests), on request (CS_DP_NATIVE=0) and if the native setup fails
+        self.native = None
+        if dist is not None and getattr(self.grad, "is_cuda", False) and os.environ.get("CS_DP_NATIVE", "1") != "0":
+            try:
+                self.native = RcclComm(dist, self.grad.device)
+            except Exception as e:  # noqa: BLE001
+                import warnings
+                warnings.warn(f"native RCCL communicator unavailable ({e}); using torch.distributed.all_reduce")
+
+    def all_reduce_grads(self):
+        """The ONE collective of the step: SUM of the flat gradient buffer over all ranks, in place."""
+        if self.native is not None:
+            self.native.all_reduce(self.grad)
+        elif self.dist is not None:
+            self.dist.all_reduce(self.grad)
 
     def broadcast_weights(self):
         """Rank 0's weights to everyone (DDP's initial parameter broadcast)."""
@@ -52,7 +111,6 @@ class DataParallel:
             raise ValueError("global batch must be divisible by the world size")
         idx = shard_of_batch(perm, step, global_batch, self.rank, self.world)
         out = self.engine.loss_grads(x, y, row_idx=idx, loss=loss, normalise=normalise)
-        if self.dist is not None:
-            self.dist.all_reduce(self.grad)                       # the ONE collective of the step
+        self.all_reduce_grads()                                   # the ONE collective of the step
         self.engine.apply_gradients(lr, 1.0 / (self.output_length * global_batch))
         return out

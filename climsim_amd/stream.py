@@ -32,6 +32,10 @@ class StreamedTrainer:
         self.side = torch.cuda.Stream(device=self.device)
         self.dist = dist
         self.world = dist.get_world_size() if dist is not None else 1
+        self._dp = None
+        if dist is not None:
+            from .dp import DataParallel
+            self._dp = DataParallel(model, dist, model.output_length)
         self.rows_seen = 0
 
     # ---- producer (side stream)
@@ -74,7 +78,7 @@ class StreamedTrainer:
                     self.model.train_on_batch(x, y, lr, row_idx=idx, loss=sums[k])
                 else:
                     self.model.loss_grads(x, y, row_idx=idx, loss=sums[k])
-                    self.dist.all_reduce(self.model.gradient_tensor())            # the ONE collective of the step
+                    self._dp.all_reduce_grads()                                   # the ONE collective of the step
                     self.model.apply_gradients(lr, 1.0 / (self.model.output_length * idx.numel() * self.world))
                 step += 1
                 k += 1

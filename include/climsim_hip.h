@@ -233,6 +233,24 @@ int  cs_cnn_apply(cs_cnn_t* h, float lr, float grad_scale, void* stream);
 int  cs_cnn_train_step(cs_cnn_t* h, const float* x_dev, int x3d, const float* y_dev, int y3d, const int64_t* row_idx_dev,
                        int64_t n, float lr, float* loss_dev, void* stream);
 
+/* ---- data parallel: one all-reduce(SUM) of a flat float32 buffer over RCCL (xGMI), on the CALLER'S stream ----------
+ * The only gradient-synchronous training in the reference is torch DDP over NCCL
+ * (online_testing/baseline_models/MLP_v2rh/training/train_mlp_h5loader.py:195-207).  Here the collective is issued
+ * on the stream the step's kernels run on, so it is ordered with them without events or a second stream.
+ * The RCCL library is bound at run time (`rccl_path` = the librccl.so the process already uses, e.g. torch/lib/librccl.so;
+ * NULL: "librccl.so.1" from the loader path): libclimsim_hip.so itself has no link-time dependency on it.
+ *   rank 0:     cs_dp_unique_id(rccl_path, id)  ->  128 opaque bytes, handed to the other ranks by the launcher's
+ *               rendezvous (torch.distributed broadcast in climsim_amd/dp.py)
+ *   every rank: cs_dp_init(&comm, rccl_path, id, world, rank, device)       (collective)
+ *   every step: cs_dp_allreduce(comm, grad_dev, n, stream)                  (in place; grad_dev of cs_*_grad_buffer)
+ * A communicator is used from one host thread; destroy it before the device is reset. */
+typedef struct cs_dp cs_dp_t;
+#define CS_DP_UNIQUE_ID_BYTES 128
+int  cs_dp_unique_id(const char* rccl_path, void* id_out);
+int  cs_dp_init(cs_dp_t** comm, const char* rccl_path, const void* id, int world, int rank, int device);
+int  cs_dp_allreduce(cs_dp_t* comm, float* buf_dev, int64_t n_floats, void* stream);
+void cs_dp_destroy(cs_dp_t* comm);
+
 const char* cs_last_error(void);
 const char* cs_version(void);
 

@@ -48,3 +48,38 @@ def test_cnn_fit_distributed_runs(pg):
     m = CNNEmulator(depth=2, channel_width=64, max_batch=64, trainable=True, init_seed=1, seed=3)
     h = m.fit(x3, y3, batch_size=64, epochs=4, learning_rate=2e-3, distributed=True)
     assert h["loss"][-1] < 0.8 * h["loss"][0] and m.iterations == 16
+
+
+def test_native_rccl_communicator_through_the_c_abi(pg):
+    """cs_dp_* (include/climsim_hip.h): the engine's own RCCL communicator, collective issued on the compute stream.
+    One rank: the sum over the group is the buffer itself; DataParallel takes this path on the GPU."""
+    import ctypes as C
+    from climsim_amd import _lib
+    from climsim_amd.dp import DataParallel, RcclComm
+    from climsim_amd.mlp import MLPEmulator
+    comm = RcclComm(pg, torch.device("cuda", 0))
+    t = torch.arange(1000, dtype=torch.float32, device="cuda") * 0.5
+    ref = t.clone()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):                       # ordered with whatever stream is current, no events needed
+        t.mul_(2.0)
+        comm.all_reduce(t)
+        t.mul_(0.5)
+    side.synchronize()
+    assert torch.equal(t, ref)
+    lib = _lib.load()
+    h = C.c_void_p()
+    ident = C.create_string_buffer(128)
+    assert lib.cs_dp_init(C.byref(h), None, ident, 2, 5, 0) != 0 and b"rank 5 of 2" in lib.cs_last_error()
+    assert lib.cs_dp_allreduce(None, None, 0, None) != 0
+    comm.close()
+    m = MLPEmulator(units=(128,), max_batch=128, seed=1)
+    dp = DataParallel(m, pg)
+    assert dp.native is not None                        # the GPU path does not go through torch.distributed.all_reduce
+    x, y = O.synth_columns(128, seed=2)
+    xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    m.loss_grads(xd, yd)
+    g0 = m.gradient_tensor().clone()
+    dp.all_reduce_grads()
+    torch.cuda.synchronize()
+    assert torch.equal(m.gradient_tensor(), g0)
