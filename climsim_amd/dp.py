@@ -32,16 +32,29 @@ class RcclComm:
         self.device = device
         path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
         self._path = path.encode() if os.path.exists(path) else None          # the RCCL torch already loaded
+        # Every rank takes the same decision at every step of the setup (a rank that raised alone would leave the
+        # others waiting in a collective): rank 0's outcome travels with the id, the outcome of the init is agreed on.
         idbuf = C.create_string_buffer(128)
-        if dist.get_rank() == 0:
-            self._check(self._lib.cs_dp_unique_id(self._path, idbuf))
-        t = torch.from_numpy(np.frombuffer(idbuf.raw, dtype=np.uint8).copy()).to(device)
+        ok0 = 1
+        if dist.get_rank() == 0 and self._lib.cs_dp_unique_id(self._path, idbuf) != 0:
+            ok0 = 0
+        msg = np.concatenate([np.asarray([ok0], np.uint8), np.frombuffer(idbuf.raw, dtype=np.uint8)])
+        t = torch.from_numpy(msg.copy()).to(device)
         dist.broadcast(t, src=0)
-        ident = C.create_string_buffer(t.cpu().numpy().tobytes(), 128)
+        msg = t.cpu().numpy()
+        if msg[0] == 0:
+            raise _lib.EngineError("rank 0 could not create an RCCL unique id: " + self._lib.cs_last_error().decode())
+        ident = C.create_string_buffer(msg[1:].tobytes(), 128)
         self._c = C.c_void_p()
         with torch.cuda.device(device):
-            self._check(self._lib.cs_dp_init(C.byref(self._c), self._path, ident, dist.get_world_size(), dist.get_rank(),
-                                             device.index if device.index is not None else torch.cuda.current_device()))
+            rc = self._lib.cs_dp_init(C.byref(self._c), self._path, ident, dist.get_world_size(), dist.get_rank(),
+                                      device.index if device.index is not None else torch.cuda.current_device())
+        err = self._lib.cs_last_error().decode() if rc != 0 else ""
+        agreed = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+        if int(agreed.item()) == 0:
+            self.close()
+            raise _lib.EngineError("RCCL communicator setup failed on some rank" + (": " + err if err else ""))
 
     def all_reduce(self, tensor):
         st = self._C.c_void_p(self._torch.cuda.current_stream(tensor.device).cuda_stream)
