@@ -171,6 +171,8 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU-baseline timing (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event pass")
     ap.add_argument("--no-extras", action="store_true", help="skip the CNN / loader side figures")
+    ap.add_argument("--train-only", action="store_true", help="counter runs: nothing but the training steps (no held-out "
+                    "evaluation, no prediction pass), so that per-kernel averages are averages over training launches")
     args = ap.parse_args()
 
     import torch
@@ -252,6 +254,13 @@ def main():
     value = B * world * args.steps / elapsed
 
     # ---- untimed: held-out error of the model that was just trained, per-kernel timing, CPU baseline
+    if args.train_only:
+        if rank == 0:
+            print(json.dumps({"metric": "training columns/sec", "value": round(value, 1), "unit": "columns/s", "n_gpus": world,
+                              "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "train_only": True}), flush=True)
+        if dist:
+            dist.destroy_process_group()
+        return
     held = model.evaluate(xv, yv)
     per_var = None
     if rank == 0:
