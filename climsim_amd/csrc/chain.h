@@ -331,6 +331,7 @@ __device__ __forceinline__ void chain_stage(u16* X, const float* bias_lds, const
         // waves 4..7 (threads 256..511).  (The dword is picked AFTER the k-loop: a use here would make hipcc wait for
         // the load before the weight queue is primed.)
         if (remap) msk = S.mask[(int64_t)(blockIdx.x >> 1) * 512 + (S.Nc == 128 ? (tid & 255) + 256 * (blockIdx.x & 1) : tid)];
+        else if (BMROWS == 32) msk[0] = reinterpret_cast<const unsigned*>(S.mask)[(int64_t)blockIdx.x * 512 + tid];   // 32-row tiles: one word per thread
         else msk = *mptr;                                      // lands during the k-loop
     }
     // deep prefetch (8 steps = 16 KiB per wave in flight) where registers allow and the contraction is long enough
@@ -351,7 +352,12 @@ __device__ __forceinline__ void chain_stage(u16* X, const float* bias_lds, const
         chain_heads<MT>(bias_lds, tgt, p, S, m0, jt0, mrow0, lane, acc, sq, ab);
     } else {
         chain_epilogue<MT, NT, EPI, ELU>(X, bias_lds, p, S, last, m0, jt0, mrow0, lane, acc, msk);
-        if (EPI == EPI_HIDDEN && mptr) *mptr = msk;
+        if (EPI == EPI_HIDDEN && mptr) {
+            // a 32-row tile has 32 elements per thread: only word 0 carries bits, and only that word is stored
+            // (12.6 -> 3.1 MB of mask traffic per pass at 8192 columns); 64 / 128-row tiles store all four
+            if (BMROWS == 32) reinterpret_cast<unsigned*>(S.mask)[(int64_t)blockIdx.x * 512 + tid] = msk[0];
+            else *mptr = msk;
+        }
     }
     __syncthreads();                         // X now holds this stage's output
     if (EPI != EPI_OUT && S.out && !(p.ablate & (4 | 16))) {
