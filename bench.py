@@ -26,9 +26,9 @@ sys.path.insert(0, REPO)
 UNITS = (512, 512, 512, 512, 512)
 # algorithmic FLOP per column of each kernel kind; chain_* are the fused-layer forms
 FLOPS_PER_COL = {"gemm_fwd": 2 * 1_193_984, "gemm_dgrad": 2 * 1_130_496, "wgrad": 2 * 1_193_984,
-                 "chain_fwd": 2 * 1_193_984, "chain_bwd": 2 * 1_130_496}
+                 "chain_fwd": 2 * 1_193_984, "chain_bwd": 2 * 1_130_496, "chain_fb": 2 * (1_193_984 + 1_130_496)}
 KERNEL_NAMES = {"gemm_fwd": "k_gemm_nt<EPI_HIDDEN|EPI_OUT>", "gemm_dgrad": "k_gemm_nt<EPI_DGRAD>", "wgrad": "k_wgrad",
-                "chain_fwd": "k_chain<BM,false>", "chain_bwd": "k_chain<BM,true>"}
+                "chain_fwd": "k_chain<BM,false>", "chain_bwd": "k_chain<BM,true>", "chain_fb": "k_chain_fb<BM>"}
 TRAIN_FLOPS_PER_COL = 7_036_928
 HBM_BYTES_PER_COL = 1008                    # 496 B x + 512 B y (fp32 storage), SURVEY 8(d)
 PEAK_BF16_TFLOPS = 2500.0                   # dense MFMA peak, MI355X_MICROARCH.md

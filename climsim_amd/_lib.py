@@ -29,8 +29,8 @@ class CsMlpCfg(C.Structure):
                 ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double), ("rho", C.c_double)]
 
 
-CS_K_COUNT = 8
-KERNEL_KINDS = ["prepare_input", "gemm_fwd", "gemm_dgrad", "wgrad", "optimizer", "memset", "chain_fwd", "chain_bwd"]
+CS_K_COUNT = 9
+KERNEL_KINDS = ["prepare_input", "gemm_fwd", "gemm_dgrad", "wgrad", "optimizer", "memset", "chain_fwd", "chain_bwd", "chain_fb"]
 
 
 class CsKernelTimes(C.Structure):

@@ -59,6 +59,10 @@ struct ChainArgs {
     const float* keep;       // [output width] 1/0 per column (output pruning) or null
     int n_real;              // k_chainw: real output width (row pitch of yhat / y); the tuned chain is 128-wide only
     int mask_bm64;           // backward with 32-row tiles over sign masks written by a 64-row forward (see chain_stage)
+    // k_chain_fb (forward + backward in one launch)
+    int fused;               // forward half: dz of the heads also goes to LDS, loss scratch moves to the bias block;
+                             // backward half: no prologue load (dz is in X) and no L2 warm-up (a prefetch of Wb issued during
+                             // the forward half would sit in front of that half's weight stream: memory operations complete in order)
     int ablate;              // timing experiments only (CS_CHAIN_ABLATE): 4 no global stores, 8 no warm-up
     unsigned long long* dbg; // optional [grid][64] s_memtime stamps (CS_CHAIN_DBG), null in production
 };
@@ -279,7 +283,7 @@ __device__ __forceinline__ void chain_epilogue(u16* __restrict__ X, const float*
 template <int MT>
 __device__ __forceinline__ void chain_heads(const float* __restrict__ bias_lds, const float4 (&tgt)[MT][4],
                                             const ChainArgs& p, const ChainStage& S, int64_t m0, int jt0, int mrow0,
-                                            int lane, f32x16_t (&acc)[MT][1], float& sq, float& ab) {
+                                            int lane, f32x16_t (&acc)[MT][1], float& sq, float& ab, u16* Xdz = nullptr) {
     const bool have_y = p.y != nullptr;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -294,7 +298,9 @@ __device__ __forceinline__ void chain_heads(const float* __restrict__ bias_lds, 
             float d[4];
             head4(v, d, n >= p.n_lin, p.keep, n, (have_y && valid) ? &tgt[a][q] : nullptr, p.loss_kind, sq, ab);
             if (valid && p.yhat) *reinterpret_cast<float4*>(p.yhat + m * S.Nc + n) = make_float4(v[0], v[1], v[2], v[3]);
-            if (p.dz_out) *reinterpret_cast<uint2*>(p.dz_out + m * p.ld_dz_out + n) = make_uint2(cvt_pk_bf16(d[0], d[1]), cvt_pk_bf16(d[2], d[3]));
+            const uint2 dpk = make_uint2(cvt_pk_bf16(d[0], d[1]), cvt_pk_bf16(d[2], d[3]));
+            if (p.dz_out) *reinterpret_cast<uint2*>(p.dz_out + m * p.ld_dz_out + n) = dpk;
+            if (Xdz) *reinterpret_cast<uint2*>(Xdz + chain_lds_off(mrow0 + a * 32 + (lane & 31), n)) = dpk;   // k_chain_fb: the backward half starts from here
         }
     }
 }
@@ -349,7 +355,7 @@ __device__ __forceinline__ void chain_stage(u16* X, const float* bias_lds, const
     if (p.ablate & 16) {                     // timing experiment: no epilogue at all
         asm volatile("" :: "v"(acc[0][0][0]));
     } else if constexpr (EPI == EPI_OUT) {
-        chain_heads<MT>(bias_lds, tgt, p, S, m0, jt0, mrow0, lane, acc, sq, ab);
+        chain_heads<MT>(bias_lds, tgt, p, S, m0, jt0, mrow0, lane, acc, sq, ab, p.fused ? X : nullptr);
     } else {
         chain_epilogue<MT, NT, EPI, ELU>(X, bias_lds, p, S, last, m0, jt0, mrow0, lane, acc, msk);
         if (EPI == EPI_HIDDEN && mptr) {
@@ -372,10 +378,7 @@ template <int BM>
 constexpr int chain_lds_bytes() { return BM * CHAIN_PITCH * 2 + CHAIN_MAX_BIAS * 4 + BM * 8; }
 
 template <int BM, bool BWD, bool ELU>
-__global__ __launch_bounds__(512) void k_chain(const ChainArgs p) {
-    extern __shared__ __attribute__((aligned(16))) u16 X[];      // [BM][CHAIN_PITCH]
-    float* bias_lds = reinterpret_cast<float*>(X + BM * CHAIN_PITCH);
-    int64_t* rows_lds = reinterpret_cast<int64_t*>(bias_lds + CHAIN_MAX_BIAS);
+__device__ __forceinline__ void chain_body(const ChainArgs& p, u16* X, float* bias_lds, int64_t* rows_lds) {
     const int tid = threadIdx.x, wid = tid >> 6;
     const int64_t m0 = (int64_t)blockIdx.x * BM;
     int slot = 0;
@@ -391,7 +394,7 @@ __global__ __launch_bounds__(512) void k_chain(const ChainArgs p) {
     // (block b runs on XCD b % 8 - a speed assumption only) each touch a distinct 1/Q of every stage's
     // weights, one 4-byte load per 128-B line, all in flight at once.
     unsigned sink = 0;
-    if (!(p.ablate & 8)) {
+    if (!(p.ablate & 8) && !(BWD && p.fused && !(p.ablate & 32))) {
         const int Q = min(32, max(1, (int)(gridDim.x >> 3)));
         const int q = (int)(blockIdx.x >> 3) % Q;
         for (int i = 0; i < p.n_stages; ++i) {
@@ -457,7 +460,7 @@ __global__ __launch_bounds__(512) void k_chain(const ChainArgs p) {
                 if (p.h0) *reinterpret_cast<uint2*>(p.h0 + (m0 + mlv[u]) * p.ldh0 + cv[u]) = pk;
             }
         }
-    } else {
+    } else if (!p.fused) {
         const int chunks = p.w_in >> 3;                          // 16-B chunks per row
         for (int g = tid; g < BM * chunks; g += 512) {
             const int ml = g / chunks, c = (g - ml * chunks) * 8;
@@ -490,7 +493,34 @@ __global__ __launch_bounds__(512) void k_chain(const ChainArgs p) {
                                                                 BM >= 64 ? (wid >> 2) * (BM / 2) : 0, tid, sq, ab, slot, pend);
         }
     }
-    if (!BWD && p.y) loss_flush(p.loss, p.loss_stripes, blockIdx.x, sq, ab, reinterpret_cast<float*>(X), tid, 8);   // (X is free: the heads stage ended with a barrier)
+    // (scratch: X is free, the heads stage ended with a barrier - except under k_chain_fb, where X now holds dz of the
+    //  heads and the bias block, which no later stage reads, takes its place)
+    if (!BWD && p.y) loss_flush(p.loss, p.loss_stripes, blockIdx.x, sq, ab, p.fused ? bias_lds : reinterpret_cast<float*>(X), tid, 8);
     chain_stamp(p, tid, slot);
     if (p.dbg && tid == 0) p.dbg[(int64_t)blockIdx.x * 64 + 63] = __builtin_amdgcn_s_memrealtime();
+}
+
+template <int BM, bool BWD, bool ELU>
+__global__ __launch_bounds__(512) void k_chain(const ChainArgs p) {
+    extern __shared__ __attribute__((aligned(16))) u16 X[];      // [BM][CHAIN_PITCH]
+    float* bias_lds = reinterpret_cast<float*>(X + BM * CHAIN_PITCH);
+    int64_t* rows_lds = reinterpret_cast<int64_t*>(bias_lds + CHAIN_MAX_BIAS);
+    chain_body<BM, BWD, ELU>(p, X, bias_lds, rows_lds);
+}
+
+// Forward and backward chain of a training step in ONE launch.  Rows are independent: the workgroup that produced
+// dz of the heads for its BM rows is the one that propagates it back, so nothing crosses workgroups between the two
+// passes and the kernel boundary (L2 write-back + invalidate, ~3 us) with the second launch ramp goes away.  dz of the
+// heads and the sign masks still travel through global memory (the weight-gradient kernel reads dz anyway): every
+// thread waits for its own stores, the barrier makes that true for the workgroup, and the loads of the backward
+// prologue then find them in this XCD's L2.
+template <int BM, bool ELU>
+__global__ __launch_bounds__(512) void k_chain_fb(const ChainArgs pf, const ChainArgs pb) {
+    extern __shared__ __attribute__((aligned(16))) u16 X[];
+    float* bias_lds = reinterpret_cast<float*>(X + BM * CHAIN_PITCH);
+    int64_t* rows_lds = reinterpret_cast<int64_t*>(bias_lds + CHAIN_MAX_BIAS);
+    chain_body<BM, false, ELU>(pf, X, bias_lds, rows_lds);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    chain_body<BM, true, ELU>(pb, X, bias_lds, rows_lds);
 }

@@ -105,6 +105,7 @@ struct cs_mlp {
     int64_t iterations = 0;
     int64_t bytes = 0;
     bool use_chain = false;
+    bool bwd_chain_done = false;   // run_forward launched k_chain_fb: run_backward goes straight to the weight gradients
     bool use_chainw = false;   // wide-model chain (chainw.h): widths any multiple of 128 up to 1024, batches up to chainw_max_n
     int64_t chainw_max_n = 8192;
     bool grads_dirty = true;   // G may hold non-zero values (cleared by cs_mlp_apply)
@@ -246,6 +247,21 @@ int chain_bm(const cs_mlp* h, int64_t n) {
     return n >= 32768 ? 128 : (n > bm32_max ? 64 : 32);
 }
 
+// Backward layer chain: dz of the heads back to dz of the first hidden layer (stage i <-> layer L-1-i).
+void chain_bwd_args(const cs_mlp* h, int64_t n, ChainArgs& c) {
+    c.n_stages = h->L - 1;
+    for (int l = h->L - 1, i = 0; l >= 1; --l, ++i) {
+        const Layer& ly = h->layers[l];
+        ChainStage& S = c.st[i];
+        S.wfrag = ly.Wb; S.bias_off = 0; S.Kc = ly.N; S.Nc = ly.Kp; S.mask = h->layers[l - 1].mask;
+        S.out = h->layers[l - 1].dZ; S.ldo = h->layers[l - 1].N;
+        S.hprev = ly.H; S.ldh = ly.Kp; S.epi = EPI_DGRAD;
+    }
+    c.ablate = h->chain_ablate; c.dbg = h->dbg ? h->dbg + (h->m_pad_max / 32) * 64 : nullptr;
+    c.dz_in = h->layers[h->L - 1].dZ; c.ld_dz_in = 128; c.w_in = 128;
+    c.n_rows = n; c.act = h->cfg.act; c.slope = (h->cfg.act == CS_ACT_RELU) ? 0.f : h->cfg.alpha;
+}
+
 int run_forward(cs_mlp* h, const float* x, const int64_t* row_idx, int64_t n, int normalise, float* yhat,
                 const float* y, float* loss, bool want_dz, hipStream_t st) {
     const int64_t m_pad = round_up(n, 128);
@@ -271,6 +287,20 @@ int run_forward(cs_mlp* h, const float* x, const int64_t* row_idx, int64_t n, in
         c.loss_kind = h->loss_kind; c.keep = h->keep;
         c.dz_out = want_dz ? h->layers[h->L - 1].dZ : nullptr; c.ld_dz_out = 128;
         const int bm = chain_bm(h, n);
+        h->bwd_chain_done = false;
+        // training on 32-row tiles: the backward chain rides in the same launch (k_chain_fb)
+        if (want_dz && bm == 32 && h->L > 1 && !(h->cfg.flags & (CS_FLAG_NO_CHAIN_FB | CS_FLAG_CHAIN_BWD32_ON_FWD64))) {
+            ChainArgs cb{};
+            chain_bwd_args(h, n, cb);
+            c.fused = 1; cb.fused = 1;
+            ProfScope ps(CS_K_CHAIN_FB, st);
+            const dim3 g((unsigned)(m_pad / 32));
+            if (h->cfg.act == CS_ACT_ELU) hipLaunchKernelGGL((k_chain_fb<32, true>), g, dim3(512), chain_lds_bytes<32>(), st, c, cb);
+            else hipLaunchKernelGGL((k_chain_fb<32, false>), g, dim3(512), chain_lds_bytes<32>(), st, c, cb);
+            HIP_TRY(hipGetLastError());
+            h->bwd_chain_done = true;
+            return CS_OK;
+        }
         ProfScope ps(CS_K_CHAIN_FWD, st);
         launch_chain<false>(h, bm, m_pad, c, st);
         HIP_TRY(hipGetLastError());
@@ -334,19 +364,11 @@ int run_backward(cs_mlp* h, int64_t n, bool atomics_needed, hipStream_t st) {
     const int64_t m_pad = round_up(n, 128);
     const int steps = (int)(m_pad / 64);
     const bool tr = !(h->cfg.flags & CS_FLAG_NO_TR_READ);
-    if (h->use_chain && h->L > 1) {
+    if (h->use_chain && h->L > 1 && h->bwd_chain_done) {
+        h->bwd_chain_done = false;                       // the forward launch carried the backward chain (k_chain_fb)
+    } else if (h->use_chain && h->L > 1) {
         ChainArgs c{};
-        c.n_stages = h->L - 1;
-        for (int l = h->L - 1, i = 0; l >= 1; --l, ++i) {
-            const Layer& ly = h->layers[l];
-            ChainStage& S = c.st[i];
-            S.wfrag = ly.Wb; S.bias_off = 0; S.Kc = ly.N; S.Nc = ly.Kp; S.mask = h->layers[l - 1].mask;
-            S.out = h->layers[l - 1].dZ; S.ldo = h->layers[l - 1].N;
-            S.hprev = ly.H; S.ldh = ly.Kp; S.epi = EPI_DGRAD;
-        }
-        c.ablate = h->chain_ablate; c.dbg = h->dbg ? h->dbg + (h->m_pad_max / 32) * 64 : nullptr;
-        c.dz_in = h->layers[h->L - 1].dZ; c.ld_dz_in = 128; c.w_in = 128;
-        c.n_rows = n; c.act = h->cfg.act; c.slope = (h->cfg.act == CS_ACT_RELU) ? 0.f : h->cfg.alpha;
+        chain_bwd_args(h, n, c);
         int bm = chain_bm(h, n);
         // 64-row forward + 32-row backward (the backward workgroups read the sign masks in the forward layout): only on
         // request (CS_FLAG_CHAIN_BWD32_ON_FWD64 / CS_CHAIN_HYBRID_MAX).  It paid while the forward pass ran 64-row tiles
@@ -517,6 +539,8 @@ int cs_mlp_create(cs_mlp_t** out, const cs_mlp_cfg* cfg) {
         for (const void* f : chain_kernels<128>()) HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, chain_lds_bytes<128>()));
         for (const void* f : chain_kernels<64>()) HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, chain_lds_bytes<64>()));
         for (const void* f : chain_kernels<32>()) HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, chain_lds_bytes<32>()));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_fb<32, false>), hipFuncAttributeMaxDynamicSharedMemorySize, chain_lds_bytes<32>()));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_fb<32, true>), hipFuncAttributeMaxDynamicSharedMemorySize, chain_lds_bytes<32>()));
     }
     // ONE arena for every device buffer of the handle: a single large hipMalloc gets 2-MiB-aligned
     // virtual memory backed by large page fragments.  (Many small hipMallocs measured ~2 us effective

@@ -72,6 +72,7 @@ typedef struct cs_mlp_cfg {
 #define CS_FLAG_DIRECT_HEAD 128   /* online_testing MLP (MLP_v2rh/training/mlp.py:41-67): no Dense(output_length)+act between the
                                      hidden stack and the heads - the output layer [n_out_lin linear || n_out_relu relu] sits on
                                      the last hidden layer (torch `final_linear` + relu on the last 8 columns)              */
+#define CS_FLAG_NO_CHAIN_FB 256    /* forward and backward chain as two launches (default: one launch on 32-row tiles)  */
 #define CS_FLAG_CHAIN_BWD32_ON_FWD64 32   /* tests: 64-row forward tiles (with CHAIN_BM64), 32-row backward tiles    */
 
 /* keras.Model(...) + compile(): allocates weights (zero), optimiser state, workspace. */
@@ -141,7 +142,8 @@ int64_t cs_mlp_device_bytes(const cs_mlp_t* h);
  * on `stream` around every kernel launch; returns summed milliseconds and launch counts per
  * kernel kind.  Synchronises the stream.  Same arithmetic as cs_mlp_train_step. */
 enum { CS_K_PREPARE = 0, CS_K_GEMM_FWD = 1, CS_K_GEMM_DGRAD = 2, CS_K_WGRAD = 3, CS_K_OPTIMIZER = 4,
-       CS_K_MEMSET = 5, CS_K_CHAIN_FWD = 6, CS_K_CHAIN_BWD = 7, CS_K_COUNT = 8 };
+       CS_K_MEMSET = 5, CS_K_CHAIN_FWD = 6, CS_K_CHAIN_BWD = 7,
+       CS_K_CHAIN_FB = 8 /* forward + backward chain in one launch */, CS_K_COUNT = 9 };
 typedef struct cs_kernel_times { float ms[CS_K_COUNT]; int32_t launches[CS_K_COUNT]; } cs_kernel_times;
 int cs_mlp_profile_step(cs_mlp_t* h, const float* x_dev, const float* y_dev, const int64_t* row_idx_dev,
                         int64_t n, int normalise, float lr, float* loss_dev, void* stream,

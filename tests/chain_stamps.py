@@ -53,7 +53,7 @@ for name, base, kind in (("fwd", 0, "chain_fwd"), ("bwd", half, "chain_bwd")):
     print(name, "grid", grid, "slots", n, "mean ticks per phase:", np.round(d.mean(axis=0)).astype(int).tolist())
     print("   per-WG ticks mean/min/max", int(tot.mean()), int(tot.min()), int(tot.max()),
           "| per-WG us mean/min/max", round(real.mean(), 1), round(real.min(), 1), round(real.max(), 1),
-          "| kernel (events) us", round(us[kind], 1), "| ticks/us", round(float((tot / real).mean()), 1))
+          "| kernel (events) us", round(us.get(kind, us.get("chain_fb", 0.0)), 1), "| ticks/us", round(float((tot / real).mean()), 1))
     print("   wall span us (100 MHz, all WGs)", (st[:, 63].max() - st[:, 62].min()) / 100.0, "start spread us", (st[:, 62].max() - st[:, 62].min()) / 100.0)
     print("   distinct (xcc,se,sh,cu) places", len(uniq), "max WGs on one place", int(cnt.max()), "WGs per xcc", np.bincount(xcc, minlength=8).tolist())
 f = buf[:half].reshape(-1, 64).astype(np.int64); f = f[f[:, 0] > 0]

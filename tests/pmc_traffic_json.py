@@ -17,6 +17,8 @@ def norm(name):
     m = re.match(r"(?:void )?k_chain<\d+, (true|false), (?:true|false)>", name)
     if m:
         return f"k_chain<BM,{m.group(1)}>"
+    if re.match(r"(?:void )?k_chain_fb<", name):
+        return "k_chain_fb<BM>"
     if name.startswith("k_wgrad") or name.startswith("void k_wgrad"):
         return "k_wgrad"
     if name.startswith("k_optimizer"):

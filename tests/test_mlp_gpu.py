@@ -60,7 +60,8 @@ def test_forward_matches_oracle(M, act, n, flags):
     assert np.all(got[:, 120:] >= 0)                      # relu head
 
 
-@pytest.mark.parametrize("flags", [0, 1, 2, 3, 4, 8, 36, 66])  # +1 = CS_FLAG_NO_TR_READ; 36 = 64-row forward + 32-row backward; 66 = first GEMM kernels
+@pytest.mark.parametrize("flags", [0, 1, 2, 3, 4, 8, 36, 66, 256])  # +1 = CS_FLAG_NO_TR_READ; 36 = 64-row forward + 32-row backward; 66 = first GEMM kernels;
+# 0 runs forward + backward chain in ONE launch (k_chain_fb, 32-row tiles), 256 = CS_FLAG_NO_CHAIN_FB: two launches
 @pytest.mark.parametrize("act,n,units", [("leakyrelu", 300, (256, 128, 512)), ("relu", 128, (512, 512)),
                                          ("elu", 1000, (256, 128, 384)),    # 384: wide chain (chainw.h), or per-layer with flag 2
                                          ("leakyrelu", 200, (768, 640, 512, 640, 640)),   # the published lot-147/trial_0027 widths
