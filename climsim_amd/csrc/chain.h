@@ -394,7 +394,10 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, u16* X, float* bi
     // (block b runs on XCD b % 8 - a speed assumption only) each touch a distinct 1/Q of every stage's
     // weights, one 4-byte load per 128-B line, all in flight at once.
     unsigned sink = 0;
-    if (!(p.ablate & 8) && !(BWD && p.fused && !(p.ablate & 32))) {
+    bool warmed = (p.ablate & 8) || (BWD && p.fused && !(p.ablate & 32));
+    auto warm_up = [&]() {
+        if (warmed) return;
+        warmed = true;
         const int Q = min(32, max(1, (int)(gridDim.x >> 3)));
         const int q = (int)(blockIdx.x >> 3) % Q;
         for (int i = 0; i < p.n_stages; ++i) {
@@ -402,7 +405,11 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, u16* X, float* bi
             const int lines = (p.st[i].Kc * p.st[i].Nc) >> 6;            // 128-B lines of bf16
             for (int ln = q * 512 + tid; ln < lines; ln += Q * 512) sink ^= w[ln * 32];
         }
-    }
+    };
+    // Forward: the warm-up loads go out BEHIND the loads of the row indices and of the gathered input rows (memory
+    // operations complete in order: in front of them they put their HBM / MALL latency into the indices -> rows
+    // chain of the prologue).  Backward: up front, next to the dz load.
+    if (BWD || (p.ablate & 64)) warm_up();
 
     // ---- prologue: biases + row indices to LDS, then the stage-0 input rows
     if (!BWD) {
@@ -442,6 +449,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, u16* X, float* bi
                     }
                 }
             }
+            warm_up();
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int g = g0 + u * 512;
@@ -468,6 +476,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, u16* X, float* bi
                 *reinterpret_cast<const uint4*>(p.dz_in + (m0 + ml) * p.ld_dz_in + c);
         }
     }
+    warm_up();
     asm volatile("" ::"v"(sink));            // warm-up loads retire here (they overlapped the prologue)
     __syncthreads();
     chain_stamp(p, tid, slot);
