@@ -15,7 +15,7 @@ PyTorch provides streams, events and memory only; there is no CPU execution path
 """
 from __future__ import annotations
 
-from typing import Callable, Iterable, Optional
+from typing import Callable, Iterable
 
 import numpy as np
 
