@@ -288,15 +288,28 @@ int run_forward(cs_mlp* h, const float* x, const int64_t* row_idx, int64_t n, in
         c.dz_out = want_dz ? h->layers[h->L - 1].dZ : nullptr; c.ld_dz_out = 128;
         const int bm = chain_bm(h, n);
         h->bwd_chain_done = false;
-        // training on 32-row tiles: the backward chain rides in the same launch (k_chain_fb)
-        if (want_dz && bm == 32 && h->L > 1 && !(h->cfg.flags & (CS_FLAG_NO_CHAIN_FB | CS_FLAG_CHAIN_BWD32_ON_FWD64))) {
+        // training: the backward chain rides in the same launch (k_chain_fb) - unless the backward pass is asked to use
+        // another tile height than the forward pass (hybrid runs)
+        static const int64_t hybrid_max = getenv("CS_CHAIN_HYBRID_MAX") ? atoll(getenv("CS_CHAIN_HYBRID_MAX")) : 0;
+        const bool forced = h->cfg.flags & (CS_FLAG_CHAIN_BM32 | CS_FLAG_CHAIN_BM64 | CS_FLAG_CHAIN_BM128);
+        const bool hybrid = (bm == 64 && !forced && n <= hybrid_max && h->cfg.act != CS_ACT_ELU) || (h->cfg.flags & CS_FLAG_CHAIN_BWD32_ON_FWD64);
+        if (want_dz && h->L > 1 && !hybrid && !(h->cfg.flags & CS_FLAG_NO_CHAIN_FB)) {
             ChainArgs cb{};
             chain_bwd_args(h, n, cb);
             c.fused = 1; cb.fused = 1;
             ProfScope ps(CS_K_CHAIN_FB, st);
-            const dim3 g((unsigned)(m_pad / 32));
-            if (h->cfg.act == CS_ACT_ELU) hipLaunchKernelGGL((k_chain_fb<32, true>), g, dim3(512), chain_lds_bytes<32>(), st, c, cb);
-            else hipLaunchKernelGGL((k_chain_fb<32, false>), g, dim3(512), chain_lds_bytes<32>(), st, c, cb);
+            const bool elu = h->cfg.act == CS_ACT_ELU;
+            const dim3 g((unsigned)(m_pad / bm));
+            if (bm == 32) {
+                if (elu) hipLaunchKernelGGL((k_chain_fb<32, true>), g, dim3(512), chain_lds_bytes<32>(), st, c, cb);
+                else hipLaunchKernelGGL((k_chain_fb<32, false>), g, dim3(512), chain_lds_bytes<32>(), st, c, cb);
+            } else if (bm == 64) {
+                if (elu) hipLaunchKernelGGL((k_chain_fb<64, true>), g, dim3(512), chain_lds_bytes<64>(), st, c, cb);
+                else hipLaunchKernelGGL((k_chain_fb<64, false>), g, dim3(512), chain_lds_bytes<64>(), st, c, cb);
+            } else {
+                if (elu) hipLaunchKernelGGL((k_chain_fb<128, true>), g, dim3(512), chain_lds_bytes<128>(), st, c, cb);
+                else hipLaunchKernelGGL((k_chain_fb<128, false>), g, dim3(512), chain_lds_bytes<128>(), st, c, cb);
+            }
             HIP_TRY(hipGetLastError());
             h->bwd_chain_done = true;
             return CS_OK;
@@ -541,6 +554,10 @@ int cs_mlp_create(cs_mlp_t** out, const cs_mlp_cfg* cfg) {
         for (const void* f : chain_kernels<32>()) HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, chain_lds_bytes<32>()));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_fb<32, false>), hipFuncAttributeMaxDynamicSharedMemorySize, chain_lds_bytes<32>()));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_fb<32, true>), hipFuncAttributeMaxDynamicSharedMemorySize, chain_lds_bytes<32>()));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_fb<64, false>), hipFuncAttributeMaxDynamicSharedMemorySize, chain_lds_bytes<64>()));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_fb<64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, chain_lds_bytes<64>()));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_fb<128, false>), hipFuncAttributeMaxDynamicSharedMemorySize, chain_lds_bytes<128>()));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_fb<128, true>), hipFuncAttributeMaxDynamicSharedMemorySize, chain_lds_bytes<128>()));
     }
     // ONE arena for every device buffer of the handle: a single large hipMalloc gets 2-MiB-aligned
     // virtual memory backed by large page fragments.  (Many small hipMallocs measured ~2 us effective
