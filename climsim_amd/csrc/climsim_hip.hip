@@ -104,6 +104,7 @@ struct cs_mlp {
     int opt_blocks = 0;        // workgroups of the optimiser launch (32x32 weight tiles + 1024-float bias slices)
     int64_t iterations = 0;
     int64_t bytes = 0;
+    int n_cu = 0;                  // compute units of the device (hipDeviceProp_t::multiProcessorCount)
     bool use_chain = false;
     bool bwd_chain_done = false;   // run_forward launched k_chain_fb: run_backward goes straight to the weight gradients
     bool use_chainw = false;   // wide-model chain (chainw.h): widths any multiple of 128 up to 1024, batches up to chainw_max_n
@@ -243,8 +244,27 @@ int chain_bm(const cs_mlp* h, int64_t n) {
     // with 64 (forward 51 vs 59 us); at 16384 rows 0.279 vs 0.232 ms.  (An earlier measurement had 64 rows ahead at 8192:
     // that was the loss atomics of 256 workgroups finishing together, see loss_flush.)  Forward and backward share the
     // tile (the sign masks are stored per workgroup and lane) except in the hybrid range of run_backward.
+    // Above 8192 rows the choice follows the number of ROUNDS the grid needs on the 256 CUs times the cost of a
+    // workgroup of that height (1 : 1.35 : 2.2 for 32 : 64 : 128 rows, fitted to the measured steps below):
+    //   rows   32-row  64-row  128-row   (ms per step, fused forward+backward launch)
+    //   12288  0.226   0.185   0.223        24576  0.364  0.350  0.306        49152  0.659  0.558  0.572
+    //   16384  0.265   0.226   0.258        32768  0.466  0.393  0.365
+    // e.g. 24576 rows are 1.5 -> 2 rounds of 64-row workgroups but one round of 128-row ones; 49152 rows are 3 rounds
+    // of 64 against 2 of 128.
     static const int64_t bm32_max = getenv("CS_CHAIN_BM32_MAX") ? atoll(getenv("CS_CHAIN_BM32_MAX")) : 8192;
-    return n >= 32768 ? 128 : (n > bm32_max ? 64 : 32);
+    if (n <= bm32_max) return 32;
+    int cus = 256;
+    if (h->n_cu > 0) cus = h->n_cu;
+    const int bms[3] = {32, 64, 128};
+    const double w[3] = {1.0, 1.35, 2.2};
+    int best = 64;
+    double best_cost = 1e30;
+    for (int i = 0; i < 3; ++i) {
+        const int64_t wgs = (n + bms[i] - 1) / bms[i];
+        const double cost = (double)((wgs + cus - 1) / cus) * w[i];
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = bms[i]; }
+    }
+    return best;
 }
 
 // Backward layer chain: dz of the heads back to dz of the first hidden layer (stage i <-> layer L-1-i).
@@ -498,6 +518,7 @@ int cs_mlp_create(cs_mlp_t** out, const cs_mlp_cfg* cfg) {
 
     cs_mlp* h = new cs_mlp();
     h->cfg = *cfg;
+    { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess) h->n_cu = v; }
     const bool direct = (cfg->flags & CS_FLAG_DIRECT_HEAD) != 0;   // online_testing MLP: final Linear on the last hidden layer
     h->L = cfg->n_hidden + (direct ? 1 : 2);
     h->m_pad_max = round_up(cfg->max_batch, 128);
