@@ -22,8 +22,7 @@ __device__ __forceinline__ int cwd_off(int row, int col) {        // element off
 }
 
 template <bool BWD>
-__global__ __launch_bounds__(512) void k_chainw(const ChainArgs p) {
-    extern __shared__ __attribute__((aligned(16))) u16 XW[];
+__device__ __forceinline__ void chainw_body(const ChainArgs& p, u16* XW) {
     u16* Xin = XW;
     u16* Xout = XW + CWD_BM * CWD_PITCH;
     float* bias_lds = reinterpret_cast<float*>(XW + 2 * CWD_BM * CWD_PITCH);
@@ -142,4 +141,21 @@ __global__ __launch_bounds__(512) void k_chainw(const ChainArgs p) {
         __syncthreads();                                         // the heads stage has no trailing barrier: XW still being read
         loss_flush(p.loss, p.loss_stripes, blockIdx.x, sq, ab, reinterpret_cast<float*>(XW), tid, 8);
     }
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(512) void k_chainw(const ChainArgs p) {
+    extern __shared__ __attribute__((aligned(16))) u16 XW[];
+    chainw_body<BWD>(p, XW);
+}
+
+// Forward and backward pass of a training step in one launch (as k_chain_fb, chain.h): rows are independent, so the
+// workgroup that produced dz of the heads and the activation copies of its 32 rows is the one that reads them back -
+// after every thread has waited for its own stores and the barrier, from this XCD's L2.
+__global__ __launch_bounds__(512) void k_chainw_fb(const ChainArgs pf, const ChainArgs pb) {
+    extern __shared__ __attribute__((aligned(16))) u16 XW[];
+    chainw_body<false>(pf, XW);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    chainw_body<true>(pb, XW);
 }

@@ -267,6 +267,20 @@ int chain_bm(const cs_mlp* h, int64_t n) {
     return best;
 }
 
+// The same for the wide chain (k_chainw: act' from the global activation copies, any output width).
+void chainw_bwd_args(const cs_mlp* h, int64_t n, ChainArgs& c) {
+    c.n_stages = h->L - 1;
+    for (int l = h->L - 1, i = 0; l >= 1; --l, ++i) {
+        const Layer& ly = h->layers[l];
+        ChainStage& S = c.st[i];
+        S.wfrag = ly.Wb; S.bias_off = 0; S.Kc = ly.N; S.Nc = ly.Kp;
+        S.out = h->layers[l - 1].dZ; S.ldo = h->layers[l - 1].N;
+        S.hprev = ly.H; S.ldh = ly.Kp; S.epi = EPI_DGRAD;
+    }
+    c.dz_in = h->layers[h->L - 1].dZ; c.ld_dz_in = h->n_outp; c.w_in = h->n_outp;
+    c.n_rows = n; c.act = h->cfg.act; c.slope = (h->cfg.act == CS_ACT_RELU) ? 0.f : h->cfg.alpha;
+}
+
 // Backward layer chain: dz of the heads back to dz of the first hidden layer (stage i <-> layer L-1-i).
 void chain_bwd_args(const cs_mlp* h, int64_t n, ChainArgs& c) {
     c.n_stages = h->L - 1;
@@ -357,6 +371,16 @@ int run_forward(cs_mlp* h, const float* x, const int64_t* row_idx, int64_t n, in
         c.loss_stripes = h->loss_striped ? LOSS_STRIPES : 1;
         c.loss_kind = h->loss_kind; c.keep = h->keep;
         c.dz_out = want_dz ? h->layers[h->L - 1].dZ : nullptr; c.ld_dz_out = h->n_outp; c.n_real = h->n_out;
+        h->bwd_chain_done = false;
+        if (want_dz && h->L > 1 && !(h->cfg.flags & CS_FLAG_NO_CHAIN_FB)) {       // training: backward pass in the same launch
+            ChainArgs cb{};
+            chainw_bwd_args(h, n, cb);
+            ProfScope ps(CS_K_CHAIN_FB, st);
+            hipLaunchKernelGGL(k_chainw_fb, dim3((unsigned)(m_pad / CWD_BM)), dim3(512), chainw_lds_bytes(), st, c, cb);
+            HIP_TRY(hipGetLastError());
+            h->bwd_chain_done = true;
+            return CS_OK;
+        }
         ProfScope ps(CS_K_CHAIN_FWD, st);
         hipLaunchKernelGGL(k_chainw<false>, dim3((unsigned)(m_pad / CWD_BM)), dim3(512), chainw_lds_bytes(), st, c);
         HIP_TRY(hipGetLastError());
@@ -415,18 +439,11 @@ int run_backward(cs_mlp* h, int64_t n, bool atomics_needed, hipStream_t st) {
         launch_chain<true>(h, bm, m_pad, c, st);
     }
     const bool wide = h->use_chainw && n <= h->chainw_max_n;
-    if (wide && h->L > 1) {
+    if (wide && h->L > 1 && h->bwd_chain_done) {
+        h->bwd_chain_done = false;                       // k_chainw_fb carried the backward pass
+    } else if (wide && h->L > 1) {
         ChainArgs c{};
-        c.n_stages = h->L - 1;
-        for (int l = h->L - 1, i = 0; l >= 1; --l, ++i) {
-            const Layer& ly = h->layers[l];
-            ChainStage& S = c.st[i];
-            S.wfrag = ly.Wb; S.bias_off = 0; S.Kc = ly.N; S.Nc = ly.Kp;
-            S.out = h->layers[l - 1].dZ; S.ldo = h->layers[l - 1].N;
-            S.hprev = ly.H; S.ldh = ly.Kp; S.epi = EPI_DGRAD;
-        }
-        c.dz_in = h->layers[h->L - 1].dZ; c.ld_dz_in = h->n_outp; c.w_in = h->n_outp;
-        c.n_rows = n; c.act = h->cfg.act; c.slope = (h->cfg.act == CS_ACT_RELU) ? 0.f : h->cfg.alpha;
+        chainw_bwd_args(h, n, c);
         ProfScope ps(CS_K_CHAIN_BWD, st);
         hipLaunchKernelGGL(k_chainw<true>, dim3((unsigned)(m_pad / CWD_BM)), dim3(512), chainw_lds_bytes(), st, c);
     }
@@ -561,6 +578,7 @@ int cs_mlp_create(cs_mlp_t** out, const cs_mlp_cfg* cfg) {
     if (h->use_chainw) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chainw<false>), hipFuncAttributeMaxDynamicSharedMemorySize, chainw_lds_bytes()));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chainw<true>), hipFuncAttributeMaxDynamicSharedMemorySize, chainw_lds_bytes()));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chainw_fb), hipFuncAttributeMaxDynamicSharedMemorySize, chainw_lds_bytes()));
     }
     if (h->L > WGRAD_MAX_LAYERS) { delete h; return fail(CS_ERR_INVALID, "too many layers"); }
     if (const char* e = getenv("CS_WGRAD_SPLITK")) h->wgrad_splitk = atoi(e);
