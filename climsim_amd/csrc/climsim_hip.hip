@@ -108,7 +108,8 @@ struct cs_mlp {
     bool use_chain = false;
     bool bwd_chain_done = false;   // run_forward launched k_chain_fb: run_backward goes straight to the weight gradients
     bool use_chainw = false;   // wide-model chain (chainw.h): widths any multiple of 128 up to 1024, batches up to chainw_max_n
-    int64_t chainw_max_n = 8192;
+    int64_t chainw_max_n = (int64_t)1 << 40;   // no limit: with the forward+backward launch the wide chain beats one GEMM per layer at every
+                                               // batch (published model: 16384 columns 0.402 vs 0.498 ms, 131072: 2.79 vs 3.56); CS_CHAINW_MAX_N lowers it
     bool grads_dirty = true;   // G may hold non-zero values (cleared by cs_mlp_apply)
     unsigned long long* dbg = nullptr;   // CS_CHAIN_DBG: [2][grid_max][64] stamps (fwd, bwd)
     int chain_ablate = 0;      // CS_CHAIN_ABLATE env, timing experiments only
