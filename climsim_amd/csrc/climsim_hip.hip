@@ -464,7 +464,9 @@ int run_backward(cs_mlp* h, int64_t n, bool atomics_needed, hipStream_t st) {
     }
     {   // weight/bias gradients of ALL layers in one grouped launch
         const bool atomics_needed_plain = false;   // k_wgrad3 always accumulates atomically into the zeroed buffer
-        const bool big = h->wgrad2_mode == 1 || (h->wgrad2_mode < 0 && n >= 16384);   // 256x256 tiles + LDS-DMA ring
+        // 256x256 tiles + LDS-DMA ring from 20480 columns (measured, cfg-MLP: 16384 columns 77 us on the 128x128 kernel vs 88;
+        // 24576: 129 vs 105)
+        const bool big = h->wgrad2_mode == 1 || (h->wgrad2_mode < 0 && n >= 20480);
         const int tdim = big ? 256 : 128;
         const bool dma_small = !big && tr && h->wgrad3 && !atomics_needed_plain;
         const int msteps = (big || dma_small) ? (int)(m_pad / WG2_ROWS) : steps;
