@@ -481,7 +481,11 @@ int run_backward(cs_mlp* h, int64_t n, bool atomics_needed, hipStream_t st) {
         // small batches: every split re-fills the LDS-DMA ring and adds a round of atomics for a handful of slabs -
         // measured (cfg-MLP, k_wgrad3): 1024 columns 26.6 us with 5 splits, 18.2 with 2; 3072: 31.9 / 27.3 with 3;
         // 4096: 34.3 / 30.3 with 3; 8192: 44.9 with 5 (best)
-        if (h->wgrad_splitk <= 0 && !big) { if (n < 2048) splitk = std::min(splitk, 2); else if (n < 6144) splitk = std::min(splitk, 3); }
+        // ... 12288: 59.5 with 5 (7: 59.8, 4: 71.7); 16384: 71.8 with 7 (5: 76.9, 10: 84.1) - two workgroups per CU there
+        if (h->wgrad_splitk <= 0 && !big) {
+            if (n < 2048) splitk = std::min(splitk, 2); else if (n < 6144) splitk = std::min(splitk, 3);
+            else if (n >= 14336) splitk = std::max(splitk, (2 * 256) / tiles);      // (not more than two rounds: 8 splits = 584 workgroups: 89.7 us)
+        }
         if (splitk < 1) splitk = 1;
         if (splitk > msteps) splitk = msteps;
         w.splitk = splitk;
