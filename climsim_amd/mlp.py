@@ -75,7 +75,7 @@ def _ptr(t):
 class MLPEmulator:
     """ClimSim baseline MLP (input_length -> units... -> output_length -> [lin || relu]) on one MI355X:
     124 -> ... -> 128 -> [120 || 8] for the v1 variable set (layer-chain kernels), e.g. 425 -> ... -> 368 -> [360 || 8]
-    for v2 (hpo_baseline_v2.py:58-101; one GEMM launch per layer)."""
+    for v2 (hpo_baseline_v2.py:58-101; wide layer-chain kernels)."""
 
     def __init__(self, units: Sequence[int] = (512, 512, 512, 512, 512), activation: str = "leakyrelu",
                  optimizer: str = "Adam", input_length: int = 124, output_length_lin: int = 120,

@@ -51,7 +51,7 @@ typedef struct cs_mlp_cfg {
     int32_t hidden[CS_MAX_HIDDEN];/* hp units_k, multiples of 128 (128..1024 in the HPO space)   */
     int32_t n_out_lin;            /* output_length_lin  = 120 (linear head)                      */
     int32_t n_out_relu;           /* output_length_relu = 8   (relu head); both multiples of 4, lin+relu <= 1024;
-                                     128 (v1) runs on the layer-chain kernels, other widths (368 = v2) per layer */
+                                     128 (v1) runs on the tuned layer-chain kernels, other widths (368 = v2) on the wide chain */
     int32_t act;                  /* cs_act                                                       */
     float   alpha;                /* LeakyReLU slope (0.15)                                       */
     int32_t optimizer;            /* cs_opt                                                       */
