@@ -1,0 +1,31 @@
+"""The bench line the driver parses: required keys and types, checked on the line committed under profiles/ (the output of
+`python bench.py` on an MI355X) - a format regression in bench.py shows up here without a GPU."""
+import json
+import os
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_committed_bench_line_has_the_contract_keys():
+    line = open(os.path.join(REPO, "profiles", "r01_bench_b8192.json")).read().strip().splitlines()[-1]
+    d = json.loads(line)
+    for k, t in (("metric", str), ("value", (int, float)), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                 ("ms_per_step", (int, float)), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
+                 ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
+        assert k in d and isinstance(d[k], t), k
+    assert d["vs_baseline"] is None and d["scaling"] == "weak" and d["higher_is_better"] is True and d["n_gpus"] == 1
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and (r["traffic"] is None or r["traffic"] > 0)
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"] and c["sample"]
+    # value = columns of the timed steps / time
+    assert abs(d["value"] - d["config"]["global_batch"] / (d["ms_per_step"] * 1e-3)) <= 0.01 * d["value"]
+
+
+def test_bench_defaults_and_flags():
+    src = open(os.path.join(REPO, "bench.py")).read()
+    for flag in ("--gpus", "--steps", "--warmup"):
+        assert f'"{flag}"' in src
+    assert 'default=1)' in src.split('"--gpus"')[1][:60]            # no flags: one GPU
