@@ -259,6 +259,8 @@ def main():
             print(json.dumps({"metric": "training columns/sec", "value": round(value, 1), "unit": "columns/s", "n_gpus": world,
                               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "train_only": True}), flush=True)
         if dist:
+            torch.cuda.synchronize()
+            dp.close()
             dist.destroy_process_group()
         return
     held = model.evaluate(xv, yv)
@@ -342,6 +344,8 @@ def main():
         sys.stdout.flush()
 
     if dist:
+        torch.cuda.synchronize()
+        dp.close()                       # the engine's own RCCL communicator goes first
         flush_c_stdio()                  # every rank empties its buffers before rank 0 prints
         dist.barrier()
         dist.destroy_process_group()

@@ -342,4 +342,5 @@ class CNNEmulator:
                 if early_stopping_patience is not None and wait >= early_stopping_patience:
                     self.stop_training = True
                     break
+        dp.close()
         return history

@@ -95,6 +95,12 @@ class DataParallel:
                 import warnings
                 warnings.warn(f"native RCCL communicator unavailable ({e}); using torch.distributed.all_reduce")
 
+    def close(self):
+        """Destroy the native communicator (before torch.distributed is torn down and long before interpreter exit)."""
+        if self.native is not None:
+            self.native.close()
+            self.native = None
+
     def all_reduce_grads(self):
         """The ONE collective of the step: SUM of the flat gradient buffer over all ranks, in place."""
         if self.native is not None:

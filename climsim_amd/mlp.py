@@ -434,6 +434,7 @@ class MLPEmulator:
                     break
         if writer:
             f.close()
+        dp.close()
         return history
 
 
