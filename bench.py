@@ -175,6 +175,7 @@ def main():
                     "evaluation, no prediction pass), so that per-kernel averages are averages over training launches")
     args = ap.parse_args()
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs between the ranks of this pool's hosts
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
