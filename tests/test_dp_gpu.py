@@ -83,3 +83,36 @@ def test_native_rccl_communicator_through_the_c_abi(pg):
     dp.all_reduce_grads()
     torch.cuda.synchronize()
     assert torch.equal(m.gradient_tensor(), g0)
+
+
+def test_streamed_trainer_with_a_process_group(pg, tmp_path):
+    """climsim_amd/stream.py under data parallelism (one rank): same weights as the single-process pass."""
+    from climsim_amd.loader import GpuColumnLoader
+    from climsim_amd.mlp import MLPEmulator
+    from climsim_amd.stream import StreamedTrainer
+    import types
+    vin = ["state_t", "state_q0001", "state_ps", "pbuf_SOLIN", "pbuf_LHFLX", "pbuf_SHFLX"]
+    vout = ["ptend_t", "ptend_q0001", "cam_out_NETSW", "cam_out_FLWDS", "cam_out_PRECSC", "cam_out_PRECC", "cam_out_SOLS", "cam_out_SOLL",
+            "cam_out_SOLSD", "cam_out_SOLLD"]
+    lens = {v: 60 if v in ("state_t", "state_q0001", "ptend_t", "ptend_q0001") else 1 for v in vin + vout}
+    rng = np.random.default_rng(0)
+    norm = (rng.normal(0, 1, 124), rng.uniform(0.5, 2, 124), rng.uniform(0.5, 2, 128))
+    du = types.SimpleNamespace(input_vars=vin, target_vars=vout, var_lens=lens, normalize=True, input_abbrev="mli", output_abbrev="mlo",
+                               save_norm=lambda: norm)
+    ld = GpuColumnLoader(du)
+    chunks = []
+    for c in range(3):
+        mli = rng.normal(0, 0.3, (2, 124, 200))
+        mlo = rng.normal(0, 0.05, (2, 128, 200))
+        mlo[:, :120] = mli[:, :120] + 1200.0 * mlo[:, :120]
+        chunks.append((mli, mlo))
+    out = []
+    for dist in (None, pg):
+        m = MLPEmulator(units=(128, 128), max_batch=128, seed=5)
+        st = StreamedTrainer(m, ld, batch_size=128, dist=dist)
+        res = st.fit_chunks(iter(chunks), learning_rate=1e-3, seed=3)
+        out.append((res, m.get_weights()))
+    assert out[0][0]["steps"] == out[1][0]["steps"] == 3 * 4
+    assert abs(out[0][0]["loss"] - out[1][0]["loss"]) <= 1e-3 * out[0][0]["loss"]
+    for a, b in zip(out[0][1], out[1][1]):
+        np.testing.assert_allclose(a, b, rtol=0, atol=1e-3 * max(1.0, float(np.abs(a).max())))
