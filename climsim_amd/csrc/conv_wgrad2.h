@@ -179,7 +179,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv_wgrad2(const CwArgs pa) {
         __builtin_amdgcn_s_barrier();                                 // ... everyone's: slot s&3 is free
         // The 2*PP 1-KiB DMA pieces of slab s+4 go out one at a time between the MFMA groups: issued together right
         // after the barrier, the 32 pieces of the workgroup queue up in the CU's vector-memory pipe (16 clk each) and
-        // every wave sits in the issue of its last piece while its MFMAs wait.
+        // every wave sits in the issue of its last piece while its MFMAs wait.  (Measured: no change of the kernel time.)
         const unsigned base_ = lds0 + (unsigned)__builtin_amdgcn_readfirstlane(s & 3) * CW2_SLAB_BYTES + my_piece;
         const char *hs_[PP], *zs_[PP];
 #pragma unroll
