@@ -75,6 +75,7 @@ SIGNATURES = {
     "cs_mlp_debug_stamps": (C.c_int, [_P, _P, _I64]),
     "cs_normalise_rows": (C.c_int, [_P, _P, _I64, _I32, _P, _P, _P, _P]),
     "cs_metrics_columns": (C.c_int, [_P, _P, _I64, _I32, _I32, _P, _P, _P, _P, _P, _P]),
+    "cs_categorical_accuracy": (C.c_int, [_P, _P, _I64, _I32, _P, C.c_int, _P]),
     "cs_loader_stack": (C.c_int, [_P, _P, _I32, _I64, _I32, _I32, _P, _P, _I32, _P, _P, _P, _P, _P]),
     "cs_cnn_create": (C.c_int, [C.POINTER(_P), C.POINTER(CsCnnCfg)]),
     "cs_cnn_destroy": (None, [_P]),

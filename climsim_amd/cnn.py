@@ -8,6 +8,8 @@ import ctypes as C
 import math
 from typing import List, Optional
 
+import os
+
 import numpy as np
 
 from . import _lib
@@ -179,7 +181,10 @@ class CNNEmulator:
             d.update({f"m{i}": a for i, a in enumerate(m)})
             d.update({f"v{i}": a for i, a in enumerate(v)})
             d["iterations"] = np.int64(it)
-        np.savez(path, **d)
+        final = path if path.endswith(".npz") else path + ".npz"       # np.savez appends .npz itself
+        tmp = final + ".tmp.npz"
+        np.savez(tmp, **d)
+        os.replace(tmp, final)                                          # a reader never sees a half-written checkpoint
 
     def load_weights(self, path: str, with_optimizer: bool = True):
         z = np.load(path if path.endswith(".npz") else path + ".npz")
@@ -303,44 +308,46 @@ class CNNEmulator:
         step_loss = torch.zeros(4, dtype=torch.float32, device=self.device)
         best, wait = math.inf, 0
         self.stop_training = False
-        for epoch in range(epochs):
-            gen.manual_seed(seed + epoch)
-            perm = torch.randperm(n, device=self.device, generator=gen) if shuffle else torch.arange(n, device=self.device)
-            epoch_sum.zero_()
-            lr = sched(self.iterations)
-            for s in range(steps):
+        try:
+            for epoch in range(epochs):
+                gen.manual_seed(seed + epoch)
+                perm = torch.randperm(n, device=self.device, generator=gen) if shuffle else torch.arange(n, device=self.device)
+                epoch_sum.zero_()
                 lr = sched(self.iterations)
+                for s in range(steps):
+                    lr = sched(self.iterations)
+                    if distributed:
+                        idx = shard_of_batch(perm, s, batch_size, rank, world)
+                        self.loss_grads(x, y, row_idx=idx, loss=step_loss, x3d=x3d, y3d=y3d)
+                        dp.all_reduce_grads()
+                        self.apply_gradients(lr, 1.0 / (60 * batch_size))
+                    else:
+                        idx = shard_of_batch(perm, s, batch_size, 0, 1)
+                        self.train_on_batch(x, y, lr, row_idx=idx, loss=step_loss, x3d=x3d, y3d=y3d)
+                    epoch_sum += step_loss
                 if distributed:
-                    idx = shard_of_batch(perm, s, batch_size, rank, world)
-                    self.loss_grads(x, y, row_idx=idx, loss=step_loss, x3d=x3d, y3d=y3d)
-                    dp.all_reduce_grads()
-                    self.apply_gradients(lr, 1.0 / (60 * batch_size))
+                    dist.all_reduce(epoch_sum)
+                row = self._losses(epoch_sum.cpu().numpy(), batch_size * steps)
+                row["lr"] = float(lr)
+                if validation_data is not None:
+                    ev = self.evaluate(validation_data[0], validation_data[1])
+                    row.update({"val_" + k: ev[k] for k in keys})
+                for k, v in row.items():
+                    history[k].append(v)
+                if verbose and rank == 0:
+                    print(f"epoch {epoch + 1}/{epochs} " + " ".join(f"{k}={v:.6g}" for k, v in row.items()), flush=True)
+                monitor = row.get("val_loss", row["loss"])
+                if not math.isfinite(monitor):
+                    raise FloatingPointError(f"non-finite loss at epoch {epoch}")
+                if rank == 0 and checkpoint:
+                    self.save_weights(checkpoint.format(epoch=epoch + 1))
+                if monitor < best:
+                    best, wait = monitor, 0
                 else:
-                    idx = shard_of_batch(perm, s, batch_size, 0, 1)
-                    self.train_on_batch(x, y, lr, row_idx=idx, loss=step_loss, x3d=x3d, y3d=y3d)
-                epoch_sum += step_loss
-            if distributed:
-                dist.all_reduce(epoch_sum)
-            row = self._losses(epoch_sum.cpu().numpy(), batch_size * steps)
-            row["lr"] = float(lr)
-            if validation_data is not None:
-                ev = self.evaluate(validation_data[0], validation_data[1])
-                row.update({"val_" + k: ev[k] for k in keys})
-            for k, v in row.items():
-                history[k].append(v)
-            if verbose and rank == 0:
-                print(f"epoch {epoch + 1}/{epochs} " + " ".join(f"{k}={v:.6g}" for k, v in row.items()), flush=True)
-            monitor = row.get("val_loss", row["loss"])
-            if not math.isfinite(monitor):
-                raise FloatingPointError(f"non-finite loss at epoch {epoch}")
-            if rank == 0 and checkpoint:
-                self.save_weights(checkpoint.format(epoch=epoch + 1))
-            if monitor < best:
-                best, wait = monitor, 0
-            else:
-                wait += 1
-                if early_stopping_patience is not None and wait >= early_stopping_patience:
-                    self.stop_training = True
-                    break
-        dp.close()
+                    wait += 1
+                    if early_stopping_patience is not None and wait >= early_stopping_patience:
+                        self.stop_training = True
+                        break
+        finally:
+            dp.close()                     # the RCCL communicator never outlives the call, also on an exception
         return history

@@ -541,6 +541,7 @@ int cs_mlp_create(cs_mlp_t** out, const cs_mlp_cfg* cfg) {
     HIP_TRY(hipSetDevice(cfg->device));
 
     cs_mlp* h = new cs_mlp();
+    struct Guard { cs_mlp* p; ~Guard() { if (p) cs_mlp_destroy(p); } } guard{h};   // every early return below releases the handle
     h->cfg = *cfg;
     { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess) h->n_cu = v; }
     const bool direct = (cfg->flags & CS_FLAG_DIRECT_HEAD) != 0;   // online_testing MLP: final Linear on the last hidden layer
@@ -587,7 +588,7 @@ int cs_mlp_create(cs_mlp_t** out, const cs_mlp_cfg* cfg) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chainw<true>), hipFuncAttributeMaxDynamicSharedMemorySize, chainw_lds_bytes()));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chainw_fb), hipFuncAttributeMaxDynamicSharedMemorySize, chainw_lds_bytes()));
     }
-    if (h->L > WGRAD_MAX_LAYERS) { delete h; return fail(CS_ERR_INVALID, "too many layers"); }
+    if (h->L > WGRAD_MAX_LAYERS) return fail(CS_ERR_INVALID, "too many layers");
     if (const char* e = getenv("CS_WGRAD_SPLITK")) h->wgrad_splitk = atoi(e);
     if (const char* e = getenv("CS_CHAIN_ABLATE")) h->chain_ablate = atoi(e);
     if (const char* e = getenv("CS_WGRAD2")) h->wgrad2_mode = atoi(e);
@@ -663,7 +664,8 @@ int cs_mlp_create(cs_mlp_t** out, const cs_mlp_cfg* cfg) {
     h->n_seg = (int)segs.size();
     if (rc == CS_OK && hipMemcpy(h->seg_dev, segs.data(), sizeof(Segment) * segs.size(), hipMemcpyHostToDevice) != hipSuccess)
         rc = fail(CS_ERR_HIP, "segment table upload failed");
-    if (rc != CS_OK) { cs_mlp_destroy(h); return rc; }
+    if (rc != CS_OK) return rc;
+    guard.p = nullptr;
     *out = h;
     return CS_OK;
 }
@@ -923,6 +925,17 @@ int cs_metrics_columns(const float* pred_dev, const float* target_dev, int64_t n
     hipLaunchKernelGGL(k_metrics_partial, dim3((unsigned)ncol, (unsigned)((n_out + 127) / 128), (unsigned)tsplit), dim3(256), 0, st,
                        pred_dev, target_dev, (int)n_steps, ncol, n_out, ps_dev, wa_dev, wb_dev, area_dev, stats_dev);
     hipLaunchKernelGGL(k_metrics_finish, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, stats_dev, items, (int)n_steps);
+    HIP_TRY(hipGetLastError());
+    return CS_OK;
+}
+
+int cs_categorical_accuracy(const float* pred_dev, const float* target_dev, int64_t n, int32_t width,
+                            unsigned long long* count_dev, int accumulate, void* stream) {
+    if (!pred_dev || !target_dev || !count_dev) return fail(CS_ERR_INVALID, "null argument");
+    if (n <= 0 || width <= 0) return fail(CS_ERR_INVALID, "empty input");
+    hipStream_t st = (hipStream_t)stream;
+    if (!accumulate) HIP_TRY(hipMemsetAsync(count_dev, 0, sizeof(unsigned long long), st));
+    hipLaunchKernelGGL(k_argmax_match, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, pred_dev, target_dev, n, (int)width, count_dev);
     HIP_TRY(hipGetLastError());
     return CS_OK;
 }

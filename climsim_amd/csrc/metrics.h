@@ -67,3 +67,37 @@ __global__ __launch_bounds__(256) void k_metrics_finish(double* __restrict__ acc
     o[2] = 1.0 - s_sq / (s_tss - s_ts * s_ts / n);
     o[3] = s_p / n - s_t / n;
 }
+
+// Keras' `accuracy` metric on a model with a multi-column output (compile(metrics=['accuracy']) with a (B,128) target
+// resolves to categorical_accuracy: argmax(y_true, -1) == argmax(y_pred, -1); step2_retrain.py:160-162).  One wave per
+// row; ties take the first maximum like tf.argmax.  count_dev += number of matching rows.
+__global__ __launch_bounds__(256) void k_argmax_match(const float* __restrict__ pred, const float* __restrict__ target,
+                                                      int64_t n, int width, unsigned long long* __restrict__ count) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wid;
+    __shared__ unsigned hits[4];
+    unsigned hit = 0;
+    if (row < n) {
+        float bp = -INFINITY, bt = -INFINITY;
+        int ip = 0x7fffffff, it = 0x7fffffff;
+        for (int c = lane; c < width; c += 64) {
+            const float p = pred[row * width + c], t = target[row * width + c];
+            if (p > bp || (p == bp && c < ip)) { bp = p; ip = c; }
+            if (t > bt || (t == bt && c < it)) { bt = t; it = c; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float op = __shfl_xor(bp, o, 64), ot = __shfl_xor(bt, o, 64);
+            const int oip = __shfl_xor(ip, o, 64), oit = __shfl_xor(it, o, 64);
+            if (op > bp || (op == bp && oip < ip)) { bp = op; ip = oip; }
+            if (ot > bt || (ot == bt && oit < it)) { bt = ot; it = oit; }
+        }
+        hit = (ip == it) ? 1u : 0u;
+    }
+    if (lane == 0) hits[wid] = hit;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned s = hits[0] + hits[1] + hits[2] + hits[3];
+        if (s) atomicAdd(count, (unsigned long long)s);
+    }
+}

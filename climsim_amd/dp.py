@@ -32,20 +32,26 @@ class RcclComm:
         self.device = device
         path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
         self._path = path.encode() if os.path.exists(path) else None          # the RCCL torch already loaded
-        # Every rank takes the same decision at every step of the setup (a rank that raised alone would leave the
-        # others waiting in a collective): rank 0's outcome travels with the id, the outcome of the init is agreed on.
-        idbuf = C.create_string_buffer(128)
-        ok0 = 1
-        if dist.get_rank() == 0 and self._lib.cs_dp_unique_id(self._path, idbuf) != 0:
-            ok0 = 0
-        msg = np.concatenate([np.asarray([ok0], np.uint8), np.frombuffer(idbuf.raw, dtype=np.uint8)])
-        t = torch.from_numpy(msg.copy()).to(device)
-        dist.broadcast(t, src=0)
-        msg = t.cpu().numpy()
-        if msg[0] == 0:
-            raise _lib.EngineError("rank 0 could not create an RCCL unique id: " + self._lib.cs_last_error().decode())
-        ident = C.create_string_buffer(msg[1:].tobytes(), 128)
+        # Every rank takes the same decision at every step of the setup: a rank that raised alone would leave the others
+        # waiting inside a collective (ncclCommInitRank included).  So (1) everything local - loading the library, binding
+        # RCCL, creating an id (every rank makes one: it proves dlopen + ncclGetUniqueId work here) - runs inside a try
+        # and its outcome is agreed on with a MIN all-reduce; (2) rank 0's id is broadcast; (3) the collective init runs
+        # on every rank or on none; (4) its outcome is agreed on again.
         self._c = C.c_void_p()
+        idbuf = C.create_string_buffer(128)
+        local_ok, err = 1, ""
+        try:
+            if self._lib.cs_dp_unique_id(self._path, idbuf) != 0:
+                local_ok, err = 0, self._lib.cs_last_error().decode()
+        except Exception as e:  # noqa: BLE001
+            local_ok, err = 0, f"{type(e).__name__}: {e}"
+        agreed = torch.tensor([local_ok], dtype=torch.int32, device=device)
+        dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+        if int(agreed.item()) == 0:
+            raise _lib.EngineError("RCCL is not usable on some rank" + (": " + err if err else ""))
+        t = torch.from_numpy(np.frombuffer(idbuf.raw, dtype=np.uint8).copy()).to(device)
+        dist.broadcast(t, src=0)
+        ident = C.create_string_buffer(t.cpu().numpy().tobytes(), 128)
         with torch.cuda.device(device):
             rc = self._lib.cs_dp_init(C.byref(self._c), self._path, ident, dist.get_world_size(), dist.get_rank(),
                                       device.index if device.index is not None else torch.cuda.current_device())
@@ -89,9 +95,12 @@ class DataParallel:
         # all_reduce remains for CPU tensors (gloo tests), on request (CS_DP_NATIVE=0) and if the native setup fails
         self.native = None
         if dist is not None and getattr(self.grad, "is_cuda", False) and os.environ.get("CS_DP_NATIVE", "1") != "0":
+            from ._lib import EngineError
             try:
                 self.native = RcclComm(dist, self.grad.device)
-            except Exception as e:  # noqa: BLE001
+            except EngineError as e:
+                # RcclComm raises EngineError on EVERY rank or on none (its setup is agreed on across the group), so the
+                # ranks cannot end up mixing native and torch collectives on the gradient; anything else propagates
                 import warnings
                 warnings.warn(f"native RCCL communicator unavailable ({e}); using torch.distributed.all_reduce")
 

@@ -323,17 +323,27 @@ class MLPEmulator:
             self.forward_batch(x[lo:hi], yhat=out[lo:hi], normalise=normalise)
         return out.cpu().numpy() if as_numpy else out
 
-    def evaluate(self, x, y, batch_size: Optional[int] = None, normalise: bool = False):
-        """model.evaluate: {'loss','mse','mae'} over the whole set (loss = mse)."""
+    def evaluate(self, x, y, batch_size: Optional[int] = None, normalise: bool = False, accuracy: bool = False):
+        """model.evaluate: {'loss','mse','mae'} over the whole set (loss = mse).  `accuracy` adds Keras' `accuracy`
+        metric of compile(metrics=['mse','mae','accuracy']) (step2_retrain.py:160-162), which for a 128-column target is
+        categorical accuracy: the share of rows with argmax(y_true) == argmax(y_pred) (cs_categorical_accuracy)."""
         torch = _torch()
         x, y = self._to_device(x, self.input_length), self._to_device(y, self.output_length)
         bs = min(batch_size or self.max_batch, self.max_batch)
         tot = torch.zeros(2, dtype=torch.float32, device=self.device)
+        hits = torch.zeros(1, dtype=torch.int64, device=self.device) if accuracy else None
+        yhat = torch.empty((bs, self.output_length), dtype=torch.float32, device=self.device) if accuracy else None
         for i, lo in enumerate(range(0, x.shape[0], bs)):
             hi = min(lo + bs, x.shape[0])
-            self.forward_batch(x[lo:hi], y=y[lo:hi], normalise=normalise, loss=tot, accumulate=i > 0)
+            self.forward_batch(x[lo:hi], yhat=yhat, y=y[lo:hi], normalise=normalise, loss=tot, accumulate=i > 0)
+            if accuracy:
+                _lib.check(self.lib.cs_categorical_accuracy(_ptr(yhat), _ptr(y[lo:hi]), hi - lo, self.output_length,
+                                                            _ptr(hits), 1, self._stream()))
         s = tot.cpu().numpy().astype(np.float64) / (self.output_length * x.shape[0])
-        return {"loss": float(s[0]), "mse": float(s[0]), "mae": float(s[1])}
+        out = {"loss": float(s[0]), "mse": float(s[0]), "mae": float(s[1])}
+        if accuracy:
+            out["accuracy"] = float(hits.item()) / x.shape[0]
+        return out
 
     def fit(self, x, y, batch_size: int = 1024, epochs: int = 1, validation_data=None, learning_rate=None,
             shuffle: bool = True, seed: int = 0, normalise: bool = False, csv_log: Optional[str] = None,
@@ -380,7 +390,12 @@ class MLPEmulator:
         gen = torch.Generator(device=self.device)
         history = {k: [] for k in ("loss", "mse", "mae", "lr")}
         if val is not None:
-            history.update({k: [] for k in ("val_loss", "val_mse", "val_mae")})
+            history.update({k: [] for k in ("val_loss", "val_mse", "val_mae", "val_accuracy")})
+        # keras.callbacks.CSVLogger writes `epoch` + the log keys in sorted order (step2_retrain.py:262; the reference's own
+        # logs: baseline_models/ED/model/ED_ClimSIM_1_3.csv:1 `epoch,accuracy,loss,lr,mae,mse,val_accuracy,val_loss,val_mae,
+        # val_mse`) and "NA" for a key without a value: the training-pass `accuracy` (argmax match, meaningless for a
+        # regression) is not accumulated by the fused training kernels, `val_accuracy` is computed on the validation pass.
+        csv_keys = sorted(["accuracy", *history.keys()])
         best, wait = math.inf, 0
         writer = None
         if csv_log and rank == 0:
@@ -388,53 +403,55 @@ class MLPEmulator:
             f = open(csv_log, "a", newline="")
             writer = csv.writer(f)
             if new:
-                writer.writerow(["epoch", *history.keys()])
+                writer.writerow(["epoch", *csv_keys])
         self.stop_training = False
-        for epoch in range(epochs):
-            gen.manual_seed(seed + epoch)            # identical permutation on every rank
-            perm = torch.randperm(n, device=self.device, generator=gen) if shuffle else torch.arange(n, device=self.device)
-            lr = sched(self.iterations)
-            # one [sum sq err, sum abs err] slot per step, written by the engine: nothing is launched to add them up
-            step_loss = torch.zeros((steps, 2), dtype=torch.float32, device=self.device)
-            for s in range(steps):
+        try:
+            for epoch in range(epochs):
+                gen.manual_seed(seed + epoch)            # identical permutation on every rank
+                perm = torch.randperm(n, device=self.device, generator=gen) if shuffle else torch.arange(n, device=self.device)
                 lr = sched(self.iterations)
+                # one [sum sq err, sum abs err] slot per step, written by the engine: nothing is launched to add them up
+                step_loss = torch.zeros((steps, 2), dtype=torch.float32, device=self.device)
+                for s in range(steps):
+                    lr = sched(self.iterations)
+                    if distributed:
+                        dp.train_step(x, y, perm, s, batch_size, lr, loss=step_loss[s], normalise=normalise)
+                    else:
+                        idx = shard_of_batch(perm, s, batch_size, 0, 1)
+                        self.train_on_batch(x, y, lr, row_idx=idx, normalise=normalise, loss=step_loss[s])
+                epoch_sum = step_loss.sum(dim=0)
                 if distributed:
-                    dp.train_step(x, y, perm, s, batch_size, lr, loss=step_loss[s], normalise=normalise)
+                    dist.all_reduce(epoch_sum)
+                tr = epoch_sum.cpu().numpy().astype(np.float64) / (self.output_length * batch_size * steps)
+                row = {"loss": float(tr[0]), "mse": float(tr[0]), "mae": float(tr[1]), "lr": float(lr)}
+                if val is not None:
+                    ev = self.evaluate(val[0], val[1], normalise=normalise, accuracy=True)
+                    row.update({"val_loss": ev["loss"], "val_mse": ev["mse"], "val_mae": ev["mae"], "val_accuracy": ev["accuracy"]})
+                for k, v in row.items():
+                    history[k].append(v)
+                if writer:
+                    writer.writerow([epoch, *[row.get(k, "NA") for k in csv_keys]])
+                    f.flush()
+                if verbose and rank == 0:
+                    print(f"epoch {epoch + 1}/{epochs} " + " ".join(f"{k}={v:.6g}" for k, v in row.items()), flush=True)
+                monitor = row.get("val_loss", row["loss"])
+                if not math.isfinite(monitor):
+                    raise FloatingPointError(f"non-finite loss at epoch {epoch}")
+                if rank == 0 and checkpoint_last:
+                    self.save_weights(checkpoint_last)
+                if monitor < best:
+                    best, wait = monitor, 0
+                    if rank == 0 and checkpoint_best:
+                        self.save_weights(checkpoint_best)
                 else:
-                    idx = shard_of_batch(perm, s, batch_size, 0, 1)
-                    self.train_on_batch(x, y, lr, row_idx=idx, normalise=normalise, loss=step_loss[s])
-            epoch_sum = step_loss.sum(dim=0)
-            if distributed:
-                dist.all_reduce(epoch_sum)
-            tr = epoch_sum.cpu().numpy().astype(np.float64) / (self.output_length * batch_size * steps)
-            row = {"loss": float(tr[0]), "mse": float(tr[0]), "mae": float(tr[1]), "lr": float(lr)}
-            if val is not None:
-                ev = self.evaluate(val[0], val[1], normalise=normalise)
-                row.update({"val_loss": ev["loss"], "val_mse": ev["mse"], "val_mae": ev["mae"]})
-            for k, v in row.items():
-                history[k].append(v)
+                    wait += 1
+                    if early_stopping_patience is not None and wait >= early_stopping_patience:
+                        self.stop_training = True
+                        break
+        finally:
             if writer:
-                writer.writerow([epoch, *[row[k] for k in history.keys()]])
-                f.flush()
-            if verbose and rank == 0:
-                print(f"epoch {epoch + 1}/{epochs} " + " ".join(f"{k}={v:.6g}" for k, v in row.items()), flush=True)
-            monitor = row.get("val_loss", row["loss"])
-            if not math.isfinite(monitor):
-                raise FloatingPointError(f"non-finite loss at epoch {epoch}")
-            if rank == 0 and checkpoint_last:
-                self.save_weights(checkpoint_last)
-            if monitor < best:
-                best, wait = monitor, 0
-                if rank == 0 and checkpoint_best:
-                    self.save_weights(checkpoint_best)
-            else:
-                wait += 1
-                if early_stopping_patience is not None and wait >= early_stopping_patience:
-                    self.stop_training = True
-                    break
-        if writer:
-            f.close()
-        dp.close()
+                f.close()
+            dp.close()                     # the engine's RCCL communicator never outlives the call, also on an exception
         return history
 
 

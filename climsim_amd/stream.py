@@ -9,7 +9,9 @@ is the training step on the main stream, and the buffer is a ring of `slots` chu
 chunk k (batches drawn from a permutation of its rows, gathered inside the first kernel), chunk k+1 is being produced.
 Raw chunks may be host arrays (pinned staging + asynchronous copy on the side stream) or device tensors (a raw shard
 resident in HBM, the high-res layout of SURVEY section 8d).  Under data parallelism every rank streams its own
-timesteps; the step is `DataParallel.train_step`'s (one all-reduce of the flat gradient).
+timesteps; the step is `DataParallel.train_step`'s (one all-reduce of the flat gradient).  Ranks agree per chunk on the
+common row count (the smallest rank's; surplus rows of larger chunks are dropped and counted in `rows_dropped`) and the
+pass ends when the first rank runs out of chunks, so every rank issues the same collectives.
 
 PyTorch provides streams, events and memory only; there is no CPU execution path.
 """
@@ -37,11 +39,20 @@ class StreamedTrainer:
             from .dp import DataParallel
             self._dp = DataParallel(model, dist, model.output_length)
         self.rows_seen = 0
+        self.rows_dropped = 0
 
     # ---- producer (side stream)
     def _produce(self, raw, free_event):
         torch = self.torch
         mli, mlo = raw
+        main = torch.cuda.current_stream(self.device)
+        device_raw = [a for a in (mli, mlo) if not isinstance(a, np.ndarray) and a is not None]
+        if device_raw:
+            # raw chunks that already live in HBM were produced on the caller's stream: the loader kernel on the side
+            # stream must not start before that work has finished (host arrays are copied on the side stream itself)
+            self.side.wait_stream(main)
+            for a in device_raw:
+                a.record_stream(self.side)
         with torch.cuda.stream(self.side):
             if free_event is not None:
                 self.side.wait_event(free_event)             # the slot's previous chunk has been consumed
@@ -53,7 +64,6 @@ class StreamedTrainer:
             x, y = self.loader.stack_raw(dev(mli), dev(mlo))
             ready = torch.cuda.Event()
             ready.record(self.side)
-        main = torch.cuda.current_stream(self.device)
         x.record_stream(main)
         y.record_stream(main)
         return x, y, ready
@@ -64,13 +74,25 @@ class StreamedTrainer:
         main = torch.cuda.current_stream(self.device)
         main.wait_event(ready)
         n = x.shape[0]
+        if self.dist is not None:
+            # Every rank streams its own timesteps, so chunks may differ in T*ncol.  The ranks must issue the SAME number of
+            # all-reduces and normalise by the SAME global row count: agree on the smallest chunk and drop the surplus
+            # rows of the larger ones (one 2-int collective per chunk, like a DistributedSampler's drop_last).
+            t = torch.tensor([n, -n], dtype=torch.int64, device=self.device)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            n_max, n = int(t[0].item()), int(-t[1].item())
+            self.rows_dropped += x.shape[0] - n
+            if n <= 0:
+                raise ValueError("a rank produced an empty chunk")
         step = step0
         # one [sum sq err, sum abs err] slot per step: the engine writes them, nothing is launched to add them up
         sums = torch.zeros((passes * ((n + self.batch - 1) // self.batch), 2), dtype=torch.float32, device=self.device)
         self._sums.append(sums)
         k = 0
         for _ in range(passes):
-            perm = torch.randperm(n, device=self.device, generator=gen)
+            perm = torch.randperm(x.shape[0], device=self.device, generator=gen)
+            if n < x.shape[0]:
+                perm = perm[:n]                      # a random subset of this rank's rows, as many as the smallest rank has
             for lo in range(0, n, self.batch):
                 idx = perm[lo:lo + self.batch]
                 lr = lr_of_step(step)
@@ -97,6 +119,7 @@ class StreamedTrainer:
         gen.manual_seed(seed)
         self._sums = []
         self.rows_seen = 0
+        self.rows_dropped = 0
         it = iter(chunks)
         ring = []                                  # [(x, y, ready)] produced, not yet consumed
         free = []                                  # `done` events of consumed chunks, oldest first
@@ -118,7 +141,12 @@ class StreamedTrainer:
                 break
         while True:
             produce_one()                          # next chunk goes out on the side stream ...
-            if not ring:
+            have = 1 if ring else 0
+            if self.dist is not None:              # the pass ends for everyone when the first rank runs out of chunks
+                t = torch.tensor([have], dtype=torch.int32, device=self.device)
+                self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+                have = int(t.item())
+            if not have:
                 break
             x, y, ready = ring.pop(0)
             done, step = self._consume(x, y, ready, lr_of_step, gen, passes_per_chunk, step)   # ... while this one trains

@@ -184,6 +184,13 @@ int cs_metrics_columns(const float* pred_dev, const float* target_dev, int64_t n
                        const double* ps_dev, const double* wa_dev, const double* wb_dev, const double* area_dev,
                        double* stats_dev, void* stream);
 
+/* Keras' `accuracy` metric for a (B, width) regression target (compile(metrics=['mse','mae','accuracy']),
+ * step2_retrain.py:160-162; for a multi-column target Keras resolves it to categorical_accuracy:
+ * argmax(y_true, -1) == argmax(y_pred, -1), first maximum on ties).  *count_dev (+)= number of matching rows of
+ * pred/target (n, width) float32; the CSVLogger columns `accuracy` / `val_accuracy` are count / n. */
+int cs_categorical_accuracy(const float* pred_dev, const float* target_dev, int64_t n, int32_t width,
+                            unsigned long long* count_dev, int accumulate, void* stream);
+
 #define CS_CNN_FLAG_TILE128 1   /* development: run every conv on the 128x128-tile kernel (A/B runs, parity cross-check) */
 typedef struct cs_cnn_cfg {
     int32_t depth;       /* hp_depth = 12            */

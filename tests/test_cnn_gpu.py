@@ -203,8 +203,8 @@ def test_cnn_error_paths(CNN):
 
 def test_cnn_full_depth_gradients(CNN):
     """The published shape (depth 12, width 406): gradients against the emulating oracle.  With depth the two bf16
-    computations decorrelate (see the forward test), so the bar is cosine >= 0.97 per tensor with a norm ratio
-    within 10 %, and the loss within 1 %."""
+    computations decorrelate (see the forward test); measured worst tensor: cosine 0.9997.  Bar: cosine >= 0.999 per
+    tensor with a norm ratio within 5 %, and the loss within 1 %."""
     depth, width, n = 12, 406, 4
     ws = CO.glorot_cnn(seed=5, bias_scale=0.02, gain=0.8, depth=depth, channels=width)
     m = CNN.CNNEmulator(depth=depth, channel_width=width, max_batch=4, trainable=True, loss="mse", dropout=0.175, seed=1)
@@ -220,7 +220,7 @@ def test_cnn_full_depth_gradients(CNN):
         c, ratio = cos_rel(g, r)
         if c < worst[0]:
             worst = (c, i, ratio)
-        assert c >= 0.97 and abs(ratio - 1) <= 0.1, (i, c, ratio)
+        assert c >= 0.999 and abs(ratio - 1) <= 0.05, (i, c, ratio)
     print("worst cosine", worst)
 
 

@@ -84,3 +84,35 @@ def test_device_loader_from_netcdf4_files(L, lowres_assets, tmp_path):
     x, y = ld.load_split("train")
     np.testing.assert_array_equal(x.cpu().numpy(), np.load(tmp_path / "npy" / "train_input.npy"))
     np.testing.assert_array_equal(y.cpu().numpy(), np.load(tmp_path / "npy" / "train_target.npy"))
+
+
+@pytest.mark.parametrize("ncol", [21600, 21601])
+def test_device_loader_highres_width_is_bit_exact(L, raw_tree, lowres_assets, ncol):
+    """BASELINE config 5: high-res timesteps are 21,600 columns wide; 21,601 adds a ragged tail (one
+    column past a multiple of the 64-column lane tile).  float64 raw fields -> float32 rows, bit-identical to the host
+    formula of data_utils.py:698-711, 807-809, 894-897, for both source dtypes."""
+    root, _ = raw_tree
+    du = make(lowres_assets, "pytorch", root)
+    ld = L.GpuColumnLoader(du)
+    rng = np.random.default_rng(ncol)
+    T = 3
+    a = rng.normal(0, 1, (T, 124, ncol)) * 50 + 100
+    b = rng.normal(0, 1, (T, 128, ncol))
+    a[2, 61, ncol - 1] = np.inf
+    a[0, 0, 0] = np.nan
+    x, y = ld.stack_raw(a, b)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        sub, div, scale = du.save_norm()
+        xr = (a.transpose(0, 2, 1).reshape(-1, 124) - sub) / div
+    xr[~np.isfinite(xr)] = 0
+    tend = ld._tend.cpu().numpy()
+    yr = b.copy()
+    m = tend >= 0
+    with np.errstate(invalid="ignore"):
+        yr[:, m] = (b[:, m] - a[:, tend[m]]) / 1200
+    yr = yr.transpose(0, 2, 1).reshape(-1, 128) * scale
+    assert tuple(x.shape) == (T * ncol, 124) and tuple(y.shape) == (T * ncol, 128)
+    np.testing.assert_array_equal(x.cpu().numpy(), np.float32(xr))
+    np.testing.assert_array_equal(y.cpu().numpy(), np.float32(yr))
+    # row index = t * ncol + column (data_utils.py:815-820): spot-check the last column of the last timestep
+    np.testing.assert_array_equal(x[-1].cpu().numpy(), np.float32(xr[-1]))

@@ -225,7 +225,14 @@ def test_fit_predict_evaluate_api(M, tmp_path):
     assert len(hist["loss"]) == 3 and hist["val_loss"][-1] < before["loss"]
     assert m.iterations == 3 * 16
     rows = open(tmp_path / "log.csv").read().strip().splitlines()
-    assert rows[0].startswith("epoch,loss,mse,mae,lr,val_loss") and len(rows) == 4
+    # keras.callbacks.CSVLogger layout (baseline_models/ED/model/ED_ClimSIM_1_3.csv:1): epoch + sorted log keys, "NA" where absent
+    assert rows[0] == "epoch,accuracy,loss,lr,mae,mse,val_accuracy,val_loss,val_mae,val_mse" and len(rows) == 4
+    last = dict(zip(rows[0].split(","), rows[-1].split(",")))
+    assert last["accuracy"] == "NA" and float(last["val_loss"]) == pytest.approx(hist["val_loss"][-1])
+    ev = m.evaluate(xv, yv, accuracy=True)
+    pv = m.predict(xv)
+    assert ev["accuracy"] == pytest.approx(float(np.mean(pv.argmax(1) == yv.argmax(1))), abs=1e-12)   # Keras categorical_accuracy
+    assert float(last["val_accuracy"]) == pytest.approx(ev["accuracy"])
     after = m.evaluate(xv, yv, batch_size=100)                      # ragged batches
     assert after["loss"] == pytest.approx(hist["val_loss"][-1], rel=1e-4)
     pred = m.predict(xv, batch_size=300)

@@ -1,0 +1,75 @@
+"""Oracle parity at the batch sizes the published throughput numbers are measured on (SURVEY section 8d:
+cfg-MLP at B in {1024, 8192, 65536}; the published model at its batch 3072) with DEFAULT engine flags, so that the kernels
+the engine picks by batch size are the ones under test:
+
+  cfg-MLP   8192  k_chain_fb<32> + k_wgrad3 (5 row splits)            - the bench.py workload
+  cfg-MLP  16384  k_chain_fb<64> + k_wgrad3 with >= 7 row splits
+  cfg-MLP  24576  k_chain_fb<128> + k_wgrad2 (256x256 LDS-DMA tiles, n >= 20480)
+  cfg-MLP  65536  k_chain_fb<128>, two rounds of workgroups + k_wgrad2
+  pub-MLP   3072  k_chainw_fb at the published model's batch (step1_results.csv:170)
+  pub-MLP  16384  k_chainw_fb + k_wgrad2-free wide path
+
+The oracle (oracle/mlp_oracle.py, bf16 rounding points emulated, float64 accumulation) takes ~1 minute for 65536 x 5x512 on
+8 host cores.  Tolerances are the ones of tests/test_mlp_gpu.py: loss 2e-3 relative, every gradient tensor
+||d||/||ref|| <= 5e-3 (accumulation order + rare 1-ulp bf16 flips)."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from oracle import mlp_oracle as O  # noqa: E402
+
+CFG = (512,) * 5
+PUB = (768, 640, 512, 640, 640)
+
+
+@pytest.fixture(scope="module")
+def M():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from climsim_amd import build
+    build.build()
+    from climsim_amd import mlp
+    return mlp
+
+
+def rel(a, b):
+    return float(np.linalg.norm(np.asarray(a, np.float64) - np.asarray(b, np.float64)) / (np.linalg.norm(b) + 1e-30))
+
+
+@pytest.mark.parametrize("units,n", [(CFG, 8192), (CFG, 16384), (CFG, 24576), (CFG, 65536), (PUB, 3072), (PUB, 16384)])
+def test_default_kernels_at_published_batch_sizes_match_oracle(M, units, n):
+    m = M.MLPEmulator(units=units, activation="leakyrelu", optimizer="Adam", max_batch=n, seed=None)
+    cfg = O.MLPConfig(hidden=tuple(units))
+    ws = O.glorot_init(cfg, 3)
+    rng = np.random.default_rng(103)
+    for i in range(1, len(ws), 2):
+        ws[i] = rng.normal(0, 0.05, ws[i].shape).astype(np.float32)
+    m.set_weights(ws)
+    x, y = O.synth_columns(n, seed=7)
+    xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    # the same rows through a permutation (the path fit() and bench.py take: gather inside the first kernel)
+    perm = torch.randperm(n, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    loss = m.loss_grads(xd, yd, row_idx=perm).cpu().numpy().astype(np.float64)
+    got = m.get_gradients(1.0 / (128 * n))
+    ref_loss, ref_mae, ref_g, ref_yhat = O.loss_and_grads(ws, x, y, cfg, bf16=True)
+    assert loss[0] / (128 * n) == pytest.approx(ref_loss, rel=2e-3)
+    assert loss[1] / (128 * n) == pytest.approx(ref_mae, rel=2e-3)
+    for i, (g, r) in enumerate(zip(got, ref_g)):
+        assert g.shape == r.shape
+        assert rel(g, r) <= 5e-3, (i, rel(g, r))
+    # prediction through the forward-only chain of the same tile height
+    pred = m.predict(xd, as_numpy=False).cpu().numpy()
+    assert np.max(np.abs(pred - ref_yhat)) <= 2e-3 * np.max(np.abs(ref_yhat))
+    # one optimiser step on top: the update applied to every parameter is the oracle's (Adam normalises, so compare the
+    # step direction in aggregate: a near-zero gradient may change sign, so cos >= 0.98) and the loss after the step went down
+    opt = O.Optimizer("Adam")
+    w1 = opt.apply(ws, ref_g, 1e-3)
+    m.train_on_batch(xd, yd, 1e-3, row_idx=perm)
+    after = m.get_weights()
+    for a, b, w0 in zip(after, w1, ws):
+        da, db = (a - w0).ravel().astype(np.float64), (b - w0).ravel().astype(np.float64)
+        cos = float(da @ db / (np.linalg.norm(da) * np.linalg.norm(db) + 1e-300))
+        assert cos >= 0.98, cos
+    m.close()

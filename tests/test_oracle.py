@@ -158,3 +158,66 @@ def test_cnn_oracle_gradients_vs_finite_differences():
     # inference forward == training forward at rate 0
     np.testing.assert_allclose(CO.loss_and_grads(ws, x3, y3, depth=2)[0]["pred"], CO.forward(ws, x3, depth=2), atol=1e-6)
     assert abs(out["mae_adjusted"] - CO.mae_adjusted(y3, out["pred"])) < 1e-6
+
+
+def _torch_opt_run(kind, ws, grads_seq, lr, **kw):
+    """The same gradient sequence through torch.optim (an implementation the builder did not write)."""
+    import torch
+    ps = [torch.nn.Parameter(torch.from_numpy(w.copy())) for w in ws]
+    opt = {"RMSprop": torch.optim.RMSprop, "RAdam": torch.optim.RAdam, "SGD": torch.optim.SGD}[kind](ps, lr=lr, **kw)
+    for grads in grads_seq:
+        for p, g in zip(ps, grads):
+            p.grad = torch.from_numpy(g.copy())
+        opt.step()
+    return [p.detach().numpy() for p in ps]
+
+
+def test_rmsprop_radam_sgd_against_torch_optim():
+    """Independent pin of the optimiser restatements: with epsilon = 0 the Keras-2.11 RMSprop and the
+    tfa-0.19 RectifiedAdam rules are algebraically torch.optim.RMSprop(alpha=rho) / torch.optim.RAdam, so the oracle must
+    reproduce torch's trajectories; the ONLY documented differences are where epsilon enters, asserted explicitly below:
+      RMSprop  Keras:  g * rsqrt(v + eps)                  torch:  g / (sqrt(v) + eps)
+      RAdam    tfa:    r*m_hat / (sqrt(v/bc2) + eps)       torch:  r*m_hat*sqrt(bc2) / (sqrt(v) + eps)
+                       (= eps_tfa  <->  eps_torch / sqrt(bc2)); threshold sma_t >= 5 (tfa) vs rho_t > 5 (torch)."""
+    rng = np.random.default_rng(0)
+    ws = [rng.normal(0, 1, (17, 9)).astype(np.float32), rng.normal(0, 1, (9,)).astype(np.float32)]
+    seq = [[rng.normal(0, 1e-2, w.shape).astype(np.float32) for w in ws] for _ in range(12)]   # crosses RAdam's switch at t = 6
+    lr = 3e-3
+    for kind, kw in (("RMSprop", dict(alpha=0.9, eps=0.0)), ("RAdam", dict(betas=(0.9, 0.999), eps=0.0)), ("SGD", {})):
+        opt = O.Optimizer(kind, eps=0.0)
+        w = [a.copy() for a in ws]
+        for grads in seq:
+            w = opt.apply(w, grads, lr)
+        ref = _torch_opt_run(kind, ws, seq, lr, **kw)
+        for a, b, w0 in zip(w, ref, ws):
+            np.testing.assert_allclose(a - w0, b - w0, rtol=2e-4, atol=5e-7)       # the accumulated UPDATE agrees (4 float32 ulp of |w| ~ 1)
+    # epsilon placement, one scalar step from zero state: v = (1-rho) g^2, Keras eps inside the root, torch outside
+    g, eps = np.float32(1e-3), 1e-7
+    k = O.Optimizer("RMSprop", eps=eps).apply([np.zeros(1, np.float32)], [np.full(1, g)], 1.0)[0][0]
+    t = _torch_opt_run("RMSprop", [np.zeros(1, np.float32)], [[np.full(1, g)]], 1.0, alpha=0.9, eps=eps)[0][0]
+    v = 0.1 * float(g) ** 2
+    assert k == pytest.approx(-float(g) / np.sqrt(v + eps), rel=1e-6)
+    assert t == pytest.approx(-float(g) / (np.sqrt(v) + eps), rel=1e-6)
+    assert abs(k - t) > 1e-4 * abs(t)                         # the two conventions are distinguishable at this gradient scale
+    # RAdam, rectified regime (t = 8 > 5): tfa's eps corresponds to torch's eps / sqrt(1 - beta2^t)
+    g = np.float32(1e-5)                                      # eps = 1 % of sqrt(v_hat) in tfa's form, 11 % in torch's
+    seq1 = [[np.full(1, g)] for _ in range(8)]
+    w_tfa = [np.zeros(1, np.float32)]
+    o = O.Optimizer("RAdam", eps=eps)
+    for grads in seq1[:-1]:
+        w_tfa = o.apply(w_tfa, grads, 1.0)
+    before = w_tfa[0][0]
+    step_tfa = o.apply(w_tfa, seq1[-1], 1.0)[0][0] - before
+    b2 = float(np.float32(0.999))                            # the variable dtype is float32: beta2 = 0.99899995..., and sma_t
+    bc2 = 1 - b2 ** 8                                         # (a difference of two ~2000s) feels its 5e-8
+    m_hat, vv = float(g), float(g) ** 2 * bc2                 # constant gradient: m/bc1 = g, v = g^2 * bc2
+    sma_inf = 2 / (1 - b2) - 1
+    sma_t = sma_inf - 2 * 8 * b2 ** 8 / bc2
+    r = np.sqrt((sma_t - 4) / (sma_inf - 4) * (sma_t - 2) / (sma_inf - 2) * sma_inf / sma_t)
+    # (float32 evaluation of sma_t moves r by ~4e-4 at t = 8: the bar is 2e-3, the two conventions are 9 % apart)
+    assert step_tfa == pytest.approx(-r * m_hat / (np.sqrt(vv / bc2) + eps), rel=2e-3)
+    torch_step = -r * m_hat * np.sqrt(bc2) / (np.sqrt(vv) + eps)
+    assert abs(step_tfa - torch_step) > 5e-2 * abs(torch_step)   # eps/sqrt(bc2) = 11x larger effective epsilon in torch's form
+    t8 = _torch_opt_run("RAdam", [np.zeros(1, np.float32)], seq1[:-1], 1.0, betas=(0.9, 0.999), eps=eps)[0][0]
+    t9 = _torch_opt_run("RAdam", [np.zeros(1, np.float32)], seq1, 1.0, betas=(0.9, 0.999), eps=eps)[0][0]
+    assert (t9 - t8) == pytest.approx(torch_step, rel=2e-3)      # and torch.optim.RAdam indeed takes the other one
