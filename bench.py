@@ -8,7 +8,11 @@ gather+normalise-cast -> 7 Dense forward -> fused MSE/dz -> 7 wgrad + 6 dgrad ->
 all-reduce of the flat fp32 gradient) -> fused optimiser + bf16 re-cast.  Nothing is skipped.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--batch PER_GPU_BATCH]
-  (N>1: launched by torch.distributed.run, one rank per GPU; weak scaling: global batch = N*batch)
+  N>1: one rank per GPU.  Either launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`
+  (RANK / LOCAL_RANK / WORLD_SIZE in the environment) or plainly as `python bench.py --gpus N`: the parent then touches no
+  GPU and starts the N ranks itself as a child process group (torch.distributed.run on 127.0.0.1), passing stdout through.
+  `value` is weak scaling (per-GPU batch fixed, global batch = N*batch); the line also carries `strong`: BASELINE
+  configs[3], global batch 8192 dealt over the N ranks (1024 per GPU at N = 8).
 
 Prints ONE JSON line on rank 0 (see DESIGN.md section "Measurement").
 """
@@ -35,14 +39,81 @@ PEAK_BF16_TFLOPS = 2500.0                   # dense MFMA peak, MI355X_MICROARCH.
 PEAK_HBM_GBS = 8000.0
 
 
+PMC_FILES = ("r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json")     # newest first
+
+
 def pmc_traffic(kernel, batch):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r01_pmc_hbm_traffic.json:
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 x2 read correction), or None when no pass matches."""
-    try:
-        with open(os.path.join(REPO, "profiles", "r01_pmc_hbm_traffic.json")) as f:
-            return json.load(f)[str(batch)][kernel]["traffic_bytes"]
-    except (OSError, KeyError, ValueError):
+    """(HBM bytes per launch of `kernel`, source file) from the committed PMC passes (profiles/rNN_pmc_hbm_traffic.json:
+    separate `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` runs of `bench.py --train-only`, gfx950 x2 read correction;
+    tests/gpu_diag.sh + tests/pmc_traffic_json.py) - counters cannot be read from inside the timed process, so the figure
+    is NOT measured in this run and carries its source.  (None, None) when no pass matches this batch."""
+    for name in PMC_FILES:
+        try:
+            with open(os.path.join(REPO, "profiles", name)) as f:
+                return json.load(f)[str(batch)][kernel]["traffic_bytes"], "profiles/" + name
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
+
+
+class ClockSampler:
+    """Shader clock (MHz) of the GPU while the timed region runs, read from sysfs (pp_dpm_sclk: the starred level is the
+    current one) by a host thread every 20 ms - nothing is launched on the GPU.  None where sysfs is not readable."""
+
+    def __init__(self, index=0):
+        import glob
+        self.path = None
+        cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+        if index < len(cards):
+            self.path = cards[index]
+        self.samples, self._stop, self._thr = [], False, None
+
+    def read(self):
+        try:
+            for line in open(self.path):
+                if "*" in line:
+                    return float(line.split(":")[1].strip().split("M")[0])
+        except Exception:
+            return None
         return None
+
+    def __enter__(self):
+        import threading
+        if self.path:
+            def loop():
+                while not self._stop:
+                    v = self.read()
+                    if v is not None:
+                        self.samples.append(v)
+                    time.sleep(0.02)
+            self._thr = threading.Thread(target=loop, daemon=True)
+            self._thr.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop = True
+        if self._thr:
+            self._thr.join(timeout=1.0)
+
+    def summary(self):
+        if not self.samples:
+            return None
+        s = sorted(self.samples)
+        return {"min": s[0], "median": s[len(s) // 2], "max": s[-1], "samples": len(s), "source": self.path}
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as children through torch.distributed.run (this
+    process makes no GPU call and is never replaced by exec) and return their exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *argv]
+    return subprocess.run(cmd, env=env).returncode
 
 
 def synth_on_device(torch, n, seed, device):
@@ -161,6 +232,42 @@ def loader_side_bench(steps=16, ncol=21600):
             "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 3)}}
 
 
+def timed_blocks(torch, dist, device, step, steps, first_step, min_seconds, max_blocks=2000):
+    """Blocks of EXACTLY `steps` steps, each bracketed by barrier + synchronize on both sides and reduced with MAX over the
+    ranks, repeated until the blocks add up to `min_seconds` of step time (a 3 ms region says little about a GPU that has
+    not reached its clocks).  Returns the per-block seconds."""
+    secs, it = [], first_step
+    while True:
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(it + i)
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if dist:
+            t = torch.tensor([el], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        secs.append(el)
+        it += steps
+        # every rank sees the same (MAX-reduced) times, so all take the same decision
+        if sum(secs) >= min_seconds or len(secs) >= max_blocks:
+            return secs
+
+
+def block_stats(secs, steps, cols_per_step):
+    s = sorted(secs)
+    med = s[len(s) // 2]
+    return {"blocks": len(s), "steps_per_block": steps, "timed_seconds": round(sum(s), 4),
+            "ms_per_step": {"min": round(s[0] / steps * 1e3, 4), "median": round(med / steps * 1e3, 4), "max": round(s[-1] / steps * 1e3, 4)},
+            "columns_per_s": {"best": round(cols_per_step * steps / s[0], 1), "median": round(cols_per_step * steps / med, 1),
+                              "worst": round(cols_per_step * steps / s[-1], 1)}}, med
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -168,6 +275,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=8192, help="per-GPU batch (columns per rank per step)")
     ap.add_argument("--rows", type=int, default=1 << 20, help="HBM-resident synthetic rows per GPU")
+    ap.add_argument("--min-seconds", type=float, default=1.0, help="repeat the --steps block until this much step time is measured")
+    ap.add_argument("--strong-global-batch", type=int, default=8192, help="N>1: global batch of the strong-scaling leg (BASELINE configs[3]); 0 = skip")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU-baseline timing (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event pass")
     ap.add_argument("--no-extras", action="store_true", help="skip the CNN / loader side figures")
@@ -176,21 +285,21 @@ def main():
     args = ap.parse_args()
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs between the ranks of this pool's hosts
-    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))   # parent: no GPU call, children do the work
+    import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback for the engine)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
     force_dist = os.environ.get("CS_BENCH_FORCE_DIST") == "1"     # development: run the N > 1 code path with a one-rank RCCL group
-    if world > 1 or force_dist:
+    multi = world > 1 or force_dist
+    if multi:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if force_dist and world == 1:
@@ -211,48 +320,75 @@ def main():
                         flags=int(os.environ.get("CS_FLAGS", "0")))   # engine flags: tuning experiments only
     x, y = synth_on_device(torch, args.rows, 20230614 + rank, device)
     xv, yv = synth_on_device(torch, 65536, 777, device)
-    grad = model.gradient_tensor()
+    model.gradient_tensor()
     loss = torch.zeros(2, dtype=torch.float32, device=device)
     lr = 1e-3
-    scale = 1.0 / (128.0 * B * world)
     gen = torch.Generator(device=device)
     gen.manual_seed(1234 + rank)
     perm = torch.randperm(args.rows, device=device, generator=gen)
-    nb = args.rows // B
 
     from climsim_amd.dp import DataParallel
-    dp = DataParallel(model, dist if (world > 1 or force_dist) else None)
+    dp = DataParallel(model, dist if multi else None)
     dp.broadcast_weights()
 
-    def step(i):
+    def make_step(b):
         # every rank owns its own HBM-resident shard of the split, so its local batch is a slice of
         # its own permutation (equivalent to the round-robin deal of a global permutation)
-        idx = perm[(i % nb) * B:(i % nb + 1) * B]
-        if world > 1 or force_dist:
-            model.loss_grads(x, y, row_idx=idx, loss=loss)
-            dp.all_reduce_grads()                                   # ONE RCCL all-reduce per step (cs_dp_allreduce, compute stream)
-            model.apply_gradients(lr, scale)
-        else:
-            model.train_on_batch(x, y, lr, row_idx=idx, loss=loss)
+        nb = args.rows // b
+        scale = 1.0 / (128.0 * b * world)
 
+        def step(i):
+            idx = perm[(i % nb) * b:(i % nb + 1) * b]
+            if multi:
+                model.loss_grads(x, y, row_idx=idx, loss=loss)
+                dp.all_reduce_grads()                               # ONE RCCL all-reduce per step (cs_dp_allreduce, compute stream)
+                model.apply_gradients(lr, scale)
+            else:
+                model.train_on_batch(x, y, lr, row_idx=idx, loss=loss)
+        return step
+
+    step = make_step(B)
     for i in range(args.warmup):
         step(i)
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    with ClockSampler(local_rank) as clk:
+        secs = timed_blocks(torch, dist, device, step, args.steps, args.warmup, args.min_seconds)
+    timing, med = block_stats(secs, args.steps, B * world)
+    ms_per_step = med / args.steps * 1e3                            # the median block: EXACTLY --steps steps between barriers
+    value = B * world * args.steps / med
+
+    # ---- N > 1: the collective on its own (HIP events on the compute stream around cs_dp_allreduce) and the strong-scaling leg
+    comm = None
+    strong = None
+    if multi:
+        evs = []
+        for i in range(20):
+            idx = perm[i * B:(i + 1) * B]
+            model.loss_grads(x, y, row_idx=idx, loss=loss)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            dp.all_reduce_grads()
+            e1.record()
+            model.apply_gradients(lr, 1.0 / (128.0 * B * world))
+            evs.append((e0, e1))
+        torch.cuda.synchronize()
+        ar = sorted(a.elapsed_time(b) * 1e3 for a, b in evs)
+        t = torch.tensor([ar[len(ar) // 2]], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    ms_per_step = elapsed / args.steps * 1e3
-    value = B * world * args.steps / elapsed
+        comm = {"collective": "ncclAllReduce(sum, float32) of the flat gradient, issued on the compute stream (cs_dp_allreduce)"
+                if dp.native is not None else "torch.distributed.all_reduce", "nranks": dist.get_world_size(),
+                "bytes": int(model.gradient_tensor().numel()) * 4, "allreduce_us_per_step": round(float(t.item()), 1),
+                "note": "median over 20 steps of the slowest rank's event pair around the collective; includes the wait for the slowest rank's gradients"}
+        gb = args.strong_global_batch
+        if gb and gb % world == 0 and gb // world >= 128:
+            sb = gb // world
+            sstep = make_step(sb)
+            for i in range(args.warmup):
+                sstep(i)
+            ssecs = timed_blocks(torch, dist, device, sstep, args.steps, args.warmup, args.min_seconds)
+            st, smed = block_stats(ssecs, args.steps, gb)
+            strong = {"scaling": "strong", "global_batch": gb, "per_gpu_batch": sb, "value": round(gb * args.steps / smed, 1), "unit": "columns/s",
+                      "ms_per_step": round(smed / args.steps * 1e3, 4), "timing": st,
+                      "config": "BASELINE configs[3]: MLP DDP, RCCL all-reduce over xGMI, global batch 8192"}
 
     # ---- untimed: held-out error of the model that was just trained, per-kernel timing, CPU baseline
     if args.train_only:
@@ -279,6 +415,7 @@ def main():
     if not args.no_profile and rank == 0:
         agg = {}
         reps = 20
+        nb = args.rows // B
         for r in range(reps):
             idx = perm[(r % nb) * B:(r % nb + 1) * B]
             for k, (ms, cnt) in model.profile_step(x, y, lr, row_idx=idx).items():
@@ -293,13 +430,14 @@ def main():
             if k in kernels:
                 kernels[k]["tflops"] = f * B / (kernels[k]["ms_per_step"] * 1e-3) / 1e12
         achieved = kernels[dom]["tflops"]
+        traffic, traffic_src = pmc_traffic(KERNEL_NAMES[dom], B)
         roofline = {"kernel": KERNEL_NAMES[dom],
                     "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
                     "avg_us_per_launch": round(kernels[dom]["avg_us_per_launch"], 2),
                     "launches_per_step": kernels[dom]["launches_per_step"],
                     "flops_per_launch": FLOPS_PER_COL[dom] * B / kernels[dom]["launches_per_step"],
-                    "traffic": pmc_traffic(KERNEL_NAMES[dom], B),
+                    "traffic": traffic, "traffic_source": traffic_src,
                     "whole_step": {"achieved": round(TRAIN_FLOPS_PER_COL * B / (ms_per_step * 1e-3) / 1e12, 2),
                                    "frac": round(TRAIN_FLOPS_PER_COL * B / (ms_per_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
                                    "hbm_algorithmic_GBs": round(HBM_BYTES_PER_COL * B / (ms_per_step * 1e-3) / 1e9, 1)}}
@@ -330,6 +468,8 @@ def main():
                                       "mse, synthetic low-res columns gathered from an HBM-resident split",
                           "per_gpu_batch": B, "global_batch": B * world, "rows_resident_per_gpu": args.rows,
                           "parallelism": f"dp{world}", "params": n_params},
+               "timing": {**timing, "value_from": "median block", "gpu_sclk_mhz": clk.summary()},
+               "comm": comm, "strong": strong,
                "heldout": {"mse": held["mse"], "mae": held["mae"], "rows": 65536, "per_variable": per_var},
                "predict": {"columns_per_s": round(predict_cps, 1), "rows": n_pred, "batch": B},
                "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu, **extras}

@@ -75,6 +75,13 @@ SIGNATURES = {
     "cs_mlp_debug_stamps": (C.c_int, [_P, _P, _I64]),
     "cs_normalise_rows": (C.c_int, [_P, _P, _I64, _I32, _P, _P, _P, _P]),
     "cs_metrics_columns": (C.c_int, [_P, _P, _I64, _I32, _I32, _P, _P, _P, _P, _P, _P]),
+    "cs_mlp_kernel_family": (C.c_int, [_P]),
+    "cs_mlp_group_create": (C.c_int, [C.POINTER(_P), C.POINTER(_P), _I32]),
+    "cs_mlp_group_destroy": (None, [_P]),
+    "cs_mlp_group_size": (_I32, [_P]),
+    "cs_mlp_group_train_step": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_I64), C.c_int, C.POINTER(_F), _P, _P]),
+    "cs_mlp_group_profile_step": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_I64), C.c_int, C.POINTER(_F), _P, _P,
+                                            C.POINTER(CsKernelTimes)]),
     "cs_categorical_accuracy": (C.c_int, [_P, _P, _I64, _I32, _P, C.c_int, _P]),
     "cs_loader_stack": (C.c_int, [_P, _P, _I32, _I64, _I32, _I32, _P, _P, _I32, _P, _P, _P, _P, _P]),
     "cs_cnn_create": (C.c_int, [C.POINTER(_P), C.POINTER(CsCnnCfg)]),

@@ -67,6 +67,15 @@ struct ChainArgs {
     unsigned long long* dbg; // optional [grid][64] s_memtime stamps (CS_CHAIN_DBG), null in production
 };
 
+// What changes from step to step (and, in a grouped launch, from member to member) apart from the weights: the batch.
+struct ChainDyn {
+    const float* x; const float* y; const int64_t* row_idx; float* loss; int64_t n_rows; int normalise;
+};
+__device__ __forceinline__ ChainDyn chain_dyn_of(const ChainArgs& p) { return ChainDyn{p.x, p.y, p.row_idx, p.loss, p.n_rows, p.normalise}; }
+
+// Grouped launches (GroupTable, kernels.h): `bid` / `ngrid` below are the workgroup index and grid size WITHIN a member
+// (blockIdx.x / gridDim.x for an ordinary launch).
+
 template <int PITCH>
 __device__ __forceinline__ int chain_lds_off_p(int row, int col) {   // element offset of (row, col)
     return row * PITCH + ((((col >> 3) ^ (row & 15))) << 3) + (col & 7);
@@ -282,9 +291,9 @@ __device__ __forceinline__ void chain_epilogue(u16* __restrict__ X, const float*
 // Heads: bias, per-column activation, yhat, squared/absolute error sums, dz of the heads.
 template <int MT>
 __device__ __forceinline__ void chain_heads(const float* __restrict__ bias_lds, const float4 (&tgt)[MT][4],
-                                            const ChainArgs& p, const ChainStage& S, int64_t m0, int jt0, int mrow0,
+                                            const ChainArgs& p, const ChainDyn& d_, const ChainStage& S, int64_t m0, int jt0, int mrow0,
                                             int lane, f32x16_t (&acc)[MT][1], float& sq, float& ab, u16* Xdz = nullptr) {
-    const bool have_y = p.y != nullptr;
+    const bool have_y = d_.y != nullptr;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int n = jt0 * 32 + 8 * q + 4 * (lane >> 5);
@@ -294,7 +303,7 @@ __device__ __forceinline__ void chain_heads(const float* __restrict__ bias_lds, 
             const int64_t m = m0 + mrow0 + a * 32 + (lane & 31);
             float v[4] = {acc[a][0][4 * q + 0] + b4.x, acc[a][0][4 * q + 1] + b4.y, acc[a][0][4 * q + 2] + b4.z,
                           acc[a][0][4 * q + 3] + b4.w};
-            const bool valid = m < p.n_rows;
+            const bool valid = m < d_.n_rows;
             float d[4];
             head4(v, d, n >= p.n_lin, p.keep, n, (have_y && valid) ? &tgt[a][q] : nullptr, p.loss_kind, sq, ab);
             if (valid && p.yhat) *reinterpret_cast<float4*>(p.yhat + m * S.Nc + n) = make_float4(v[0], v[1], v[2], v[3]);
@@ -305,39 +314,39 @@ __device__ __forceinline__ void chain_heads(const float* __restrict__ bias_lds, 
     }
 }
 
-__device__ __forceinline__ void chain_stamp(const ChainArgs& p, int tid, int& slot) {
-    if (p.dbg && tid == 0 && slot < 64) p.dbg[(int64_t)blockIdx.x * 64 + slot] = __builtin_amdgcn_s_memtime();
+__device__ __forceinline__ void chain_stamp(const ChainArgs& p, int bid, int tid, int& slot) {
+    if (p.dbg && tid == 0 && slot < 64) p.dbg[(int64_t)bid * 64 + slot] = __builtin_amdgcn_s_memtime();
     ++slot;
 }
 
 template <int BMROWS, int MT, int NT, int EPI, bool ELU>
 __device__ __forceinline__ void chain_stage(u16* X, const float* bias_lds, const int64_t* rows_lds, const ChainArgs& p,
-                                            const ChainStage& S, bool last, int64_t m0, int jt0, int mrow0, int tid,
+                                            const ChainDyn& d_, int bid, const ChainStage& S, bool last, int64_t m0, int jt0, int mrow0, int tid,
                                             float& sq, float& ab, int& slot, ChainPending& pend) {
     const int lane = tid & 63;
     f32x16_t acc[MT][NT];
     float4 tgt[MT][4];                                         // heads: target rows, in flight during the k-loop
     if constexpr (EPI == EPI_OUT) {
-        if (p.y) {
+        if (d_.y) {
 #pragma unroll
             for (int a = 0; a < MT; ++a) {
                 const int64_t r = rows_lds[mrow0 + a * 32 + (lane & 31)];
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    tgt[a][q] = *reinterpret_cast<const float4*>(p.y + (r >= 0 ? r : 0) * S.Nc + jt0 * 32 + 8 * q + 4 * (lane >> 5));
+                    tgt[a][q] = *reinterpret_cast<const float4*>(d_.y + (r >= 0 ? r : 0) * S.Nc + jt0 * 32 + 8 * q + 4 * (lane >> 5));
             }
         }
     }
     u32x4_t msk = u32x4_t{0u, 0u, 0u, 0u};
-    u32x4_t* mptr = S.mask ? S.mask + (int64_t)blockIdx.x * 512 + tid : nullptr;
+    u32x4_t* mptr = S.mask ? S.mask + (int64_t)bid * 512 + tid : nullptr;
     const bool remap = BMROWS == 32 && p.mask_bm64;            // 32-row tiles over the sign masks of a 64-row forward pass
     if (EPI == EPI_DGRAD && !ELU) {
         // The forward pass ran 64-row tiles, this pass 32-row tiles: workgroup 2i+a0 covers row tile a0 of forward
         // workgroup i.  Forward layout: tile t = a*NT+b in dword t>>1, half t&1; 128-wide stages put rows 32..63 on
         // waves 4..7 (threads 256..511).  (The dword is picked AFTER the k-loop: a use here would make hipcc wait for
         // the load before the weight queue is primed.)
-        if (remap) msk = S.mask[(int64_t)(blockIdx.x >> 1) * 512 + (S.Nc == 128 ? (tid & 255) + 256 * (blockIdx.x & 1) : tid)];
-        else if (BMROWS == 32) msk[0] = reinterpret_cast<const unsigned*>(S.mask)[(int64_t)blockIdx.x * 512 + tid];   // 32-row tiles: one word per thread
+        if (remap) msk = S.mask[(int64_t)(bid >> 1) * 512 + (S.Nc == 128 ? (tid & 255) + 256 * (bid & 1) : tid)];
+        else if (BMROWS == 32) msk[0] = reinterpret_cast<const unsigned*>(S.mask)[(int64_t)bid * 512 + tid];   // 32-row tiles: one word per thread
         else msk = *mptr;                                      // lands during the k-loop
     }
     // deep prefetch (8 steps = 16 KiB per wave in flight) where registers allow and the contraction is long enough
@@ -347,21 +356,21 @@ __device__ __forceinline__ void chain_stage(u16* X, const float* bias_lds, const
     if (MT <= 2 && (S.Kc & 127) == 0) chain_mma<BMROWS, MT, NT, 8, true>(X, S.wfrag, S.Kc >> 4, S.Nc >> 5, jt0, mrow0, tid, acc, pend, m0);
     else chain_mma<BMROWS, MT, NT, 4, true>(X, S.wfrag, S.Kc >> 4, S.Nc >> 5, jt0, mrow0, tid, acc, pend, m0);
     if (EPI == EPI_DGRAD && !ELU && remap) {
-        const int a0 = blockIdx.x & 1;
+        const int a0 = bid & 1;
         msk[0] = S.Nc == 512 ? (a0 ? msk[1] : msk[0]) : (S.Nc == 256 ? msk[0] >> (16 * a0) : msk[0]);
     }
     __syncthreads();                         // every wave has finished reading X for this stage
-    chain_stamp(p, tid, slot);
+    chain_stamp(p, bid, tid, slot);
     if (p.ablate & 16) {                     // timing experiment: no epilogue at all
         asm volatile("" :: "v"(acc[0][0][0]));
     } else if constexpr (EPI == EPI_OUT) {
-        chain_heads<MT>(bias_lds, tgt, p, S, m0, jt0, mrow0, lane, acc, sq, ab, p.fused ? X : nullptr);
+        chain_heads<MT>(bias_lds, tgt, p, d_, S, m0, jt0, mrow0, lane, acc, sq, ab, p.fused ? X : nullptr);
     } else {
         chain_epilogue<MT, NT, EPI, ELU>(X, bias_lds, p, S, last, m0, jt0, mrow0, lane, acc, msk);
         if (EPI == EPI_HIDDEN && mptr) {
             // a 32-row tile has 32 elements per thread: only word 0 carries bits, and only that word is stored
             // (12.6 -> 3.1 MB of mask traffic per pass at 8192 columns); 64 / 128-row tiles store all four
-            if (BMROWS == 32) reinterpret_cast<unsigned*>(S.mask)[(int64_t)blockIdx.x * 512 + tid] = msk[0];
+            if (BMROWS == 32) reinterpret_cast<unsigned*>(S.mask)[(int64_t)bid * 512 + tid] = msk[0];
             else *mptr = msk;
         }
     }
@@ -370,7 +379,7 @@ __device__ __forceinline__ void chain_stage(u16* X, const float* bias_lds, const
         if (last) chain_copy_out<BMROWS>(X, S.out, S.ldo, S.Nc, m0, tid);     // nobody comes after: copy now
         else pend = ChainPending{S.out, S.ldo, S.Nc};                         // the next stage copies it
     }
-    chain_stamp(p, tid, slot);
+    chain_stamp(p, bid, tid, slot);
 }
 
 // dynamic LDS: [BM][CHAIN_PITCH] bf16 activations | CHAIN_MAX_BIAS floats | BM int64 row indices
@@ -378,15 +387,15 @@ template <int BM>
 constexpr int chain_lds_bytes() { return BM * CHAIN_PITCH * 2 + CHAIN_MAX_BIAS * 4 + BM * 8; }
 
 template <int BM, bool BWD, bool ELU>
-__device__ __forceinline__ void chain_body(const ChainArgs& p, u16* X, float* bias_lds, int64_t* rows_lds) {
+__device__ __forceinline__ void chain_body(const ChainArgs& p, const ChainDyn& d_, int bid, int ngrid, u16* X, float* bias_lds, int64_t* rows_lds) {
     const int tid = threadIdx.x, wid = tid >> 6;
-    const int64_t m0 = (int64_t)blockIdx.x * BM;
+    const int64_t m0 = (int64_t)bid * BM;
     int slot = 0;
-    chain_stamp(p, tid, slot);
+    chain_stamp(p, bid, tid, slot);
     if (p.dbg && tid == 0) {                 // development: 100 MHz wall clock + placement (HW_ID, XCC_ID) of this workgroup
-        p.dbg[(int64_t)blockIdx.x * 64 + 61] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) |
+        p.dbg[(int64_t)bid * 64 + 61] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) |
                                                (unsigned)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
-        p.dbg[(int64_t)blockIdx.x * 64 + 62] = __builtin_amdgcn_s_memrealtime();
+        p.dbg[(int64_t)bid * 64 + 62] = __builtin_amdgcn_s_memrealtime();
     }
 
     // ---- L2 warm-up.  The bf16 weights were written by the optimiser kernel on other XCDs, so at
@@ -398,8 +407,8 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, u16* X, float* bi
     auto warm_up = [&]() {
         if (warmed) return;
         warmed = true;
-        const int Q = min(32, max(1, (int)(gridDim.x >> 3)));
-        const int q = (int)(blockIdx.x >> 3) % Q;
+        const int Q = min(32, max(1, ngrid >> 3));
+        const int q = (bid >> 3) % Q;
         for (int i = 0; i < p.n_stages; ++i) {
             const unsigned* w = reinterpret_cast<const unsigned*>(p.st[i].wfrag);
             const int lines = (p.st[i].Kc * p.st[i].Nc) >> 6;            // 128-B lines of bf16
@@ -416,7 +425,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, u16* X, float* bi
         {   // all bias loads and the row-index load in flight together (one memory latency, not eight)
             float bv[CHAIN_MAX_STAGES / 2];
             int64_t rv = -1;
-            if (tid < BM && m0 + tid < p.n_rows) rv = p.row_idx ? p.row_idx[m0 + tid] : m0 + tid;
+            if (tid < BM && m0 + tid < d_.n_rows) rv = d_.row_idx ? d_.row_idx[m0 + tid] : m0 + tid;
 #pragma unroll
             for (int i = 0; i < CHAIN_MAX_STAGES / 2; ++i)
                 bv[i] = (i < p.n_stages && tid < p.bias_len[i]) ? p.bias_src[i][tid] : 0.f;
@@ -439,7 +448,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, u16* X, float* bi
                 if (g < items) {
                     const int64_t src = rows_lds[mlv[u]];
                     if (src >= 0 && cv[u] < p.n_in) {
-                        const float* xr = p.x + src * p.n_in + cv[u];
+                        const float* xr = d_.x + src * p.n_in + cv[u];
                         if (cv[u] + 3 < p.n_in && (p.n_in & 3) == 0) xv[u] = *reinterpret_cast<const float4*>(xr);
                         else {
                             float t[4] = {0.f, 0.f, 0.f, 0.f};
@@ -455,7 +464,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, u16* X, float* bi
                 const int g = g0 + u * 512;
                 if (g >= items) continue;
                 float v[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
-                if (p.normalise && rows_lds[mlv[u]] >= 0) {
+                if (d_.normalise && rows_lds[mlv[u]] >= 0) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         if (cv[u] + j < p.n_in) {
@@ -479,7 +488,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, u16* X, float* bi
     warm_up();
     asm volatile("" ::"v"(sink));            // warm-up loads retire here (they overlapped the prologue)
     __syncthreads();
-    chain_stamp(p, tid, slot);
+    chain_stamp(p, bid, tid, slot);
 
     float sq = 0.f, ab = 0.f;
     ChainPending pend{nullptr, 0, 0};
@@ -488,25 +497,25 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, u16* X, float* bi
         const bool last = (i + 1 == p.n_stages);
         constexpr int E = BWD ? EPI_DGRAD : EPI_HIDDEN;
         if (S.Nc == 512) {          // wave = all BM rows x 64 columns
-            chain_stage<BM, BM / 32, 2, E, ELU>(X, bias_lds, rows_lds, p, S, last, m0, wid * 2, 0, tid, sq, ab, slot, pend);
+            chain_stage<BM, BM / 32, 2, E, ELU>(X, bias_lds, rows_lds, p, d_, bid, S, last, m0, wid * 2, 0, tid, sq, ab, slot, pend);
         } else if (S.Nc == 256) {   // wave = all BM rows x 32 columns
-            chain_stage<BM, BM / 32, 1, E, ELU>(X, bias_lds, rows_lds, p, S, last, m0, wid, 0, tid, sq, ab, slot, pend);
+            chain_stage<BM, BM / 32, 1, E, ELU>(X, bias_lds, rows_lds, p, d_, bid, S, last, m0, wid, 0, tid, sq, ab, slot, pend);
         } else if (!BWD && S.epi == EPI_OUT) {   // heads: 128 wide, wave = half the rows x 32 columns
             // (32-row tiles: four column waves cover the tile; waves 4-7 repeat their work - identical values to
             //  identical places - and are dropped from the loss sums)
-            chain_stage<BM, (BM >= 64 ? BM / 64 : 1), 1, EPI_OUT, ELU>(X, bias_lds, rows_lds, p, S, last, m0, wid & 3,
+            chain_stage<BM, (BM >= 64 ? BM / 64 : 1), 1, EPI_OUT, ELU>(X, bias_lds, rows_lds, p, d_, bid, S, last, m0, wid & 3,
                                                                       BM >= 64 ? (wid >> 2) * (BM / 2) : 0, tid, sq, ab, slot, pend);
             if (BM < 64 && wid >= 4) { sq = 0.f; ab = 0.f; }
         } else {                    // 128: wave = half the rows x 32 columns
-            chain_stage<BM, (BM >= 64 ? BM / 64 : 1), 1, E, ELU>(X, bias_lds, rows_lds, p, S, last, m0, wid & 3,
+            chain_stage<BM, (BM >= 64 ? BM / 64 : 1), 1, E, ELU>(X, bias_lds, rows_lds, p, d_, bid, S, last, m0, wid & 3,
                                                                 BM >= 64 ? (wid >> 2) * (BM / 2) : 0, tid, sq, ab, slot, pend);
         }
     }
     // (scratch: X is free, the heads stage ended with a barrier - except under k_chain_fb, where X now holds dz of the
     //  heads and the bias block, which no later stage reads, takes its place)
-    if (!BWD && p.y) loss_flush(p.loss, p.loss_stripes, blockIdx.x, sq, ab, p.fused ? bias_lds : reinterpret_cast<float*>(X), tid, 8);
-    chain_stamp(p, tid, slot);
-    if (p.dbg && tid == 0) p.dbg[(int64_t)blockIdx.x * 64 + 63] = __builtin_amdgcn_s_memrealtime();
+    if (!BWD && d_.y) loss_flush(d_.loss, p.loss_stripes, bid, sq, ab, p.fused ? bias_lds : reinterpret_cast<float*>(X), tid, 8);
+    chain_stamp(p, bid, tid, slot);
+    if (p.dbg && tid == 0) p.dbg[(int64_t)bid * 64 + 63] = __builtin_amdgcn_s_memrealtime();
 }
 
 template <int BM, bool BWD, bool ELU>
@@ -514,7 +523,7 @@ __global__ __launch_bounds__(512) void k_chain(const ChainArgs p) {
     extern __shared__ __attribute__((aligned(16))) u16 X[];      // [BM][CHAIN_PITCH]
     float* bias_lds = reinterpret_cast<float*>(X + BM * CHAIN_PITCH);
     int64_t* rows_lds = reinterpret_cast<int64_t*>(bias_lds + CHAIN_MAX_BIAS);
-    chain_body<BM, BWD, ELU>(p, X, bias_lds, rows_lds);
+    chain_body<BM, BWD, ELU>(p, chain_dyn_of(p), (int)blockIdx.x, (int)gridDim.x, X, bias_lds, rows_lds);
 }
 
 // Forward and backward chain of a training step in ONE launch.  Rows are independent: the workgroup that produced
@@ -528,8 +537,29 @@ __global__ __launch_bounds__(512) void k_chain_fb(const ChainArgs pf, const Chai
     extern __shared__ __attribute__((aligned(16))) u16 X[];
     float* bias_lds = reinterpret_cast<float*>(X + BM * CHAIN_PITCH);
     int64_t* rows_lds = reinterpret_cast<int64_t*>(bias_lds + CHAIN_MAX_BIAS);
-    chain_body<BM, false, ELU>(pf, X, bias_lds, rows_lds);
+    const ChainDyn d = chain_dyn_of(pf);
+    chain_body<BM, false, ELU>(pf, d, (int)blockIdx.x, (int)gridDim.x, X, bias_lds, rows_lds);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    chain_body<BM, true, ELU>(pb, X, bias_lds, rows_lds);
+    chain_body<BM, true, ELU>(pb, d, (int)blockIdx.x, (int)gridDim.x, X, bias_lds, rows_lds);
+}
+
+// The same for K members in ONE launch (many trials per GPU / ensembles; host side: cs_mlp_group_*): member arguments live
+// in device memory (two ChainArgs do not fit the kernel-argument segment K times), the per-step batch of every member
+// comes by value.
+struct ChainPair { ChainArgs pf, pb; };
+struct ChainDynTable { ChainDyn d[CS_GROUP_MAX]; };
+template <int BM, bool ELU>
+__global__ __launch_bounds__(512) void k_chain_fb_group(const ChainPair* __restrict__ members, const GroupTable tab, const ChainDynTable dyn) {
+    extern __shared__ __attribute__((aligned(16))) u16 X[];
+    float* bias_lds = reinterpret_cast<float*>(X + BM * CHAIN_PITCH);
+    int64_t* rows_lds = reinterpret_cast<int64_t*>(bias_lds + CHAIN_MAX_BIAS);
+    const int m = group_member(tab, (int)blockIdx.x);
+    const int bid = (int)blockIdx.x - tab.begin[m], ngrid = tab.begin[m + 1] - tab.begin[m];
+    const ChainPair& P = members[tab.idx[m]];
+    const ChainDyn d = dyn.d[m];
+    chain_body<BM, false, ELU>(P.pf, d, bid, ngrid, X, bias_lds, rows_lds);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    chain_body<BM, true, ELU>(P.pb, d, bid, ngrid, X, bias_lds, rows_lds);
 }

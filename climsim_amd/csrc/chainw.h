@@ -22,18 +22,18 @@ __device__ __forceinline__ int cwd_off(int row, int col) {        // element off
 }
 
 template <bool BWD>
-__device__ __forceinline__ void chainw_body(const ChainArgs& p, u16* XW) {
+__device__ __forceinline__ void chainw_body(const ChainArgs& p, const ChainDyn& d_, int bid, u16* XW) {
     u16* Xin = XW;
     u16* Xout = XW + CWD_BM * CWD_PITCH;
     float* bias_lds = reinterpret_cast<float*>(XW + 2 * CWD_BM * CWD_PITCH);
     int64_t* rows_lds = reinterpret_cast<int64_t*>(bias_lds + CHAIN_MAX_BIAS);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int64_t m0 = (int64_t)blockIdx.x * CWD_BM;
+    const int64_t m0 = (int64_t)bid * CWD_BM;
 
     if (!BWD) {
         for (int i = 0; i < p.n_stages; ++i)
             for (int t = tid; t < p.bias_len[i]; t += 512) bias_lds[p.st[i].bias_off + t] = p.bias_src[i][t];
-        if (tid < CWD_BM) rows_lds[tid] = (m0 + tid < p.n_rows) ? (p.row_idx ? p.row_idx[m0 + tid] : m0 + tid) : -1;
+        if (tid < CWD_BM) rows_lds[tid] = (m0 + tid < d_.n_rows) ? (d_.row_idx ? d_.row_idx[m0 + tid] : m0 + tid) : -1;
         __syncthreads();
         const int groups = p.kp0 >> 2;                           // 4 features per item
         for (int g = tid; g < CWD_BM * groups; g += 512) {
@@ -42,8 +42,8 @@ __device__ __forceinline__ void chainw_body(const ChainArgs& p, u16* XW) {
             float v[4] = {0.f, 0.f, 0.f, 0.f};
             if (src >= 0) {
                 for (int j = 0; j < 4 && c + j < p.n_in; ++j) {
-                    float t = p.x[src * p.n_in + c + j];
-                    if (p.normalise) { t = (t - p.sub[c + j]) / p.div[c + j]; t = (fabsf(t) <= 3.402823466e38f) ? t : 0.f; }
+                    float t = d_.x[src * p.n_in + c + j];
+                    if (d_.normalise) { t = (t - p.sub[c + j]) / p.div[c + j]; t = (fabsf(t) <= 3.402823466e38f) ? t : 0.f; }
                     v[j] = t;
                 }
             }
@@ -72,7 +72,7 @@ __device__ __forceinline__ void chainw_body(const ChainArgs& p, u16* XW) {
                 chain_mma<CWD_BM, 1, 1, 4, true, CWD_PITCH>(Xin, S.wfrag, ks, ntiles, tile, 0, tid, acc1, none, m0);
                 const f32x16_t& acc = acc1[0][0];
                 const int64_t m = m0 + mrow;
-                const bool row_ok = m < p.n_rows;
+                const bool row_ok = m < d_.n_rows;
                 const int64_t yrow = row_ok ? rows_lds[mrow] : 0;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -82,8 +82,8 @@ __device__ __forceinline__ void chainw_body(const ChainArgs& p, u16* XW) {
                     float v[4] = {acc[4 * q + 0] + b4.x, acc[4 * q + 1] + b4.y, acc[4 * q + 2] + b4.z, acc[4 * q + 3] + b4.w};
                     float d[4];
                     float4 t4;
-                    if (p.y && valid) t4 = *reinterpret_cast<const float4*>(p.y + yrow * p.n_real + n);
-                    head4(v, d, n >= p.n_lin, p.keep, n, (p.y && valid) ? &t4 : nullptr, p.loss_kind, sq, ab);
+                    if (d_.y && valid) t4 = *reinterpret_cast<const float4*>(d_.y + yrow * p.n_real + n);
+                    head4(v, d, n >= p.n_lin, p.keep, n, (d_.y && valid) ? &t4 : nullptr, p.loss_kind, sq, ab);
                     if (valid && p.yhat) *reinterpret_cast<float4*>(p.yhat + m * p.n_real + n) = make_float4(v[0], v[1], v[2], v[3]);
                     if (p.dz_out) *reinterpret_cast<uint2*>(p.dz_out + m * p.ld_dz_out + n) = make_uint2(cvt_pk_bf16(d[0], d[1]), cvt_pk_bf16(d[2], d[3]));
                 }
@@ -137,16 +137,16 @@ __device__ __forceinline__ void chainw_body(const ChainArgs& p, u16* XW) {
         }
         u16* t = Xin; Xin = Xout; Xout = t;
     }
-    if (!BWD && p.y) {
+    if (!BWD && d_.y) {
         __syncthreads();                                         // the heads stage has no trailing barrier: XW still being read
-        loss_flush(p.loss, p.loss_stripes, blockIdx.x, sq, ab, reinterpret_cast<float*>(XW), tid, 8);
+        loss_flush(d_.loss, p.loss_stripes, bid, sq, ab, reinterpret_cast<float*>(XW), tid, 8);
     }
 }
 
 template <bool BWD>
 __global__ __launch_bounds__(512) void k_chainw(const ChainArgs p) {
     extern __shared__ __attribute__((aligned(16))) u16 XW[];
-    chainw_body<BWD>(p, XW);
+    chainw_body<BWD>(p, chain_dyn_of(p), (int)blockIdx.x, XW);
 }
 
 // Forward and backward pass of a training step in one launch (as k_chain_fb, chain.h): rows are independent, so the
@@ -154,8 +154,22 @@ __global__ __launch_bounds__(512) void k_chainw(const ChainArgs p) {
 // after every thread has waited for its own stores and the barrier, from this XCD's L2.
 __global__ __launch_bounds__(512) void k_chainw_fb(const ChainArgs pf, const ChainArgs pb) {
     extern __shared__ __attribute__((aligned(16))) u16 XW[];
-    chainw_body<false>(pf, XW);
+    const ChainDyn d = chain_dyn_of(pf);
+    chainw_body<false>(pf, d, (int)blockIdx.x, XW);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    chainw_body<true>(pb, XW);
+    chainw_body<true>(pb, d, (int)blockIdx.x, XW);
+}
+
+// K members in one launch (see k_chain_fb_group, chain.h)
+__global__ __launch_bounds__(512) void k_chainw_fb_group(const ChainPair* __restrict__ members, const GroupTable tab, const ChainDynTable dyn) {
+    extern __shared__ __attribute__((aligned(16))) u16 XW[];
+    const int m = group_member(tab, (int)blockIdx.x);
+    const int bid = (int)blockIdx.x - tab.begin[m];
+    const ChainPair& P = members[tab.idx[m]];
+    const ChainDyn d = dyn.d[m];
+    chainw_body<false>(P.pf, d, bid, XW);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    chainw_body<true>(P.pb, d, bid, XW);
 }

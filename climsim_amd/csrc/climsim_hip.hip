@@ -169,7 +169,7 @@ void internal_to_keras(const cs_mlp* h, const float* src, float* dst) {
     memcpy(br, src + last.b_off + nl, sizeof(float) * nr);
 }
 
-int launch_optimizer(cs_mlp* h, float lr, float grad_scale, bool recast_only, hipStream_t st) {
+OptArgs fill_opt_args(cs_mlp* h, float lr, float grad_scale, bool recast_only) {
     OptArgs a{};
     a.P = h->P; a.M = h->M; a.V = h->V; a.G = h->G;
     a.n_seg = h->n_seg; a.seg = h->seg_dev;
@@ -202,6 +202,11 @@ int launch_optimizer(cs_mlp* h, float lr, float grad_scale, bool recast_only, hi
         a.radam_r = a.radam_rect
             ? sqrtf((sma_t - 4.f) / (sma_inf - 4.f) * (sma_t - 2.f) / (sma_inf - 2.f) * sma_inf / sma_t) : 0.f;
     }
+    return a;
+}
+
+int launch_optimizer(cs_mlp* h, float lr, float grad_scale, bool recast_only, hipStream_t st) {
+    const OptArgs a = fill_opt_args(h, lr, grad_scale, recast_only);
     {
         ProfScope ps(CS_K_OPTIMIZER, st);
         hipLaunchKernelGGL(k_optimizer, dim3((unsigned)h->opt_blocks), dim3(256), 0, st, a);
@@ -234,10 +239,10 @@ void launch_chain(const cs_mlp* h, int bm, int64_t m_pad, const ChainArgs& c, hi
     }
 }
 
-int chain_bm(const cs_mlp* h, int64_t n) {
-    if (h->cfg.flags & CS_FLAG_CHAIN_BM32) return 32;
-    if (h->cfg.flags & CS_FLAG_CHAIN_BM64) return 64;
-    if (h->cfg.flags & CS_FLAG_CHAIN_BM128) return 128;
+int chain_bm_of(int flags, int n_cu, int64_t n) {
+    if (flags & CS_FLAG_CHAIN_BM32) return 32;
+    if (flags & CS_FLAG_CHAIN_BM64) return 64;
+    if (flags & CS_FLAG_CHAIN_BM128) return 128;
     // Every workgroup streams ALL weights once, whatever its row count.  128-row tiles halve the weight bytes per FLOP
     // (the per-CU vector-memory path tops out near 64 B/clk, which is exactly the MFMA rate at 64 rows) but need >= 256
     // tiles to fill the chip.  32-row tiles put a workgroup on every CU from 8192 rows down, but 256 workgroups then pull
@@ -255,7 +260,7 @@ int chain_bm(const cs_mlp* h, int64_t n) {
     static const int64_t bm32_max = getenv("CS_CHAIN_BM32_MAX") ? atoll(getenv("CS_CHAIN_BM32_MAX")) : 8192;
     if (n <= bm32_max) return 32;
     int cus = 256;
-    if (h->n_cu > 0) cus = h->n_cu;
+    if (n_cu > 0) cus = n_cu;
     const int bms[3] = {32, 64, 128};
     const double w[3] = {1.0, 1.35, 2.2};
     int best = 64;
@@ -267,6 +272,8 @@ int chain_bm(const cs_mlp* h, int64_t n) {
     }
     return best;
 }
+
+int chain_bm(const cs_mlp* h, int64_t n) { return chain_bm_of(h->cfg.flags, h->n_cu, n); }
 
 // The same for the wide chain (k_chainw: act' from the global activation copies, any output width).
 void chainw_bwd_args(const cs_mlp* h, int64_t n, ChainArgs& c) {
@@ -297,30 +304,38 @@ void chain_bwd_args(const cs_mlp* h, int64_t n, ChainArgs& c) {
     c.n_rows = n; c.act = h->cfg.act; c.slope = (h->cfg.act == CS_ACT_RELU) ? 0.f : h->cfg.alpha;
 }
 
+// Forward layer chain (tuned or wide): stage i <-> layer i.
+void chain_fwd_args(const cs_mlp* h, bool wide, const float* x, const int64_t* row_idx, int64_t n, int normalise, float* yhat,
+                    const float* y, float* loss, bool striped, bool want_dz, ChainArgs& c) {
+    const Layer& l0 = h->layers[0];
+    c.n_stages = h->L;
+    for (int l = 0; l < h->L; ++l) {
+        const Layer& ly = h->layers[l];
+        ChainStage& S = c.st[l];
+        S.wfrag = ly.Wf; S.bias_off = ly.bias_off; S.Kc = ly.Kp; S.Nc = ly.N;
+        c.bias_src[l] = h->P + ly.b_off; c.bias_len[l] = ly.N;
+        // prediction / evaluation keeps nothing for a backward pass: no activation copies, no sign masks
+        if (l + 1 < h->L) { S.out = want_dz ? h->layers[l + 1].H : nullptr; S.ldo = h->layers[l + 1].Kp; S.epi = EPI_HIDDEN; S.mask = (want_dz && !wide) ? ly.mask : nullptr; }
+        else { S.out = nullptr; S.ldo = 0; S.epi = EPI_OUT; S.mask = nullptr; }
+    }
+    if (!wide) { c.ablate = h->chain_ablate; c.dbg = h->dbg; }
+    c.x = x; c.row_idx = row_idx; c.n_in = h->cfg.n_in; c.kp0 = l0.Kp; c.sub = h->sub; c.div = h->div;
+    c.normalise = normalise; c.h0 = want_dz ? l0.H : nullptr; c.ldh0 = l0.Kp; c.n_rows = n;
+    c.act = h->cfg.act; c.slope = (h->cfg.act == CS_ACT_RELU) ? 0.f : h->cfg.alpha;
+    c.n_lin = h->cfg.n_out_lin; c.yhat = yhat; c.y = y; c.loss = loss;
+    c.loss_stripes = striped ? LOSS_STRIPES : 1;
+    c.loss_kind = h->loss_kind; c.keep = h->keep;
+    c.dz_out = want_dz ? h->layers[h->L - 1].dZ : nullptr;
+    if (wide) { c.ld_dz_out = h->n_outp; c.n_real = h->n_out; } else { c.ld_dz_out = 128; }
+}
+
 int run_forward(cs_mlp* h, const float* x, const int64_t* row_idx, int64_t n, int normalise, float* yhat,
                 const float* y, float* loss, bool want_dz, hipStream_t st) {
     const int64_t m_pad = round_up(n, 128);
     const Layer& l0 = h->layers[0];
     if (h->use_chain) {
         ChainArgs c{};
-        c.n_stages = h->L;
-        for (int l = 0; l < h->L; ++l) {
-            const Layer& ly = h->layers[l];
-            ChainStage& S = c.st[l];
-            S.wfrag = ly.Wf; S.bias_off = ly.bias_off; S.Kc = ly.Kp; S.Nc = ly.N;
-            c.bias_src[l] = h->P + ly.b_off; c.bias_len[l] = ly.N;
-            // prediction / evaluation keeps nothing for a backward pass: no activation copies, no sign masks
-            if (l + 1 < h->L) { S.out = want_dz ? h->layers[l + 1].H : nullptr; S.ldo = h->layers[l + 1].Kp; S.epi = EPI_HIDDEN; S.mask = want_dz ? ly.mask : nullptr; }
-            else { S.out = nullptr; S.ldo = 0; S.epi = EPI_OUT; S.mask = nullptr; }
-        }
-        c.ablate = h->chain_ablate; c.dbg = h->dbg;
-        c.x = x; c.row_idx = row_idx; c.n_in = h->cfg.n_in; c.kp0 = l0.Kp; c.sub = h->sub; c.div = h->div;
-        c.normalise = normalise; c.h0 = want_dz ? l0.H : nullptr; c.ldh0 = l0.Kp; c.n_rows = n;
-        c.act = h->cfg.act; c.slope = (h->cfg.act == CS_ACT_RELU) ? 0.f : h->cfg.alpha;
-        c.n_lin = h->cfg.n_out_lin; c.yhat = yhat; c.y = y; c.loss = loss;
-        c.loss_stripes = h->loss_striped ? LOSS_STRIPES : 1;
-        c.loss_kind = h->loss_kind; c.keep = h->keep;
-        c.dz_out = want_dz ? h->layers[h->L - 1].dZ : nullptr; c.ld_dz_out = 128;
+        chain_fwd_args(h, false, x, row_idx, n, normalise, yhat, y, loss, h->loss_striped, want_dz, c);
         const int bm = chain_bm(h, n);
         h->bwd_chain_done = false;
         // training: the backward chain rides in the same launch (k_chain_fb) - unless the backward pass is asked to use
@@ -356,22 +371,7 @@ int run_forward(cs_mlp* h, const float* x, const int64_t* row_idx, int64_t n, in
     }
     if (h->use_chainw && n <= h->chainw_max_n) {
         ChainArgs c{};
-        c.n_stages = h->L;
-        for (int l = 0; l < h->L; ++l) {
-            const Layer& ly = h->layers[l];
-            ChainStage& S = c.st[l];
-            S.wfrag = ly.Wf; S.bias_off = ly.bias_off; S.Kc = ly.Kp; S.Nc = ly.N;
-            c.bias_src[l] = h->P + ly.b_off; c.bias_len[l] = ly.N;
-            if (l + 1 < h->L) { S.out = want_dz ? h->layers[l + 1].H : nullptr; S.ldo = h->layers[l + 1].Kp; S.epi = EPI_HIDDEN; }
-            else { S.out = nullptr; S.ldo = 0; S.epi = EPI_OUT; }
-        }
-        c.x = x; c.row_idx = row_idx; c.n_in = h->cfg.n_in; c.kp0 = l0.Kp; c.sub = h->sub; c.div = h->div;
-        c.normalise = normalise; c.h0 = want_dz ? l0.H : nullptr; c.ldh0 = l0.Kp; c.n_rows = n;
-        c.act = h->cfg.act; c.slope = (h->cfg.act == CS_ACT_RELU) ? 0.f : h->cfg.alpha;
-        c.n_lin = h->cfg.n_out_lin; c.yhat = yhat; c.y = y; c.loss = loss;
-        c.loss_stripes = h->loss_striped ? LOSS_STRIPES : 1;
-        c.loss_kind = h->loss_kind; c.keep = h->keep;
-        c.dz_out = want_dz ? h->layers[h->L - 1].dZ : nullptr; c.ld_dz_out = h->n_outp; c.n_real = h->n_out;
+        chain_fwd_args(h, true, x, row_idx, n, normalise, yhat, y, loss, h->loss_striped, want_dz, c);
         h->bwd_chain_done = false;
         if (want_dz && h->L > 1 && !(h->cfg.flags & CS_FLAG_NO_CHAIN_FB)) {       // training: backward pass in the same launch
             ChainArgs cb{};
@@ -937,6 +937,289 @@ int cs_categorical_accuracy(const float* pred_dev, const float* target_dev, int6
     if (!accumulate) HIP_TRY(hipMemsetAsync(count_dev, 0, sizeof(unsigned long long), st));
     hipLaunchKernelGGL(k_argmax_match, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, pred_dev, target_dev, n, (int)width, count_dev);
     HIP_TRY(hipGetLastError());
+    return CS_OK;
+}
+
+}  // extern "C"
+
+
+// ---------------------------------------------------------------------------------------------- grouped launches
+// Many trials per GPU / ensembles (hpo_baseline_v1.py:221-260 runs five workers per GPU, each a small
+// model at batch 48..3072; rpn_model_v1_data.py:71-163 trains a 32-member ensemble of one shape): a small-batch step of ONE
+// model leaves most of the chip idle (n/32 workgroups on 256 CUs, and every workgroup streams all weights whatever n is).
+// A group runs the step of K members as THREE launches - layer chains, weight gradients, optimisers - whose grids are the
+// concatenation of the members' grids.  Members keep their own handles (weights, optimiser state, checkpoints).
+struct cs_mlp_group {
+    std::vector<cs_mlp*> m;
+    bool wide = false, elu = false;
+    int device = 0;
+    ChainPair* pairs_dev = nullptr;      // [k] forward + backward chain arguments (everything but the batch)
+    WgradArgs* wg_dev = nullptr;         // [k] weight-gradient arguments for the batch sizes of `wg_n`
+    OptArgs* opt_dev = nullptr;          // [k] optimiser arguments without the step's scalars
+    std::vector<int64_t> wg_n;           // batch size each WgradArgs was built for (0 = never)
+    int wg_splitk = 0;
+    std::vector<float*> opt_G;           // gradient buffer each OptArgs / WgradArgs was built for (rebindable)
+};
+
+namespace {
+
+int group_bm(const cs_mlp_group* g, int64_t total_rows) {
+    // the tile height follows the TOTAL number of rows in the launch (chain_bm's table: workgroups x cost per workgroup)
+    if (g->wide) return CWD_BM;
+    return chain_bm_of(g->m[0]->cfg.flags, g->m[0]->n_cu, total_rows);
+}
+
+void wgrad_args_for(const cs_mlp* h, int64_t n, int splitk, WgradArgs& w) {
+    const int64_t m_pad = round_up(n, 128);
+    w = WgradArgs{};
+    w.n_layers = h->L; w.m_pad = m_pad; w.splitk = splitk; w.use_atomics = 1;
+    int wg = 0;
+    for (int l = 0; l < h->L; ++l) {
+        const Layer& ly = h->layers[l];
+        WgradLayer& d = w.L[l];
+        d.H = ly.H; d.ldh = ly.Kp; d.Z = ly.dZ; d.ldz = ly.N;
+        d.dW = h->G + ly.w_off; d.N = ly.N; d.k_real = ly.K; d.db = h->G + ly.b_off;
+        d.tiles_k = (ly.Kp + 127) / 128; d.tiles_n = (ly.N + 127) / 128; d.wg_begin = wg;
+        wg += d.tiles_k * d.tiles_n * splitk;
+    }
+}
+
+int wgrad_tiles128(const cs_mlp* h) {
+    int t = 0;
+    for (int l = 0; l < h->L; ++l) t += ((h->layers[l].Kp + 127) / 128) * ((h->layers[l].N + 127) / 128);
+    return t;
+}
+
+template <typename K>
+int set_lds(K kernel, int bytes) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    return CS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cs_mlp_kernel_family(const cs_mlp_t* h) {
+    if (!h) return -1;
+    const int fam = h->use_chain ? 1 : (h->use_chainw ? 2 : 0);
+    return fam | ((h->cfg.act == CS_ACT_ELU) ? 16 : 0);
+}
+
+int cs_mlp_group_create(cs_mlp_group_t** out, cs_mlp_t* const* members, int32_t k) {
+    if (!out || !members) return fail(CS_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (k < 1 || k > CS_GROUP_MAX) return fail(CS_ERR_INVALID, "a group has 1..%d members (got %d)", CS_GROUP_MAX, k);
+    for (int i = 0; i < k; ++i) {
+        if (!members[i]) return fail(CS_ERR_INVALID, "member %d is null", i);
+        for (int j = 0; j < i; ++j)
+            if (members[j] == members[i]) return fail(CS_ERR_INVALID, "member %d appears twice", i);
+    }
+    const int fam = cs_mlp_kernel_family(members[0]);
+    if ((fam & 15) == 0) return fail(CS_ERR_INVALID, "grouped launches need the layer-chain kernels (hidden widths multiples of 128 up to 1024, no CS_FLAG_NO_CHAIN)");
+    for (int i = 0; i < k; ++i) {
+        const cs_mlp* h = members[i];
+        if (cs_mlp_kernel_family(h) != fam) return fail(CS_ERR_INVALID, "member %d is of another kernel family (tuned / wide chain, ELU or not) than member 0", i);
+        if (h->cfg.device != members[0]->cfg.device) return fail(CS_ERR_INVALID, "member %d lives on another device", i);
+        if (h->L < 2) return fail(CS_ERR_INVALID, "member %d has no hidden layer", i);
+        if (h->cfg.flags & (CS_FLAG_NO_CHAIN_FB | CS_FLAG_NO_TR_READ | CS_FLAG_CHAIN_BWD32_ON_FWD64))
+            return fail(CS_ERR_INVALID, "member %d carries a development flag the grouped kernels do not implement", i);
+    }
+    HIP_TRY(hipSetDevice(members[0]->cfg.device));
+    cs_mlp_group* g = new cs_mlp_group();
+    struct Guard { cs_mlp_group* p; ~Guard() { if (p) cs_mlp_group_destroy(p); } } guard{g};
+    g->m.assign(members, members + k);
+    g->wide = (fam & 15) == 2; g->elu = (fam & 16) != 0; g->device = members[0]->cfg.device;
+    g->wg_n.assign((size_t)k, 0);
+    g->opt_G.assign((size_t)k, nullptr);
+    HIP_TRY(hipMalloc((void**)&g->pairs_dev, sizeof(ChainPair) * k));
+    HIP_TRY(hipMalloc((void**)&g->wg_dev, sizeof(WgradArgs) * k));
+    HIP_TRY(hipMalloc((void**)&g->opt_dev, sizeof(OptArgs) * k));
+    std::vector<ChainPair> pairs((size_t)k);
+    for (int i = 0; i < k; ++i) {
+        cs_mlp* h = g->m[(size_t)i];
+        ChainPair& P = pairs[(size_t)i];
+        P = ChainPair{};
+        chain_fwd_args(h, g->wide, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, true, true, P.pf);
+        if (g->wide) chainw_bwd_args(h, 0, P.pb); else chain_bwd_args(h, 0, P.pb);
+        P.pf.fused = 1; P.pb.fused = 1;
+        P.pf.dbg = nullptr; P.pb.dbg = nullptr;
+    }
+    HIP_TRY(hipMemcpy(g->pairs_dev, pairs.data(), sizeof(ChainPair) * k, hipMemcpyHostToDevice));
+    if (g->wide) {
+        if (int rc = set_lds(k_chainw_fb_group, chainw_lds_bytes())) return rc;
+    } else {
+        if (int rc = set_lds(k_chain_fb_group<32, false>, chain_lds_bytes<32>())) return rc;
+        if (int rc = set_lds(k_chain_fb_group<32, true>, chain_lds_bytes<32>())) return rc;
+        if (int rc = set_lds(k_chain_fb_group<64, false>, chain_lds_bytes<64>())) return rc;
+        if (int rc = set_lds(k_chain_fb_group<64, true>, chain_lds_bytes<64>())) return rc;
+        if (int rc = set_lds(k_chain_fb_group<128, false>, chain_lds_bytes<128>())) return rc;
+        if (int rc = set_lds(k_chain_fb_group<128, true>, chain_lds_bytes<128>())) return rc;
+    }
+    if (int rc = set_lds(k_wgrad3_group, WG3_LDS_BYTES)) return rc;
+    guard.p = nullptr;
+    *out = g;
+    return CS_OK;
+}
+
+void cs_mlp_group_destroy(cs_mlp_group_t* g) {
+    if (!g) return;
+    if (g->pairs_dev) (void)hipFree(g->pairs_dev);
+    if (g->wg_dev) (void)hipFree(g->wg_dev);
+    if (g->opt_dev) (void)hipFree(g->opt_dev);
+    delete g;
+}
+
+int32_t cs_mlp_group_size(const cs_mlp_group_t* g) { return g ? (int32_t)g->m.size() : 0; }
+
+int cs_mlp_group_train_step(cs_mlp_group_t* g, const float* const* x_dev, const float* const* y_dev,
+                            const int64_t* const* row_idx_dev, const int64_t* n, int normalise, const float* lr,
+                            float* loss_dev, void* stream) {
+    if (!g || !x_dev || !y_dev || !n || !lr || !loss_dev) return fail(CS_ERR_INVALID, "null argument");
+    const int k = (int)g->m.size();
+    hipStream_t st = (hipStream_t)stream;
+    // ---- who takes part (n[i] == 0 leaves member i out of this step), checks
+    int act[CS_GROUP_MAX], na = 0;
+    int64_t total_rows = 0;
+    for (int i = 0; i < k; ++i) {
+        if (n[i] == 0) continue;
+        cs_mlp* h = g->m[(size_t)i];
+        if (int rc = check_batch(h, n[i])) return rc;
+        if (!x_dev[i] || !y_dev[i]) return fail(CS_ERR_INVALID, "member %d: x_dev / y_dev missing", i);
+        if (normalise && !h->have_norm) return fail(CS_ERR_STATE, "member %d: normalise requested before cs_mlp_set_norm", i);
+        if (g->wide && n[i] > h->chainw_max_n) return fail(CS_ERR_INVALID, "member %d: batch above the wide chain's limit", i);
+        act[na++] = i;
+        total_rows += round_up(n[i], 128);
+    }
+    if (na == 0) return CS_OK;
+    bool tables_stale = false;
+    for (int a = 0; a < na; ++a) {
+        cs_mlp* h = g->m[(size_t)act[a]];
+        if (h->grads_dirty) {
+            ProfScope ps(CS_K_MEMSET, st);
+            HIP_TRY(hipMemsetAsync(h->G, 0, sizeof(float) * h->n_params, st));
+        }
+        h->grads_dirty = true;
+        if (g->opt_G[(size_t)act[a]] != h->G) tables_stale = true;
+    }
+    // ---- weight-gradient split count for THIS set of members; per-member tables are rebuilt when a batch size, the split
+    // count or a gradient buffer changed (rare: a blocking upload after the stream has drained)
+    int tiles = 0;
+    for (int a = 0; a < na; ++a) tiles += wgrad_tiles128(g->m[(size_t)act[a]]);
+    int64_t n_min = n[act[0]];
+    for (int a = 1; a < na; ++a) n_min = std::min(n_min, n[act[a]]);
+    int splitk = std::max(1, (365 + tiles / 2) / tiles);
+    if (n_min < 2048) splitk = std::min(splitk, 2); else if (n_min < 6144) splitk = std::min(splitk, 3);
+    splitk = (int)std::min<int64_t>(splitk, round_up(n_min, 128) / WG2_ROWS);
+    if (splitk != g->wg_splitk) tables_stale = true;
+    for (int a = 0; a < na; ++a)
+        if (g->wg_n[(size_t)act[a]] != n[act[a]]) tables_stale = true;
+    if (tables_stale) {
+        HIP_TRY(hipStreamSynchronize(st));
+        std::vector<WgradArgs> wg((size_t)k);
+        std::vector<OptArgs> oa((size_t)k);
+        for (int i = 0; i < k; ++i) {
+            cs_mlp* h = g->m[(size_t)i];
+            const int64_t ni = n[i] ? n[i] : (g->wg_n[(size_t)i] ? g->wg_n[(size_t)i] : 128);
+            wgrad_args_for(h, ni, splitk, wg[(size_t)i]);
+            g->wg_n[(size_t)i] = n[i] ? n[i] : g->wg_n[(size_t)i];
+            const float* ls = h->opt_loss_src; float* ld = h->opt_loss_dst; float* lz = h->opt_loss_zero;
+            oa[(size_t)i] = fill_opt_args(h, 0.f, 0.f, false);
+            h->opt_loss_src = ls; h->opt_loss_dst = ld; h->opt_loss_zero = lz;
+            g->opt_G[(size_t)i] = h->G;
+        }
+        g->wg_splitk = splitk;
+        HIP_TRY(hipMemcpy(g->wg_dev, wg.data(), sizeof(WgradArgs) * k, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(g->opt_dev, oa.data(), sizeof(OptArgs) * k, hipMemcpyHostToDevice));
+    }
+    // ---- launch 1: forward + backward layer chains of every member
+    const int bm = group_bm(g, total_rows);
+    GroupTable tab{};
+    ChainDynTable dyn{};
+    tab.k = na;
+    for (int a = 0; a < na; ++a) {
+        const int i = act[a];
+        cs_mlp* h = g->m[(size_t)i];
+        tab.idx[a] = i;
+        tab.begin[a + 1] = tab.begin[a] + (int)(round_up(n[i], 128) / bm);
+        float* slot = h->loss_ring + LOSS_STRIPES * LOSS_STRIPE_FLOATS * h->loss_cur;
+        dyn.d[a] = ChainDyn{x_dev[i], y_dev[i], row_idx_dev ? row_idx_dev[i] : nullptr, slot, n[i], normalise};
+        h->opt_loss_src = slot; h->opt_loss_dst = loss_dev + 2 * i;
+        h->opt_loss_zero = h->loss_ring + LOSS_STRIPES * LOSS_STRIPE_FLOATS * (h->loss_cur ^ 1);
+        h->loss_cur ^= 1;
+    }
+    {
+        ProfScope ps(CS_K_CHAIN_FB, st);
+        const dim3 grid((unsigned)tab.begin[na]);
+        if (g->wide) hipLaunchKernelGGL(k_chainw_fb_group, grid, dim3(512), chainw_lds_bytes(), st, g->pairs_dev, tab, dyn);
+        else if (bm == 32) {
+            if (g->elu) hipLaunchKernelGGL((k_chain_fb_group<32, true>), grid, dim3(512), chain_lds_bytes<32>(), st, g->pairs_dev, tab, dyn);
+            else hipLaunchKernelGGL((k_chain_fb_group<32, false>), grid, dim3(512), chain_lds_bytes<32>(), st, g->pairs_dev, tab, dyn);
+        } else if (bm == 64) {
+            if (g->elu) hipLaunchKernelGGL((k_chain_fb_group<64, true>), grid, dim3(512), chain_lds_bytes<64>(), st, g->pairs_dev, tab, dyn);
+            else hipLaunchKernelGGL((k_chain_fb_group<64, false>), grid, dim3(512), chain_lds_bytes<64>(), st, g->pairs_dev, tab, dyn);
+        } else {
+            if (g->elu) hipLaunchKernelGGL((k_chain_fb_group<128, true>), grid, dim3(512), chain_lds_bytes<128>(), st, g->pairs_dev, tab, dyn);
+            else hipLaunchKernelGGL((k_chain_fb_group<128, false>), grid, dim3(512), chain_lds_bytes<128>(), st, g->pairs_dev, tab, dyn);
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    // ---- launch 2: weight + bias gradients of every layer of every member
+    GroupTable wt{};
+    wt.k = na;
+    for (int a = 0; a < na; ++a) {
+        wt.idx[a] = act[a];
+        wt.begin[a + 1] = wt.begin[a] + wgrad_tiles128(g->m[(size_t)act[a]]) * splitk;
+    }
+    {
+        ProfScope ps(CS_K_WGRAD, st);
+        hipLaunchKernelGGL(k_wgrad3_group, dim3((unsigned)wt.begin[na]), dim3(256), WG3_LDS_BYTES, st, g->wg_dev, wt);
+    }
+    HIP_TRY(hipGetLastError());
+    // ---- launch 3: optimisers (each member with its own rule, step count and learning rate)
+    GroupTable ot{};
+    OptDynTable od{};
+    ot.k = na;
+    for (int a = 0; a < na; ++a) {
+        const int i = act[a];
+        cs_mlp* h = g->m[(size_t)i];
+        ot.idx[a] = i;
+        ot.begin[a + 1] = ot.begin[a] + h->opt_blocks;
+        const OptArgs o = fill_opt_args(h, lr[i], 1.0f / ((float)h->n_out * (float)n[i]), false);
+        od.d[a] = OptDyn{h->G, o.loss_src, o.loss_dst, o.loss_zero, o.lr, o.grad_scale, o.alpha, o.bc1, o.bc2, o.radam_r, o.radam_rect};
+        h->iterations += 1;
+        h->grads_dirty = false;
+    }
+    {
+        ProfScope ps(CS_K_OPTIMIZER, st);
+        hipLaunchKernelGGL(k_optimizer_group, dim3((unsigned)ot.begin[na]), dim3(256), 0, st, g->opt_dev, ot, od);
+    }
+    HIP_TRY(hipGetLastError());
+    return CS_OK;
+}
+
+int cs_mlp_group_profile_step(cs_mlp_group_t* g, const float* const* x_dev, const float* const* y_dev,
+                              const int64_t* const* row_idx_dev, const int64_t* n, int normalise, const float* lr,
+                              float* loss_dev, void* stream, cs_kernel_times* out) {
+    if (!out) return fail(CS_ERR_INVALID, "null argument");
+    memset(out, 0, sizeof(*out));
+    Profiler prof;
+    prof.st = (hipStream_t)stream;
+    g_prof = &prof;
+    int rc = cs_mlp_group_train_step(g, x_dev, y_dev, row_idx_dev, n, normalise, lr, loss_dev, stream);
+    g_prof = nullptr;
+    hipError_t e = hipStreamSynchronize(prof.st);
+    for (auto& r : prof.recs) {
+        float ms = 0.f;
+        if (e == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess && r.kind >= 0 && r.kind < CS_K_COUNT) {
+            out->ms[r.kind] += ms;
+            out->launches[r.kind] += 1;
+        }
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(CS_ERR_HIP, "stream synchronize failed: %s", hipGetErrorString(e));
     return CS_OK;
 }
 

@@ -460,6 +460,22 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs pa) {
     }
 }
 
+// ---------------------------------------------------------------- grouped launches
+// ONE grid = the concatenation of the grids of K independent members (same-family models with their own weights, e.g.
+// hyper-parameter trials or ensemble members; host side cs_mlp_group_*); `begin` holds the prefix sums of their workgroup
+// counts.
+#define CS_GROUP_MAX 32
+struct GroupTable {
+    int k;                           // members taking part in this launch
+    int begin[CS_GROUP_MAX + 1];     // prefix sums of their workgroup counts
+    int idx[CS_GROUP_MAX];           // slot -> index into the group's device tables (a step may leave members out)
+};
+__device__ __forceinline__ int group_member(const GroupTable& t, int b) {
+    int m = 0;
+    while (m + 1 < t.k && b >= t.begin[m + 1]) ++m;
+    return m;
+}
+
 // ---------------------------------------------------------------- optimiser
 struct Segment {          // one parameter tensor of the flat buffer
     int64_t off;          // offset in floats (multiple of 4)
@@ -549,10 +565,9 @@ __device__ __forceinline__ void opt_update4(const OptArgs& a, int64_t i0, float 
 // are 1 KiB each and hold exactly 16 x 32 (forward) or 32 x 16 (backward) elements of the tile.  (One thread per 4
 // consecutive n wrote the forward copy as four scattered 2-byte stores and the backward copy as scattered 8-byte ones:
 // 16.7 us for 1.2 M parameters.)
-__global__ __launch_bounds__(256) void k_optimizer(const OptArgs a) {
-    __shared__ __attribute__((aligned(16))) u16 tile[32][40];
+__device__ __forceinline__ void optimizer_body(const OptArgs& a, const int bid, u16 (*tile)[40]) {
     const int tid = threadIdx.x;
-    if (blockIdx.x == 0 && tid == 0 && a.loss_dst) {
+    if (bid == 0 && tid == 0 && a.loss_dst) {
         float s0 = 0.f, s1 = 0.f;
         for (int i = 0; i < LOSS_STRIPES; ++i) {
             s0 += a.loss_src[i * LOSS_STRIPE_FLOATS]; s1 += a.loss_src[i * LOSS_STRIPE_FLOATS + 1];
@@ -561,9 +576,9 @@ __global__ __launch_bounds__(256) void k_optimizer(const OptArgs a) {
         a.loss_dst[0] = s0; a.loss_dst[1] = s1;
     }
     int s = 0;
-    while (s + 1 < a.n_seg && (int)blockIdx.x >= a.seg[s + 1].blk_begin) ++s;
+    while (s + 1 < a.n_seg && bid >= a.seg[s + 1].blk_begin) ++s;
     const Segment sg = a.seg[s];
-    const int rel = blockIdx.x - sg.blk_begin;
+    const int rel = bid - sg.blk_begin;
     float wv[4] = {0.f, 0.f, 0.f, 0.f};
     if (sg.Kp == 0) {                                   // bias: 1024 floats per workgroup
         const int64_t i = (int64_t)rel * 1024 + tid * 4;
@@ -599,4 +614,26 @@ __global__ __launch_bounds__(256) void k_optimizer(const OptArgs a) {
         const int64_t blk = (int64_t)(nt * 2 + nb) * (sg.Kp >> 5) + kt;
         *reinterpret_cast<uint4*>(sg.Wb + ((blk * 64 + L) << 3)) = v;
     }
+}
+
+__global__ __launch_bounds__(256) void k_optimizer(const OptArgs a) {
+    __shared__ __attribute__((aligned(16))) u16 tile[32][40];
+    optimizer_body(a, (int)blockIdx.x, tile);
+}
+
+// K members in one launch: the per-member arguments that never change live in device memory (OptArgs with the step's
+// scalars left blank), the scalars of this step come by value.
+struct OptDyn {
+    float* G; const float* loss_src; float* loss_dst; float* loss_zero;
+    float lr, grad_scale, alpha, bc1, bc2, radam_r; int radam_rect;
+};
+struct OptDynTable { OptDyn d[CS_GROUP_MAX]; };
+__global__ __launch_bounds__(256) void k_optimizer_group(const OptArgs* __restrict__ members, const GroupTable tab, const OptDynTable dyn) {
+    __shared__ __attribute__((aligned(16))) u16 tile[32][40];
+    const int m = group_member(tab, (int)blockIdx.x);
+    OptArgs a = members[tab.idx[m]];
+    const OptDyn& d = dyn.d[m];
+    a.G = d.G; a.loss_src = d.loss_src; a.loss_dst = d.loss_dst; a.loss_zero = d.loss_zero;
+    a.lr = d.lr; a.grad_scale = d.grad_scale; a.alpha = d.alpha; a.bc1 = d.bc1; a.bc2 = d.bc2; a.radam_r = d.radam_r; a.radam_rect = d.radam_rect;
+    optimizer_body(a, (int)blockIdx.x - tab.begin[m], tile);
 }

@@ -174,12 +174,10 @@ __device__ __forceinline__ bf16x8_t frag_w3(const u16* tile, int mb, int cb, int
     return u.v;
 }
 
-__global__ __launch_bounds__(256) void k_wgrad3(const WgradArgs pa) {
-    extern __shared__ __attribute__((aligned(16))) u16 ring[];    // [stage][H|Z][32][128]
+__device__ __forceinline__ void wgrad3_body(const WgradArgs& pa, const int work, u16* ring) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wk = wid >> 1, wn = wid & 1;
-    const int work = xcd_work_id(blockIdx.x, gridDim.x);
     int li = 0;
     while (li + 1 < pa.n_layers && work >= pa.L[li + 1].wg_begin) ++li;
     const WgradLayer& p = pa.L[li];
@@ -288,4 +286,18 @@ __global__ __launch_bounds__(256) void k_wgrad3(const WgradArgs pa) {
             if (lane < 32) atomicAdd(p.db + n0 + wn * 64 + j * 32 + lane, v);
         }
     }
+}
+
+__global__ __launch_bounds__(256) void k_wgrad3(const WgradArgs pa) {
+    extern __shared__ __attribute__((aligned(16))) u16 ring[];    // [stage][H|Z][32][128]
+    wgrad3_body(pa, xcd_work_id(blockIdx.x, gridDim.x), ring);
+}
+
+// K members in one launch (csrc/group.h): the grid is the concatenation of the members' grids; consecutive work ids
+// (= the tiles of one member, layer and split, which share operand rows) still land on one XCD.
+__global__ __launch_bounds__(256) void k_wgrad3_group(const WgradArgs* __restrict__ members, const GroupTable tab) {
+    extern __shared__ __attribute__((aligned(16))) u16 ring[];
+    const int work = xcd_work_id(blockIdx.x, gridDim.x);
+    const int m = group_member(tab, work);
+    wgrad3_body(members[tab.idx[m]], work - tab.begin[m], ring);
 }

@@ -1,8 +1,11 @@
 """Many trials per GPU: the reference's hyper-parameter search trains ~8k small MLPs, several
 workers per GPU, each a separate process (baseline_v1/hpo_baseline_v1.py:64-137 search space, :221-245 RandomSearch with
 objective val_loss over 12 epochs, :255-260 workers_per_gpu).  A single small-batch step leaves most of an MI355X idle
-(32..96 workgroups on 256 CUs), so here one process drives K independent engines, each on its own HIP stream, and
-issues their steps round-robin: the GPU overlaps the trials, the data splits are shared in HBM.
+(32..96 workgroups on 256 CUs, each streaming all weights: the step time is flat from 1024 to 8192 columns), so here one
+process drives all trials and steps them TOGETHER: trials of one kernel family form a group (climsim_amd/group.py,
+cs_mlp_group_*) whose step is one launch of all layer chains, one of all weight gradients and one of all optimisers; the
+(few) families run on separate HIP streams, the data splits are shared in HBM.  `grouped=False` keeps the first form -
+K engines on K streams, stepped round-robin - for comparison.
 
     pool = TrialPool([dict(units=(256, 384), activation="relu", optimizer="Adam", batch_size=3072), ...])
     results = pool.fit(x, y, validation_data=(xv, yv), epochs=12)        # [{"val_loss": ..., "history": ...}, ...]
@@ -32,20 +35,26 @@ def sample_trial(rng: np.random.Generator) -> dict:
 
 
 class TrialPool:
-    def __init__(self, trials: Sequence[dict], device: Optional[int] = None, seed: int = 0, **model_kw):
+    def __init__(self, trials: Sequence[dict], device: Optional[int] = None, seed: int = 0, grouped: bool = True, **model_kw):
         import torch
+        from .group import MLPGroup, group_by_family
         self.trials = [dict(t) for t in trials]
         self.models: List[MLPEmulator] = []
-        self.streams = []
         for i, t in enumerate(self.trials):
             bs = int(t.get("batch_size", 3072))
             self.models.append(MLPEmulator(units=t["units"], activation=t.get("activation", "leakyrelu"),
                                            optimizer=t.get("optimizer", "Adam"), max_batch=max(bs, 4096), device=device,
                                            seed=seed + i, **model_kw))
-            self.streams.append(torch.cuda.Stream(device=self.models[-1].device))
         self.device = self.models[0].device
+        # buckets of trials that step together: one per kernel family (grouped), or one per trial
+        self.buckets = group_by_family(self.models) if grouped else [[i] for i in range(len(self.models))]
+        self.groups = [MLPGroup([self.models[i] for i in b]) if (grouped and len(b) > 1) else None for b in self.buckets]
+        self.streams = [torch.cuda.Stream(device=self.device) for _ in self.buckets]
 
     def close(self):
+        for g in self.groups:
+            if g is not None:
+                g.close()
         for m in self.models:
             m.close()
 
@@ -79,16 +88,27 @@ class TrialPool:
                 ep_sum[k].zero_()
             for s in self.streams:
                 s.wait_stream(cur)
-            for step in range(max(steps)):                       # round-robin: one step of every live trial per turn
-                for k, m in enumerate(self.models):
-                    if step >= steps[k]:
+            for step in range(max(steps)):                       # one step of every live trial per turn
+                for b, (members, grp) in enumerate(zip(self.buckets, self.groups)):
+                    live = [step < steps[k] for k in members]
+                    if not any(live):
                         continue
-                    with torch.cuda.stream(self.streams[k]):
-                        idx = perms[k][step * bss[k]:(step + 1) * bss[k]]
-                        m.train_on_batch(x, y, scheds[k](m.iterations), row_idx=idx, loss=st_loss[k])
-                        ep_sum[k] += st_loss[k]
+                    with torch.cuda.stream(self.streams[b]):
+                        if grp is None:
+                            k = members[0]
+                            idx = perms[k][step * bss[k]:(step + 1) * bss[k]]
+                            self.models[k].train_on_batch(x, y, scheds[k](self.models[k].iterations), row_idx=idx, loss=st_loss[k])
+                            ep_sum[k] += st_loss[k]
+                        else:                                    # ONE launch per kernel kind for the whole bucket
+                            idx = [perms[k][step * bss[k]:(step + 1) * bss[k]] if a else None for k, a in zip(members, live)]
+                            lrs = [scheds[k](self.models[k].iterations) for k in members]
+                            out = grp.train_on_batch(x, y, lrs, row_idx=idx, active=live)
+                            for j, (k, a) in enumerate(zip(members, live)):
+                                if a:
+                                    ep_sum[k] += out[j]
+            bucket_of = {k: b for b, members in enumerate(self.buckets) for k in members}
             for k, m in enumerate(self.models):
-                with torch.cuda.stream(self.streams[k]):
+                with torch.cuda.stream(self.streams[bucket_of[k]]):
                     if val is not None:
                         ev = m.evaluate(val[0], val[1])
                         hist[k]["val_loss"].append(ev["loss"])

@@ -184,6 +184,33 @@ int cs_metrics_columns(const float* pred_dev, const float* target_dev, int64_t n
                        const double* ps_dev, const double* wa_dev, const double* wb_dev, const double* area_dev,
                        double* stats_dev, void* stream);
 
+/* ---- many trials per GPU / ensembles: K members, ONE grouped launch per kernel kind --------------------------------
+ * The reference searches ~8k small MLPs, five worker processes per GPU (hpo_baseline_v1.py:221-245, 255-260, batch
+ * 48..3072), and trains a 32-member ensemble of one shape (baseline_models/RPN/training/rpn_model_v1_data.py:71-163).
+ * A small-batch step of one model occupies n/32 of the 256 CUs; a group runs the step of K members - each with its own
+ * handle, weights, optimiser rule, learning rate, step count and batch - as three launches (layer chains, weight
+ * gradients, optimisers) whose grids are the members' grids laid end to end.  Members must be of one kernel family
+ * (cs_mlp_kernel_family: 1 = hidden widths 128/256/512 and 128 outputs, 2 = any widths up to 1024; +16 = ELU) on one
+ * device; they need not share an architecture.  Results per member are those of cs_mlp_train_step on that member alone
+ * (same kernels bodies, same arithmetic). */
+typedef struct cs_mlp_group cs_mlp_group_t;
+#define CS_GROUP_MAX_MEMBERS 32
+int cs_mlp_kernel_family(const cs_mlp_t* h);
+int cs_mlp_group_create(cs_mlp_group_t** g, cs_mlp_t* const* members, int32_t k);   /* members are borrowed, not owned */
+void cs_mlp_group_destroy(cs_mlp_group_t* g);
+int32_t cs_mlp_group_size(const cs_mlp_group_t* g);
+/* One optimiser step of every member i with n[i] > 0 (n[i] == 0 leaves a member out of this step).  Host arrays of k
+ * entries: x_dev[i] / y_dev[i] device rows (members may share a split), row_idx_dev[i] gathered rows or NULL (the array
+ * itself may be NULL), n[i] batch size, lr[i] learning rate; loss_dev (device, k x 2 floats) receives each member's
+ * [sum of squared errors, sum of absolute errors].  Asynchronous on `stream`. */
+int cs_mlp_group_train_step(cs_mlp_group_t* g, const float* const* x_dev, const float* const* y_dev,
+                            const int64_t* const* row_idx_dev, const int64_t* n, int normalise, const float* lr,
+                            float* loss_dev, void* stream);
+/* cs_mlp_profile_step for a group: event pairs around the three launches. */
+int cs_mlp_group_profile_step(cs_mlp_group_t* g, const float* const* x_dev, const float* const* y_dev,
+                              const int64_t* const* row_idx_dev, const int64_t* n, int normalise, const float* lr,
+                              float* loss_dev, void* stream, cs_kernel_times* out);
+
 /* Keras' `accuracy` metric for a (B, width) regression target (compile(metrics=['mse','mae','accuracy']),
  * step2_retrain.py:160-162; for a multi-column target Keras resolves it to categorical_accuracy:
  * argmax(y_true, -1) == argmax(y_pred, -1), first maximum on ties).  *count_dev (+)= number of matching rows of

@@ -29,3 +29,17 @@ def test_bench_defaults_and_flags():
     for flag in ("--gpus", "--steps", "--warmup"):
         assert f'"{flag}"' in src
     assert 'default=1)' in src.split('"--gpus"')[1][:60]            # no flags: one GPU
+
+
+def test_bench_gpus_n_starts_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher (the driver's command shape): the parent must start two ranks itself
+    instead of exiting.  Without a GPU here every rank stops at the "needs a GPU" check - which proves the children ran
+    with RANK / WORLD_SIZE set and that the parent returned their failure code."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0
+    assert "must be launched with torch.distributed.run" not in (r.stdout + r.stderr)
+    assert (r.stdout + r.stderr).count("bench.py needs a GPU") >= 1
