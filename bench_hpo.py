@@ -22,7 +22,7 @@ from climsim_amd.hpo import TrialPool, sample_trial  # noqa: E402
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 STEPS = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 g = torch.Generator(device="cuda").manual_seed(0)
-n = max(64 * B, 65536)
+n = max((STEPS + 10) * B, 65536)                                    # an epoch of STEPS distinct batches per trial
 x = (torch.rand((n, 124), device="cuda", generator=g) - 0.5).contiguous()
 y = (torch.rand((n, 128), device="cuda", generator=g) * 0.1).contiguous()
 
@@ -51,6 +51,19 @@ for K in (1, 2, 4, 8, 16, 32):
         res["streams"][K] = round(rate([cfg] * K, False)[0], 1)
 one = res["streams"][1]
 
+# where a grouped step of 8 trials spends its time: event pairs around its three launches (cs_mlp_group_profile_step)
+pool = TrialPool([cfg] * 8, grouped=True)
+pool.fit(x, y, epochs=1, steps_per_epoch=5)
+grp = pool.groups[0]
+agg = {}
+for r in range(20):
+    idx = [torch.randint(0, n, (B,), device="cuda", generator=g) for _ in range(8)]
+    for kind, (ms, cnt) in grp.profile_step(x, y, 1e-3, row_idx=idx).items():
+        if cnt:
+            agg[kind] = agg.get(kind, 0.0) + ms / 20
+kernels_k8 = {k: round(v * 1e3, 1) for k, v in agg.items()}
+pool.close()
+
 # eight architectures drawn from the reference's search space (widths 128..1024, 2..12 layers; fixed seed)
 rng = np.random.default_rng(7)
 mix = []
@@ -75,5 +88,5 @@ res_rpn = {"members": 32, "units": list(rpn["units"]), "one_member_columns_per_s
 
 print(json.dumps({"metric": "aggregate training columns/sec of K concurrent trials", "unit": "columns/s", "batch": B,
                   "model": "cfg-MLP 5x512", "columns_per_s_by_K": res, "ms_per_grouped_step_by_K": step_ms,
-                  "speedup_vs_one": {f: {k: round(v / one, 2) for k, v in d.items()} for f, d in res.items()},
+                  "grouped_step_us_by_kernel_K8": kernels_k8, "speedup_vs_one": {f: {k: round(v / one, 2) for k, v in d.items()} for f, d in res.items()},
                   "search_space_mix": res_mix, "rpn_ensemble": res_rpn}))

@@ -387,7 +387,7 @@ template <int BM>
 constexpr int chain_lds_bytes() { return BM * CHAIN_PITCH * 2 + CHAIN_MAX_BIAS * 4 + BM * 8; }
 
 template <int BM, bool BWD, bool ELU>
-__device__ __forceinline__ void chain_body(const ChainArgs& p, const ChainDyn& d_, int bid, int ngrid, u16* X, float* bias_lds, int64_t* rows_lds) {
+__device__ __forceinline__ void chain_body(const ChainArgs& p, const ChainDyn& d_, int bid, int wQ, int wq, u16* X, float* bias_lds, int64_t* rows_lds) {
     const int tid = threadIdx.x, wid = tid >> 6;
     const int64_t m0 = (int64_t)bid * BM;
     int slot = 0;
@@ -401,14 +401,14 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const ChainDyn& d
     // ---- L2 warm-up.  The bf16 weights were written by the optimiser kernel on other XCDs, so at
     // launch they sit in HBM / Infinity Cache, not in this XCD's L2.  The workgroups that share an XCD
     // (block b runs on XCD b % 8 - a speed assumption only) each touch a distinct 1/Q of every stage's
-    // weights, one 4-byte load per 128-B line, all in flight at once.
+    // weights, one 4-byte load per 128-B line, all in flight at once.  (wQ, wq) = how many workgroups of this model
+    // share this XCD and which of them this one is: chain_warm_share for an ordinary launch.
     unsigned sink = 0;
     bool warmed = (p.ablate & 8) || (BWD && p.fused && !(p.ablate & 32));
     auto warm_up = [&]() {
         if (warmed) return;
         warmed = true;
-        const int Q = min(32, max(1, ngrid >> 3));
-        const int q = (bid >> 3) % Q;
+        const int Q = wQ, q = wq;
         for (int i = 0; i < p.n_stages; ++i) {
             const unsigned* w = reinterpret_cast<const unsigned*>(p.st[i].wfrag);
             const int lines = (p.st[i].Kc * p.st[i].Nc) >> 6;            // 128-B lines of bf16
@@ -518,12 +518,16 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const ChainDyn& d
     if (p.dbg && tid == 0) p.dbg[(int64_t)bid * 64 + 63] = __builtin_amdgcn_s_memrealtime();
 }
 
+// ordinary launch: block b sits on XCD b % 8, so blocks b, b+8, b+16, ... share an L2
+__device__ __forceinline__ int chain_warm_Q(int ngrid) { return min(32, max(1, ngrid >> 3)); }
+
 template <int BM, bool BWD, bool ELU>
 __global__ __launch_bounds__(512) void k_chain(const ChainArgs p) {
     extern __shared__ __attribute__((aligned(16))) u16 X[];      // [BM][CHAIN_PITCH]
     float* bias_lds = reinterpret_cast<float*>(X + BM * CHAIN_PITCH);
     int64_t* rows_lds = reinterpret_cast<int64_t*>(bias_lds + CHAIN_MAX_BIAS);
-    chain_body<BM, BWD, ELU>(p, chain_dyn_of(p), (int)blockIdx.x, (int)gridDim.x, X, bias_lds, rows_lds);
+    const int Q = chain_warm_Q((int)gridDim.x);
+    chain_body<BM, BWD, ELU>(p, chain_dyn_of(p), (int)blockIdx.x, Q, (int)(blockIdx.x >> 3) % Q, X, bias_lds, rows_lds);
 }
 
 // Forward and backward chain of a training step in ONE launch.  Rows are independent: the workgroup that produced
@@ -538,10 +542,11 @@ __global__ __launch_bounds__(512) void k_chain_fb(const ChainArgs pf, const Chai
     float* bias_lds = reinterpret_cast<float*>(X + BM * CHAIN_PITCH);
     int64_t* rows_lds = reinterpret_cast<int64_t*>(bias_lds + CHAIN_MAX_BIAS);
     const ChainDyn d = chain_dyn_of(pf);
-    chain_body<BM, false, ELU>(pf, d, (int)blockIdx.x, (int)gridDim.x, X, bias_lds, rows_lds);
+    const int Q = chain_warm_Q((int)gridDim.x), q = (int)(blockIdx.x >> 3) % Q;
+    chain_body<BM, false, ELU>(pf, d, (int)blockIdx.x, Q, q, X, bias_lds, rows_lds);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    chain_body<BM, true, ELU>(pb, d, (int)blockIdx.x, (int)gridDim.x, X, bias_lds, rows_lds);
+    chain_body<BM, true, ELU>(pb, d, (int)blockIdx.x, Q, q, X, bias_lds, rows_lds);
 }
 
 // The same for K members in ONE launch (many trials per GPU / ensembles; host side: cs_mlp_group_*): member arguments live
@@ -554,12 +559,22 @@ __global__ __launch_bounds__(512) void k_chain_fb_group(const ChainPair* __restr
     extern __shared__ __attribute__((aligned(16))) u16 X[];
     float* bias_lds = reinterpret_cast<float*>(X + BM * CHAIN_PITCH);
     int64_t* rows_lds = reinterpret_cast<int64_t*>(bias_lds + CHAIN_MAX_BIAS);
-    const int m = group_member(tab, (int)blockIdx.x);
-    const int bid = (int)blockIdx.x - tab.begin[m], ngrid = tab.begin[m + 1] - tab.begin[m];
+    // Every member has its own weights, and an XCD's L2 (4 MiB) holds about one cfg-MLP's operand copies (4.65 MB): the
+    // work ids (members laid end to end) are dealt so that every XCD gets a CONTIGUOUS run of them (xcd_work_id) and so
+    // streams the weights of as few members as possible - 8 equal members: one each.  (Dealing them round-robin,
+    // blockIdx -> member, made every XCD stream all members' weights from Infinity Cache: 8 x 1024 columns 122 us against
+    // 88 us for one model at 8192.)
+    const int T = (int)gridDim.x, w = xcd_work_id((int)blockIdx.x, T);
+    const int m = group_member(tab, w);
+    const int bid = w - tab.begin[m];
+    const int x8 = (int)blockIdx.x & 7, q8 = T >> 3, r8 = T & 7;
+    const int run_lo = x8 < r8 ? x8 * (q8 + 1) : r8 * (q8 + 1) + (x8 - r8) * q8, run_hi = run_lo + (x8 < r8 ? q8 + 1 : q8);
+    const int lo = max(run_lo, tab.begin[m]), hi = min(run_hi, tab.begin[m + 1]);
+    const int Q = min(32, max(1, hi - lo)), q = (w - lo) % Q;          // this member's workgroups on this XCD share the warm-up
     const ChainPair& P = members[tab.idx[m]];
     const ChainDyn d = dyn.d[m];
-    chain_body<BM, false, ELU>(P.pf, d, bid, ngrid, X, bias_lds, rows_lds);
+    chain_body<BM, false, ELU>(P.pf, d, bid, Q, q, X, bias_lds, rows_lds);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    chain_body<BM, true, ELU>(P.pb, d, bid, ngrid, X, bias_lds, rows_lds);
+    chain_body<BM, true, ELU>(P.pb, d, bid, Q, q, X, bias_lds, rows_lds);
 }

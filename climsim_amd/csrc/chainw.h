@@ -164,8 +164,9 @@ __global__ __launch_bounds__(512) void k_chainw_fb(const ChainArgs pf, const Cha
 // K members in one launch (see k_chain_fb_group, chain.h)
 __global__ __launch_bounds__(512) void k_chainw_fb_group(const ChainPair* __restrict__ members, const GroupTable tab, const ChainDynTable dyn) {
     extern __shared__ __attribute__((aligned(16))) u16 XW[];
-    const int m = group_member(tab, (int)blockIdx.x);
-    const int bid = (int)blockIdx.x - tab.begin[m];
+    const int w = xcd_work_id((int)blockIdx.x, (int)gridDim.x);       // a contiguous run of work ids per XCD (k_chain_fb_group)
+    const int m = group_member(tab, w);
+    const int bid = w - tab.begin[m];
     const ChainPair& P = members[tab.idx[m]];
     const ChainDyn d = dyn.d[m];
     chainw_body<false>(P.pf, d, bid, XW);

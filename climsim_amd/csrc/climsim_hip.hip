@@ -972,7 +972,7 @@ int group_bm(const cs_mlp_group* g, int64_t total_rows) {
 void wgrad_args_for(const cs_mlp* h, int64_t n, int splitk, WgradArgs& w) {
     const int64_t m_pad = round_up(n, 128);
     w = WgradArgs{};
-    w.n_layers = h->L; w.m_pad = m_pad; w.splitk = splitk; w.use_atomics = 1;
+    w.n_layers = h->L; w.m_pad = m_pad; w.splitk = splitk; w.use_atomics = splitk > 1 ? 1 : 0;   // one split: plain stores
     int wg = 0;
     for (int l = 0; l < h->L; ++l) {
         const Layer& ly = h->layers[l];

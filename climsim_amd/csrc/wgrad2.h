@@ -276,14 +276,20 @@ __device__ __forceinline__ void wgrad3_body(const WgradArgs& pa, const int work,
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int k = k0 + wk * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (k < p.k_real) atomicAdd(p.dW + (int64_t)k * p.N + n, acc[i][j][r]);
+                if (k < p.k_real) {
+                    float* dst = p.dW + (int64_t)k * p.N + n;
+                    if (pa.use_atomics) atomicAdd(dst, acc[i][j][r]); else *dst = acc[i][j][r];   // one split: the tile is written once
+                }
             }
         }
     if (do_bias) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const float v = bsum[j] + __shfl_xor(bsum[j], 32, 64);
-            if (lane < 32) atomicAdd(p.db + n0 + wn * 64 + j * 32 + lane, v);
+            if (lane < 32) {
+                float* dst = p.db + n0 + wn * 64 + j * 32 + lane;
+                if (pa.use_atomics) atomicAdd(dst, v); else *dst = v;
+            }
         }
     }
 }
