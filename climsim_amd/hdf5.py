@@ -13,8 +13,11 @@ itself, from the published HDF5 file-format specification (version 3.0):
 * datasets: fixed-point / floating-point / fixed-length string types of either byte order;
   compact, contiguous and chunked (v1 B-tree chunk index, layout message v3; layout v4 with a
   single chunk, implicit or fixed-array index) storage; deflate, shuffle and fletcher32 filters;
-* attributes, references, variable-length and compound types are not read (not needed for
-  `ds[var].values`); such datasets raise `Hdf5Unsupported` when accessed, the others stay readable.
+* attributes stored in the object header (`Hdf5File.attrs(name)`): numeric, fixed-length and variable-length string
+  values (global heap) - what Keras' `.h5` checkpoints carry (`layer_names`, `weight_names`, `keras_version`,
+  step2_retrain.py:253-261); attributes in dense storage are not read;
+* references, variable-length and compound DATASET types are not read (not needed for `ds[var].values`); such datasets
+  raise `Hdf5Unsupported` when accessed, the others stay readable.
 
 `read_hdf5(path)` returns {name: ndarray} for every dataset below the root group (nested groups
 joined with '/'); `Hdf5File` is the lazy form.
@@ -56,6 +59,7 @@ class Hdf5File:
             self._f.close()
             raise ValueError(f"{path}: not an HDF5 file (empty)")
         self._objects: Dict[str, int] = {}       # dataset name -> object header address
+        self._groups: Dict[str, int] = {}        # group path ('' = root) -> object header address
         self._read_superblock()
         self._walk(self.root_addr, "", set())
 
@@ -169,6 +173,7 @@ class Hdf5File:
         if 0x08 in types or (0x01 in types and 0x03 in types):      # a dataset
             self._objects[prefix.rstrip("/")] = addr
             return
+        self._groups[prefix.rstrip("/")] = addr
         for mtype, p, size in msgs:
             if mtype == 0x11:                     # symbol table: v1 B-tree + local heap
                 btree, heap = self._addr(p), self._addr(p + self.so)
@@ -327,6 +332,74 @@ class Hdf5File:
             yield from direct(root, start)
         else:
             yield from indirect(root, cur_rows)
+
+
+    # ------------------------------------------------------------------ attributes
+    def groups(self) -> List[str]:
+        return list(self._groups)
+
+    def _parse_dataspace(self, p: int):
+        b = self.buf
+        ver, rank = b[p], b[p + 1]
+        if ver == 2 and b[p + 3] == 2:
+            return None                           # null dataspace: no elements
+        q = p + (8 if ver == 1 else 4)
+        return tuple(self._u(q + i * self.sl, self.sl) for i in range(rank))
+
+    def _global_heap_object(self, addr: int, index: int) -> bytes:
+        b = self.buf
+        if b[addr:addr + 4] != b"GCOL":
+            raise Hdf5Unsupported(f"{self.path}: bad global heap collection at {addr}")
+        end = addr + self._u(addr + 8, self.sl)
+        q = addr + 8 + self.sl
+        while q + 8 + self.sl <= end:
+            idx, size = self._u(q, 2), self._u(q + 8, self.sl)
+            if idx == 0:
+                break
+            if idx == index:
+                return bytes(b[q + 8 + self.sl:q + 8 + self.sl + size])
+            q += 8 + self.sl + ((size + 7) & ~7)
+        raise Hdf5Unsupported(f"{self.path}: global heap object {index} not found at {addr}")
+
+    def attrs(self, name: str = "") -> Dict[str, object]:
+        """Attributes of the dataset or group `name` ('' = the root group) that live in its object header: numbers and
+        fixed-length strings come back as numpy arrays / scalars (bytes for 'S' types, like h5py), variable-length
+        strings as str."""
+        name = name.strip("/")
+        addr = self._objects.get(name, self._groups.get(name))
+        if addr is None:
+            raise KeyError(name)
+        b = self.buf
+        out: Dict[str, object] = {}
+        for mtype, p, size in self._messages(addr):
+            if mtype != 0x0C:
+                continue
+            ver = b[p]
+            nsz, tsz, ssz = self._u(p + 2, 2), self._u(p + 4, 2), self._u(p + 6, 2)
+            q = p + 8 + (1 if ver == 3 else 0)
+            pad = (lambda n: (n + 7) & ~7) if ver == 1 else (lambda n: n)
+            aname = bytes(b[q:q + nsz]).split(b"\x00")[0].decode("utf-8", "replace")
+            q += pad(nsz)
+            tpos = q
+            q += pad(tsz)
+            shape = self._parse_dataspace(q)
+            q += pad(ssz)
+            cls, bits0, tsize = b[tpos] & 0x0F, b[tpos + 1], self._u(tpos + 4, 4)
+            count = 0 if shape is None else int(np.prod(shape)) if shape else 1
+            if cls in (0, 1, 3):
+                order = ">" if bits0 & 1 else "<"
+                dt = np.dtype(f"S{tsize}") if cls == 3 else np.dtype(f"{order}{'f' if cls == 1 else ('i' if bits0 & 0x08 else 'u')}{tsize}")
+                arr = np.frombuffer(bytes(b[q:q + count * tsize]), dtype=dt, count=count)
+                out[aname] = arr.reshape(shape) if shape else (arr[0] if count else arr)
+            elif cls == 9 and (bits0 & 0x0F) == 1:          # variable-length string(s): {length, global heap address, index}
+                vals = []
+                for i in range(count):
+                    e = q + i * (4 + self.so + 4)
+                    gaddr, gidx = self._addr(e + 4), self._u(e + 4 + self.so, 4)
+                    vals.append("" if gaddr is None else self._global_heap_object(gaddr, gidx).split(b"\x00")[0].decode("utf-8", "replace"))
+                out[aname] = (np.asarray(vals, dtype=object).reshape(shape) if shape else (vals[0] if vals else ""))
+            # other classes (compound, references, ...) are skipped
+        return out
 
     # ------------------------------------------------------------------ datasets
     def keys(self) -> List[str]:
@@ -638,3 +711,127 @@ def write_hdf5_dataset(path: str, name: str, array) -> None:
         f.write(sb + root + bt + heap + heap_data + snod + dset)
         f.write(b"\x00" * (a_data - (a_dset + len(dset))))
         f.write(a.tobytes())
+
+
+# ---------------------------------------------------------------------------------------------- tree writer
+# Groups, datasets and attributes - what a Keras `.h5` checkpoint consists of (model.save / save_weights through h5py:
+# step2_retrain.py:253-261).  Same conservative choices as `write_hdf5_dataset`: superblock 0, version-1 object headers,
+# symbol-table groups (one v1 B-tree leaf + one symbol node per group; the file-wide "group leaf node K" is sized for the
+# largest group), contiguous little-endian datasets, version-1 attribute messages with fixed-length strings - the forms
+# every HDF5 library version reads.
+ATTRS = "@attrs"
+
+
+def _dtype_message(a: np.ndarray) -> bytes:
+    if a.dtype.kind == "S":
+        return struct.pack("<BBBBI", 0x13, 0x01, 0, 0, max(a.dtype.itemsize, 1))          # string, null-padded, ASCII
+    if a.dtype == np.float32:
+        return struct.pack("<BBBBI", 0x11, 0x20, 31, 0, 4) + struct.pack("<HHBBBBI", 0, 32, 23, 8, 0, 23, 127)
+    if a.dtype == np.float64:
+        return struct.pack("<BBBBI", 0x11, 0x20, 63, 0, 8) + struct.pack("<HHBBBBI", 0, 64, 52, 11, 0, 52, 1023)
+    if a.dtype.kind in "iu" and a.dtype.itemsize in (1, 2, 4, 8):
+        return struct.pack("<BBBBI", 0x10, 0x08 if a.dtype.kind == "i" else 0x00, 0, 0, a.dtype.itemsize) + struct.pack(
+            "<HH", 0, 8 * a.dtype.itemsize)
+    raise Hdf5Unsupported(f"write_hdf5_tree: dtype {a.dtype}")
+
+
+def _as_le_array(v) -> np.ndarray:
+    if isinstance(v, str):
+        v = v.encode("utf-8")
+    if isinstance(v, bytes):
+        return np.asarray(v, dtype=f"S{max(len(v), 1)}")
+    a = np.asarray(v)
+    if a.dtype.kind == "U":
+        a = np.char.encode(a, "utf-8")
+    if a.dtype.kind == "O":
+        raise Hdf5Unsupported("write_hdf5_tree: object arrays")
+    if a.dtype.kind == "b":
+        a = a.astype(np.uint8)
+    if a.dtype.kind in "fiu":
+        a = a.astype(a.dtype.newbyteorder("<"), copy=False)
+    return a if a.flags.c_contiguous else np.ascontiguousarray(a)      # (ascontiguousarray would turn a scalar into shape (1,))
+
+
+def _dataspace_message(shape) -> bytes:
+    return struct.pack("<BBB5x", 1, len(shape), 0) + b"".join(struct.pack("<Q", int(n)) for n in shape)
+
+
+def _attribute_message(name: str, value) -> bytes:
+    a = _as_le_array(value)
+    nm = name.encode("utf-8") + b"\x00"
+    dt, sp = _dtype_message(a), _dataspace_message(a.shape)
+    return (struct.pack("<BBHHH", 1, 0, len(nm), len(dt), len(sp)) + _pad8(nm) + _pad8(dt) + _pad8(sp) + a.tobytes())
+
+
+class _TreeWriter:
+    INT_K = 16
+
+    def __init__(self, tree: dict):
+        self.tree = tree
+        self.buf = bytearray(96)                  # superblock goes here at the end
+        self.leaf_k = max(4, (self._max_children(tree) + 1) // 2)
+
+    def _max_children(self, node) -> int:
+        kids = [k for k in node if k != ATTRS]
+        return max([len(kids)] + [self._max_children(node[k]) for k in kids if isinstance(node[k], dict)])
+
+    def _alloc(self, data: bytes) -> int:
+        self.buf += b"\x00" * (-len(self.buf) % 8)
+        addr = len(self.buf)
+        self.buf += data
+        return addr
+
+    def _dataset(self, value) -> int:
+        a = _as_le_array(value)
+        data_addr = self._alloc(a.tobytes() if a.size else b"")
+        fill = struct.pack("<BBBB", 2, 2, 2, 0)
+        layout = struct.pack("<BBQQ", 3, 1, data_addr if a.size else _UNDEF, a.nbytes)
+        return self._alloc(_ohdr_v1([(0x01, _dataspace_message(a.shape)), (0x03, _dtype_message(a)), (0x05, fill), (0x08, layout)]))
+
+    def _group(self, node: dict):
+        """-> (object header address, b-tree address, local heap address)"""
+        names = sorted((k for k in node if k != ATTRS), key=lambda s: s.encode("utf-8"))
+        child = {k: (self._group(node[k])[0] if isinstance(node[k], dict) else self._dataset(node[k])) for k in names}
+        heap_data = bytearray(_pad8(b"\x00"))
+        offs = {}
+        for k in names:
+            offs[k] = len(heap_data)
+            heap_data += _pad8(k.encode("utf-8") + b"\x00")
+        heap_data += b"\x00" * (-len(heap_data) % 16)
+        heap_data_addr = self._alloc(bytes(heap_data))
+        heap_addr = self._alloc(b"HEAP" + struct.pack("<B3xQQQ", 0, len(heap_data), 1, heap_data_addr))      # free-list head 1 = none
+        snod = bytearray(b"SNOD" + struct.pack("<BBH", 1, 0, len(names)))
+        for k in names:
+            snod += struct.pack("<QQII16x", offs[k], child[k], 0, 0)
+        snod += b"\x00" * (8 + 2 * self.leaf_k * 40 - len(snod))
+        snod_addr = self._alloc(bytes(snod))
+        bt_len = 24 + (2 * self.INT_K + 1) * 8 + 2 * self.INT_K * 8
+        if names:
+            bt = b"TREE" + struct.pack("<BBHQQ", 0, 0, 1, _UNDEF, _UNDEF) + struct.pack("<QQQ", 0, snod_addr, offs[names[-1]])
+        else:
+            bt = b"TREE" + struct.pack("<BBHQQ", 0, 0, 0, _UNDEF, _UNDEF)
+        bt_addr = self._alloc(bt + b"\x00" * (bt_len - len(bt)))
+        msgs = [(0x11, struct.pack("<QQ", bt_addr, heap_addr))]
+        msgs += [(0x0C, _attribute_message(k, v)) for k, v in node.get(ATTRS, {}).items()]
+        return self._alloc(_ohdr_v1(msgs)), bt_addr, heap_addr
+
+    def finish(self) -> bytes:
+        root, bt, heap = self._group(self.tree)
+        eof = len(self.buf)
+        sb = SIGNATURE + struct.pack("<BBBBBBBBHHI", 0, 0, 0, 0, 0, 8, 8, 0, self.leaf_k, self.INT_K, 0)
+        sb += struct.pack("<QQQQ", 0, _UNDEF, eof, _UNDEF)
+        sb += struct.pack("<QQII", 0, root, 1, 0) + struct.pack("<QQ", bt, heap)
+        assert len(sb) == 96
+        self.buf[0:96] = sb
+        return bytes(self.buf)
+
+
+def write_hdf5_tree(path: str, tree: dict) -> None:
+    """Write nested groups: `tree` maps names to arrays (datasets) or dicts (groups); the key '@attrs' of a dict holds that
+    group's attributes (numbers, numeric arrays, str / bytes, arrays of bytes).  Written atomically (tmp + replace)."""
+    import os
+    data = _TreeWriter(tree).finish()
+    tmp = path + ".tmp"
+    with open(tmp, "wb") as f:
+        f.write(data)
+    os.replace(tmp, path)

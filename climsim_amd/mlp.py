@@ -212,9 +212,17 @@ class MLPEmulator:
         self.iterations = int(iterations)
 
     def save_weights(self, path: str):
-        """Weights + optimiser state as .npz (Keras-ordered arrays w0..., m0..., v0...)."""
+        """Checkpoint = weights + optimiser state.  `*.h5`: Keras' legacy-H5 layout, the format of the reference's
+        ModelCheckpoint(save_weights_only=False) files (step2_retrain.py:253-261; climsim_amd/keras_h5.py) - a
+        reference-built Keras model can `load_weights` it; anything else: .npz (Keras-ordered arrays w0..., m0..., v0...)."""
         ws = self.get_weights()
         m, v, it = self.get_optimizer_state()
+        if path.endswith((".h5", ".hdf5")):
+            if self.direct_head:
+                raise ValueError("the Keras .h5 layout describes the baseline MLP (Dense(output_length) + two heads); use .npz")
+            from .keras_h5 import save_keras_h5
+            save_keras_h5(path, ws, self.activation, full_model=True, optimizer_state={"m": m, "v": v, "iterations": it})
+            return
         blob = {f"w{i}": a for i, a in enumerate(ws)}
         blob.update({f"m{i}": a for i, a in enumerate(m)})
         blob.update({f"v{i}": a for i, a in enumerate(v)})
@@ -225,6 +233,15 @@ class MLPEmulator:
         os.replace(tmp, path)
 
     def load_weights(self, path: str, with_optimizer: bool = True):
+        """Load a checkpoint written by `save_weights`, or a Keras `.h5` file of the reference (model.save / save_weights /
+        ModelCheckpoint: e.g. the published baseline_models/MLP/model/*.best.h5) - weights are taken in `layer_names` order."""
+        if path.endswith((".h5", ".hdf5")):
+            from .keras_h5 import load_keras_h5
+            ws, opt = load_keras_h5(path, with_optimizer=True)
+            self.set_weights(ws)
+            if with_optimizer and opt is not None:
+                self.set_optimizer_state(opt["m"], opt["v"], opt["iterations"])
+            return
         z = np.load(path)
         n = len(self._shapes())
         self.set_weights([z[f"w{i}"] for i in range(n)])

@@ -165,6 +165,15 @@ def test_weights_and_optimizer_state_roundtrip(M, tmp_path):
     np.testing.assert_allclose(l1, l2, rtol=1e-5)
     with pytest.raises(ValueError):
         m.set_weights(ws[:-1])
+    # the same through a Keras-layout .h5 checkpoint (climsim_amd/keras_h5.py; step2_retrain.py:253-261)
+    ph = str(tmp_path / "ckpt.h5")
+    m.save_weights(ph)
+    m3 = M.MLPEmulator(units=(128, 256), seed=None, max_batch=1024)
+    m3.load_weights(ph)
+    for a, b in zip(m3.get_weights(), m.get_weights()):
+        np.testing.assert_array_equal(a, b)
+    assert m3.iterations == m.iterations
+    np.testing.assert_allclose(m3.train_on_batch(xd, yd, 1e-3).cpu().numpy(), m.train_on_batch(xd, yd, 1e-3).cpu().numpy(), rtol=1e-5)
 
 
 def test_in_kernel_normalise_gather_and_inf_nan_rule(M, lowres_assets):
