@@ -60,6 +60,7 @@ SIGNATURES = {
     "cs_dp_destroy": (None, [_P]),
     "cs_mlp_set_norm": (C.c_int, [_P, _P, _P]),
     "cs_mlp_set_head_options": (C.c_int, [_P, C.c_int, _P, C.c_int64]),
+    "cs_mlp_set_dropout": (C.c_int, [_P, C.c_double, C.c_uint64]),
     "cs_mlp_set_weights": (C.c_int, [_P, _P, _I64, _P]),
     "cs_mlp_get_weights": (C.c_int, [_P, _P, _I64, _P]),
     "cs_mlp_get_opt_state": (C.c_int, [_P, _P, _P, _I64, C.POINTER(_I64), _P]),

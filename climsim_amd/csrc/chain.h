@@ -38,6 +38,7 @@ struct ChainStage {
     u32x4_t* mask;           // sign mask of this stage's output tile: [row tile][512 threads] x 128 bit
     int Kc, Nc;              // contraction length, output width
     int epi;                 // EPI_HIDDEN / EPI_OUT / EPI_DGRAD
+    unsigned drop_key;       // k_chainw, training forward: hash key of this stage's dropout mask (mlp_drop_hash2)
 };
 
 struct ChainArgs {
@@ -59,6 +60,10 @@ struct ChainArgs {
     const float* keep;       // [output width] 1/0 per column (output pruning) or null
     int n_real;              // k_chainw: real output width (row pitch of yhat / y); the tuned chain is 128-wide only
     int mask_bm64;           // backward with 32-row tiles over sign masks written by a 64-row forward (see chain_stage)
+    // k_chainw only: nn.Dropout(p) on the hidden layers while training (online_testing/.../mlp.py:39-44): forward keeps an
+    // activation iff its 16 hash bits >= drop_thr and scales it by drop_scale = 1/(1-p); backward multiplies by bwd_scale
+    // (= drop_scale, or 1 without dropout) where the stored activation is positive.  ReLU only (a dropped unit passes no gradient).
+    unsigned drop_thr; float drop_scale; float bwd_scale;
     // k_chain_fb (forward + backward in one launch)
     int fused;               // forward half: dz of the heads also goes to LDS, loss scratch moves to the bias block;
                              // backward half: no prologue load (dz is in X) and no L2 warm-up (a prefetch of Wb issued during

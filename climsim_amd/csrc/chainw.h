@@ -116,12 +116,20 @@ __device__ __forceinline__ void chainw_body(const ChainArgs& p, const ChainDyn& 
                         const float4 b4 = *reinterpret_cast<const float4*>(bias_lds + S.bias_off + n);
                         v[0] = act_fwd(v[0] + b4.x, p.act, p.slope); v[1] = act_fwd(v[1] + b4.y, p.act, p.slope);
                         v[2] = act_fwd(v[2] + b4.z, p.act, p.slope); v[3] = act_fwd(v[3] + b4.w, p.act, p.slope);
+                        if (p.drop_thr) {                            // training-mode nn.Dropout: relu(dropout(z)) == dropout(relu(z))
+                            const unsigned h0 = mlp_drop_hash2(m0 + mrow, n, S.drop_key), h1 = mlp_drop_hash2(m0 + mrow, n + 2, S.drop_key);
+                            v[0] = (h0 & 0xffffu) >= p.drop_thr ? v[0] * p.drop_scale : 0.f;
+                            v[1] = (h0 >> 16) >= p.drop_thr ? v[1] * p.drop_scale : 0.f;
+                            v[2] = (h1 & 0xffffu) >= p.drop_thr ? v[2] * p.drop_scale : 0.f;
+                            v[3] = (h1 >> 16) >= p.drop_thr ? v[3] * p.drop_scale : 0.f;
+                        }
                     } else {
                         const uint2 h2 = hh[b][q];
                         v[0] *= act_bwd_from_h(bf2f((u16)(h2.x & 0xffff)), p.act, p.slope);
                         v[1] *= act_bwd_from_h(bf2f((u16)(h2.x >> 16)), p.act, p.slope);
                         v[2] *= act_bwd_from_h(bf2f((u16)(h2.y & 0xffff)), p.act, p.slope);
                         v[3] *= act_bwd_from_h(bf2f((u16)(h2.y >> 16)), p.act, p.slope);
+                        if (p.drop_thr) { v[0] *= p.bwd_scale; v[1] *= p.bwd_scale; v[2] *= p.bwd_scale; v[3] *= p.bwd_scale; }
                     }
                     *reinterpret_cast<uint2*>(Xout + cwd_off(mrow, n)) = make_uint2(cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3]));
                 }

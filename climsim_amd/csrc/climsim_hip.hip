@@ -41,6 +41,10 @@ int fail(int code, const char* fmt, ...) {
     } while (0)
 
 inline int64_t round_up(int64_t v, int64_t q) { return (v + q - 1) / q * q; }
+inline unsigned mix32(unsigned x) {            // lowbias32 (kernels.h) on the host
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
 
 // Optional per-launch HIP-event timing (cs_mlp_profile_step): events are recorded on the SAME
 // stream the kernels run on, immediately before and after each launch.
@@ -87,6 +91,8 @@ struct cs_mlp {
     int64_t n_params = 0;      // floats of the internal (padded) flat buffers P, M, V, G
     int64_t n_params_keras = 0;  // floats of the Keras-ordered weight list (what set/get_weights exchange)
     int n_out = 128, n_outp = 128;
+    double dropout = 0.0;          // cs_mlp_set_dropout: nn.Dropout(p) on the hidden layers while training (wide chain only)
+    unsigned long long drop_seed = 0;
     int loss_kind = CS_LOSS_MSE;   // cs_mlp_set_head_options
     float* keep = nullptr;         // [n_outp] 1/0 per output column, or null (no output pruning)
     float* keep_store = nullptr;   // the arena slot `keep` points to when pruning is on
@@ -287,6 +293,7 @@ void chainw_bwd_args(const cs_mlp* h, int64_t n, ChainArgs& c) {
     }
     c.dz_in = h->layers[h->L - 1].dZ; c.ld_dz_in = h->n_outp; c.w_in = h->n_outp;
     c.n_rows = n; c.act = h->cfg.act; c.slope = (h->cfg.act == CS_ACT_RELU) ? 0.f : h->cfg.alpha;
+    if (h->dropout > 0.0) { c.drop_thr = (unsigned)(h->dropout * 65536.0); c.drop_scale = c.bwd_scale = 1.f / (1.f - (float)h->dropout); }
 }
 
 // Backward layer chain: dz of the heads back to dz of the first hidden layer (stage i <-> layer L-1-i).
@@ -327,6 +334,14 @@ void chain_fwd_args(const cs_mlp* h, bool wide, const float* x, const int64_t* r
     c.loss_kind = h->loss_kind; c.keep = h->keep;
     c.dz_out = want_dz ? h->layers[h->L - 1].dZ : nullptr;
     if (wide) { c.ld_dz_out = h->n_outp; c.n_real = h->n_out; } else { c.ld_dz_out = 128; }
+    if (wide && want_dz && h->dropout > 0.0) {
+        // training pass only (prediction / evaluation = eval mode); a fresh mask per optimiser step and layer
+        c.drop_thr = (unsigned)(h->dropout * 65536.0);
+        c.drop_scale = c.bwd_scale = 1.f / (1.f - (float)h->dropout);
+        const unsigned base = mix32((unsigned)h->drop_seed ^ mix32((unsigned)(h->drop_seed >> 32) + 0x9e3779b9u));
+        for (int l = 0; l + 1 < h->L; ++l)
+            c.st[l].drop_key = mix32(base + 0x9e3779b9u * (unsigned)(l + 1) + 0x85ebca6bu * (unsigned)(h->iterations + 1));
+    }
 }
 
 int run_forward(cs_mlp* h, const float* x, const int64_t* row_idx, int64_t n, int normalise, float* yhat,
@@ -703,6 +718,23 @@ int cs_mlp_set_head_options(cs_mlp_t* h, int loss_kind, const float* keep_host, 
     return CS_OK;
 }
 
+int cs_mlp_set_dropout(cs_mlp_t* h, double rate, uint64_t seed) {
+    if (!h) return fail(CS_ERR_INVALID, "null handle");
+    if (!(rate >= 0.0 && rate < 1.0)) return fail(CS_ERR_INVALID, "dropout rate %g outside [0, 1)", rate);
+    if (rate > 0.0) {
+        if (h->cfg.act != CS_ACT_RELU) return fail(CS_ERR_INVALID, "dropout is built for ReLU stacks (Linear -> Dropout -> ReLU, MLP_v2rh/training/mlp.py:41-52)");
+        if (h->use_chain) { h->use_chain = false; h->use_chainw = true; }    // the wide chain carries the dropout epilogue
+        if (!h->use_chainw) return fail(CS_ERR_INVALID, "dropout needs the wide layer-chain kernels (widths up to 1024, no CS_FLAG_NO_CHAIN)");
+        h->chainw_max_n = (int64_t)1 << 40;
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chainw<false>), hipFuncAttributeMaxDynamicSharedMemorySize, chainw_lds_bytes()));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chainw<true>), hipFuncAttributeMaxDynamicSharedMemorySize, chainw_lds_bytes()));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chainw_fb), hipFuncAttributeMaxDynamicSharedMemorySize, chainw_lds_bytes()));
+    }
+    h->dropout = rate;
+    h->drop_seed = seed;
+    return CS_OK;
+}
+
 int cs_mlp_set_weights(cs_mlp_t* h, const float* host, int64_t n, void* stream) {
     if (!h || !host) return fail(CS_ERR_INVALID, "null argument");
     if (n != h->n_params_keras) return fail(CS_ERR_INVALID, "expected %lld floats, got %lld", (long long)h->n_params_keras, (long long)n);
@@ -1022,6 +1054,7 @@ int cs_mlp_group_create(cs_mlp_group_t** out, cs_mlp_t* const* members, int32_t 
         if (cs_mlp_kernel_family(h) != fam) return fail(CS_ERR_INVALID, "member %d is of another kernel family (tuned / wide chain, ELU or not) than member 0", i);
         if (h->cfg.device != members[0]->cfg.device) return fail(CS_ERR_INVALID, "member %d lives on another device", i);
         if (h->L < 2) return fail(CS_ERR_INVALID, "member %d has no hidden layer", i);
+        if (h->dropout > 0.0) return fail(CS_ERR_INVALID, "member %d trains with dropout (a fresh mask key per step): not built for grouped launches", i);
         if (h->cfg.flags & (CS_FLAG_NO_CHAIN_FB | CS_FLAG_NO_TR_READ | CS_FLAG_CHAIN_BWD32_ON_FWD64))
             return fail(CS_ERR_INVALID, "member %d carries a development flag the grouped kernels do not implement", i);
     }

@@ -35,10 +35,7 @@ struct ConvArgs {
     int ablate;                                      // development (CS_CONV_ABLATE): 1 no DMA in the loop, 2 no MFMA, 4 no epilogue
 };
 
-__device__ __forceinline__ unsigned lowbias32(unsigned x) {
-    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
-    return x;
-}
+// (lowbias32: kernels.h)
 // Dropout decisions of the channel pair (n, n+1), n even, of row m: one 32-bit hash, 16 bits per element;
 // keep iff its 16 bits >= thr16 = floor(rate * 65536).  Shared with oracle/cnn_oracle.py dropout_keep.
 __device__ __forceinline__ unsigned drop_hash2(int64_t m, int n, unsigned key) {

@@ -56,6 +56,19 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// 32-bit mixer (lowbias32) and the dropout decisions built on it.  MLP form: one hash per column pair (n, n+1), n even, of
+// row m (widths up to 1024), 16 bits per element; an element is KEPT iff its 16 bits >= thr16 = floor(rate * 65536).
+// Shared with oracle/online_mlp_oracle.py (dropout_keep_mlp); the CNN has its own row pitch (cnn.h drop_hash2).
+__device__ __forceinline__ unsigned lowbias32(unsigned x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ unsigned mlp_drop_hash2(int64_t m, int n, unsigned key) {
+    unsigned k = (unsigned)m * 512u + ((unsigned)n >> 1);
+    k ^= (unsigned)(m >> 23) * 0x9e3779b9u;
+    return lowbias32(k ^ key);
+}
+
 // Loss sums of a workgroup -> global memory.  Device-scope float atomics on ONE address retire at ~12.5 ns each on this
 // part (measured: 256 workgroups x 8 waves x 2 sums finishing together kept the forward kernel open for 51 us after its
 // last workgroup had ended), so: one pair of atomics per WORKGROUP (LDS reduction over the waves), and - where the

@@ -161,6 +161,12 @@ class MLPEmulator:
                                                     0 if keep is None else keep.size))
         self.loss_name, self.output_keep = loss, keep
 
+    def set_dropout(self, rate: float, seed: int = 0):
+        """nn.Dropout(rate) behind every hidden layer while training (cs_mlp_set_dropout; ReLU stacks, wide chain);
+        prediction / evaluation stay in eval mode."""
+        _lib.check(self.lib.cs_mlp_set_dropout(self._h, float(rate), int(seed) & 0xFFFFFFFFFFFFFFFF))
+        self.dropout, self.dropout_seed = float(rate), int(seed)
+
     def _shapes(self):
         dims = [self.input_length, *self.units] + ([] if self.direct_head else [self.output_length])
         sh = []

@@ -67,14 +67,15 @@ class MLP:
 
     def __init__(self, in_dims: int, out_dims: int, hidden_dims, layers: int, dropout: float = 0.0,
                  output_prune: bool = False, strato_lev_out: int = 15, *, loss: str = "mse", n_relu: int = 8,
-                 max_batch: int = 8192, device: Optional[int] = None, seed: Optional[int] = 0, eps: float = 1e-8, flags: int = 0):
+                 max_batch: int = 8192, device: Optional[int] = None, seed: Optional[int] = 0, eps: float = 1e-8, flags: int = 0,
+                 dropout_seed: int = 0):
         if isinstance(hidden_dims, (list, tuple)):
             assert len(hidden_dims) == layers, "Length of hidden_dims should be equal to layers"      # mlp.py:33
             hidden = [int(h) for h in hidden_dims]
         else:
             hidden = [int(hidden_dims)] * layers
-        if dropout:
-            raise NotImplementedError("dropout > 0 is not built (the reference configuration trains with dropout 0.0)")
+        if not 0.0 <= float(dropout) < 1.0:
+            raise ValueError("dropout must be in [0, 1)")
         if output_prune and out_dims < 240 + strato_lev_out:
             raise ValueError("output pruning addresses columns up to 240 + strato_lev_out")
         self.in_dims, self.out_dims, self.hidden_dims, self.layers = in_dims, out_dims, hidden, layers
@@ -85,6 +86,11 @@ class MLP:
                                   device=device, seed=None, epsilon=eps, flags=flags, direct_head=True, loss=loss,
                                   output_keep=self.keep if output_prune else None)
         self.loss_name = loss
+        self.dropout = float(dropout)
+        if self.dropout > 0.0:
+            # training-mode nn.Dropout (mlp.py:39-44); torch's random stream is not reproducible by anyone else: the mask is a
+            # counter hash of (dropout_seed, optimiser step, layer, row, column), shared with oracle/online_mlp_oracle.py
+            self.engine.set_dropout(self.dropout, dropout_seed)
         if seed is not None:
             self.load_state_dict(self._torch_default_init(seed))
 

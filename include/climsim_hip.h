@@ -93,6 +93,13 @@ int cs_mlp_set_norm(cs_mlp_t* h, const float* input_sub, const float* input_div)
  * (loss_sums[0]) is the sum of SmoothL1 terms instead of squared errors; loss_sums[1] is always the sum of |e|. */
 int cs_mlp_set_head_options(cs_mlp_t* h, int loss_kind, const float* keep_host, int64_t n);
 
+/* nn.Dropout(p) behind every hidden Linear while TRAINING (online_testing/baseline_models/MLP_v2rh/training/mlp.py:39-52:
+ * Sequential(Linear, Dropout) then relu; the shipped configuration uses p = 0).  Kept activations are scaled by 1/(1-p),
+ * prediction and evaluation run in eval mode.  torch's Philox stream cannot be reproduced by anyone else: the mask is a
+ * counter hash of (seed, optimiser step, layer, row, column) that the oracle shares.  ReLU stacks on the wide layer-chain
+ * kernels only (a model on the tuned chain is moved there). */
+int cs_mlp_set_dropout(cs_mlp_t* h, double rate, uint64_t seed);
+
 /* model.set_weights / model.get_weights: one flat float32 host buffer in Keras order
  * [W0(in,out), b0, ..., W_up(.,128), b_up, W_lin(128,120), b_lin, W_relu(128,8), b_relu].
  * set_weights also refreshes the bf16 operand copies.  get_* synchronise `stream`. */

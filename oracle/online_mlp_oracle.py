@@ -53,12 +53,48 @@ def keep_mask(n_out: int, output_prune: bool, strato_lev_out: int) -> np.ndarray
     return keep
 
 
-def forward(pairs: Pairs, x, keep, n_relu: int = 8, bf16: bool = False, keep_acts: bool = False):
+def _lowbias32(x):
+    x = np.asarray(x, np.uint32).copy()
+    with np.errstate(over="ignore"):
+        x ^= x >> np.uint32(16); x *= np.uint32(0x7FEB352D); x ^= x >> np.uint32(15); x *= np.uint32(0x846CA68B); x ^= x >> np.uint32(16)
+    return x
+
+
+def dropout_key_mlp(seed: int, step: int, layer: int) -> np.uint32:
+    """Key of the mask of hidden layer `layer` (0-based) at optimiser step `step` (0-based: `iterations` before the step) -
+    climsim_hip.hip chain_fwd_args."""
+    seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    base = _lowbias32(np.uint32(seed & 0xFFFFFFFF) ^ _lowbias32(np.uint32(((seed >> 32) + 0x9E3779B9) & 0xFFFFFFFF)))
+    return _lowbias32(np.uint32((int(base) + 0x9E3779B9 * (layer + 1) + 0x85EBCA6B * (step + 1)) & 0xFFFFFFFF))
+
+
+def dropout_keep_mlp(seed: int, step: int, layer: int, rows: int, width: int, rate: float) -> np.ndarray:
+    """Boolean keep mask (rows, width) of training-mode nn.Dropout(rate) as the engine draws it (kernels.h mlp_drop_hash2):
+    one 32-bit hash per column pair of a row, 16 bits per element, keep iff bits >= floor(rate * 65536).  (torch's own
+    Philox stream, mlp.py:44, cannot be reproduced outside torch: engine and oracle share this counter hash instead.)"""
+    m = np.arange(rows, dtype=np.uint64)[:, None]
+    n = np.arange(width, dtype=np.uint64)[None, :]
+    with np.errstate(over="ignore"):
+        k = ((m * np.uint64(512) + (n >> np.uint64(1))) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        k = k ^ ((m >> np.uint64(23)).astype(np.uint32) * np.uint32(0x9E3779B9))
+    h = _lowbias32(k ^ dropout_key_mlp(seed, step, layer))
+    bits = np.where((n & np.uint64(1)).astype(bool), h >> np.uint32(16), h & np.uint32(0xFFFF))
+    return bits >= np.uint32(int(rate * 65536.0))
+
+
+def forward(pairs: Pairs, x, keep, n_relu: int = 8, bf16: bool = False, keep_acts: bool = False, dropout=None):
+    """`dropout` = None (eval mode) or (rate, seed, step): training-mode forward, relu(dropout(linear(x))) (mlp.py:41-52),
+    kept activations scaled by float32 1/(1-rate)."""
     q = bf16_round if bf16 else (lambda a: np.asarray(a, F32))
     h = q(x)
     hs = [h]
-    for w, b in pairs[:-1]:
-        h = q(np.maximum(_mm(h, q(w)) + b, 0).astype(F32))
+    for li, (w, b) in enumerate(pairs[:-1]):
+        a = np.maximum(_mm(h, q(w)) + b, 0).astype(F32)
+        if dropout is not None and dropout[0] > 0:
+            rate, seed, step = dropout
+            scale = F32(1) / (F32(1) - F32(rate))
+            a = np.where(dropout_keep_mlp(seed, step, li, a.shape[0], a.shape[1], rate), a * scale, F32(0)).astype(F32)
+        h = q(a)
         hs.append(h)
     w, b = pairs[-1]
     y = (_mm(h, q(w)) + b).astype(F32)
@@ -79,10 +115,11 @@ def loss_value(pred, y, kind: str) -> float:
     raise ValueError(kind)
 
 
-def loss_and_grads(pairs: Pairs, x, y, keep, kind: str = "mse", n_relu: int = 8, bf16: bool = False):
-    """(loss, [(dW (in,out), db)], prediction): gradients of the MEAN loss over batch x outputs."""
+def loss_and_grads(pairs: Pairs, x, y, keep, kind: str = "mse", n_relu: int = 8, bf16: bool = False, dropout=None):
+    """(loss, [(dW (in,out), db)], prediction): gradients of the MEAN loss over batch x outputs.  `dropout` as in forward."""
     q = bf16_round if bf16 else (lambda a: np.asarray(a, F32))
-    pred, hs = forward(pairs, x, keep, n_relu, bf16, keep_acts=True)
+    pred, hs = forward(pairs, x, keep, n_relu, bf16, keep_acts=True, dropout=dropout)
+    bscale = F32(1) / (F32(1) - F32(dropout[0])) if dropout is not None and dropout[0] > 0 else F32(1)
     e = (pred - np.asarray(y, F32)).astype(F32)
     if kind == "mse":
         dz = 2 * e
@@ -101,7 +138,7 @@ def loss_and_grads(pairs: Pairs, x, y, keep, kind: str = "mse", n_relu: int = 8,
         w, _ = pairs[li]
         grads[li] = ((_mm(hs[li].T, dz) * scale).astype(F32), (dz.astype(np.float64).sum(axis=0) * scale).astype(F32))
         if li > 0:
-            dz = q((_mm(dz, q(w).T) * (hs[li] > 0)).astype(F32))
+            dz = q((_mm(dz, q(w).T) * (hs[li] > 0) * bscale).astype(F32))       # a dropped unit has h = 0: no gradient
     return loss_value(pred, y, kind), grads, pred
 
 

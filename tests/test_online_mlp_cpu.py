@@ -59,3 +59,37 @@ def test_state_dict_round_trip_and_keep_mask():
     keep = OO.keep_mask(368, True, 12)
     assert keep.sum() == 368 - 48 and not keep[60:72].any() and keep[72] == 1 and not keep[240:252].any() and keep[-8:].all()
     assert OO.keep_mask(368, False, 15).all()
+
+
+def test_oracle_dropout_mask_and_gradients():
+    """Training-mode dropout of the oracle (the mask the HIP engine shares): Bernoulli law of the counter hash, inverted
+    scaling, eval mode untouched, and the hand-derived backward against central differences of its own forward loss."""
+    keep = OO.dropout_keep_mlp(seed=7, step=3, layer=1, rows=4096, width=256, rate=0.2)
+    assert abs(keep.mean() - 0.8) < 3e-3
+    assert not np.array_equal(keep, OO.dropout_keep_mlp(7, 4, 1, 4096, 256, 0.2))          # new step, new mask
+    assert not np.array_equal(keep, OO.dropout_keep_mlp(7, 3, 2, 4096, 256, 0.2))          # per layer
+    assert np.array_equal(keep[:100], OO.dropout_keep_mlp(7, 3, 1, 100, 256, 0.2))         # a function of (row, column) only
+    assert abs(np.corrcoef(keep[:-1, :].ravel(), keep[1:, :].ravel())[0, 1]) < 0.01         # rows are independent
+    rng = np.random.default_rng(0)
+    dims = [12, 128, 128, 16]
+    pairs = [(rng.normal(0, 0.3, (a, b)).astype(np.float32), rng.normal(0, 0.1, b).astype(np.float32)) for a, b in zip(dims[:-1], dims[1:])]
+    x = rng.normal(0, 1, (64, 12)).astype(np.float32)
+    y = rng.normal(0, 1, (64, 16)).astype(np.float32)
+    kp = np.ones(16, np.float32)
+    d = (0.3, 11, 0)
+    p_eval = OO.forward(pairs, x, kp)
+    p_tr, hs = OO.forward(pairs, x, kp, keep_acts=True, dropout=d)
+    assert not np.allclose(p_eval, p_tr)
+    k0 = OO.dropout_keep_mlp(11, 0, 0, 64, 128, 0.3)
+    assert np.all(hs[1][~k0] == 0)                                                          # dropped units are exactly zero
+    loss, grads, _ = OO.loss_and_grads(pairs, x, y, kp, "mse", dropout=d)
+    for trial in range(3):
+        dirs = [(rng.normal(0, 1, w.shape).astype(np.float32), rng.normal(0, 1, b.shape).astype(np.float32)) for w, b in pairs]
+        eps = 1e-3
+        vals = []
+        for sgn in (1, -1):
+            pp = [(w + np.float32(sgn * eps) * dw, b + np.float32(sgn * eps) * db) for (w, b), (dw, db) in zip(pairs, dirs)]
+            vals.append(OO.loss_value(OO.forward(pp, x, kp, dropout=d), y, "mse"))
+        fd = (vals[0] - vals[1]) / (2 * eps)
+        an = float(sum((gw.astype(np.float64) * dw).sum() + (gb.astype(np.float64) * db).sum() for (gw, gb), (dw, db) in zip(grads, dirs)))
+        assert abs(fd - an) <= 2e-2 * abs(an) + 1e-6, (trial, fd, an)

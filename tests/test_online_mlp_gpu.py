@@ -148,8 +148,8 @@ def test_state_dict_fit_and_errors(OM):
     assert all(a > b for a, b in zip(h["loss"], h["loss"][1:]))
     assert h["lr"] == [4e-3, 4e-3, 2e-3, 2e-3, 1e-3, 1e-3]
     assert abs(m.evaluate(x[:512], y[:512]) - h["val_loss"][-1]) < 1e-6
-    with pytest.raises(NotImplementedError):
-        OM.MLP(64, 368, 128, 2, dropout=0.1)
+    md = OM.MLP(64, 368, 128, 2, dropout=0.1, max_batch=256)          # dropout is built (test_training_mode_dropout_follows_the_oracle)
+    assert md.dropout == 0.1
     with pytest.raises(AssertionError):
         OM.MLP(64, 368, [128], 2)
     with pytest.raises(ValueError):
@@ -179,3 +179,42 @@ def test_export_wrapper_matches_device_pipeline(OM, tmp_path):
     ref = y / scale
     assert np.abs(out - ref).max() <= 3e-2 * np.abs(ref).max()       # fp32 TorchScript vs bf16 engine
     assert not out[:, 120:148].any() and not out[:, 300:315].any()
+
+
+@pytest.mark.parametrize("name,rate", [("v2rh_mse_prune12", 0.1), ("huber_prune15", 0.25)])
+def test_training_mode_dropout_follows_the_oracle(OM, name, rate):
+    """`MLP(..., dropout=p)` (mlp.py:39-44: Sequential(Linear, Dropout) -> relu): the training pass draws the mask the oracle
+    draws (shared counter hash; torch's own stream is not reproducible), so loss and every gradient tensor are held to the
+    bf16-emulating oracle at the usual tolerances; prediction / evaluation stay in eval mode; every optimiser step draws a
+    new mask."""
+    n_in, n_out, hidden, prune, lev, loss, nb = CASES[name]
+    m = OM.MLP(n_in, n_out, hidden, len(hidden), dropout=rate, output_prune=prune, strato_lev_out=lev, loss=loss, max_batch=256, seed=None,
+               dropout_seed=1234567890123)
+    m.load_state_dict(init_state(name))
+    x, y = batches(name)[0]
+    pairs = OO.from_state_dict(init_state(name))
+    keep = OO.keep_mask(n_out, prune, lev)
+    # eval mode: identical to the model without dropout
+    op = OO.forward(pairs, x, keep, bf16=True)
+    pred = m.forward(x, as_numpy=True)
+    assert np.abs(pred - op).max() <= 2e-3 * np.abs(op).max()
+    ev = m.evaluate(x, y)
+    assert abs(ev - OO.loss_value(op, y, loss)) <= 2e-3 * ev
+    # training mode, step 0
+    ol, og, _ = OO.loss_and_grads(pairs, x, y, keep, loss, bf16=True, dropout=(rate, 1234567890123, 0))
+    ol_eval, _, _ = OO.loss_and_grads(pairs, x, y, keep, loss, bf16=True)
+    lv = m.loss_grads(x, y)
+    assert abs(lv - ol) <= 2e-3 * ol and abs(ol - ol_eval) > 1e-3 * ol_eval      # the mask matters, and it is the oracle's
+    g, osd = m.gradients(), OO.to_state_dict(og)
+    for k in g:
+        assert rel(g[k], osd[k]) <= 5e-3, (k, rel(g[k], osd[k]))
+    assert m.loss_grads(x, y) == pytest.approx(lv, rel=1e-5)                       # same step -> same mask
+    # optimiser steps: the mask key follows the step counter
+    opt = OO.TorchAdam(lr=LR)
+    for step in range(3):
+        l_ref, grads, _ = OO.loss_and_grads(pairs, x, y, keep, loss, bf16=True, dropout=(rate, 1234567890123, step))
+        pairs = opt.apply(pairs, grads)
+        l_eng = m.train_step(x, y, LR)
+        assert abs(l_eng - l_ref) <= 2e-2 * l_ref, (step, l_eng, l_ref)
+    with pytest.raises(ValueError):
+        OM.MLP(n_in, n_out, hidden, len(hidden), dropout=1.0, max_batch=64)
