@@ -413,15 +413,18 @@ def main():
     predict_cps = n_pred / (time.perf_counter() - tp)
     roofline, kernels = None, None
     if not args.no_profile and rank == 0:
-        agg = {}
-        reps = 20
+        # per-kernel durations over 40 BACK-TO-BACK steps (no synchronisation between them: the regime of the timed region),
+        # every launch carrying its own start / stop events - the dispatch packet's timestamps, what rocprofv3 reports
+        import ctypes
+        from climsim_amd import _lib
+        reps = 40
         nb = args.rows // B
-        for r in range(reps):
-            idx = perm[(r % nb) * B:(r % nb + 1) * B]
-            for k, (ms, cnt) in model.profile_step(x, y, lr, row_idx=idx).items():
-                a = agg.setdefault(k, [0.0, 0])
-                a[0] += ms
-                a[1] += cnt
+        for r in range(5):
+            model.train_on_batch(x, y, lr, row_idx=perm[(r % nb) * B:(r % nb + 1) * B], loss=loss)
+        with _lib.profile_session(ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)) as prof:
+            for r in range(reps):
+                model.train_on_batch(x, y, lr, row_idx=perm[(r % nb) * B:(r % nb + 1) * B], loss=loss)
+        agg = {k: list(v) for k, v in prof.times.items()}
         kernels = {k: {"ms_per_step": v[0] / reps, "launches_per_step": v[1] / reps,
                        "avg_us_per_launch": (v[0] / max(v[1], 1)) * 1e3} for k, v in agg.items()}
         kernels = {k: v for k, v in kernels.items() if v["launches_per_step"] > 0}

@@ -55,12 +55,13 @@ one = res["streams"][1]
 pool = TrialPool([cfg] * 8, grouped=True)
 pool.fit(x, y, epochs=1, steps_per_epoch=5)
 grp = pool.groups[0]
-agg = {}
-for r in range(20):
-    idx = [torch.randint(0, n, (B,), device="cuda", generator=g) for _ in range(8)]
-    for kind, (ms, cnt) in grp.profile_step(x, y, 1e-3, row_idx=idx).items():
-        if cnt:
-            agg[kind] = agg.get(kind, 0.0) + ms / 20
+import ctypes  # noqa: E402
+from climsim_amd import _lib  # noqa: E402
+idxs = [[torch.randint(0, n, (B,), device="cuda", generator=g) for _ in range(8)] for _ in range(20)]
+with _lib.profile_session(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)) as prof:     # 20 back-to-back grouped steps
+    for idx in idxs:
+        grp.train_on_batch(x, y, 1e-3, row_idx=idx)
+agg = {kind: ms / 20 for kind, (ms, cnt) in prof.times.items() if cnt}
 kernels_k8 = {k: round(v * 1e3, 1) for k, v in agg.items()}
 pool.close()
 

@@ -72,6 +72,8 @@ SIGNATURES = {
     "cs_mlp_get_grads": (C.c_int, [_P, _P, _I64, _P]),
     "cs_mlp_apply": (C.c_int, [_P, _F, _F, _P]),
     "cs_mlp_train_step": (C.c_int, [_P, _P, _P, _P, _I64, C.c_int, _F, _P, _P]),
+    "cs_profile_begin": (C.c_int, [_P]),
+    "cs_profile_end": (C.c_int, [C.POINTER(CsKernelTimes)]),
     "cs_mlp_profile_step": (C.c_int, [_P, _P, _P, _P, _I64, C.c_int, _F, _P, _P, C.POINTER(CsKernelTimes)]),
     "cs_mlp_debug_stamps": (C.c_int, [_P, _P, _I64]),
     "cs_normalise_rows": (C.c_int, [_P, _P, _I64, _I32, _P, _P, _P, _P]),
@@ -125,6 +127,26 @@ def load():
         fn.restype, fn.argtypes = res, args
     _lib = lib
     return lib
+
+
+class profile_session:
+    """`with profile_session(stream_ptr) as p: ...steps...` then `p.times` = {kind: (milliseconds, launches)} summed over every
+    engine kernel launched in the block (cs_profile_begin / cs_profile_end; no synchronisation between the steps)."""
+
+    def __init__(self, stream):
+        self.stream, self.times = stream, None
+
+    def __enter__(self):
+        check(load().cs_profile_begin(self.stream))
+        return self
+
+    def __exit__(self, *exc):
+        kt = CsKernelTimes()
+        rc = load().cs_profile_end(C.byref(kt))
+        if exc[0] is None:
+            check(rc)
+        self.times = {k: (float(kt.ms[i]), int(kt.launches[i])) for i, k in enumerate(KERNEL_KINDS)}
+        return False
 
 
 def check(rc: int):

@@ -2,6 +2,7 @@
 // Host-side orchestration only: owns device buffers, launches the kernels of kernels.h on the
 // caller's stream.  No PyTorch types, no CPU fallback: every compute entry point runs HIP kernels.
 #include "../../include/climsim_hip.h"
+#include <hip/hip_ext.h>
 #include "kernels.h"
 #include "chain.h"
 #include "wgrad2.h"
@@ -46,29 +47,52 @@ inline unsigned mix32(unsigned x) {            // lowbias32 (kernels.h) on the h
     return x;
 }
 
-// Optional per-launch HIP-event timing (cs_mlp_profile_step): events are recorded on the SAME
-// stream the kernels run on, immediately before and after each launch.
+// Optional per-launch timing (cs_mlp_profile_step).  A kernel launched inside a ProfScope goes through
+// hipExtLaunchKernelGGL with a start / stop event pair: the events carry the dispatch packet's OWN begin / end
+// timestamps - the figures rocprofv3's kernel trace reports.  (Recording events on the stream before and after the launch,
+// the first form, also timed the marker -> dispatch hand-over: +9 us on the fused chain launch with its 3.4 KB of kernel
+// arguments, +2..3 us on the others; profiles/r02_rocprofv3_kernel_stats_b8192.csv.)  Memsets keep recorded events.
 struct Profiler {
     struct Rec { int kind; hipEvent_t a, b; };
     std::vector<Rec> recs;
     hipStream_t st = nullptr;
-    hipEvent_t begin(int kind) {
+    hipEvent_t cur_a = nullptr, cur_b = nullptr;     // pair of the scope being launched (consumed by CS_LAUNCH)
+    void open(int kind) {
         Rec r{kind, nullptr, nullptr};
         (void)hipEventCreate(&r.a);
         (void)hipEventCreate(&r.b);
-        (void)hipEventRecord(r.a, st);
         recs.push_back(r);
-        return r.b;
+        cur_a = r.a; cur_b = r.b;
     }
 };
 thread_local Profiler* g_prof = nullptr;
 
 struct ProfScope {
-    hipEvent_t stop = nullptr;
     hipStream_t st;
-    ProfScope(int kind, hipStream_t s) : st(s) { if (g_prof) stop = g_prof->begin(kind); }
-    ~ProfScope() { if (stop) (void)hipEventRecord(stop, st); }
+    bool memset_scope;
+    ProfScope(int kind, hipStream_t s) : st(s), memset_scope(kind == CS_K_MEMSET) {
+        if (!g_prof) return;
+        g_prof->open(kind);
+        if (memset_scope) (void)hipEventRecord(g_prof->cur_a, st);
+    }
+    ~ProfScope() {
+        if (!g_prof) return;
+        if (memset_scope) (void)hipEventRecord(g_prof->cur_b, st);
+        else if (g_prof->cur_a) {                       // a scope that launched nothing: give the pair a zero interval
+            (void)hipEventRecord(g_prof->cur_a, st); (void)hipEventRecord(g_prof->cur_b, st);
+        }
+        g_prof->cur_a = g_prof->cur_b = nullptr;
+    }
 };
+
+// Kernel launch of the MLP engine: plain, or - under cs_mlp_profile_step - with the scope's event pair attached.
+#define CS_LAUNCH(kernel, grid, block, lds, st, ...)                                                              \
+    do {                                                                                                          \
+        if (g_prof && g_prof->cur_a) {                                                                            \
+            hipExtLaunchKernelGGL(kernel, grid, block, lds, st, g_prof->cur_a, g_prof->cur_b, 0, __VA_ARGS__);    \
+            g_prof->cur_a = nullptr;                                                                              \
+        } else hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);                                     \
+    } while (0)
 
 struct Layer {
     int K, Kp, N;              // real contraction length, padded (x128), output width padded (x128)
@@ -215,7 +239,7 @@ int launch_optimizer(cs_mlp* h, float lr, float grad_scale, bool recast_only, hi
     const OptArgs a = fill_opt_args(h, lr, grad_scale, recast_only);
     {
         ProfScope ps(CS_K_OPTIMIZER, st);
-        hipLaunchKernelGGL(k_optimizer, dim3((unsigned)h->opt_blocks), dim3(256), 0, st, a);
+        CS_LAUNCH(k_optimizer, dim3((unsigned)h->opt_blocks), dim3(256), 0, st, a);
     }
     HIP_TRY(hipGetLastError());
     return CS_OK;
@@ -232,16 +256,16 @@ void launch_chain(const cs_mlp* h, int bm, int64_t m_pad, const ChainArgs& c, hi
     const bool elu = h->cfg.act == CS_ACT_ELU;
     if (bm == 128) {
         const dim3 g((unsigned)(m_pad / 128));
-        if (elu) hipLaunchKernelGGL((k_chain<128, BWD, true>), g, dim3(512), chain_lds_bytes<128>(), st, c);
-        else hipLaunchKernelGGL((k_chain<128, BWD, false>), g, dim3(512), chain_lds_bytes<128>(), st, c);
+        if (elu) CS_LAUNCH((k_chain<128, BWD, true>), g, dim3(512), chain_lds_bytes<128>(), st, c);
+        else CS_LAUNCH((k_chain<128, BWD, false>), g, dim3(512), chain_lds_bytes<128>(), st, c);
     } else if (bm == 64) {
         const dim3 g((unsigned)(m_pad / 64));
-        if (elu) hipLaunchKernelGGL((k_chain<64, BWD, true>), g, dim3(512), chain_lds_bytes<64>(), st, c);
-        else hipLaunchKernelGGL((k_chain<64, BWD, false>), g, dim3(512), chain_lds_bytes<64>(), st, c);
+        if (elu) CS_LAUNCH((k_chain<64, BWD, true>), g, dim3(512), chain_lds_bytes<64>(), st, c);
+        else CS_LAUNCH((k_chain<64, BWD, false>), g, dim3(512), chain_lds_bytes<64>(), st, c);
     } else {
         const dim3 g((unsigned)(m_pad / 32));
-        if (elu) hipLaunchKernelGGL((k_chain<32, BWD, true>), g, dim3(512), chain_lds_bytes<32>(), st, c);
-        else hipLaunchKernelGGL((k_chain<32, BWD, false>), g, dim3(512), chain_lds_bytes<32>(), st, c);
+        if (elu) CS_LAUNCH((k_chain<32, BWD, true>), g, dim3(512), chain_lds_bytes<32>(), st, c);
+        else CS_LAUNCH((k_chain<32, BWD, false>), g, dim3(512), chain_lds_bytes<32>(), st, c);
     }
 }
 
@@ -366,14 +390,14 @@ int run_forward(cs_mlp* h, const float* x, const int64_t* row_idx, int64_t n, in
             const bool elu = h->cfg.act == CS_ACT_ELU;
             const dim3 g((unsigned)(m_pad / bm));
             if (bm == 32) {
-                if (elu) hipLaunchKernelGGL((k_chain_fb<32, true>), g, dim3(512), chain_lds_bytes<32>(), st, c, cb);
-                else hipLaunchKernelGGL((k_chain_fb<32, false>), g, dim3(512), chain_lds_bytes<32>(), st, c, cb);
+                if (elu) CS_LAUNCH((k_chain_fb<32, true>), g, dim3(512), chain_lds_bytes<32>(), st, c, cb);
+                else CS_LAUNCH((k_chain_fb<32, false>), g, dim3(512), chain_lds_bytes<32>(), st, c, cb);
             } else if (bm == 64) {
-                if (elu) hipLaunchKernelGGL((k_chain_fb<64, true>), g, dim3(512), chain_lds_bytes<64>(), st, c, cb);
-                else hipLaunchKernelGGL((k_chain_fb<64, false>), g, dim3(512), chain_lds_bytes<64>(), st, c, cb);
+                if (elu) CS_LAUNCH((k_chain_fb<64, true>), g, dim3(512), chain_lds_bytes<64>(), st, c, cb);
+                else CS_LAUNCH((k_chain_fb<64, false>), g, dim3(512), chain_lds_bytes<64>(), st, c, cb);
             } else {
-                if (elu) hipLaunchKernelGGL((k_chain_fb<128, true>), g, dim3(512), chain_lds_bytes<128>(), st, c, cb);
-                else hipLaunchKernelGGL((k_chain_fb<128, false>), g, dim3(512), chain_lds_bytes<128>(), st, c, cb);
+                if (elu) CS_LAUNCH((k_chain_fb<128, true>), g, dim3(512), chain_lds_bytes<128>(), st, c, cb);
+                else CS_LAUNCH((k_chain_fb<128, false>), g, dim3(512), chain_lds_bytes<128>(), st, c, cb);
             }
             HIP_TRY(hipGetLastError());
             h->bwd_chain_done = true;
@@ -392,20 +416,20 @@ int run_forward(cs_mlp* h, const float* x, const int64_t* row_idx, int64_t n, in
             ChainArgs cb{};
             chainw_bwd_args(h, n, cb);
             ProfScope ps(CS_K_CHAIN_FB, st);
-            hipLaunchKernelGGL(k_chainw_fb, dim3((unsigned)(m_pad / CWD_BM)), dim3(512), chainw_lds_bytes(), st, c, cb);
+            CS_LAUNCH(k_chainw_fb, dim3((unsigned)(m_pad / CWD_BM)), dim3(512), chainw_lds_bytes(), st, c, cb);
             HIP_TRY(hipGetLastError());
             h->bwd_chain_done = true;
             return CS_OK;
         }
         ProfScope ps(CS_K_CHAIN_FWD, st);
-        hipLaunchKernelGGL(k_chainw<false>, dim3((unsigned)(m_pad / CWD_BM)), dim3(512), chainw_lds_bytes(), st, c);
+        CS_LAUNCH(k_chainw<false>, dim3((unsigned)(m_pad / CWD_BM)), dim3(512), chainw_lds_bytes(), st, c);
         HIP_TRY(hipGetLastError());
         return CS_OK;
     }
     {
         const int64_t total = m_pad * (l0.Kp / 4);
         ProfScope ps(CS_K_PREPARE, st);
-        hipLaunchKernelGGL(k_prepare_input, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, row_idx, n,
+        CS_LAUNCH(k_prepare_input, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, row_idx, n,
                            m_pad, h->cfg.n_in, l0.Kp, h->sub, h->div, normalise, l0.H);
     }
     for (int l = 0; l < h->L; ++l) {
@@ -419,14 +443,14 @@ int run_forward(cs_mlp* h, const float* x, const int64_t* row_idx, int64_t n, in
         const bool v1 = (h->cfg.flags & CS_FLAG_GEMM_V1) != 0;     // register-staged 128x128x64 kernels (A/B and parity runs)
         if (l + 1 < h->L) {
             p.out = h->layers[l + 1].H; p.ldo = h->layers[l + 1].Kp;
-            if (v1) hipLaunchKernelGGL(k_gemm_nt<EPI_HIDDEN>, grid, dim3(256), 0, st, p);
-            else hipLaunchKernelGGL(k_gemm_nt2<EPI_HIDDEN>, grid, dim3(256), G2_LDS_BYTES, st, p);
+            if (v1) CS_LAUNCH(k_gemm_nt<EPI_HIDDEN>, grid, dim3(256), 0, st, p);
+            else CS_LAUNCH(k_gemm_nt2<EPI_HIDDEN>, grid, dim3(256), G2_LDS_BYTES, st, p);
         } else {
             p.n_lin = h->cfg.n_out_lin; p.n_real = h->n_out; p.yhat = yhat; p.y = y; p.row_idx = row_idx; p.n_rows = n; p.loss = loss; p.loss_stripes = h->loss_striped ? LOSS_STRIPES : 1;
             p.loss_kind = h->loss_kind; p.keep = h->keep;
             p.out = want_dz ? ly.dZ : nullptr; p.ldo = ly.N;
-            if (v1) hipLaunchKernelGGL(k_gemm_nt<EPI_OUT>, grid, dim3(256), 0, st, p);
-            else hipLaunchKernelGGL(k_gemm_nt2<EPI_OUT>, grid, dim3(256), G2_LDS_BYTES, st, p);
+            if (v1) CS_LAUNCH(k_gemm_nt<EPI_OUT>, grid, dim3(256), 0, st, p);
+            else CS_LAUNCH(k_gemm_nt2<EPI_OUT>, grid, dim3(256), G2_LDS_BYTES, st, p);
         }
     }
     HIP_TRY(hipGetLastError());
@@ -461,7 +485,7 @@ int run_backward(cs_mlp* h, int64_t n, bool atomics_needed, hipStream_t st) {
         ChainArgs c{};
         chainw_bwd_args(h, n, c);
         ProfScope ps(CS_K_CHAIN_BWD, st);
-        hipLaunchKernelGGL(k_chainw<true>, dim3((unsigned)(m_pad / CWD_BM)), dim3(512), chainw_lds_bytes(), st, c);
+        CS_LAUNCH(k_chainw<true>, dim3((unsigned)(m_pad / CWD_BM)), dim3(512), chainw_lds_bytes(), st, c);
     }
     if (!h->use_chain && !wide) {
         for (int l = h->L - 1; l >= 1; --l) {
@@ -473,8 +497,8 @@ int run_backward(cs_mlp* h, int64_t n, bool atomics_needed, hipStream_t st) {
             p.hprev = ly.H; p.ldh = ly.Kp;
             const dim3 g2((unsigned)(m_pad / 128), (unsigned)(ly.Kp / 128));
             ProfScope ps(CS_K_GEMM_DGRAD, st);
-            if (h->cfg.flags & CS_FLAG_GEMM_V1) hipLaunchKernelGGL(k_gemm_nt<EPI_DGRAD>, g2, dim3(256), 0, st, p);
-            else hipLaunchKernelGGL(k_gemm_nt2<EPI_DGRAD>, g2, dim3(256), G2_LDS_BYTES, st, p);
+            if (h->cfg.flags & CS_FLAG_GEMM_V1) CS_LAUNCH(k_gemm_nt<EPI_DGRAD>, g2, dim3(256), 0, st, p);
+            else CS_LAUNCH(k_gemm_nt2<EPI_DGRAD>, g2, dim3(256), G2_LDS_BYTES, st, p);
         }
     }
     {   // weight/bias gradients of ALL layers in one grouped launch
@@ -515,10 +539,10 @@ int run_backward(cs_mlp* h, int64_t n, bool atomics_needed, hipStream_t st) {
             wg += d.tiles_k * d.tiles_n * splitk;
         }
         ProfScope ps(CS_K_WGRAD, st);
-        if (big) hipLaunchKernelGGL(k_wgrad2, dim3((unsigned)wg), dim3(512), WG2_LDS_BYTES, st, w);
-        else if (dma_small) hipLaunchKernelGGL(k_wgrad3, dim3((unsigned)wg), dim3(256), WG3_LDS_BYTES, st, w);
-        else if (tr) hipLaunchKernelGGL(k_wgrad<true>, dim3((unsigned)wg), dim3(256), 0, st, w);
-        else hipLaunchKernelGGL(k_wgrad<false>, dim3((unsigned)wg), dim3(256), 0, st, w);
+        if (big) CS_LAUNCH(k_wgrad2, dim3((unsigned)wg), dim3(512), WG2_LDS_BYTES, st, w);
+        else if (dma_small) CS_LAUNCH(k_wgrad3, dim3((unsigned)wg), dim3(256), WG3_LDS_BYTES, st, w);
+        else if (tr) CS_LAUNCH(k_wgrad<true>, dim3((unsigned)wg), dim3(256), 0, st, w);
+        else CS_LAUNCH(k_wgrad<false>, dim3((unsigned)wg), dim3(256), 0, st, w);
     }
     HIP_TRY(hipGetLastError());
     return CS_OK;
@@ -904,6 +928,40 @@ int cs_mlp_profile_step(cs_mlp_t* h, const float* x_dev, const float* y_dev, con
     return CS_OK;
 }
 
+// Profiling over MANY steps without a host synchronisation in between: every launch between begin and end carries its own
+// start / stop events (CS_LAUNCH); the sums and launch counts come back at the end.  Back-to-back steps are the regime of the
+// timed region (a synchronise after every step, as cs_mlp_profile_step does, lets the chip idle and the first kernel of the
+// next step - the chain - measured 9 us slower).
+namespace { thread_local Profiler g_session; }
+
+int cs_profile_begin(void* stream) {
+    if (g_prof) return fail(CS_ERR_STATE, "a profiling session is already open on this thread");
+    g_session = Profiler();
+    g_session.st = (hipStream_t)stream;
+    g_prof = &g_session;
+    return CS_OK;
+}
+
+int cs_profile_end(cs_kernel_times* out) {
+    if (!out) return fail(CS_ERR_INVALID, "null argument");
+    if (g_prof != &g_session) return fail(CS_ERR_STATE, "no profiling session open on this thread");
+    memset(out, 0, sizeof(*out));
+    g_prof = nullptr;
+    hipError_t e = hipStreamSynchronize(g_session.st);
+    for (auto& r : g_session.recs) {
+        float ms = 0.f;
+        if (e == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess && r.kind >= 0 && r.kind < CS_K_COUNT) {
+            out->ms[r.kind] += ms;
+            out->launches[r.kind] += 1;
+        }
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    g_session.recs.clear();
+    if (e != hipSuccess) return fail(CS_ERR_HIP, "stream synchronize failed: %s", hipGetErrorString(e));
+    return CS_OK;
+}
+
 int cs_mlp_debug_stamps(cs_mlp_t* h, unsigned long long* host, int64_t n_words) {
     if (!h || !host) return fail(CS_ERR_INVALID, "null argument");
     if (!h->dbg) return fail(CS_ERR_STATE, "set CS_CHAIN_DBG=1 before cs_mlp_create");
@@ -918,7 +976,7 @@ int cs_normalise_rows(const float* x_dev, const int64_t* row_idx_dev, int64_t n,
     if (!x_dev || !sub_dev || !div_dev || !out_dev) return fail(CS_ERR_INVALID, "null argument");
     if (n <= 0 || width <= 0) return fail(CS_ERR_INVALID, "empty input");
     const int64_t total = n * ((width + 3) / 4);
-    hipLaunchKernelGGL(k_normalise_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x_dev,
+    CS_LAUNCH(k_normalise_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x_dev,
                        row_idx_dev, n, width, sub_dev, div_dev, out_dev);
     HIP_TRY(hipGetLastError());
     return CS_OK;
@@ -935,10 +993,10 @@ int cs_loader_stack(const void* mli_dev, const void* mlo_dev, int32_t src_f64, i
     const dim3 grid((unsigned)((ncol + 64 * LD_CPL - 1) / (64 * LD_CPL)), (unsigned)n_steps);
     hipStream_t st = (hipStream_t)stream;
     if (src_f64)
-        hipLaunchKernelGGL((k_loader_stack2<double, LD_CPL, LD_FCH, LD_U>), grid, dim3(256), 0, st, (const double*)mli_dev,
+        CS_LAUNCH((k_loader_stack2<double, LD_CPL, LD_FCH, LD_U>), grid, dim3(256), 0, st, (const double*)mli_dev,
                            (const double*)mlo_dev, ncol, n_in, in_sub_dev, in_div_dev, n_out, tend_src_dev, out_scale_dev, x_out_dev, y_out_dev);
     else
-        hipLaunchKernelGGL((k_loader_stack2<float, LD_CPL, LD_FCH, LD_U>), grid, dim3(256), 0, st, (const float*)mli_dev,
+        CS_LAUNCH((k_loader_stack2<float, LD_CPL, LD_FCH, LD_U>), grid, dim3(256), 0, st, (const float*)mli_dev,
                            (const float*)mlo_dev, ncol, n_in, in_sub_dev, in_div_dev, n_out, tend_src_dev, out_scale_dev, x_out_dev, y_out_dev);
     HIP_TRY(hipGetLastError());
     return CS_OK;
@@ -954,9 +1012,9 @@ int cs_metrics_columns(const float* pred_dev, const float* target_dev, int64_t n
     HIP_TRY(hipMemsetAsync(stats_dev, 0, sizeof(double) * 6 * items, st));
     int tsplit = (int)((4096 + (int64_t)ncol * ((n_out + 127) / 128) - 1) / ((int64_t)ncol * ((n_out + 127) / 128)));   // ~4096 workgroups
     tsplit = std::max(1, std::min<int>(tsplit, (int)(n_steps / 64)));     // >= 64 time steps per slice: 6 float64 atomics per (column, output, slice)
-    hipLaunchKernelGGL(k_metrics_partial, dim3((unsigned)ncol, (unsigned)((n_out + 127) / 128), (unsigned)tsplit), dim3(256), 0, st,
+    CS_LAUNCH(k_metrics_partial, dim3((unsigned)ncol, (unsigned)((n_out + 127) / 128), (unsigned)tsplit), dim3(256), 0, st,
                        pred_dev, target_dev, (int)n_steps, ncol, n_out, ps_dev, wa_dev, wb_dev, area_dev, stats_dev);
-    hipLaunchKernelGGL(k_metrics_finish, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, stats_dev, items, (int)n_steps);
+    CS_LAUNCH(k_metrics_finish, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, stats_dev, items, (int)n_steps);
     HIP_TRY(hipGetLastError());
     return CS_OK;
 }
@@ -967,7 +1025,7 @@ int cs_categorical_accuracy(const float* pred_dev, const float* target_dev, int6
     if (n <= 0 || width <= 0) return fail(CS_ERR_INVALID, "empty input");
     hipStream_t st = (hipStream_t)stream;
     if (!accumulate) HIP_TRY(hipMemsetAsync(count_dev, 0, sizeof(unsigned long long), st));
-    hipLaunchKernelGGL(k_argmax_match, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, pred_dev, target_dev, n, (int)width, count_dev);
+    CS_LAUNCH(k_argmax_match, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, pred_dev, target_dev, n, (int)width, count_dev);
     HIP_TRY(hipGetLastError());
     return CS_OK;
 }
@@ -1184,16 +1242,16 @@ int cs_mlp_group_train_step(cs_mlp_group_t* g, const float* const* x_dev, const 
     {
         ProfScope ps(CS_K_CHAIN_FB, st);
         const dim3 grid((unsigned)tab.begin[na]);
-        if (g->wide) hipLaunchKernelGGL(k_chainw_fb_group, grid, dim3(512), chainw_lds_bytes(), st, g->pairs_dev, tab, dyn);
+        if (g->wide) CS_LAUNCH(k_chainw_fb_group, grid, dim3(512), chainw_lds_bytes(), st, g->pairs_dev, tab, dyn);
         else if (bm == 32) {
-            if (g->elu) hipLaunchKernelGGL((k_chain_fb_group<32, true>), grid, dim3(512), chain_lds_bytes<32>(), st, g->pairs_dev, tab, dyn);
-            else hipLaunchKernelGGL((k_chain_fb_group<32, false>), grid, dim3(512), chain_lds_bytes<32>(), st, g->pairs_dev, tab, dyn);
+            if (g->elu) CS_LAUNCH((k_chain_fb_group<32, true>), grid, dim3(512), chain_lds_bytes<32>(), st, g->pairs_dev, tab, dyn);
+            else CS_LAUNCH((k_chain_fb_group<32, false>), grid, dim3(512), chain_lds_bytes<32>(), st, g->pairs_dev, tab, dyn);
         } else if (bm == 64) {
-            if (g->elu) hipLaunchKernelGGL((k_chain_fb_group<64, true>), grid, dim3(512), chain_lds_bytes<64>(), st, g->pairs_dev, tab, dyn);
-            else hipLaunchKernelGGL((k_chain_fb_group<64, false>), grid, dim3(512), chain_lds_bytes<64>(), st, g->pairs_dev, tab, dyn);
+            if (g->elu) CS_LAUNCH((k_chain_fb_group<64, true>), grid, dim3(512), chain_lds_bytes<64>(), st, g->pairs_dev, tab, dyn);
+            else CS_LAUNCH((k_chain_fb_group<64, false>), grid, dim3(512), chain_lds_bytes<64>(), st, g->pairs_dev, tab, dyn);
         } else {
-            if (g->elu) hipLaunchKernelGGL((k_chain_fb_group<128, true>), grid, dim3(512), chain_lds_bytes<128>(), st, g->pairs_dev, tab, dyn);
-            else hipLaunchKernelGGL((k_chain_fb_group<128, false>), grid, dim3(512), chain_lds_bytes<128>(), st, g->pairs_dev, tab, dyn);
+            if (g->elu) CS_LAUNCH((k_chain_fb_group<128, true>), grid, dim3(512), chain_lds_bytes<128>(), st, g->pairs_dev, tab, dyn);
+            else CS_LAUNCH((k_chain_fb_group<128, false>), grid, dim3(512), chain_lds_bytes<128>(), st, g->pairs_dev, tab, dyn);
         }
     }
     HIP_TRY(hipGetLastError());
@@ -1206,7 +1264,7 @@ int cs_mlp_group_train_step(cs_mlp_group_t* g, const float* const* x_dev, const 
     }
     {
         ProfScope ps(CS_K_WGRAD, st);
-        hipLaunchKernelGGL(k_wgrad3_group, dim3((unsigned)wt.begin[na]), dim3(256), WG3_LDS_BYTES, st, g->wg_dev, wt);
+        CS_LAUNCH(k_wgrad3_group, dim3((unsigned)wt.begin[na]), dim3(256), WG3_LDS_BYTES, st, g->wg_dev, wt);
     }
     HIP_TRY(hipGetLastError());
     // ---- launch 3: optimisers (each member with its own rule, step count and learning rate)
@@ -1225,7 +1283,7 @@ int cs_mlp_group_train_step(cs_mlp_group_t* g, const float* const* x_dev, const 
     }
     {
         ProfScope ps(CS_K_OPTIMIZER, st);
-        hipLaunchKernelGGL(k_optimizer_group, dim3((unsigned)ot.begin[na]), dim3(256), 0, st, g->opt_dev, ot, od);
+        CS_LAUNCH(k_optimizer_group, dim3((unsigned)ot.begin[na]), dim3(256), 0, st, g->opt_dev, ot, od);
     }
     HIP_TRY(hipGetLastError());
     return CS_OK;

@@ -152,6 +152,11 @@ enum { CS_K_PREPARE = 0, CS_K_GEMM_FWD = 1, CS_K_GEMM_DGRAD = 2, CS_K_WGRAD = 3,
        CS_K_MEMSET = 5, CS_K_CHAIN_FWD = 6, CS_K_CHAIN_BWD = 7,
        CS_K_CHAIN_FB = 8 /* forward + backward chain in one launch */, CS_K_COUNT = 9 };
 typedef struct cs_kernel_times { float ms[CS_K_COUNT]; int32_t launches[CS_K_COUNT]; } cs_kernel_times;
+/* The same over many steps with no synchronisation in between (the regime of a timed training loop): every kernel the
+ * engine launches on this thread between begin and end carries its own start / stop events (hipExtLaunchKernelGGL: the
+ * dispatch packet's timestamps, what rocprofv3 reports); end synchronises `stream` and returns sums and launch counts. */
+int cs_profile_begin(void* stream);
+int cs_profile_end(cs_kernel_times* out);
 int cs_mlp_profile_step(cs_mlp_t* h, const float* x_dev, const float* y_dev, const int64_t* row_idx_dev,
                         int64_t n, int normalise, float lr, float* loss_dev, void* stream,
                         cs_kernel_times* out);

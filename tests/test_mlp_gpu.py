@@ -140,8 +140,9 @@ def test_training_curve_tracks_oracle(M):
     got = m.get_weights()
     # Adam normalises tiny gradients, so individual weights may differ by O(lr) where g ~ 0;
     # compare in aggregate
-    for a, b, w0 in zip(got, w, ws):
-        assert rel(a - w0, b - w0) <= 0.15
+    worst = max(rel(a - w0, b - w0) for a, b, w0 in zip(got, w, ws))
+    print("worst relative difference of the 12-step weight movement:", worst)
+    assert worst <= 2e-2                      # measured 2.7e-3 (a bar of 0.15 stood here while the measured value was this)
 
 
 def test_weights_and_optimizer_state_roundtrip(M, tmp_path):
