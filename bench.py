@@ -66,10 +66,15 @@ class ClockSampler:
         cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
         if index < len(cards):
             self.path = cards[index]
+            hw = sorted(glob.glob(os.path.join(os.path.dirname(cards[index]), "hwmon", "hwmon*", "freq1_input")))
+            if hw:
+                self.path = hw[0]                # current shader clock in Hz (pp_dpm_sclk's starred level is 94 MHz on some boxes of the pool)
         self.samples, self._stop, self._thr = [], False, None
 
     def read(self):
         try:
+            if self.path.endswith("freq1_input"):
+                return float(open(self.path).read()) / 1e6
             for line in open(self.path):
                 if "*" in line:
                     return float(line.split(":")[1].strip().split("M")[0])
