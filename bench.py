@@ -299,6 +299,12 @@ def main():
     args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback for the engine)")
+    # development / tests: every rank on cuda:0 with gloo collectives, so that the N > 1 flow of this file (barriers, MAX over
+    # ranks, strong leg, comm figures, rank 0's line) can run on a one-GPU box; RCCL cannot put two ranks on one device
+    share_gpu = os.environ.get("CS_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
+        os.environ["CS_DP_NATIVE"] = "0"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
@@ -310,6 +316,8 @@ def main():
         if force_dist and world == 1:
             os.environ.setdefault("MASTER_PORT", "29517")
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+        elif share_gpu:
+            dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=device)
 
