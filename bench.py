@@ -331,7 +331,9 @@ def main():
     B = args.batch
     sb_max = args.strong_global_batch // world if (multi and args.strong_global_batch and args.strong_global_batch % world == 0) else 0
     model = MLPEmulator(units=UNITS, activation="leakyrelu", optimizer="Adam", max_batch=max(B, sb_max), seed=0, device=local_rank,
-                        flags=int(os.environ.get("CS_FLAGS", "0")))   # engine flags: tuning experiments only
+                        flags=int(os.environ.get("CS_FLAGS", "0")),   # engine flags: tuning experiments only
+                        cooperative=not share_gpu)                     # one process per GPU: batches <= 4096 columns (--batch, the strong
+                                                                       # leg at N >= 2) may take the cooperative chain
     x, y = synth_on_device(torch, args.rows, 20230614 + rank, device)
     xv, yv = synth_on_device(torch, 65536, 777, device)
     model.gradient_tensor()

@@ -15,6 +15,8 @@ CS_FLAG_CHAIN_BM128 = 8
 CS_FLAG_CHAIN_BM32 = 16
 CS_FLAG_CHAIN_BWD32_ON_FWD64 = 32
 CS_FLAG_GEMM_V1 = 64
+CS_FLAG_NO_CHAIN_FB = 256
+CS_FLAG_COOP = 512
 
 ACT = {"relu": 0, "elu": 1, "leakyrelu": 2}
 OPT = {"Adam": 0, "RAdam": 1, "RMSprop": 2, "SGD": 3, "AdamTorch": 4}

@@ -9,6 +9,7 @@
 #include "loader.h"
 #include "gemm2.h"
 #include "chainw.h"
+#include "coop.h"
 #include "metrics.h"
 
 #include <cmath>
@@ -146,6 +147,14 @@ struct cs_mlp {
     bool wgrad3 = true;        // small-batch wgrad through the LDS-DMA ring (CS_WGRAD3=0: register-staged k_wgrad)
     int wgrad2_mode = -1;      // CS_WGRAD2 env: 0 never, 1 always, -1 by batch size
     int wgrad_splitk = 0;      // 0 = automatic (CS_WGRAD_SPLITK env overrides, for tuning runs)
+    // cooperative chain (coop.h): C workgroups per 32-row tile for batches of up to 4096 columns
+    int coop_mode = 0;         // 0 off (default), -1 members by batch size (CS_FLAG_COOP / CS_COOP=1), 2 / 4 / 8 forced (CS_COOP=2|4|8)
+    unsigned* coop_arrive = nullptr;   // [tiles][2 * CHAIN_MAX_STAGES] monotonic arrival counters
+    unsigned* coop_error = nullptr;    // set by a bounded wait that ran out
+    unsigned* coop_xcc = nullptr;      // [tiles] XCC ids seen per tile (roll call of the members)
+    unsigned coop_epoch = 0;
+    int coop_c_last = 0; int64_t coop_tiles_last = 0;
+    bool coop_used = false;
     std::vector<void*> allocs;
 };
 
@@ -382,6 +391,39 @@ int run_forward(cs_mlp* h, const float* x, const int64_t* row_idx, int64_t n, in
         static const int64_t hybrid_max = getenv("CS_CHAIN_HYBRID_MAX") ? atoll(getenv("CS_CHAIN_HYBRID_MAX")) : 0;
         const bool forced = h->cfg.flags & (CS_FLAG_CHAIN_BM32 | CS_FLAG_CHAIN_BM64 | CS_FLAG_CHAIN_BM128);
         const bool hybrid = (bm == 64 && !forced && n <= hybrid_max && h->cfg.act != CS_ACT_ELU) || (h->cfg.flags & CS_FLAG_CHAIN_BWD32_ON_FWD64);
+        // small batches: C workgroups per row tile, each streaming 1/C of every layer (coop.h) - as long as every workgroup of
+        // the launch gets its own CU (they wait for one another)
+        int coop_c = 0;
+        if (want_dz && h->L > 1 && !hybrid && !forced && !(h->cfg.flags & CS_FLAG_NO_CHAIN_FB) && h->coop_mode != 0 && h->coop_arrive) {
+            coop_c = h->coop_mode > 0 ? h->coop_mode : (n <= 1024 ? 8 : n <= 2048 ? 4 : 0);   // (2 members at <= 4096 columns measured 0.9x: not built)
+            const int64_t wgs = (m_pad / 32) * coop_c;
+            if (!(coop_c == 4 || coop_c == 8) || wgs > (h->n_cu > 0 ? h->n_cu : 256) || m_pad / 32 > 256) coop_c = 0;
+        }
+        if (coop_c) {
+            ChainArgs cb{};
+            chain_bwd_args(h, n, cb);
+            c.dbg = nullptr; cb.dbg = nullptr;
+            if (h->coop_c_last != coop_c || h->coop_tiles_last != m_pad / 32) {     // another launch shape: the counters start over
+                HIP_TRY(hipMemsetAsync(h->coop_arrive, 0, sizeof(unsigned) * 256 * 2 * CHAIN_MAX_STAGES, st));
+                HIP_TRY(hipMemsetAsync(h->coop_xcc, 0, sizeof(unsigned) * 256, st));
+                if (!h->coop_used) HIP_TRY(hipMemsetAsync(h->coop_error, 0, 256, st));
+                h->coop_epoch = 0; h->coop_c_last = coop_c; h->coop_tiles_last = m_pad / 32;
+            }
+            if (h->coop_epoch >= 0x0fffffffu) {                                      // far from wrapping epoch * 8
+                HIP_TRY(hipMemsetAsync(h->coop_arrive, 0, sizeof(unsigned) * 256 * 2 * CHAIN_MAX_STAGES, st));
+                h->coop_epoch = 0;
+            }
+            static const int warm = getenv("CS_COOP_WARM") ? atoi(getenv("CS_COOP_WARM")) : 0;
+            CoopArgs co{coop_c, ++h->coop_epoch, h->coop_arrive, h->coop_xcc, h->coop_error, warm, h->dbg};
+            h->coop_used = true;
+            ProfScope ps(CS_K_CHAIN_FB, st);
+            const dim3 cg((unsigned)((m_pad / 32) * coop_c));
+            if (coop_c == 8) CS_LAUNCH(k_chain_coop_fb<8>, cg, dim3(512), coop_lds_bytes(), st, c, cb, co);
+            else CS_LAUNCH(k_chain_coop_fb<4>, cg, dim3(512), coop_lds_bytes(), st, c, cb, co);
+            HIP_TRY(hipGetLastError());
+            h->bwd_chain_done = true;
+            return CS_OK;
+        }
         if (want_dz && h->L > 1 && !hybrid && !(h->cfg.flags & CS_FLAG_NO_CHAIN_FB)) {
             ChainArgs cb{};
             chain_bwd_args(h, n, cb);
@@ -634,6 +676,12 @@ int cs_mlp_create(cs_mlp_t** out, const cs_mlp_cfg* cfg) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad2), hipFuncAttributeMaxDynamicSharedMemorySize, WG2_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad3), hipFuncAttributeMaxDynamicSharedMemorySize, WG3_LDS_BYTES));
     if (const char* e = getenv("CS_WGRAD3")) h->wgrad3 = atoi(e) != 0;
+    if (cfg->flags & CS_FLAG_COOP) h->coop_mode = -1;
+    if (const char* e = getenv("CS_COOP")) { const int v = atoi(e); h->coop_mode = v == 1 ? -1 : v; }
+    if (h->use_chain) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_coop_fb<4>), hipFuncAttributeMaxDynamicSharedMemorySize, coop_lds_bytes()));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_coop_fb<8>), hipFuncAttributeMaxDynamicSharedMemorySize, coop_lds_bytes()));
+    }
     if (h->use_chain) {
         for (const void* f : chain_kernels<128>()) HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, chain_lds_bytes<128>()));
         for (const void* f : chain_kernels<64>()) HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, chain_lds_bytes<64>()));
@@ -670,6 +718,11 @@ int cs_mlp_create(cs_mlp_t** out, const cs_mlp_cfg* cfg) {
         }
     }
     A((void**)&h->seg_dev, sizeof(Segment) * 2 * h->L);
+    if (h->use_chain) {
+        A((void**)&h->coop_arrive, sizeof(unsigned) * 256 * 2 * CHAIN_MAX_STAGES);
+        A((void**)&h->coop_error, 256);
+        A((void**)&h->coop_xcc, sizeof(unsigned) * 256);
+    }
     if (getenv("CS_CHAIN_DBG")) A((void**)&h->dbg, (size_t)2 * (h->m_pad_max / 32) * 64 * 8);
     if (h->use_chain)
         for (int l = 0; l + 1 < h->L; ++l) A((void**)&h->layers[l].mask, (size_t)(h->m_pad_max / 32) * 512 * 16);
@@ -770,8 +823,23 @@ int cs_mlp_set_weights(cs_mlp_t* h, const float* host, int64_t n, void* stream) 
     return launch_optimizer(h, 0.f, 0.f, true, st);
 }
 
+namespace {
+// A bounded wait of the cooperative chain ran out (a member of a tile was not resident in time): the results since then are
+// wrong.  Reported at the points where the host reads the model back.
+int coop_check(cs_mlp* h, hipStream_t st) {
+    if (!h->coop_used) return CS_OK;
+    unsigned flag = 0;
+    HIP_TRY(hipMemcpyAsync(&flag, h->coop_error, sizeof flag, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (flag) return fail(CS_ERR_STATE, "the cooperative layer chain timed out waiting for a member workgroup (results since then are invalid); "
+                                        "CS_FLAG_COOP needs the device to itself: one cooperative launch at a time");
+    return CS_OK;
+}
+}  // namespace
+
 int cs_mlp_get_weights(cs_mlp_t* h, float* host, int64_t n, void* stream) {
     if (!h || !host) return fail(CS_ERR_INVALID, "null argument");
+    if (int rc = coop_check(h, (hipStream_t)stream)) return rc;
     if (n != h->n_params_keras) return fail(CS_ERR_INVALID, "expected %lld floats, got %lld", (long long)h->n_params_keras, (long long)n);
     std::vector<float> tmp((size_t)h->n_params);
     hipStream_t st = (hipStream_t)stream;
@@ -783,6 +851,7 @@ int cs_mlp_get_weights(cs_mlp_t* h, float* host, int64_t n, void* stream) {
 
 int cs_mlp_get_grads(cs_mlp_t* h, float* host, int64_t n, void* stream) {
     if (!h || !host) return fail(CS_ERR_INVALID, "null argument");
+    if (int rc = coop_check(h, (hipStream_t)stream)) return rc;
     if (n != h->n_params_keras) return fail(CS_ERR_INVALID, "expected %lld floats, got %lld", (long long)h->n_params_keras, (long long)n);
     std::vector<float> tmp((size_t)h->n_params);
     hipStream_t st = (hipStream_t)stream;

@@ -82,10 +82,12 @@ class MLPEmulator:
                  output_length_relu: int = 8, alpha: float = 0.15, max_batch: int = 8192,
                  device: Optional[int] = None, seed: Optional[int] = 0, beta_1: float = 0.9,
                  beta_2: float = 0.999, epsilon: float = 1e-7, rho: float = 0.9, flags: int = 0,
-                 direct_head: bool = False, loss: str = "mse", output_keep=None):
+                 direct_head: bool = False, loss: str = "mse", output_keep=None, cooperative: bool = False):
         """`direct_head`, `loss` ('mse' | 'mae' | 'huber'), `output_keep` (1/0 per output column) and optimizer
         'AdamTorch' are the pieces of the online-testing MLP (climsim_amd/online_mlp.py); the baseline models leave
-        them at their defaults."""
+        them at their defaults.  `cooperative`: training steps of up to 4096 columns split every 32-row tile over 8 / 4 / 2
+        workgroups (CS_FLAG_COOP, csrc/coop.h: 1.4x at batch 1024) - only when this process is the one user of the GPU
+        for such launches (the workgroups of a cooperative launch wait for one another)."""
         torch = _torch()
         if not torch.cuda.is_available():
             raise _lib.EngineError("MLPEmulator needs a ROCm GPU (no CPU fallback)")
@@ -99,6 +101,8 @@ class MLPEmulator:
         self.direct_head, self.loss_name = bool(direct_head), loss
         if self.direct_head:
             flags |= _lib.FLAG_DIRECT_HEAD
+        if cooperative:
+            flags |= _lib.CS_FLAG_COOP
         self.units = tuple(int(u) for u in units)
         self.activation, self.optimizer_name = activation, optimizer
         self.input_length, self.output_length = input_length, output_length_lin + output_length_relu

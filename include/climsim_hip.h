@@ -72,6 +72,11 @@ typedef struct cs_mlp_cfg {
 #define CS_FLAG_DIRECT_HEAD 128   /* online_testing MLP (MLP_v2rh/training/mlp.py:41-67): no Dense(output_length)+act between the
                                      hidden stack and the heads - the output layer [n_out_lin linear || n_out_relu relu] sits on
                                      the last hidden layer (torch `final_linear` + relu on the last 8 columns)              */
+#define CS_FLAG_COOP 512           /* training steps of up to 4096 columns on the COOPERATIVE chain (csrc/coop.h): a 32-row tile is split over
+                                    * 8 / 4 / 2 workgroups that exchange layer outputs inside the launch (1.4x at 1024 columns).  The
+                                    * workgroups of such a launch wait for one another, so it needs every one of them resident: the caller
+                                    * guarantees that NO OTHER cooperative launch (another stream, another process) runs on the device
+                                    * at the same time.  A wait that runs out sets an error that cs_mlp_get_weights / get_grads report. */
 #define CS_FLAG_NO_CHAIN_FB 256    /* forward and backward chain as two launches (default: one launch on 32-row tiles)  */
 #define CS_FLAG_CHAIN_BWD32_ON_FWD64 32   /* tests: 64-row forward tiles (with CHAIN_BM64), 32-row backward tiles    */
 

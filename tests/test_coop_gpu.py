@@ -1,0 +1,89 @@
+"""Cooperative layer chain (csrc/coop.h, CS_FLAG_COOP): a 32-row tile split over C = 8 / 4 / 2 workgroups that exchange
+every layer's output inside the launch (write-through stores + agent-scope arrival counters + sc1 loads).  Held to the
+bf16-emulating oracle with the tolerances of tests/test_mlp_gpu.py, for every member count, activation and stage shape
+(512 / 256 / 128-wide layers: 128-wide stages have fewer computing members than the tile has), over several steps so that
+the monotonic arrival counters go through several epochs, and to the one-workgroup-per-tile chain on the same inputs."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from oracle import mlp_oracle as O  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def M():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from climsim_amd import build
+    build.build()
+    from climsim_amd import mlp
+    return mlp
+
+
+def rel(a, b):
+    return float(np.linalg.norm(np.asarray(a, np.float64) - np.asarray(b, np.float64)) / (np.linalg.norm(b) + 1e-30))
+
+
+def make(M, units, act, opt="Adam", max_batch=4096, cooperative=True, seed=3):
+    m = M.MLPEmulator(units=units, activation=act, optimizer=opt, max_batch=max_batch, seed=None, cooperative=cooperative)
+    cfg = O.MLPConfig(hidden=tuple(units), act=act)
+    ws = O.glorot_init(cfg, seed)
+    rng = np.random.default_rng(seed + 100)
+    for i in range(1, len(ws), 2):
+        ws[i] = rng.normal(0, 0.05, ws[i].shape).astype(np.float32)
+    m.set_weights(ws)
+    return m, cfg, ws
+
+
+# n -> members per tile: <= 1024: 8, <= 2048: 4; above: one workgroup per tile (the plain chain)
+@pytest.mark.parametrize("act,n,units", [("leakyrelu", 1000, (512, 512, 512, 512, 512)),      # cfg-MLP, C = 8, ragged rows
+                                         ("relu", 300, (256, 128, 512)),                       # mixed widths, C = 8
+                                         ("elu", 2048, (512, 256)),                            # C = 4
+                                         ("leakyrelu", 1536, (512, 512)),                      # C = 4, ragged
+                                         ("relu", 77, (128, 128, 128))])                       # every stage narrower than the tile's members
+def test_coop_loss_and_gradients_match_oracle(M, act, n, units):
+    m, cfg, ws = make(M, units, act)
+    x, y = O.synth_columns(n, seed=7)
+    xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    perm = torch.randperm(n, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    loss = m.loss_grads(xd, yd, row_idx=perm).cpu().numpy().astype(np.float64)
+    ref_loss, ref_mae, ref_g, _ = O.loss_and_grads(ws, x, y, cfg, bf16=True)
+    assert loss[0] / (128 * n) == pytest.approx(ref_loss, rel=2e-3)
+    assert loss[1] / (128 * n) == pytest.approx(ref_mae, rel=2e-3)
+    for i, (g, r) in enumerate(zip(m.get_gradients(1.0 / (128 * n)), ref_g)):
+        assert g.shape == r.shape and rel(g, r) <= 5e-3, (i, rel(g, r))
+    m.close()
+
+
+def test_coop_training_tracks_oracle_and_the_plain_chain(M):
+    units, n = (512, 512, 512), 1024
+    a, cfg, ws = make(M, units, "leakyrelu", cooperative=True)
+    b, _, _ = make(M, units, "leakyrelu", cooperative=False)
+    x, y = O.synth_columns(n, seed=21)
+    xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    opt = O.Optimizer("Adam")
+    w = ws
+    la, lb, lr_ = [], [], []
+    for it in range(12):                                             # 12 epochs of the arrival counters
+        la.append(float(a.train_on_batch(xd, yd, 1e-3)[0]) / (128 * n))
+        lb.append(float(b.train_on_batch(xd, yd, 1e-3)[0]) / (128 * n))
+        w, l, _ = O.train_step(w, opt, x, y, cfg, 1e-3, bf16=True)
+        lr_.append(l)
+    np.testing.assert_allclose(la, lr_, rtol=2e-2)
+    np.testing.assert_allclose(la, lb, rtol=5e-3)                   # two decompositions of the same arithmetic
+    for wa, wo, w0 in zip(a.get_weights(), w, ws):                  # get_weights also reports a timed-out wait
+        assert rel(wa - w0, wo - w0) <= 2e-2
+    # another batch size on the same handle: another member count, counters start over
+    x2, y2 = O.synth_columns(2048, seed=22)
+    l2 = a.loss_grads(torch.from_numpy(x2).cuda(), torch.from_numpy(y2).cuda()).cpu().numpy()
+    ref2, _, g2, _ = O.loss_and_grads(a.get_weights(), x2, y2, cfg, bf16=True)
+    assert l2[0] / (128 * 2048) == pytest.approx(ref2, rel=2e-3)
+    for g, r in zip(a.get_gradients(1.0 / (128 * 2048)), g2):
+        assert rel(g, r) <= 5e-3
+    # above 2048 columns the handle falls back to one workgroup per tile
+    x3, y3 = O.synth_columns(2176, seed=23)
+    m3, cfg3, ws3 = make(M, units, "leakyrelu", max_batch=2176)
+    l3 = m3.loss_grads(torch.from_numpy(x3).cuda(), torch.from_numpy(y3).cuda()).cpu().numpy()
+    assert l3[0] / (128 * 2176) == pytest.approx(O.loss_and_grads(ws3, x3, y3, cfg3, bf16=True)[0], rel=2e-3)
