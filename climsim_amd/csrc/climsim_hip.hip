@@ -149,7 +149,7 @@ struct cs_mlp {
     int wgrad_splitk = 0;      // 0 = automatic (CS_WGRAD_SPLITK env overrides, for tuning runs)
     // cooperative chain (coop.h): C workgroups per 32-row tile for batches of up to 4096 columns
     int coop_mode = 0;         // 0 off (default), -1 members by batch size (CS_FLAG_COOP / CS_COOP=1), 2 / 4 / 8 forced (CS_COOP=2|4|8)
-    unsigned* coop_arrive = nullptr;   // [tiles][2 * CHAIN_MAX_STAGES] monotonic arrival counters
+    unsigned* coop_arrive = nullptr;   // [tiles] roll-call counters + [tiles][2 * CHAIN_MAX_STAGES][8] arrival flags behind them
     unsigned* coop_error = nullptr;    // set by a bounded wait that ran out
     unsigned* coop_xcc = nullptr;      // [tiles] XCC ids seen per tile (roll call of the members)
     unsigned coop_epoch = 0;
@@ -404,17 +404,17 @@ int run_forward(cs_mlp* h, const float* x, const int64_t* row_idx, int64_t n, in
             chain_bwd_args(h, n, cb);
             c.dbg = nullptr; cb.dbg = nullptr;
             if (h->coop_c_last != coop_c || h->coop_tiles_last != m_pad / 32) {     // another launch shape: the counters start over
-                HIP_TRY(hipMemsetAsync(h->coop_arrive, 0, sizeof(unsigned) * 256 * 2 * CHAIN_MAX_STAGES, st));
+                HIP_TRY(hipMemsetAsync(h->coop_arrive, 0, sizeof(unsigned) * 256 * (1 + 2 * CHAIN_MAX_STAGES * 8), st));
                 HIP_TRY(hipMemsetAsync(h->coop_xcc, 0, sizeof(unsigned) * 256, st));
                 if (!h->coop_used) HIP_TRY(hipMemsetAsync(h->coop_error, 0, 256, st));
                 h->coop_epoch = 0; h->coop_c_last = coop_c; h->coop_tiles_last = m_pad / 32;
             }
             if (h->coop_epoch >= 0x0fffffffu) {                                      // far from wrapping epoch * 8
-                HIP_TRY(hipMemsetAsync(h->coop_arrive, 0, sizeof(unsigned) * 256 * 2 * CHAIN_MAX_STAGES, st));
+                HIP_TRY(hipMemsetAsync(h->coop_arrive, 0, sizeof(unsigned) * 256 * (1 + 2 * CHAIN_MAX_STAGES * 8), st));
                 h->coop_epoch = 0;
             }
             static const int warm = getenv("CS_COOP_WARM") ? atoi(getenv("CS_COOP_WARM")) : 0;
-            CoopArgs co{coop_c, ++h->coop_epoch, h->coop_arrive, h->coop_xcc, h->coop_error, warm, h->dbg};
+            CoopArgs co{coop_c, ++h->coop_epoch, h->coop_arrive, h->coop_arrive + 256, h->coop_xcc, h->coop_error, warm, h->dbg};
             h->coop_used = true;
             ProfScope ps(CS_K_CHAIN_FB, st);
             const dim3 cg((unsigned)((m_pad / 32) * coop_c));
@@ -719,7 +719,7 @@ int cs_mlp_create(cs_mlp_t** out, const cs_mlp_cfg* cfg) {
     }
     A((void**)&h->seg_dev, sizeof(Segment) * 2 * h->L);
     if (h->use_chain) {
-        A((void**)&h->coop_arrive, sizeof(unsigned) * 256 * 2 * CHAIN_MAX_STAGES);
+        A((void**)&h->coop_arrive, sizeof(unsigned) * 256 * (1 + 2 * CHAIN_MAX_STAGES * 8));
         A((void**)&h->coop_error, 256);
         A((void**)&h->coop_xcc, sizeof(unsigned) * 256);
     }

@@ -10,12 +10,11 @@
 //
 // Protocol per stage (MI355X_MICROARCH.md "inter-workgroup visibility", form R1; placement-independent):
 //   producer: the slice is stored WRITE-THROUGH (global_store ... sc1), every storing wave drains (s_waitcnt vmcnt(0)),
-//             workgroup barrier, ONE lane adds 1 to the stage's arrival counter (agent scope, relaxed);
-//   consumer: ONE lane polls the counter (relaxed agent loads, s_sleep, BOUNDED: on a time-out the error word is set and the
-//             kernel runs on - a wrong result that the host reports, never a hang), barrier, then the other members' slices
-//             are read with sc1 loads (they bypass this CU's L1, which another CU's stores never refresh).
-// Counters are monotonic: stage s of step e is complete at e * (active members of s); the host clears them when the
-// shape of the launch changes.  Members of a tile get consecutive work ids, i.e. sit on one XCD (speed only).
+//             workgroup barrier, ONE lane stores the step's epoch into the member's flag word of the stage (agent scope);
+//   consumer: lane m of wave 0 polls member m's flag (relaxed agent loads, s_sleep, BOUNDED: on a time-out the error word is
+//             set and the kernel runs on - a wrong result that the host reports, never a hang), barrier, then the other
+//             members' slices are read with sc1 loads (they bypass this CU's L1, which another CU's stores never refresh).
+// Epochs are monotonic (no flag is ever cleared inside a launch); the host clears them when the launch shape changes.  Members of a tile get consecutive work ids, i.e. sit on one XCD (speed only).
 //
 // A wave's weights of stage s+1 are requested (ordinary 16-B loads into registers) right after the arrival of stage s -
 // behind the drain, which would otherwise wait for them - and land while the workgroup waits for the others and gathers.
@@ -38,7 +37,8 @@
 struct CoopArgs {
     int C;                       // members per row tile: 2, 4 or 8
     unsigned epoch;              // 1, 2, ...: steps since the counters were cleared
-    unsigned* arrive;            // [tiles][2 * CHAIN_MAX_STAGES] arrival counters (the last one of a tile: the roll call below)
+    unsigned* arrive;            // [tiles] roll-call counters (monotonic: C arrivals per step)
+    unsigned* flags;             // [tiles][2 * CHAIN_MAX_STAGES][8] per-member arrival flags: the epoch of the last step that published
     unsigned* xcc_mask;          // [tiles] OR of (1 << XCC_ID) of the members that ever worked on the tile
     unsigned* error;             // set to 1 when a bounded wait ran out
     int warm;                    // development (CS_COOP_WARM): 4 = take the write-through (sc1) path even when the members share an XCD
@@ -82,21 +82,24 @@ __device__ __forceinline__ void coop_load4_sc1(const void* p0, const void* p1, c
 // (already in X), -1 / -1 for a member that produced nothing in this stage.
 template <class REQ>
 __device__ __forceinline__ void coop_exchange(const CoopArgs& co, int tile, int seq, int need, const u16* __restrict__ src, int ld, int64_t m0,
-                                              int width, int own_lo, int own_hi, u16* X, int tid, bool published, int& slot, REQ request_next) {
+                                              int width, int own_lo, int own_hi, u16* X, int tid, bool published, int& slot, bool same_xcd, int member, REQ request_next) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // every storing wave drains its write-through stores
     __syncthreads();
     coop_stamp(co, slot, tid);                                       // [2] epilogue + publish drained
-    unsigned* ctr = co.arrive + (size_t)tile * (2 * CHAIN_MAX_STAGES) + seq;
-    if (tid == 0) {
-        if (published) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // arrival: every publishing member owns ONE flag word per stage and writes the step's epoch into it - write-through, or,
+    // for a tile whose members share an XCD, plainly (it is in the shared L2 once waited for, like the payload; a
+    // read-modify-write counter at agent scope is resolved at the memory side, and polling it costs a fabric round trip)
+    unsigned* flags = co.flags + ((size_t)tile * (2 * CHAIN_MAX_STAGES) + seq) * 8;
+    if (tid == 0 && published) {
+        if (same_xcd) { *reinterpret_cast<volatile unsigned*>(flags + member) = co.epoch; }
+        else __hip_atomic_store(flags + member, co.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // The next stage's weights are requested HERE - behind the drain above (a request in front of it would be waited for by
     // it: memory operations complete in order) - and land while this workgroup waits for the others and gathers.
     request_next();
-    if (tid == 0) {
-        const unsigned want = co.epoch * (unsigned)need;
+    if (tid < need) {                                                // lane m of wave 0 watches member m's flag (sc1 loads: served by L2)
         int spins = 0;
-        while ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
+        while ((int)(__hip_atomic_load(flags + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - co.epoch) < 0) {
             if (++spins > COOP_SPIN_LIMIT) { __hip_atomic_store(co.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
             __builtin_amdgcn_s_sleep(1);
         }
@@ -279,7 +282,7 @@ __global__ __launch_bounds__(512) void k_chain_coop_fb(const ChainArgs pf, const
     // ---- roll call: which XCDs do the members of this tile sit on?  (Dispatch puts consecutive work ids on one XCD, but that
     // is an observation, not a contract.)  Every member ORs its XCC id into the tile's mask and arrives; the answer is read
     // after the prologue.  The mask only ever grows, so a tile that was EVER split over XCDs keeps the write-through path.
-    unsigned* roll = co.arrive + (size_t)tile * (2 * CHAIN_MAX_STAGES) + (2 * CHAIN_MAX_STAGES - 1);
+    unsigned* roll = co.arrive + tile;
     if (tid == 0) {
         const unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 15u;       // HW_REG_XCC_ID[3:0]
         __hip_atomic_fetch_or(co.xcc_mask + tile, 1u << xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -338,11 +341,11 @@ __global__ __launch_bounds__(512) void k_chain_coop_fb(const ChainArgs pf, const
         if (S.epi == EPI_OUT) {
             coop_stage<EPI_OUT, QN>(pf, S, C, member, X, red, bias_lds, rows_lds, m0, tid, sq, ab, lo, hi, co, slot, same_xcd, wq);
             // dz of the heads: the input of the backward pass, every member needs all of it
-            coop_exchange(co, tile, seq, need, pf.dz_out, pf.ld_dz_out, m0, S.Nc, lo, hi, X, tid, lo >= 0, slot,
+            coop_exchange(co, tile, seq, need, pf.dz_out, pf.ld_dz_out, m0, S.Nc, lo, hi, X, tid, lo >= 0, slot, same_xcd, member,
                           [&]() { coop_request_weights<QN>(pb.st[0], C, member, tid, wq); });                    // first backward stage
         } else {
             coop_stage<EPI_HIDDEN, QN>(pf, S, C, member, X, red, bias_lds, rows_lds, m0, tid, sq, ab, lo, hi, co, slot, same_xcd, wq);
-            coop_exchange(co, tile, seq, need, S.out, S.ldo, m0, S.Nc, lo, hi, X, tid, lo >= 0, slot,
+            coop_exchange(co, tile, seq, need, S.out, S.ldo, m0, S.Nc, lo, hi, X, tid, lo >= 0, slot, same_xcd, member,
                           [&]() { coop_request_weights<QN>(pf.st[i + 1], C, member, tid, wq); });               // (a hidden stage is never the last forward one)
         }
     }
@@ -353,7 +356,7 @@ __global__ __launch_bounds__(512) void k_chain_coop_fb(const ChainArgs pf, const
         int lo, hi;
         coop_stage<EPI_DGRAD, QN>(pb, S, C, member, X, red, bias_lds, rows_lds, m0, tid, sq, ab, lo, hi, co, slot, same_xcd, wq);
         if (i + 1 < pb.n_stages)
-            coop_exchange(co, tile, seq, min(C, S.Nc >> 5), S.out, S.ldo, m0, S.Nc, lo, hi, X, tid, lo >= 0, slot,
+            coop_exchange(co, tile, seq, min(C, S.Nc >> 5), S.out, S.ldo, m0, S.Nc, lo, hi, X, tid, lo >= 0, slot, same_xcd, member,
                           [&]() { coop_request_weights<QN>(pb.st[i + 1], C, member, tid, wq); });
     }
 }
