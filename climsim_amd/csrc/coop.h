@@ -97,37 +97,47 @@ __device__ __forceinline__ void coop_exchange(const CoopArgs& co, int tile, int 
     // The next stage's weights are requested HERE - behind the drain above (a request in front of it would be waited for by
     // it: memory operations complete in order) - and land while this workgroup waits for the others and gathers.
     request_next();
-    if (tid < need) {                                                // lane m of wave 0 watches member m's flag (sc1 loads: served by L2)
-        int spins = 0;
-        while ((int)(__hip_atomic_load(flags + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - co.epoch) < 0) {
-            if (++spins > COOP_SPIN_LIMIT) { __hip_atomic_store(co.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-            __builtin_amdgcn_s_sleep(1);
-        }
-    }
-    __syncthreads();
-    coop_stamp(co, slot, tid);                                       // [3] all members arrived
-    // gather: thread -> row tid >> 4, 16-B chunks (tid & 15) + 16 j of that row, j < width / 128 (<= 4): up to four sc1 loads in
-    // flight per thread, no index arithmetic beyond shifts (an it / chunks-per-row division per load cost more than the loads)
+    // Wait and gather, wave by wave: the 8 waves divide the `need` publishing members between them (8 / need waves per member,
+    // each a band of rows); a wave polls ITS member's flag (lane 0; sc1 loads, served by L2) and fetches that member's slice as
+    // soon as it is there - the slices of early members are in LDS by the time the last one arrives, instead of a workgroup-wide
+    // wait followed by a workgroup-wide gather.
     {
-        const int r = tid >> 4, c0 = tid & 15, nj = width >> 7;
-        const int own_c0 = own_lo >> 3, own_c1 = own_hi >> 3;       // (-1 >> 3 == -1: nothing is skipped for a member without a slice)
-        const u16* rowp = src + (m0 + r) * ld;
-        const void* ptr[4];
-        bool take[4];
+        const int wid = tid >> 6, lane = tid & 63;
+        const int nsh = __builtin_ctz(need);                         // need = 1, 2, 4, 8
+        const int parts = 8 >> nsh, psh = 3 - nsh;                   // waves per member, log2
+        const int mslot = wid >> psh, part = wid & (parts - 1);
+        const int ws = width >> nsh;                                 // slice width of a publishing member (columns)
+        if (mslot != member || !published) {
+            if (lane == 0) {
+                int spins = 0;
+                while ((int)(__hip_atomic_load(flags + mslot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - co.epoch) < 0) {
+                    if (++spins > COOP_SPIN_LIMIT) { __hip_atomic_store(co.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            // this wave's band: rows [part * 32 / parts, +32 / parts) x the slice's ws / 8 chunks: (32 >> psh) * (ws >> 3) <= 256 chunks
+            const int cps = ws >> 3, csh = __builtin_ctz(cps);        // chunks per row of the slice (4, 8, 16, 32, 64)
+            const int rows = 32 >> psh, total = rows << csh;
+            const void* ptr[4];
+            int dst[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int c = c0 + 16 * j;
-            take[j] = j < nj && !(c >= own_c0 && c < own_c1);
-            ptr[j] = rowp + (take[j] ? c : c0) * 8;                  // (a skipped slot re-reads a valid address of the row)
+            for (int j = 0; j < 4; ++j) {
+                const int it = lane + 64 * j;
+                const bool ok = it < total;
+                const int itc = ok ? it : 0;
+                const int r = part * rows + (itc >> csh), c = (mslot << csh) + (itc & (cps - 1));
+                ptr[j] = src + (m0 + r) * ld + c * 8;
+                dst[j] = ok ? chain_lds_off(r, c * 8) : -1;
+            }
+            uint4 v[4];
+            coop_load4_sc1(ptr[0], ptr[1], ptr[2], ptr[3], v);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (dst[j] >= 0) *reinterpret_cast<uint4*>(X + dst[j]) = v[j];
         }
-        uint4 v[4];
-        coop_load4_sc1(ptr[0], ptr[1], ptr[2], ptr[3], v);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (take[j]) *reinterpret_cast<uint4*>(X + chain_lds_off(r, (c0 + 16 * j) * 8)) = v[j];
     }
     __syncthreads();
-    coop_stamp(co, slot, tid);                                       // [4] gathered
+    coop_stamp(co, slot, tid);                                       // [3] gathered
 }
 
 // This wave's weights of a stage: one 16-B load per lane and k16-step of its part of the contraction, up to QN = 64 / C

@@ -25,14 +25,14 @@ _lib.check(m.lib.cs_mlp_debug_stamps(m._h, buf.ctypes.data_as(C.c_void_p), words
 st = buf.reshape(256, 128).astype(np.int64)
 st = st[st[:, 0] > 0]
 print("workgroups", st.shape[0])
-names = ["k-loop(w0)", "k-loop(all)", "epi+publish", "wait", "gather"]
+names = ["k-loop(w0)", "k-loop(all)", "epi+publish", "wait+gather"]
 t0 = st[:, 0]
 pos = 1
 L = 7
 rows = []
 for i in range(2 * L - 1):
     last = i == 2 * L - 2
-    k = 2 if last else 5
+    k = 2 if last else 4
     seg = st[:, pos:pos + k]
     prev = st[:, pos - 1]
     d = np.diff(np.concatenate([prev[:, None], seg], axis=1), axis=1)
