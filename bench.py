@@ -282,6 +282,8 @@ def main():
     ap.add_argument("--rows", type=int, default=1 << 20, help="HBM-resident synthetic rows per GPU")
     ap.add_argument("--min-seconds", type=float, default=1.0, help="repeat the --steps block until this much step time is measured")
     ap.add_argument("--strong-global-batch", type=int, default=8192, help="N>1: global batch of the strong-scaling leg (BASELINE configs[3]); 0 = skip")
+    ap.add_argument("--grad-payload", choices=("fp32", "bf16"), default="fp32", help="N>1: what the gradient all-reduce sends (fp32 = the reference's DDP; "
+                    "bf16 = half the bytes, cs_dp_allreduce_bf16); both are timed and reported in `comm` either way")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU-baseline timing (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event pass")
     ap.add_argument("--no-extras", action="store_true", help="skip the CNN / loader side figures")
@@ -344,7 +346,7 @@ def main():
     perm = torch.randperm(args.rows, device=device, generator=gen)
 
     from climsim_amd.dp import DataParallel
-    dp = DataParallel(model, dist if multi else None)
+    dp = DataParallel(model, dist if multi else None, grad_payload=args.grad_payload)
     dp.broadcast_weights()
 
     def make_step(b):
@@ -376,24 +378,34 @@ def main():
     comm = None
     strong = None
     if multi:
-        evs = []
-        for i in range(20):
-            idx = perm[i * B:(i + 1) * B]
-            model.loss_grads(x, y, row_idx=idx, loss=loss)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            dp.all_reduce_grads()
-            e1.record()
-            model.apply_gradients(lr, 1.0 / (128.0 * B * world))
-            evs.append((e0, e1))
-        torch.cuda.synchronize()
-        ar = sorted(a.elapsed_time(b) * 1e3 for a, b in evs)
-        t = torch.tensor([ar[len(ar) // 2]], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        comm = {"collective": "ncclAllReduce(sum, float32) of the flat gradient, issued on the compute stream (cs_dp_allreduce)"
+        def collective_us(payload):
+            """median over 20 steps of the slowest rank's event pair around the collective (all ranks run the same sequence)"""
+            keep, dp.payload = dp.payload, payload
+            evs = []
+            for i in range(20):
+                idx = perm[i * B:(i + 1) * B]
+                model.loss_grads(x, y, row_idx=idx, loss=loss)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                dp.all_reduce_grads()
+                e1.record()
+                model.apply_gradients(lr, 1.0 / (128.0 * B * world))
+                evs.append((e0, e1))
+            torch.cuda.synchronize()
+            dp.payload = keep
+            ar = sorted(a.elapsed_time(b) * 1e3 for a, b in evs)
+            t = torch.tensor([ar[len(ar) // 2]], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return round(float(t.item()), 1)
+
+        n_grad = int(model.gradient_tensor().numel())
+        us = {pl: collective_us(pl) for pl in ("fp32", "bf16")}
+        comm = {"collective": ("ncclAllReduce(sum) of the flat gradient, issued on the compute stream (cs_dp_allreduce%s)" % ("_bf16" if dp.payload == "bf16" else ""))
                 if dp.native is not None else "torch.distributed.all_reduce", "nranks": dist.get_world_size(),
-                "bytes": int(model.gradient_tensor().numel()) * 4, "allreduce_us_per_step": round(float(t.item()), 1),
-                "note": "median over 20 steps of the slowest rank's event pair around the collective; includes the wait for the slowest rank's gradients"}
+                "payload": dp.payload, "bytes": n_grad * (2 if dp.payload == "bf16" else 4), "allreduce_us_per_step": us[dp.payload],
+                "allreduce_us_fp32_payload": us["fp32"], "allreduce_us_bf16_payload": us["bf16"],
+                "note": "median over 20 steps of the slowest rank's event pair around the collective; includes the wait for the slowest "
+                        "rank's gradients; the timed steps use `payload` (--grad-payload; bf16 adds a pack and an unpack kernel inside the pair)"}
         gb = args.strong_global_batch
         if gb and gb % world == 0 and gb // world >= 128:
             sb = gb // world

@@ -59,6 +59,7 @@ SIGNATURES = {
     "cs_dp_unique_id": (C.c_int, [C.c_char_p, _P]),
     "cs_dp_init": (C.c_int, [C.POINTER(_P), C.c_char_p, _P, C.c_int, C.c_int, C.c_int]),
     "cs_dp_allreduce": (C.c_int, [_P, _P, C.c_int64, _P]),
+    "cs_dp_allreduce_bf16": (C.c_int, [_P, _P, C.c_int64, _P]),
     "cs_dp_destroy": (None, [_P]),
     "cs_mlp_set_norm": (C.c_int, [_P, _P, _P]),
     "cs_mlp_set_head_options": (C.c_int, [_P, C.c_int, _P, C.c_int64]),

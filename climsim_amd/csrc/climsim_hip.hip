@@ -1422,7 +1422,28 @@ int rccl_fail(const char* what, int rc) {
 }
 }  // namespace
 
-struct cs_dp { void* comm = nullptr; int world = 1, rank = 0, device = 0; };
+struct cs_dp { void* comm = nullptr; int world = 1, rank = 0, device = 0; u16* half = nullptr; int64_t half_cap = 0; };
+
+// bf16 gradient payload (cs_dp_allreduce_bf16): 8 values per thread, round-to-nearest-even like every other bf16 store of the engine
+__global__ __launch_bounds__(256) void k_dp_pack_bf16(const float* __restrict__ src, u16* __restrict__ dst, int64_t n) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i + 8 <= n) {
+        const float4 a = *reinterpret_cast<const float4*>(src + i), b = *reinterpret_cast<const float4*>(src + i + 4);
+        *reinterpret_cast<uint4*>(dst + i) = make_uint4(cvt_pk_bf16(a.x, a.y), cvt_pk_bf16(a.z, a.w), cvt_pk_bf16(b.x, b.y), cvt_pk_bf16(b.z, b.w));
+    } else {
+        for (int64_t j = i; j < n; ++j) dst[j] = (u16)(cvt_pk_bf16(src[j], 0.f) & 0xffffu);
+    }
+}
+__global__ __launch_bounds__(256) void k_dp_unpack_bf16(const u16* __restrict__ src, float* __restrict__ dst, int64_t n) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i + 8 <= n) {
+        const uint4 v = *reinterpret_cast<const uint4*>(src + i);
+        *reinterpret_cast<float4*>(dst + i) = make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u));
+        *reinterpret_cast<float4*>(dst + i + 4) = make_float4(__uint_as_float(v.z << 16), __uint_as_float(v.z & 0xffff0000u), __uint_as_float(v.w << 16), __uint_as_float(v.w & 0xffff0000u));
+    } else {
+        for (int64_t j = i; j < n; ++j) dst[j] = __uint_as_float((unsigned)src[j] << 16);
+    }
+}
 
 extern "C" {
 
@@ -1457,8 +1478,28 @@ int cs_dp_allreduce(cs_dp_t* c, float* buf, int64_t n, void* stream) {
     return CS_OK;
 }
 
+int cs_dp_allreduce_bf16(cs_dp_t* c, float* buf, int64_t n, void* stream) {
+    if (!c || !c->comm || !buf || n <= 0) return fail(CS_ERR_INVALID, "bad argument");
+    if (((uintptr_t)buf & 15) != 0) return fail(CS_ERR_INVALID, "gradient buffer must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    if (c->half_cap < n) {
+        if (c->half) HIP_TRY(hipFree(c->half));
+        c->half = nullptr; c->half_cap = 0;
+        HIP_TRY(hipMalloc(&c->half, (size_t)((n + 7) & ~(int64_t)7) * sizeof(u16)));
+        c->half_cap = n;
+    }
+    const unsigned grid = (unsigned)((n + 2047) / 2048);
+    hipLaunchKernelGGL(k_dp_pack_bf16, dim3(grid), dim3(256), 0, st, buf, c->half, n);
+    if (int rc = g_rccl.AllReduce(c->half, c->half, (size_t)n, /*ncclBfloat16*/ 9, /*ncclSum*/ 0, c->comm, st))
+        return rccl_fail("ncclAllReduce", rc);
+    hipLaunchKernelGGL(k_dp_unpack_bf16, dim3(grid), dim3(256), 0, st, c->half, buf, n);
+    HIP_TRY(hipGetLastError());
+    return CS_OK;
+}
+
 void cs_dp_destroy(cs_dp_t* c) {
     if (!c) return;
+    if (c->half) (void)hipFree(c->half);
     if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
     delete c;
 }

@@ -302,6 +302,12 @@ typedef struct cs_dp cs_dp_t;
 int  cs_dp_unique_id(const char* rccl_path, void* id_out);
 int  cs_dp_init(cs_dp_t** comm, const char* rccl_path, const void* id, int world, int rank, int device);
 int  cs_dp_allreduce(cs_dp_t* comm, float* buf_dev, int64_t n_floats, void* stream);
+/* Same collective with HALF the bytes on the links: buf_dev is rounded to bf16 (nearest-even) into a buffer the
+ * communicator owns, summed over the ranks as ncclBfloat16, and widened back into buf_dev - three operations on `stream`,
+ * nothing else changes (the optimiser keeps its float32 moments and master weights).  An option, not the default: DDP in
+ * the reference reduces float32 (train_mlp_h5loader.py:195-207); the reduced sums carry bf16 rounding (2^-9 relative per
+ * hop), every rank still receives the SAME buffer.  buf_dev must be 16-byte aligned. */
+int  cs_dp_allreduce_bf16(cs_dp_t* comm, float* buf_dev, int64_t n_floats, void* stream);
 void cs_dp_destroy(cs_dp_t* comm);
 
 const char* cs_last_error(void);

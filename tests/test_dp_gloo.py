@@ -58,13 +58,18 @@ class OracleEngine:
         self.ws = self.opt.apply(self.ws, gs, lr)
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, payload="fp32"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     x, y = O.synth_columns(N_ROWS, seed=3)
     ws = O.glorot_init(CFG, seed=rank)          # ranks start DIFFERENT: broadcast must fix it
     eng = OracleEngine(ws)
-    dp = DataParallel(eng, dist)
+    dp = DataParallel(eng, dist, grad_payload=payload)
+    if payload == "bf16":                       # the collective alone: bf16(bf16(a) + bf16(b)), the same on both ranks
+        v = torch.Generator().manual_seed(100 + rank)
+        eng.grad.copy_(torch.randn(eng.grad.numel(), generator=v) * 3.0)
+        dp.all_reduce_grads()
+        np.save(os.path.join(out_dir, f"sum{rank}.npy"), eng.grad.numpy())
     dp.broadcast_weights()
     g = torch.Generator().manual_seed(7)
     perm = torch.randperm(N_ROWS, generator=g)
@@ -101,3 +106,30 @@ def test_two_rank_gloo_matches_single_process(tmp_path):
         a, b = w0[f"arr_{i}"], w1[f"arr_{i}"]
         np.testing.assert_array_equal(a, b)                       # ranks stay bit-identical
         np.testing.assert_allclose(a, ref, rtol=2e-4, atol=2e-6)  # == training on the global batch
+
+
+def test_two_rank_gloo_bf16_gradient_payload(tmp_path):
+    """DataParallel(grad_payload="bf16") - what cs_dp_allreduce_bf16 does on the GPU, here through torch.distributed: the
+    sums cross as bf16, both ranks receive the same buffer, training stays within bf16 gradient rounding of the fp32 run."""
+    port = 29500 + (os.getpid() + 37) % 1000
+    mp.spawn(_worker, args=(2, port, str(tmp_path), "bf16"), nprocs=2, join=True)
+    s0, s1 = np.load(tmp_path / "sum0.npy"), np.load(tmp_path / "sum1.npy")
+    np.testing.assert_array_equal(s0, s1)
+    n = s0.size
+    parts = [(torch.randn(n, generator=torch.Generator().manual_seed(100 + r)) * 3.0).to(torch.bfloat16) for r in range(2)]
+    want = (parts[0].float() + parts[1].float()).to(torch.bfloat16).float().numpy()
+    np.testing.assert_array_equal(s0, want)
+    w0 = np.load(tmp_path / "rank0.npz")
+    w1 = np.load(tmp_path / "rank1.npz")
+    x, y = O.synth_columns(N_ROWS, seed=3)
+    ws = O.glorot_init(CFG, seed=0)
+    opt = O.Optimizer("Adam")
+    perm = torch.randperm(N_ROWS, generator=torch.Generator().manual_seed(7)).numpy()
+    for s in range(STEPS):
+        idx = perm[s * GLOBAL_BATCH:(s + 1) * GLOBAL_BATCH]
+        ws, _, _ = O.train_step(ws, opt, x[idx], y[idx], CFG, 1e-3)
+    for i, ref in enumerate(ws):
+        a, b = w0[f"arr_{i}"], w1[f"arr_{i}"]
+        np.testing.assert_array_equal(a, b)                       # replicas stay bit-identical to each other
+        # Adam normalises the step: a 2^-8 relative change of a gradient moves a weight by a small fraction of lr per step
+        np.testing.assert_allclose(a, ref, rtol=0, atol=STEPS * 1e-3 * 0.05)

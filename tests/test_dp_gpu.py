@@ -83,6 +83,38 @@ def test_native_rccl_communicator_through_the_c_abi(pg):
     dp.all_reduce_grads()
     torch.cuda.synchronize()
     assert torch.equal(m.gradient_tensor(), g0)
+    dp.close()
+
+
+def test_bf16_gradient_payload_through_the_c_abi(pg):
+    """cs_dp_allreduce_bf16: the buffer crosses the links as bf16 (round-to-nearest-even) and comes back widened; with one
+    rank the result is exactly the bf16 rounding of the input, for every tail length of the 8-wide pack kernels."""
+    from climsim_amd.dp import DataParallel, RcclComm
+    from climsim_amd.mlp import MLPEmulator
+    comm = RcclComm(pg, torch.device("cuda", 0))
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for n in (1, 7, 8, 2048, 2049, 1_194_880 + 3):
+        t = torch.randn(n + 4, device="cuda", generator=g)[:n] * 37.0          # 16-byte aligned start, ragged end
+        t[::5] = 0.0
+        want = t.to(torch.bfloat16).to(torch.float32)
+        guard = t.clone()
+        comm.all_reduce(t, "bf16")
+        torch.cuda.synchronize()
+        assert torch.equal(t, want), n
+        assert not torch.equal(want, guard) or n == 1
+    comm.close()
+    m = MLPEmulator(units=(128,), max_batch=128, seed=1)
+    dp = DataParallel(m, pg, grad_payload="bf16")
+    assert dp.native is not None and dp.payload == "bf16"
+    x, y = O.synth_columns(128, seed=2)
+    m.loss_grads(torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda())
+    g0 = m.gradient_tensor().clone()
+    dp.all_reduce_grads()
+    torch.cuda.synchronize()
+    assert torch.equal(m.gradient_tensor(), g0.to(torch.bfloat16).to(torch.float32))
+    dp.close()
+    with pytest.raises(ValueError):
+        DataParallel(m, pg, grad_payload="fp8")
 
 
 def test_streamed_trainer_with_a_process_group(pg, tmp_path):

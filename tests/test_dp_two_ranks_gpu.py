@@ -25,8 +25,9 @@ def _data():
     return O.synth_columns(ROWS, seed=4)
 
 
-def _fit_worker(rank, world, port, out_dir):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), CS_DP_NATIVE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+def _fit_worker(rank, world, port, out_dir, payload="fp32"):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), CS_DP_NATIVE="0", HSA_ENABLE_IPC_MODE_LEGACY="0",
+                      CS_DP_PAYLOAD=payload)
     import torch.distributed as dist
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -72,10 +73,10 @@ def _stream_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def _spawn(fn, tmp_path):
+def _spawn(fn, tmp_path, *extra):
     import torch.multiprocessing as mp
-    port = 29600 + os.getpid() % 300
-    mp.spawn(fn, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    port = 29600 + (os.getpid() + 17 * len(extra)) % 300
+    mp.spawn(fn, args=(2, port, str(tmp_path), *extra), nprocs=2, join=True)
 
 
 def test_two_ranks_on_one_gpu_equal_single_rank_training(tmp_path):
@@ -96,6 +97,28 @@ def test_two_ranks_on_one_gpu_equal_single_rank_training(tmp_path):
         np.testing.assert_allclose(a, r, rtol=0, atol=2e-4 * max(1.0, float(np.abs(r).max())))   # float atomics order only
     np.testing.assert_allclose(w0["loss"], h["loss"], rtol=1e-3)
     np.testing.assert_allclose(w1["loss"], h["loss"], rtol=1e-3)
+
+
+def test_two_ranks_bf16_gradient_payload(tmp_path):
+    """CS_DP_PAYLOAD=bf16 (DataParallel(grad_payload="bf16")): the gradient sums cross as bf16; the replicas still end
+    bit-identical to each other and within bf16 gradient rounding of single-rank fp32 training (Adam normalises the step)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    _spawn(_fit_worker, tmp_path, "bf16")
+    w0, w1 = np.load(tmp_path / "fit0.npz"), np.load(tmp_path / "fit1.npz")
+    from climsim_amd.mlp import MLPEmulator
+    x, y = _data()
+    m = MLPEmulator(units=UNITS, max_batch=GLOBAL_BATCH, seed=7)
+    h = m.fit(x, y, batch_size=GLOBAL_BATCH, epochs=EPOCHS, learning_rate=1e-3, seed=3)
+    steps = EPOCHS * (ROWS // GLOBAL_BATCH)
+    moved = 0.0
+    for i, r in enumerate(m.get_weights()):
+        a, b = w0[f"arr_{i}"], w1[f"arr_{i}"]
+        np.testing.assert_array_equal(a, b)
+        np.testing.assert_allclose(a, r, rtol=0, atol=steps * 1e-3 * 0.05)
+        moved = max(moved, float(np.abs(a - r).max()))
+    assert moved > 0.0                                                        # the payload really was rounded
+    np.testing.assert_allclose(w0["loss"], h["loss"], rtol=5e-3)
 
 
 def test_two_ranks_streaming_unequal_chunks_stay_in_step(tmp_path):
