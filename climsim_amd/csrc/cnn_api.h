@@ -26,7 +26,7 @@ struct cs_cnn {
     int conv_ablate = 0;                 // CS_CONV_ABLATE (development)
     int cpw = 0;                         // contraction pad of the trunk channels (32- or 64-granular)
     float *P = nullptr, *M = nullptr, *V = nullptr, *G = nullptr, *G_own = nullptr;
-    CnnSeg* seg_dev = nullptr; int n_seg = 0, opt_blocks = 0;
+    CnnSeg* seg_dev = nullptr; int n_seg = 0, opt_blocks = 0, opt_blocks2 = 0, opt_pitch = 40; bool opt_tiles = false;
     ConvWgradItem* items_dev = nullptr; int n_items = 0, total_tiles = 0;
     CwTile* cw_tiles_dev = nullptr; int n_cw_tiles = 0, n_cu = 256;      // conv_wgrad2.h
     int* cw_prefix_dev = nullptr; int n_cw_convs = 0, cw_splits = 0;
@@ -113,7 +113,8 @@ int cnn_launch_optimizer(cs_cnn* h, float lr, float grad_scale, bool recast_only
     a.omb1 = (float)(1.0 - h->cfg.beta1); a.omb2 = (float)(1.0 - h->cfg.beta2);
     a.alpha = lr * sqrtf(1.f - powf(b2, t)) / (1.f - powf(b1, t));
     a.eps = (float)h->cfg.eps;
-    hipLaunchKernelGGL(k_cnn_optimizer, dim3((unsigned)h->opt_blocks), dim3(256), 0, st, a);
+    if (h->opt_tiles) hipLaunchKernelGGL(k_cnn_optimizer, dim3((unsigned)h->opt_blocks), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_cnn_optimizer2, dim3((unsigned)h->opt_blocks2), dim3(256), (size_t)32 * h->opt_pitch * 2, st, a, h->opt_pitch);
     HIP_TRY(hipGetLastError());
     return CS_OK;
 }
@@ -359,6 +360,15 @@ int cs_cnn_create(cs_cnn_t** out, const cs_cnn_cfg* cfg) {
     for (auto& sg : segs) {
         sg.blk_begin = h->opt_blocks;
         h->opt_blocks += sg.kind == 0 ? sg.taps * ((sg.cin + 31) / 32) * ((sg.cout + 31) / 32) : (int)((sg.size + 255) / 256);
+        sg.blk_begin2 = h->opt_blocks2;
+        h->opt_blocks2 += sg.kind == 0 ? sg.taps * ((sg.cin + 31) / 32) : (int)((sg.size + 255) / 256);
+        if (sg.kind == 0) h->opt_pitch = std::max(h->opt_pitch, (int)round_up(sg.cout, 32) + 8);
+    }
+    if (const char* e = getenv("CS_CNN_OPT_TILES")) h->opt_tiles = atoi(e) != 0;
+    if (!h->opt_tiles && hipFuncSetAttribute(reinterpret_cast<const void*>(k_cnn_optimizer2), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             32 * h->opt_pitch * 2) != hipSuccess) {
+        cs_cnn_destroy(h);
+        return fail(CS_ERR_HIP, "optimiser LDS setup failed");
     }
     if (hipMemcpy(h->seg_dev, segs.data(), segs.size() * sizeof(CnnSeg), hipMemcpyHostToDevice) != hipSuccess) {
         cs_cnn_destroy(h);

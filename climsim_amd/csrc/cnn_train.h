@@ -253,6 +253,7 @@ struct CnnSeg {
     u16* Wd; int ldd, kpd, slot0, flip;
     float* dst; int dst_off, ncols;     // kind 1: dst[i]; kind 2: dst[c*10 + dst_off + j]; kind 3: dst[dst_off + j]
     int blk_begin;            // first workgroup of this tensor: 32(c_in) x 32(c_out) tiles per tap, or 256-element slices
+    int blk_begin2;           // the same for k_cnn_optimizer2: 32(c_in) x c_out strips per tap
 };
 struct CnnOptArgs {
     float *P, *M, *V, *G;
@@ -299,6 +300,117 @@ __device__ __forceinline__ float cnn_opt_update(const CnnOptArgs& a, int64_t i) 
     a.P[i] = w;
     a.G[i] = 0.f;
     return w;
+}
+
+// four consecutive parameters at a 16-byte aligned offset
+__device__ __forceinline__ void cnn_opt_update4(const CnnOptArgs& a, int64_t i, float (&o)[4]) {
+    float4 w = *reinterpret_cast<const float4*>(a.P + i);
+    if (!a.recast_only) {
+        float4 g = *reinterpret_cast<const float4*>(a.G + i);
+        g.x *= a.grad_scale; g.y *= a.grad_scale; g.z *= a.grad_scale; g.w *= a.grad_scale;
+        if (a.kind == 3) {
+            w.x -= a.lr * g.x; w.y -= a.lr * g.y; w.z -= a.lr * g.z; w.w -= a.lr * g.w;
+        } else {
+            float4 m = *reinterpret_cast<const float4*>(a.M + i), v = *reinterpret_cast<const float4*>(a.V + i);
+            m.x += (g.x - m.x) * a.omb1; m.y += (g.y - m.y) * a.omb1; m.z += (g.z - m.z) * a.omb1; m.w += (g.w - m.w) * a.omb1;
+            v.x += (g.x * g.x - v.x) * a.omb2; v.y += (g.y * g.y - v.y) * a.omb2;
+            v.z += (g.z * g.z - v.z) * a.omb2; v.w += (g.w * g.w - v.w) * a.omb2;
+            w.x -= (m.x * a.alpha) / (sqrtf(v.x) + a.eps); w.y -= (m.y * a.alpha) / (sqrtf(v.y) + a.eps);
+            w.z -= (m.z * a.alpha) / (sqrtf(v.z) + a.eps); w.w -= (m.w * a.alpha) / (sqrtf(v.w) + a.eps);
+            *reinterpret_cast<float4*>(a.M + i) = m; *reinterpret_cast<float4*>(a.V + i) = v;
+        }
+        *reinterpret_cast<float4*>(a.P + i) = w;
+        *reinterpret_cast<float4*>(a.G + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    o[0] = w.x; o[1] = w.y; o[2] = w.z; o[3] = w.w;
+}
+
+// Strip form of the optimiser (the one that runs; the 32 x 32-tile kernel below stays behind CS_CNN_OPT_TILES=1 as the second
+// implementation the parity test compares with).  One workgroup = one tap x 32 c_in rows x ALL c_out of a conv kernel: in the
+// Keras layout [tap][c_in][c_out] that is ONE contiguous run of 32 * c_out floats, so gradient, moments and weights stream
+// through in whole 16-byte pieces at consecutive addresses (the tiled kernel touched every 128-byte line from two or more
+// workgroups on different XCDs: PMC 323 MB fetched + 464 MB written per launch for 424 MB of algorithmic traffic, 0.224 ms).
+// The updated strip is kept as bf16 in LDS and leaves twice: rows of the data-gradient pack [c_in][slot*kpd + c_out] (whole
+// 832-byte rows), and 64-byte pieces of the forward pack [c_out][tap*kpf + c_in]; the workgroup -> strip map gives every XCD a
+// contiguous run of strips so that the two halves of a forward-pack line meet in one L2.
+__global__ __launch_bounds__(256) void k_cnn_optimizer2(const CnnOptArgs a, int pitch) {
+    extern __shared__ __attribute__((aligned(16))) u16 strip[];            // [32][pitch], pitch = round_up(c_out, 32) + 8
+    const int tid = threadIdx.x;
+    const int work = xcd_work_id(blockIdx.x, gridDim.x);
+    int lo = 0, hi = a.n_seg - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (a.seg[mid].blk_begin2 <= work) lo = mid; else hi = mid - 1;
+    }
+    const CnnSeg s = a.seg[lo];
+    const int rel = work - s.blk_begin2;
+    if (s.kind != 0) {
+        const int64_t r = (int64_t)rel * 256 + tid;
+        if (r >= s.size) return;
+        const float w = cnn_opt_update(a, s.off + r);
+        if (s.kind == 1) s.dst[r] = w;
+        else if (s.kind == 2) { const int c = (int)(r / s.ncols), j = (int)(r - (int64_t)c * s.ncols); s.dst[c * 10 + s.dst_off + j] = w; }
+        else s.dst[s.dst_off + r] = w;
+        return;
+    }
+    const int tiles_i = (s.cin + 31) >> 5;
+    const int t = rel / tiles_i, it = rel - t * tiles_i;
+    const int rows = min(32, s.cin - 32 * it);
+    for (int i = tid; i < 32 * pitch / 8; i += 256) reinterpret_cast<uint4*>(strip)[i] = make_uint4(0u, 0u, 0u, 0u);   // pad rows / columns stay zero
+    __syncthreads();
+    const int64_t base = s.off + ((int64_t)t * s.cin + 32 * it) * s.cout;
+    const int n_el = rows * s.cout;
+    const int peel = min(n_el, (int)((4 - (base & 3)) & 3));
+    const int groups = (n_el - peel) >> 2;
+    const int tail0 = peel + 4 * groups;
+    auto put = [&](int e, float w) { const int r = e / s.cout; strip[r * pitch + (e - r * s.cout)] = (u16)(cvt_pk_bf16(w, 0.f) & 0xffffu); };
+    if (tid < peel) put(tid, cnn_opt_update(a, base + tid));
+    if (tid >= 64 && tid < 64 + n_el - tail0) put(tail0 + tid - 64, cnn_opt_update(a, base + tail0 + tid - 64));
+    for (int g = tid; g < groups; g += 256) {
+        const int e = peel + 4 * g;
+        float w[4];
+        cnn_opt_update4(a, base + e, w);
+        int r = e / s.cout, c = e - r * s.cout;
+        const unsigned p01 = cvt_pk_bf16(w[0], w[1]), p23 = cvt_pk_bf16(w[2], w[3]);
+        const u16 h[4] = {(u16)(p01 & 0xffffu), (u16)(p01 >> 16), (u16)(p23 & 0xffffu), (u16)(p23 >> 16)};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            strip[r * pitch + c] = h[q];
+            if (++c == s.cout) { c = 0; ++r; }
+        }
+    }
+    __syncthreads();
+    if (s.Wd) {                                                            // data-gradient pack: rows of kpd bf16 along c_out
+        u16* d0 = s.Wd + (int64_t)(32 * it) * s.ldd + (s.slot0 + (s.flip ? s.taps - 1 - t : t)) * s.kpd;
+        if (((s.ldd | s.kpd) & 7) == 0) {
+            const int ppr = s.kpd >> 3;
+            for (int i = tid; i < rows * ppr; i += 256) {
+                const int r = i / ppr, pc = i - r * ppr;
+                *reinterpret_cast<uint4*>(d0 + (int64_t)r * s.ldd + 8 * pc) = *reinterpret_cast<const uint4*>(strip + r * pitch + 8 * pc);
+            }
+        } else {
+            for (int i = tid; i < rows * s.kpd; i += 256) {
+                const int r = i / s.kpd, c = i - r * s.kpd;
+                d0[(int64_t)r * s.ldd + c] = strip[r * pitch + c];
+            }
+        }
+    }
+    {                                                                      // forward pack: 8 c_in per 16-byte piece, 4 pieces per c_out row
+        u16* f0 = s.Wf + t * s.kpf + 32 * it;
+        const bool wide = ((s.ldf | s.kpf) & 7) == 0;
+        for (int i = tid; i < s.cout * 4; i += 256) {
+            const int co = i >> 2, q = i & 3;
+            if (32 * it + 8 * q >= s.kpf) continue;
+            u16 v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = strip[(8 * q + e) * pitch + co];
+            u16* d = f0 + (int64_t)co * s.ldf + 8 * q;
+            if (wide && 32 * it + 8 * q + 7 < s.kpf)
+                *reinterpret_cast<uint4*>(d) = make_uint4((unsigned)v[0] | ((unsigned)v[1] << 16), (unsigned)v[2] | ((unsigned)v[3] << 16),
+                                                          (unsigned)v[4] | ((unsigned)v[5] << 16), (unsigned)v[6] | ((unsigned)v[7] << 16));
+            else { for (int e = 0; e < 8; ++e) if (32 * it + 8 * q + e < s.kpf) d[e] = v[e]; }
+        }
+    }
 }
 
 // Conv kernels: one workgroup = one 32(c_in) x 32(c_out) tile of one tap; the updated tile goes through LDS so that both

@@ -248,6 +248,37 @@ def test_cnn_kernel_families_agree(CNN):
         assert c >= 0.999 and abs(ratio - 1) <= 1e-2, (i, c, ratio)
 
 
+@pytest.mark.parametrize("depth,width", [(2, 406), (2, 64), (1, 200)])
+def test_cnn_optimizer_forms_agree(CNN, depth, width, monkeypatch):
+    """k_cnn_optimizer2 (strips of one tap x 32 c_in x all c_out: the form that runs) against k_cnn_optimizer (32 x 32 tiles,
+    CS_CNN_OPT_TILES=1): the same per-element arithmetic, so weights, Adam slots (through a second step) and both bf16 operand
+    packs (through predictions and the next step's gradients) must come out bit-identical, pad rows and columns included."""
+    n = 8
+    ws = CO.glorot_cnn(seed=9, bias_scale=0.05, depth=depth, channels=width)
+    x3, y3 = make_xy(n, 12)
+    res = []
+    for tiles in ("1", "0"):
+        monkeypatch.setenv("CS_CNN_OPT_TILES", tiles)
+        m = CNN.CNNEmulator(depth=depth, channel_width=width, max_batch=16, trainable=True, loss="mse", dropout=0.0, seed=3)
+        m.set_weights(ws)
+        p0 = m.predict(x3)                                    # packs written by the recast-only pass
+        g = m.gradient_tensor()
+        gen = torch.Generator(device="cuda").manual_seed(17)
+        for step in range(3):                                 # deterministic gradients: the weight-gradient atomics are not
+            g.copy_(torch.randn(g.numel(), device="cuda", generator=gen) * (0.5 + step))
+            m.apply_gradients(2e-3, 0.37)
+            assert float(g.abs().max()) == 0.0                # the optimiser hands the buffer back zeroed
+        p1 = m.predict(x3)                                    # forward pack after three updates
+        m.loss_grads(x3, y3)                                  # the data-gradient pack feeds every conv's weight gradient
+        res.append((p0, p1, m.get_weights(), m.get_gradients(1.0)))
+    np.testing.assert_array_equal(res[0][0], res[1][0])
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+    for a, b in zip(res[0][2], res[1][2]):
+        np.testing.assert_array_equal(a, b)
+    for a, b in zip(res[0][3], res[1][3]):                   # float atomics order differs run to run: not bitwise
+        np.testing.assert_allclose(a, b, rtol=0, atol=1e-4 * max(1e-6, float(np.abs(b).max())))
+
+
 def test_cnn_full_size_training_is_stable(CNN):
     """Published shape (depth 12, width 406, batch 512, dropout 0.175, mae_adjusted, Adam, the reference's cyclical
     schedule): 40 steps from Keras' default initialisation stay finite and reduce the loss; evaluation (dropout off) of
