@@ -557,15 +557,20 @@ int run_backward(cs_mlp* h, int64_t n, bool atomics_needed, hipStream_t st) {
         int tiles = 0;
         for (int l = 0; l < h->L; ++l)
             tiles += ((h->layers[l].Kp + tdim - 1) / tdim) * ((h->layers[l].N + tdim - 1) / tdim);
-        const int target = big ? 256 : 365;               // workgroups: ~1 per CU (128 KiB LDS) or ~1.4 (atomics grow with splits)
-        int splitk = h->wgrad_splitk > 0 ? h->wgrad_splitk : (target + tiles / 2) / tiles;
-        // small batches: every split re-fills the LDS-DMA ring and adds a round of atomics for a handful of slabs -
-        // measured (cfg-MLP, k_wgrad3): 1024 columns 26.6 us with 5 splits, 18.2 with 2; 3072: 31.9 / 27.3 with 3;
-        // 4096: 34.3 / 30.3 with 3; 8192: 44.9 with 5 (best)
-        // ... 12288: 59.5 with 5 (7: 59.8, 4: 71.7); 16384: 71.8 with 7 (5: 76.9, 10: 84.1) - two workgroups per CU there
-        if (h->wgrad_splitk <= 0 && !big) {
+        // Row splits.  256 x 256 tiles: ~one workgroup per CU (128 KiB LDS).  128 x 128 tiles (k_wgrad3, two workgroups fit a
+        // CU): ONE round of at most n_cu workgroups up to ~11k columns, one round of two per CU above - measured with the
+        // loader-wave kernel (cfg-MLP, 73 tiles, us): 6144 columns 2/3/4/5 splits 39.6/33.7/45.5/37.7; 8192: 49.2/40.4/54.3/44.2
+        // (6: 42.3); 10240: 3/5/6 46.0/50.4/47.0; 12288: 3/5/6/7 53.3/56.9/52.7/56.6; 16384: 3/5/6/7 72.3/75.9/67.2/69.1.
+        // A split count that leaves some CUs with one workgroup more than others (4 x 73 = 292) costs more than it spreads.
+        // Small batches: every split re-fills the ring and adds a round of atomics for a handful of slabs (1024 columns:
+        // 26.6 us with 5 splits, 18.2 with 2).
+        const int ncu = h->n_cu > 0 ? h->n_cu : 256;
+        int splitk;
+        if (h->wgrad_splitk > 0) splitk = h->wgrad_splitk;
+        else if (big) splitk = (256 + tiles / 2) / tiles;
+        else {
+            splitk = n < 11264 ? ncu / tiles : (7 * ncu / 4) / tiles;
             if (n < 2048) splitk = std::min(splitk, 2); else if (n < 6144) splitk = std::min(splitk, 3);
-            else if (n >= 14336) splitk = std::max(splitk, (2 * 256) / tiles);      // (not more than two rounds: 8 splits = 584 workgroups: 89.7 us)
         }
         if (splitk < 1) splitk = 1;
         if (splitk > msteps) splitk = msteps;
@@ -582,7 +587,7 @@ int run_backward(cs_mlp* h, int64_t n, bool atomics_needed, hipStream_t st) {
         }
         ProfScope ps(CS_K_WGRAD, st);
         if (big) CS_LAUNCH(k_wgrad2, dim3((unsigned)wg), dim3(512), WG2_LDS_BYTES, st, w);
-        else if (dma_small) CS_LAUNCH(k_wgrad3, dim3((unsigned)wg), dim3(256), WG3_LDS_BYTES, st, w);
+        else if (dma_small) CS_LAUNCH(k_wgrad3<4>, dim3((unsigned)wg), dim3(WG3_THREADS), WG3_LDS_BYTES, st, w);
         else if (tr) CS_LAUNCH(k_wgrad<true>, dim3((unsigned)wg), dim3(256), 0, st, w);
         else CS_LAUNCH(k_wgrad<false>, dim3((unsigned)wg), dim3(256), 0, st, w);
     }
@@ -674,7 +679,7 @@ int cs_mlp_create(cs_mlp_t** out, const cs_mlp_cfg* cfg) {
     if (const char* e = getenv("CS_CHAIN_ABLATE")) h->chain_ablate = atoi(e);
     if (const char* e = getenv("CS_WGRAD2")) h->wgrad2_mode = atoi(e);
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad2), hipFuncAttributeMaxDynamicSharedMemorySize, WG2_LDS_BYTES));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad3), hipFuncAttributeMaxDynamicSharedMemorySize, WG3_LDS_BYTES));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad3<4>), hipFuncAttributeMaxDynamicSharedMemorySize, WG3_LDS_BYTES));
     if (const char* e = getenv("CS_WGRAD3")) h->wgrad3 = atoi(e) != 0;
     if (cfg->flags & CS_FLAG_COOP) h->coop_mode = -1;
     if (const char* e = getenv("CS_COOP")) { const int v = atoi(e); h->coop_mode = v == 1 ? -1 : v; }
@@ -1333,7 +1338,7 @@ int cs_mlp_group_train_step(cs_mlp_group_t* g, const float* const* x_dev, const 
     }
     {
         ProfScope ps(CS_K_WGRAD, st);
-        CS_LAUNCH(k_wgrad3_group, dim3((unsigned)wt.begin[na]), dim3(256), WG3_LDS_BYTES, st, g->wg_dev, wt);
+        CS_LAUNCH(k_wgrad3_group, dim3((unsigned)wt.begin[na]), dim3(WG3_THREADS), WG3_LDS_BYTES, st, g->wg_dev, wt);
     }
     HIP_TRY(hipGetLastError());
     // ---- launch 3: optimisers (each member with its own rule, step count and learning rate)

@@ -162,7 +162,9 @@ __global__ __launch_bounds__(512) void k_wgrad2(const WgradArgs pa) {
 // (The register-staged k_wgrad has one stage in flight and spends ~10x the MFMA time waiting on loads;
 // 256x256 tiles would need 4x the split partial sums, i.e. 4x the atomics, at this size.)
 #define WG3_STAGE_ELEMS (2 * WG2_ROWS * 128)
-#define WG3_LDS_BYTES (WG2_STAGES * WG3_STAGE_ELEMS * 2)
+#define WG3_LDS_BYTES (4 * WG3_STAGE_ELEMS * 2)
+#define WG3_COMPUTE_WAVES 4
+#define WG3_THREADS 384                   // 4 compute waves + 2 loader waves
 
 __device__ __forceinline__ bf16x8_t frag_w3(const u16* tile, int mb, int cb, int lane) {
     union { bf16x8_t v; s16x4_t h[2]; } u;
@@ -174,10 +176,13 @@ __device__ __forceinline__ bf16x8_t frag_w3(const u16* tile, int mb, int cb, int
     return u.v;
 }
 
+// SLOTS: ring slots of 16 KiB.  4 = 64 KiB, two workgroups per CU, is what is built (8 slots, one workgroup per CU with seven
+// stages requested ahead, measured 40.0 against 38.1 us at 8192 columns and 1-2 us slower at 1024-4096).
+template <int SLOTS>
 __device__ __forceinline__ void wgrad3_body(const WgradArgs& pa, const int work, u16* ring) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wk = wid >> 1, wn = wid & 1;
+    const int wk = (wid >> 1) & 1, wn = wid & 1;
     int li = 0;
     while (li + 1 < pa.n_layers && work >= pa.L[li + 1].wg_begin) ++li;
     const WgradLayer& p = pa.L[li];
@@ -190,20 +195,44 @@ __device__ __forceinline__ void wgrad3_body(const WgradArgs& pa, const int work,
     const int s_end = (int)((int64_t)steps * (split + 1) / pa.splitk);
     const int nst = (pa.ablate & 2) ? 0 : s_end - s_begin;
 
-    // a 1-KiB DMA piece = 4 rows of 256 B; lane i -> row i>>4, physical chunk i&15, which holds logical
-    // chunk (((p>>2) ^ (m&3)) << 2) | (p&3)  (swz_tn).  Pieces 2*wid, 2*wid+1 of each operand per wave.
-    const int prow = lane >> 4, pch = lane & 15;
-    const u16* hsrc[2]; const u16* zsrc[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int ml = 4 * (2 * wid + j) + prow;
-        const int c = ((((pch >> 2) ^ (ml & 3)) << 2) | (pch & 3)) * 8;
-        hsrc[j] = p.H + (int64_t)ml * p.ldh + k0 + c;
-        zsrc[j] = p.Z + (int64_t)ml * p.ldz + n0 + c;
-    }
+    // Waves 0..3 compute (64 x 64 each), waves 4, 5 do nothing but request operand slabs: a 1-KiB LDS-DMA piece costs the wave
+    // that issues it 100-185 clocks when it sits between ds_reads and MFMAs (MI355X_MICROARCH.md, "LDS-DMA piece issue cost")
+    // and ~20 in a wave that does nothing else (contraction at 8192 columns 39.9 -> 32.3 us).  (Reading the fragments of
+    // stage s + 1 under the MFMAs of stage s - barriers one stage earlier, 64 more VGPRs - measured slower: 35.1 / 42.8 us.)
+    // A piece = 4 rows of 256 B; lane i -> row i>>4, physical chunk i&15, which holds logical chunk
+    // (((p>>2) ^ (m&3)) << 2) | (p&3)  (swz_tn).  Loader lw requests pieces 4*lw .. 4*lw+3 of both operands.
     typedef u16 __attribute__((address_space(3))) * lds_p;
     const unsigned lds0 = (unsigned)(uintptr_t)((lds_p)ring);
-    const unsigned my_piece = __builtin_amdgcn_readfirstlane((unsigned)(2 * wid) * 1024u);
+    if (wid >= WG3_COMPUTE_WAVES) {
+        if (nst <= 0) return;
+        const int lw = wid - WG3_COMPUTE_WAVES;
+        const int prow = lane >> 4, pch = lane & 15;
+        const int c = ((((pch >> 2) ^ (prow & 3)) << 2) | (pch & 3)) * 8;
+        const u16* hb = p.H + (int64_t)(16 * lw + prow) * p.ldh + k0 + c;
+        const u16* zb = p.Z + (int64_t)(16 * lw + prow) * p.ldz + n0 + c;
+        const unsigned mine = (unsigned)__builtin_amdgcn_readfirstlane(4 * lw) * 1024u;
+#define WG3_ISSUE(st)                                                                                  \
+    {                                                                                                   \
+        const int sc_ = min((st), nst - 1);                                                             \
+        const int64_t roff = (int64_t)(s_begin + sc_) * WG2_ROWS;                                       \
+        const unsigned base = lds0 + (unsigned)((st) & (SLOTS - 1)) * (WG3_STAGE_ELEMS * 2) + mine;     \
+        if (!(pa.ablate & 8)) _Pragma("unroll") for (int j = 0; j < 4; ++j) {                           \
+            dma16(hb + (roff + 4 * j) * p.ldh, base + (unsigned)j * 1024u);                             \
+            dma16(zb + (roff + 4 * j) * p.ldz, base + WG2_ROWS * 256u + (unsigned)j * 1024u);           \
+        }                                                                                               \
+    }
+#pragma unroll
+        for (int st = 0; st < SLOTS - 1; ++st) WG3_ISSUE(st)
+        for (int t = 0; t < nst; ++t) {
+            // stage t has landed: SLOTS - 2 younger stages (8 pieces each from this wave) may still be in flight
+            asm volatile("s_waitcnt vmcnt(%0)" ::"i"(8 * (SLOTS - 2)) : "memory");
+            __builtin_amdgcn_s_barrier();                             // ... and the compute waves are done with stage t - 1
+            WG3_ISSUE(t + SLOTS - 1)                                  // into its slot
+        }
+#undef WG3_ISSUE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
 
     f32x16_t acc[2][2];
 #pragma unroll
@@ -215,51 +244,33 @@ __device__ __forceinline__ void wgrad3_body(const WgradArgs& pa, const int work,
     float bsum[2] = {0.f, 0.f};
     const bool do_bias = (k0 == 0) && (wk == 0);
 
-    if (nst > 0) {
-#define WG3_ISSUE(st)                                                                                  \
-    {                                                                                                   \
-        const int sc_ = min((st), nst - 1);                                                             \
-        const int64_t roff = (int64_t)(s_begin + sc_) * WG2_ROWS;                                       \
-        const unsigned base = lds0 + (unsigned)((st) & (WG2_STAGES - 1)) * (WG3_STAGE_ELEMS * 2) + my_piece; \
-        dma16(hsrc[0] + roff * p.ldh, base);                                                            \
-        dma16(hsrc[1] + roff * p.ldh, base + 1024u);                                                    \
-        dma16(zsrc[0] + roff * p.ldz, base + WG2_ROWS * 256u);                                          \
-        dma16(zsrc[1] + roff * p.ldz, base + WG2_ROWS * 256u + 1024u);                                  \
-    }
-        WG3_ISSUE(0)
-        WG3_ISSUE(1)
-        WG3_ISSUE(2)
-        for (int s = 0; s < nst; ++s) {
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            WG3_ISSUE(s + 3)
-            const u16* Hs = ring + (s & (WG2_STAGES - 1)) * WG3_STAGE_ELEMS;
-            const u16* Zs = Hs + WG2_ROWS * 128;
+    for (int s = 0; s < nst; ++s) {
+        __builtin_amdgcn_s_barrier();
+        if (pa.ablate & 4) continue;                                  // timing experiment: requests and barriers only
+        const u16* Hs = ring + (s & (SLOTS - 1)) * WG3_STAGE_ELEMS;
+        const u16* Zs = Hs + WG2_ROWS * 128;
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                bf16x8_t fh[2], fz[2];
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8_t fh[2], fz[2];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) fh[i] = frag_w3(Hs, kk * 16, wk * 64 + i * 32, lane);
+            for (int i = 0; i < 2; ++i) fh[i] = frag_w3(Hs, kk * 16, wk * 64 + i * 32, lane);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) fz[j] = frag_w3(Zs, kk * 16, wn * 64 + j * 32, lane);
-                if (do_bias) {
+            for (int j = 0; j < 2; ++j) fz[j] = frag_w3(Zs, kk * 16, wn * 64 + j * 32, lane);
+            if (do_bias) {
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        union { bf16x8_t v; u16 s[8]; } u;
-                        u.v = fz[j];
+                for (int j = 0; j < 2; ++j) {
+                    union { bf16x8_t v; u16 s[8]; } u;
+                    u.v = fz[j];
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) bsum[j] += bf2f(u.s[e]);
-                    }
+                    for (int e = 0; e < 8; ++e) bsum[j] += bf2f(u.s[e]);
                 }
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[i], fz[j], acc[i][j], 0, 0, 0);
             }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[i], fz[j], acc[i][j], 0, 0, 0);
         }
-#undef WG3_ISSUE
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     if (pa.ablate & 1) {
 #pragma unroll
@@ -294,16 +305,17 @@ __device__ __forceinline__ void wgrad3_body(const WgradArgs& pa, const int work,
     }
 }
 
-__global__ __launch_bounds__(256) void k_wgrad3(const WgradArgs pa) {
+template <int SLOTS>
+__global__ __launch_bounds__(WG3_THREADS) void k_wgrad3(const WgradArgs pa) {
     extern __shared__ __attribute__((aligned(16))) u16 ring[];    // [stage][H|Z][32][128]
-    wgrad3_body(pa, xcd_work_id(blockIdx.x, gridDim.x), ring);
+    wgrad3_body<SLOTS>(pa, xcd_work_id(blockIdx.x, gridDim.x), ring);
 }
 
 // K members in one launch (csrc/group.h): the grid is the concatenation of the members' grids; consecutive work ids
 // (= the tiles of one member, layer and split, which share operand rows) still land on one XCD.
-__global__ __launch_bounds__(256) void k_wgrad3_group(const WgradArgs* __restrict__ members, const GroupTable tab) {
+__global__ __launch_bounds__(WG3_THREADS) void k_wgrad3_group(const WgradArgs* __restrict__ members, const GroupTable tab) {
     extern __shared__ __attribute__((aligned(16))) u16 ring[];
     const int work = xcd_work_id(blockIdx.x, gridDim.x);
     const int m = group_member(tab, work);
-    wgrad3_body(members[tab.idx[m]], work - tab.begin[m], ring);
+    wgrad3_body<4>(members[tab.idx[m]], work - tab.begin[m], ring);
 }
