@@ -10,6 +10,7 @@
 #include "gemm2.h"
 #include "chainw.h"
 #include "coop.h"
+#define CS_WGRAD_PARTS 2          // partial-sum buffers beside the gradient buffer (training steps with <= 3 row splits)
 #include "metrics.h"
 
 #include <cmath>
@@ -155,6 +156,9 @@ struct cs_mlp {
     unsigned coop_epoch = 0;
     int coop_c_last = 0; int64_t coop_tiles_last = 0;
     bool coop_used = false;
+    // training step without gradient atomics (WgradArgs.plain): extra partial-sum buffers, how many of them hold this step's
+    // contributions (consumed by the optimiser launch that follows), and whether the backward pass runs inside a step
+    float* Gx = nullptr; int gx_parts = 0; bool in_step = false;
     std::vector<void*> allocs;
 };
 
@@ -211,6 +215,8 @@ void internal_to_keras(const cs_mlp* h, const float* src, float* dst) {
 OptArgs fill_opt_args(cs_mlp* h, float lr, float grad_scale, bool recast_only) {
     OptArgs a{};
     a.P = h->P; a.M = h->M; a.V = h->V; a.G = h->G;
+    a.Gx = h->Gx; a.gx_stride = h->n_params; a.gx_n = recast_only ? 0 : h->gx_parts;
+    if (!recast_only) h->gx_parts = 0;
     a.n_seg = h->n_seg; a.seg = h->seg_dev;
     a.kind = h->cfg.optimizer; a.lr = lr; a.grad_scale = grad_scale;
     a.recast_only = recast_only ? 1 : 0;
@@ -576,6 +582,11 @@ int run_backward(cs_mlp* h, int64_t n, bool atomics_needed, hipStream_t st) {
         if (splitk > msteps) splitk = msteps;
         w.splitk = splitk;
         w.use_atomics = (big || dma_small || splitk > 1 || atomics_needed) ? 1 : 0;
+        static const bool plain_on = !(getenv("CS_WGRAD_PLAIN") && atoi(getenv("CS_WGRAD_PLAIN")) == 0);
+        if (dma_small && h->in_step && !atomics_needed && plain_on && h->Gx && splitk >= 2 && splitk <= CS_WGRAD_PARTS + 1) {
+            w.plain = 1; w.use_atomics = 0; w.g_base = h->G; w.part = h->Gx; w.part_stride = h->n_params;
+            h->gx_parts = splitk - 1;
+        }
         int wg = 0;
         for (int l = 0; l < h->L; ++l) {
             const Layer& ly = h->layers[l];
@@ -707,6 +718,7 @@ int cs_mlp_create(cs_mlp_t** out, const cs_mlp_cfg* cfg) {
     A((void**)&h->M, sizeof(float) * off);
     A((void**)&h->V, sizeof(float) * off);
     A((void**)&h->G, sizeof(float) * off);
+    A((void**)&h->Gx, sizeof(float) * off * CS_WGRAD_PARTS);
     A((void**)&h->loss_ring, sizeof(float) * 2 * LOSS_STRIPES * LOSS_STRIPE_FLOATS);
     A((void**)&h->keep_store, sizeof(float) * h->n_outp);
     A((void**)&h->sub, sizeof(float) * cfg->n_in);
@@ -971,8 +983,10 @@ int cs_mlp_train_step(cs_mlp_t* h, const float* x_dev, const float* y_dev, const
     rc = run_forward(h, x_dev, row_idx_dev, n, normalise, nullptr, y_dev, slot, true, st);
     h->loss_striped = false;
     if (rc) return rc;
+    h->in_step = true;
     rc = run_backward(h, n, false, st);
-    if (rc) return rc;
+    h->in_step = false;
+    if (rc) { h->gx_parts = 0; return rc; }
     h->opt_loss_src = slot; h->opt_loss_dst = loss_dev; h->opt_loss_zero = h->loss_ring + LOSS_STRIPES * LOSS_STRIPE_FLOATS * (h->loss_cur ^ 1);
     h->loss_cur ^= 1;
     return cs_mlp_apply(h, lr, 1.0f / ((float)h->n_out * (float)n), stream);

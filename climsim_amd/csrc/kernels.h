@@ -328,6 +328,11 @@ struct WgradArgs {               // ALL layers of the step in one launch: grid.x
     int splitk;                  // row-range splits per tile (same for every layer)
     int use_atomics;             // splitk > 1 or accumulate
     int ablate;                  // timing experiments only (CS_WGRAD_ABLATE): 1 no result flush, 2 no contraction loop
+    // k_wgrad3 inside a training step (cs_mlp_train_step): no atomics - row split 0 STORES its tile into the gradient buffer,
+    // split s > 0 into partial-sum buffer s - 1 (part + (s - 1) * part_stride, same layout), and the optimiser kernel that
+    // follows adds them up while it reads the gradient (OptArgs.Gx).  With one round of workgroups every tile's atomics used
+    // to leave at the same moment at the end of the launch: 8 us of a 38 us kernel at 8192 columns.
+    int plain; float* g_base; float* part; int64_t part_stride;
 };
 
 // LDS tile [64 m][128 cols] bf16 (256-B rows).  The four 64-B units of a row are XOR-swizzled with
@@ -515,6 +520,8 @@ struct OptArgs {
     // train_step hands the step's loss sums over without a memset launch: copy loss_src -> loss_dst, zero loss_zero
     // (both internal accumulators are LOSS_STRIPES x LOSS_STRIPE_FLOATS floats, see loss_flush)
     const float* loss_src; float* loss_dst; float* loss_zero;
+    // partial sums that k_wgrad3 stored beside the gradient buffer (WgradArgs.plain): g = G[i] + sum_p Gx[p * gx_stride + i]
+    const float* Gx; int64_t gx_stride; int gx_n;
 };
 
 // Update rules (float32, one thread = 4 parameters):
@@ -530,7 +537,11 @@ __device__ __forceinline__ void opt_update4(const OptArgs& a, int64_t i0, float 
     const float4 w = *reinterpret_cast<const float4*>(a.P + i0);
     wv[0] = w.x; wv[1] = w.y; wv[2] = w.z; wv[3] = w.w;
     if (a.recast_only) return;
-    const float4 g = *reinterpret_cast<const float4*>(a.G + i0);
+    float4 g = *reinterpret_cast<const float4*>(a.G + i0);
+    for (int q = 0; q < a.gx_n; ++q) {
+        const float4 e = *reinterpret_cast<const float4*>(a.Gx + q * a.gx_stride + i0);
+        g.x += e.x; g.y += e.y; g.z += e.z; g.w += e.w;
+    }
     const float gv[4] = {g.x * a.grad_scale, g.y * a.grad_scale, g.z * a.grad_scale, g.w * a.grad_scale};
     if (a.kind == 3) {
 #pragma unroll

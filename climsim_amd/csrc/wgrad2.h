@@ -231,6 +231,7 @@ __device__ __forceinline__ void wgrad3_body(const WgradArgs& pa, const int work,
         }
 #undef WG3_ISSUE
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                 // the clamped tail requests have landed: the ring is free (result staging)
         return;
     }
 
@@ -272,6 +273,7 @@ __device__ __forceinline__ void wgrad3_body(const WgradArgs& pa, const int work,
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[i], fz[j], acc[i][j], 0, 0, 0);
         }
     }
+    if (nst > 0) __builtin_amdgcn_s_barrier();                        // pairs with the loaders' last barrier
     if (pa.ablate & 1) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -279,26 +281,55 @@ __device__ __forceinline__ void wgrad3_body(const WgradArgs& pa, const int work,
             for (int j = 0; j < 2; ++j) asm volatile("" :: "v"(acc[i][j]));
         return;
     }
+    float* dW = p.dW; float* db = p.db;
+    if (pa.plain && split > 0) {                                      // this row split's own buffer (WgradArgs.plain)
+        float* mine = pa.part + (int64_t)(split - 1) * pa.part_stride;
+        dW = mine + (p.dW - pa.g_base); db = mine + (p.db - pa.g_base);
+    }
+    if (!pa.use_atomics) {
+        // Stores, not atomics: the 32 x 32 result tiles go through this wave's quarter of the (now idle) ring so that a lane
+        // stores 16 bytes of one row instead of 4 bytes of sixteen rows (16 instead of 64 store instructions per wave, whole
+        // 128-byte row segments)
+        float* reg = reinterpret_cast<float*>(ring) + wid * (4 * 32 * 32);        // 16 KiB per wave = the whole 64 KiB ring
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int k = k0 + wk * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (k < p.k_real) {
-                    float* dst = p.dW + (int64_t)k * p.N + n;
-                    if (pa.use_atomics) atomicAdd(dst, acc[i][j][r]); else *dst = acc[i][j][r];   // one split: the tile is written once
+                for (int r = 0; r < 16; ++r)
+                    reg[(i * 2 + j) * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = acc[i][j][r];
+        // (a wave reads back what it wrote itself: LDS operations of one wave complete in order, no barrier)
+        const int rr = lane >> 3, c4 = (lane & 7) * 4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int pass = 0; pass < 4; ++pass) {
+                    const int row = pass * 8 + rr;
+                    const float4 v = *reinterpret_cast<const float4*>(reg + (i * 2 + j) * 1024 + row * 32 + c4);
+                    const int k = k0 + wk * 64 + i * 32 + row;
+                    if (k < p.k_real) *reinterpret_cast<float4*>(dW + (int64_t)k * p.N + n0 + wn * 64 + j * 32 + c4) = v;
+                }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int k = k0 + wk * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (k < p.k_real) atomicAdd(dW + (int64_t)k * p.N + n, acc[i][j][r]);
                 }
             }
-        }
+    }
     if (do_bias) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const float v = bsum[j] + __shfl_xor(bsum[j], 32, 64);
             if (lane < 32) {
-                float* dst = p.db + n0 + wn * 64 + j * 32 + lane;
+                float* dst = db + n0 + wn * 64 + j * 32 + lane;
                 if (pa.use_atomics) atomicAdd(dst, v); else *dst = v;
             }
         }

@@ -76,3 +76,34 @@ def test_default_kernels_at_published_batch_sizes_match_oracle(M, units, n):
         cos = float(da @ db / (np.linalg.norm(da) * np.linalg.norm(db) + 1e-300))
         assert cos >= 0.98, cos
     m.close()
+
+
+@pytest.mark.parametrize("n,opt", [(2500, "Adam"), (8192, "Adam"), (8192, "RAdam"), (6000, "SGD")])
+def test_training_step_without_gradient_atomics_equals_the_two_call_form(M, n, opt):
+    """cs_mlp_train_step lets k_wgrad3 STORE its row splits into separate buffers that the optimiser kernel adds up
+    (WgradArgs.plain, 2 or 3 splits); cs_mlp_loss_grads + cs_mlp_apply - what data-parallel training calls - accumulates with
+    float atomics into one buffer.  Same gradients up to the order of float additions, so the same weights after several
+    steps (every optimiser family reads the extra buffers), and the gradient buffer is handed back zeroed either way."""
+    cfg = O.MLPConfig(hidden=CFG)
+    ws = O.glorot_init(cfg, 5)
+    a = M.MLPEmulator(units=CFG, optimizer=opt, max_batch=n, seed=None)
+    b = M.MLPEmulator(units=CFG, optimizer=opt, max_batch=n, seed=None)
+    a.set_weights(ws); b.set_weights(ws)
+    x, y = O.synth_columns(n, seed=11)
+    xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    for it in range(4):
+        perm = torch.randperm(n, device="cuda", generator=torch.Generator(device="cuda").manual_seed(it))
+        la = a.train_on_batch(xd, yd, 1e-3, row_idx=perm).cpu().numpy()
+        lb = b.loss_grads(xd, yd, row_idx=perm).cpu().numpy()
+        b.apply_gradients(1e-3, 1.0 / (128 * n))
+        np.testing.assert_allclose(la, lb, rtol=2e-3)
+    assert float(a.gradient_tensor().abs().max()) == 0.0 and float(b.gradient_tensor().abs().max()) == 0.0
+    for wa, wb, w0 in zip(a.get_weights(), b.get_weights(), ws):
+        assert rel(wa - w0, wb - w0) <= 2e-3, rel(wa - w0, wb - w0)
+    # and a gradient read after a training step still sees one clean buffer
+    g1 = a.loss_grads(xd, yd).cpu().numpy()
+    ga = a.get_gradients(1.0)
+    b.set_weights(a.get_weights())
+    b.loss_grads(xd, yd)
+    for u, v in zip(ga, b.get_gradients(1.0)):
+        assert rel(u, v) <= 1e-4
