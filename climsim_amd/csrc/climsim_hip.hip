@@ -598,7 +598,13 @@ int run_backward(cs_mlp* h, int64_t n, bool atomics_needed, hipStream_t st) {
         }
         ProfScope ps(CS_K_WGRAD, st);
         if (big) CS_LAUNCH(k_wgrad2, dim3((unsigned)wg), dim3(512), WG2_LDS_BYTES, st, w);
-        else if (dma_small) CS_LAUNCH(k_wgrad3<4>, dim3((unsigned)wg), dim3(WG3_THREADS), WG3_LDS_BYTES, st, w);
+        else if (dma_small) {
+            // one round of workgroups: 64-row stages (the whole LDS as ring); more: 32-row stages, two workgroups per CU
+            static const int rows_env = getenv("CS_WGRAD3_ROWS") ? atoi(getenv("CS_WGRAD3_ROWS")) : 0;
+            const bool r64 = (rows_env ? rows_env == 64 : wg <= ncu) && (m_pad / 64) >= splitk;
+            if (r64) CS_LAUNCH((k_wgrad3<4, 64>), dim3((unsigned)wg), dim3(WG3_THREADS), WG3_LDS_BYTES_64, st, w);
+            else CS_LAUNCH((k_wgrad3<4, 32>), dim3((unsigned)wg), dim3(WG3_THREADS), WG3_LDS_BYTES, st, w);
+        }
         else if (tr) CS_LAUNCH(k_wgrad<true>, dim3((unsigned)wg), dim3(256), 0, st, w);
         else CS_LAUNCH(k_wgrad<false>, dim3((unsigned)wg), dim3(256), 0, st, w);
     }
@@ -690,7 +696,8 @@ int cs_mlp_create(cs_mlp_t** out, const cs_mlp_cfg* cfg) {
     if (const char* e = getenv("CS_CHAIN_ABLATE")) h->chain_ablate = atoi(e);
     if (const char* e = getenv("CS_WGRAD2")) h->wgrad2_mode = atoi(e);
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad2), hipFuncAttributeMaxDynamicSharedMemorySize, WG2_LDS_BYTES));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad3<4>), hipFuncAttributeMaxDynamicSharedMemorySize, WG3_LDS_BYTES));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad3<4, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, WG3_LDS_BYTES));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad3<4, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, WG3_LDS_BYTES_64));
     if (const char* e = getenv("CS_WGRAD3")) h->wgrad3 = atoi(e) != 0;
     if (cfg->flags & CS_FLAG_COOP) h->coop_mode = -1;
     if (const char* e = getenv("CS_COOP")) { const int v = atoi(e); h->coop_mode = v == 1 ? -1 : v; }

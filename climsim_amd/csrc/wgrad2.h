@@ -163,6 +163,7 @@ __global__ __launch_bounds__(512) void k_wgrad2(const WgradArgs pa) {
 // 256x256 tiles would need 4x the split partial sums, i.e. 4x the atomics, at this size.)
 #define WG3_STAGE_ELEMS (2 * WG2_ROWS * 128)
 #define WG3_LDS_BYTES (4 * WG3_STAGE_ELEMS * 2)
+#define WG3_LDS_BYTES_64 (4 * 2 * WG3_STAGE_ELEMS * 2)      // four 64-row stages
 #define WG3_COMPUTE_WAVES 4
 #define WG3_THREADS 384                   // 4 compute waves + 2 loader waves
 
@@ -176,9 +177,11 @@ __device__ __forceinline__ bf16x8_t frag_w3(const u16* tile, int mb, int cb, int
     return u.v;
 }
 
-// SLOTS: ring slots of 16 KiB.  4 = 64 KiB, two workgroups per CU, is what is built (8 slots, one workgroup per CU with seven
-// stages requested ahead, measured 40.0 against 38.1 us at 8192 columns and 1-2 us slower at 1024-4096).
-template <int SLOTS>
+// SLOTS ring slots of R-row stages (R x 128 columns of both operands).  R = 32: 16 KiB stages, 64 KiB ring, two workgroups per CU
+// (8 such slots, one workgroup per CU with seven stages requested ahead, measured 40.0 against 38.1 us at 8192 columns).
+// R = 64: 32 KiB stages, 128 KiB ring, one workgroup per CU - half the barriers, and the fragment reads of a stage's second
+// half run under the MFMAs of its first (with one compute wave per SIMD nothing else hides the LDS latency).
+template <int SLOTS, int R>
 __device__ __forceinline__ void wgrad3_body(const WgradArgs& pa, const int work, u16* ring) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -190,7 +193,9 @@ __device__ __forceinline__ void wgrad3_body(const WgradArgs& pa, const int work,
     const int ntile = p.tiles_k * p.tiles_n;
     const int split = rel / ntile, tile = rel - split * ntile;
     const int k0 = (tile % p.tiles_k) * 128, n0 = (tile / p.tiles_k) * 128;
-    const int steps = (int)(pa.m_pad / WG2_ROWS);
+    constexpr int STAGE_ELEMS = 2 * R * 128;                         // H [R][128] | Z [R][128]
+    constexpr int PPL = R / 8;                                        // 1-KiB pieces per operand, stage and loader wave
+    const int steps = (int)(pa.m_pad / R);
     const int s_begin = (int)((int64_t)steps * split / pa.splitk);
     const int s_end = (int)((int64_t)steps * (split + 1) / pa.splitk);
     const int nst = (pa.ablate & 2) ? 0 : s_end - s_begin;
@@ -208,24 +213,24 @@ __device__ __forceinline__ void wgrad3_body(const WgradArgs& pa, const int work,
         const int lw = wid - WG3_COMPUTE_WAVES;
         const int prow = lane >> 4, pch = lane & 15;
         const int c = ((((pch >> 2) ^ (prow & 3)) << 2) | (pch & 3)) * 8;
-        const u16* hb = p.H + (int64_t)(16 * lw + prow) * p.ldh + k0 + c;
-        const u16* zb = p.Z + (int64_t)(16 * lw + prow) * p.ldz + n0 + c;
-        const unsigned mine = (unsigned)__builtin_amdgcn_readfirstlane(4 * lw) * 1024u;
+        const u16* hb = p.H + (int64_t)(4 * PPL * lw + prow) * p.ldh + k0 + c;
+        const u16* zb = p.Z + (int64_t)(4 * PPL * lw + prow) * p.ldz + n0 + c;
+        const unsigned mine = (unsigned)__builtin_amdgcn_readfirstlane(PPL * lw) * 1024u;
 #define WG3_ISSUE(st)                                                                                  \
     {                                                                                                   \
         const int sc_ = min((st), nst - 1);                                                             \
-        const int64_t roff = (int64_t)(s_begin + sc_) * WG2_ROWS;                                       \
-        const unsigned base = lds0 + (unsigned)((st) & (SLOTS - 1)) * (WG3_STAGE_ELEMS * 2) + mine;     \
-        if (!(pa.ablate & 8)) _Pragma("unroll") for (int j = 0; j < 4; ++j) {                           \
+        const int64_t roff = (int64_t)(s_begin + sc_) * R;                                              \
+        const unsigned base = lds0 + (unsigned)((st) & (SLOTS - 1)) * (STAGE_ELEMS * 2) + mine;         \
+        if (!(pa.ablate & 8)) _Pragma("unroll") for (int j = 0; j < PPL; ++j) {                         \
             dma16(hb + (roff + 4 * j) * p.ldh, base + (unsigned)j * 1024u);                             \
-            dma16(zb + (roff + 4 * j) * p.ldz, base + WG2_ROWS * 256u + (unsigned)j * 1024u);           \
+            dma16(zb + (roff + 4 * j) * p.ldz, base + R * 256u + (unsigned)j * 1024u);                  \
         }                                                                                               \
     }
 #pragma unroll
         for (int st = 0; st < SLOTS - 1; ++st) WG3_ISSUE(st)
         for (int t = 0; t < nst; ++t) {
-            // stage t has landed: SLOTS - 2 younger stages (8 pieces each from this wave) may still be in flight
-            asm volatile("s_waitcnt vmcnt(%0)" ::"i"(8 * (SLOTS - 2)) : "memory");
+            // stage t has landed: SLOTS - 2 younger stages (2 * PPL pieces each from this wave) may still be in flight
+            asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * PPL * (SLOTS - 2)) : "memory");
             __builtin_amdgcn_s_barrier();                             // ... and the compute waves are done with stage t - 1
             WG3_ISSUE(t + SLOTS - 1)                                  // into its slot
         }
@@ -248,10 +253,10 @@ __device__ __forceinline__ void wgrad3_body(const WgradArgs& pa, const int work,
     for (int s = 0; s < nst; ++s) {
         __builtin_amdgcn_s_barrier();
         if (pa.ablate & 4) continue;                                  // timing experiment: requests and barriers only
-        const u16* Hs = ring + (s & (SLOTS - 1)) * WG3_STAGE_ELEMS;
-        const u16* Zs = Hs + WG2_ROWS * 128;
+        const u16* Hs = ring + (s & (SLOTS - 1)) * STAGE_ELEMS;
+        const u16* Zs = Hs + R * 128;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+        for (int kk = 0; kk < R / 16; ++kk) {
             bf16x8_t fh[2], fz[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) fh[i] = frag_w3(Hs, kk * 16, wk * 64 + i * 32, lane);
@@ -336,10 +341,10 @@ __device__ __forceinline__ void wgrad3_body(const WgradArgs& pa, const int work,
     }
 }
 
-template <int SLOTS>
+template <int SLOTS, int R>
 __global__ __launch_bounds__(WG3_THREADS) void k_wgrad3(const WgradArgs pa) {
-    extern __shared__ __attribute__((aligned(16))) u16 ring[];    // [stage][H|Z][32][128]
-    wgrad3_body<SLOTS>(pa, xcd_work_id(blockIdx.x, gridDim.x), ring);
+    extern __shared__ __attribute__((aligned(16))) u16 ring[];    // [stage][H|Z][R][128]
+    wgrad3_body<SLOTS, R>(pa, xcd_work_id(blockIdx.x, gridDim.x), ring);
 }
 
 // K members in one launch (csrc/group.h): the grid is the concatenation of the members' grids; consecutive work ids
@@ -348,5 +353,5 @@ __global__ __launch_bounds__(WG3_THREADS) void k_wgrad3_group(const WgradArgs* _
     extern __shared__ __attribute__((aligned(16))) u16 ring[];
     const int work = xcd_work_id(blockIdx.x, gridDim.x);
     const int m = group_member(tab, work);
-    wgrad3_body<4>(members[tab.idx[m]], work - tab.begin[m], ring);
+    wgrad3_body<4, 32>(members[tab.idx[m]], work - tab.begin[m], ring);
 }
