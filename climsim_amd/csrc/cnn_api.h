@@ -253,6 +253,7 @@ int cs_cnn_create(cs_cnn_t** out, const cs_cnn_cfg* cfg) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv2<CONV_BWD>), hipFuncAttributeMaxDynamicSharedMemorySize, CV2_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wgrad2<8>), hipFuncAttributeMaxDynamicSharedMemorySize, CW2_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wgrad2<4>), hipFuncAttributeMaxDynamicSharedMemorySize, CW2_LDS_BYTES));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wgrad2l), hipFuncAttributeMaxDynamicSharedMemorySize, CW2_LDS_BYTES));
     if (const char* e = getenv("CS_CW2_WAVES")) h->cw_waves = atoi(e) == 4 ? 4 : 8;
     {
         hipDeviceProp_t prop;
@@ -522,7 +523,9 @@ int cs_cnn_loss_grads(cs_cnn_t* h, const float* x_dev, int x3d, const float* y_d
         splits = std::max(1, std::min(splits, ca.slabs / 8 > 0 ? ca.slabs / 8 : 1));
         ca.splits = splits;
         const int grid = ca.n_tiles * splits;
-        if (h->cw_waves == 8) hipLaunchKernelGGL(k_conv_wgrad2<8>, dim3((unsigned)grid), dim3(512), CW2_LDS_BYTES, st, ca);
+        static const bool loaders = !(getenv("CS_CW2_LOADERS") && atoi(getenv("CS_CW2_LOADERS")) == 0);
+        if (h->cw_waves == 8 && loaders) hipLaunchKernelGGL(k_conv_wgrad2l, dim3((unsigned)grid), dim3(640), CW2_LDS_BYTES, st, ca);
+        else if (h->cw_waves == 8) hipLaunchKernelGGL(k_conv_wgrad2<8>, dim3((unsigned)grid), dim3(512), CW2_LDS_BYTES, st, ca);
         else hipLaunchKernelGGL(k_conv_wgrad2<4>, dim3((unsigned)grid), dim3(256), CW2_LDS_BYTES, st, ca);
     }
     ConvWgradArgs wa{};

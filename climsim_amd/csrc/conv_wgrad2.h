@@ -232,3 +232,153 @@ __global__ __launch_bounds__(NW * 64) void k_conv_wgrad2(const CwArgs pa) {
 #undef CW2_ISSUE
 #undef CW2_FRAG
 }
+
+// The same kernel with the operand requests moved to TWO LOADER WAVES (waves 8, 9): a 1-KiB LDS-DMA piece costs the wave that
+// issues it 100-185 clocks when it sits between ds_reads and MFMAs and ~20 in a wave that does nothing else (k_wgrad3,
+// contraction 39.9 -> 32.3 us from this change alone).  The eight compute waves (64 x 112 each) keep
+// the software pipeline of k_conv_wgrad2<8> minus its four pieces per slab and their running source state; loader lw owns
+// pieces 8 lw .. 8 lw + 7 of both operands.  A barrier still promises "slab s + 1 has landed, slab s is out of use".
+__global__ __launch_bounds__(640) void k_conv_wgrad2l(const CwArgs pa) {
+    constexpr int IT = 4;
+    extern __shared__ __attribute__((aligned(16))) u16 cw_ring[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = (wid >> 1) & 3, wn = wid & 1;
+    const int work = xcd_work_id(blockIdx.x, gridDim.x);
+    int lo = 0, hi = pa.n_convs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (pa.conv_prefix[mid] * pa.splits <= work) lo = mid; else hi = mid - 1;
+    }
+    const int cfirst = pa.conv_prefix[lo], ctiles = pa.conv_prefix[lo + 1] - cfirst;
+    const int rel = work - cfirst * pa.splits;
+    const int split = rel / ctiles;
+    const int tile_u = __builtin_amdgcn_readfirstlane(cfirst + (rel - split * ctiles));
+    const int s0 = (int)((int64_t)pa.slabs * split / pa.splits), s1 = (int)((int64_t)pa.slabs * (split + 1) / pa.splits);
+    if (s0 >= s1) return;
+    const CwTile T = pa.tiles[tile_u];
+    const int nsl = s1 - s0;
+    typedef u16 __attribute__((address_space(3))) * lds_p;
+    const unsigned lds0 = (unsigned)(uintptr_t)((lds_p)cw_ring);
+
+    if (wid >= 8) {
+        // ---- loader: pieces 8 lw .. 8 lw + 7 (a piece = 2 rows of 512 B) of H and of Z, per-lane running state as in k_conv_wgrad2
+        constexpr int PL = 8;
+        const int lw = wid - 8;
+        const unsigned my_piece = (unsigned)__builtin_amdgcn_readfirstlane(PL * lw) * 1024u;
+        const char* zpage = reinterpret_cast<const char*>(pa.zeros);
+        const char* opage = zpage + 64;
+        const int prow = lane >> 5, pch = lane & 31;
+        const int64_t ldh2 = (int64_t)T.ldh * 2, ldz2 = (int64_t)T.ldz * 2;
+        const int linc = 32 % pa.seq;
+        const char *hp[PL], *zp[PL];
+        int mi[PL], lv[PL], hk[PL], lvhi[PL];
+#pragma unroll
+        for (int j = 0; j < PL; ++j) {
+            const int ml_ = 2 * (PL * lw + j) + prow;
+            const int lc_ = ((((pch >> 2) ^ (ml_ & 3)) << 2) | ((pch & 3) ^ (((ml_ >> 3) & 1) << 1))) * 8;
+            const int kk_ = T.k0 + lc_;
+            const int tap_ = kk_ / T.kpt, c_ = kk_ - tap_ * T.kpt;
+            const int sh_ = (T.taps == 3 && tap_ < 3) ? tap_ - 1 : 0;
+            hk[j] = tap_ < T.taps ? 0 : (kk_ == T.taps * T.kpt ? 1 : 2);
+            mi[j] = s0 * 32 + ml_;
+            lv[j] = mi[j] % pa.seq + sh_;
+            hp[j] = reinterpret_cast<const char*>(T.H + c_) + (int64_t)(mi[j] + sh_) * ldh2;
+            zp[j] = reinterpret_cast<const char*>(T.Z + T.n0 + lc_) + (int64_t)mi[j] * ldz2;
+            lvhi[j] = pa.seq + sh_;
+        }
+#define CW2L_ISSUE(slot)                                                                               \
+    {                                                                                                   \
+        const unsigned base_ = lds0 + (unsigned)(slot) * CW2_SLAB_BYTES + my_piece;                     \
+        _Pragma("unroll") for (int j = 0; j < PL; ++j) {                                                \
+            const bool in_ = mi[j] < (int)pa.m_rows;                                                    \
+            const char* hs_ = hk[j] == 0 ? ((in_ && lv[j] >= 0 && lv[j] < pa.seq) ? hp[j] : zpage) : ((hk[j] == 1 && in_) ? opage : zpage); \
+            const char* zs_ = in_ ? zp[j] : zpage;                                                      \
+            hp[j] += 32 * ldh2; zp[j] += 32 * ldz2; mi[j] += 32;                                        \
+            lv[j] += linc; if (lv[j] >= lvhi[j]) lv[j] -= pa.seq;                                       \
+            dma16(hs_, base_ + 1024u * j);                                                              \
+            dma16(zs_, base_ + 1024u * j + 16384u);                                                     \
+        }                                                                                               \
+    }
+        CW2L_ISSUE(0) CW2L_ISSUE(1) CW2L_ISSUE(2) CW2L_ISSUE(3)
+        asm volatile("s_waitcnt vmcnt(48)" ::: "memory");              // slab 0 has landed (three younger slabs x 16 pieces of this wave)
+        __builtin_amdgcn_s_barrier();
+        for (int s = 0; s < nsl; ++s) {
+            asm volatile("s_waitcnt vmcnt(32)" ::: "memory");          // slab s + 1 has landed
+            __builtin_amdgcn_s_barrier();                               // ... and slab s is out of use: its slot takes slab s + 4
+            CW2L_ISSUE(__builtin_amdgcn_readfirstlane(s & 3))
+        }
+#undef CW2L_ISSUE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the run-ahead pieces must not outlive the kernel
+        return;
+    }
+
+    f32x4_t acc[IT][7];
+#pragma unroll
+    for (int i = 0; i < IT; ++i)
+#pragma unroll
+        for (int j = 0; j < 7; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    int fo_h[IT], fo_z[7];
+    {
+        const int mrow = 8 * (lane >> 4) + ((lane & 15) >> 2);
+#pragma unroll
+        for (int i = 0; i < IT; ++i) fo_h[i] = swz_cw(mrow, wm * (16 * IT) + i * 16 + (lane & 3) * 4);
+#pragma unroll
+        for (int j = 0; j < 7; ++j) fo_z[j] = 32 * 256 + swz_cw(mrow, wn * 112 + j * 16 + (lane & 3) * 4);
+    }
+    typedef s16x4_t __attribute__((address_space(3))) * lds_v4;
+#define CW2_FRAG(dst, slab, off)                                                                       \
+    {                                                                                                   \
+        union { bf16x8_t v; s16x4_t h[2]; } u_;                                                         \
+        u_.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)((slab) + (off)));                    \
+        u_.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)((slab) + (off) + 4 * 256));          \
+        dst = u_.v;                                                                                     \
+    }
+    bf16x8_t fh[IT], fz[7];
+    __builtin_amdgcn_s_barrier();                                       // slab 0 has landed
+#pragma unroll
+    for (int i = 0; i < IT; ++i) CW2_FRAG(fh[i], cw_ring, fo_h[i])
+#pragma unroll
+    for (int j = 0; j < 7; ++j) CW2_FRAG(fz[j], cw_ring, fo_z[j])
+    for (int s = 0; s < nsl; ++s) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // my reads of slab s are done
+        __builtin_amdgcn_s_barrier();
+        const u16* nx = cw_ring + ((s + 1) & 3) * (CW2_SLAB_BYTES / 2);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+#pragma unroll
+            for (int i = 0; i < IT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[i], fz[j], acc[i][j], 0, 0, 0);
+            CW2_FRAG(fz[j], nx, fo_z[j])
+        }
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            acc[i][6] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[i], fz[6], acc[i][6], 0, 0, 0);
+            CW2_FRAG(fh[i], nx, fo_h[i])
+        }
+        CW2_FRAG(fz[6], nx, fo_z[6])
+    }
+#undef CW2_FRAG
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int kb = T.k0 + wm * (16 * IT) + i * 16 + 4 * (lane >> 4);
+        const int tap = kb / T.kpt, c = kb - tap * T.kpt;
+        if (tap < T.taps) {
+            float* row = T.dW + ((int64_t)tap * T.cin + c) * T.cout;
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                const int n = T.n0 + wn * 112 + j * 16 + (lane & 15);
+                if (n < T.cout) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (c + r < T.cin) atomicAdd(row + (int64_t)r * T.cout + n, acc[i][j][r]);
+                }
+            }
+        } else if (kb == T.taps * T.kpt && T.db) {
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                const int n = T.n0 + wn * 112 + j * 16 + (lane & 15);
+                if (n < T.cout) atomicAdd(T.db + n, acc[i][j][0]);
+            }
+        }
+    }
+}
