@@ -524,7 +524,7 @@ int cs_cnn_loss_grads(cs_cnn_t* h, const float* x_dev, int x3d, const float* y_d
         ca.splits = splits;
         const int grid = ca.n_tiles * splits;
         static const bool loaders = !(getenv("CS_CW2_LOADERS") && atoi(getenv("CS_CW2_LOADERS")) == 0);
-        if (h->cw_waves == 8 && loaders) hipLaunchKernelGGL(k_conv_wgrad2l, dim3((unsigned)grid), dim3(640), CW2_LDS_BYTES, st, ca);
+        if (h->cw_waves == 8 && loaders) hipLaunchKernelGGL(k_conv_wgrad2l, dim3((unsigned)grid), dim3(512 + 64 * CW2L_LOADERS), CW2_LDS_BYTES, st, ca);
         else if (h->cw_waves == 8) hipLaunchKernelGGL(k_conv_wgrad2<8>, dim3((unsigned)grid), dim3(512), CW2_LDS_BYTES, st, ca);
         else hipLaunchKernelGGL(k_conv_wgrad2<4>, dim3((unsigned)grid), dim3(256), CW2_LDS_BYTES, st, ca);
     }

@@ -233,12 +233,15 @@ __global__ __launch_bounds__(NW * 64) void k_conv_wgrad2(const CwArgs pa) {
 #undef CW2_FRAG
 }
 
-// The same kernel with the operand requests moved to TWO LOADER WAVES (waves 8, 9): a 1-KiB LDS-DMA piece costs the wave that
+// The same kernel with the operand requests moved to FOUR LOADER WAVES (waves 8..11): a 1-KiB LDS-DMA piece costs the wave that
 // issues it 100-185 clocks when it sits between ds_reads and MFMAs and ~20 in a wave that does nothing else (k_wgrad3,
 // contraction 39.9 -> 32.3 us from this change alone).  The eight compute waves (64 x 112 each) keep
 // the software pipeline of k_conv_wgrad2<8> minus its four pieces per slab and their running source state; loader lw owns
-// pieces 8 lw .. 8 lw + 7 of both operands.  A barrier still promises "slab s + 1 has landed, slab s is out of use".
-__global__ __launch_bounds__(640) void k_conv_wgrad2l(const CwArgs pa) {
+// pieces 4 lw .. 4 lw + 3 of both operands.  A barrier still promises "slab s + 1 has landed, slab s is out of use".
+// Measured (depth 12, width 406, batch 512, step): 4.11 ms with k_conv_wgrad2<8>, 4.39 with two loader waves (32 pieces per
+// slab: the loaders' own issue rate became the limit), 3.98 with four; 168 VGPRs at three waves per SIMD, 8 bytes of scratch.
+#define CW2L_LOADERS 4
+__global__ __launch_bounds__(512 + 64 * CW2L_LOADERS) void k_conv_wgrad2l(const CwArgs pa) {
     constexpr int IT = 4;
     extern __shared__ __attribute__((aligned(16))) u16 cw_ring[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -263,7 +266,7 @@ __global__ __launch_bounds__(640) void k_conv_wgrad2l(const CwArgs pa) {
 
     if (wid >= 8) {
         // ---- loader: pieces 8 lw .. 8 lw + 7 (a piece = 2 rows of 512 B) of H and of Z, per-lane running state as in k_conv_wgrad2
-        constexpr int PL = 8;
+        constexpr int PL = 16 / CW2L_LOADERS;
         const int lw = wid - 8;
         const unsigned my_piece = (unsigned)__builtin_amdgcn_readfirstlane(PL * lw) * 1024u;
         const char* zpage = reinterpret_cast<const char*>(pa.zeros);
@@ -301,10 +304,10 @@ __global__ __launch_bounds__(640) void k_conv_wgrad2l(const CwArgs pa) {
         }                                                                                               \
     }
         CW2L_ISSUE(0) CW2L_ISSUE(1) CW2L_ISSUE(2) CW2L_ISSUE(3)
-        asm volatile("s_waitcnt vmcnt(48)" ::: "memory");              // slab 0 has landed (three younger slabs x 16 pieces of this wave)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"i"(3 * 2 * PL) : "memory");   // slab 0 has landed (three younger slabs x 2 PL pieces of this wave)
         __builtin_amdgcn_s_barrier();
         for (int s = 0; s < nsl; ++s) {
-            asm volatile("s_waitcnt vmcnt(32)" ::: "memory");          // slab s + 1 has landed
+            asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * 2 * PL) : "memory");   // slab s + 1 has landed
             __builtin_amdgcn_s_barrier();                               // ... and slab s is out of use: its slot takes slab s + 4
             CW2L_ISSUE(__builtin_amdgcn_readfirstlane(s & 3))
         }

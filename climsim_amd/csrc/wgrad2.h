@@ -165,7 +165,8 @@ __global__ __launch_bounds__(512) void k_wgrad2(const WgradArgs pa) {
 #define WG3_LDS_BYTES (4 * WG3_STAGE_ELEMS * 2)
 #define WG3_LDS_BYTES_64 (4 * 2 * WG3_STAGE_ELEMS * 2)      // four 64-row stages
 #define WG3_COMPUTE_WAVES 4
-#define WG3_THREADS 384                   // 4 compute waves + 2 loader waves
+#define WG3_LOADERS 2                     // (4 measured the same within box-to-box noise: 33.5 / 49.7 / 63.1 us at 8192 / 12288 / 16384 columns)
+#define WG3_THREADS (256 + 64 * WG3_LOADERS)  // 4 compute waves + the loader waves
 
 __device__ __forceinline__ bf16x8_t frag_w3(const u16* tile, int mb, int cb, int lane) {
     union { bf16x8_t v; s16x4_t h[2]; } u;
@@ -194,7 +195,7 @@ __device__ __forceinline__ void wgrad3_body(const WgradArgs& pa, const int work,
     const int split = rel / ntile, tile = rel - split * ntile;
     const int k0 = (tile % p.tiles_k) * 128, n0 = (tile / p.tiles_k) * 128;
     constexpr int STAGE_ELEMS = 2 * R * 128;                         // H [R][128] | Z [R][128]
-    constexpr int PPL = R / 8;                                        // 1-KiB pieces per operand, stage and loader wave
+    constexpr int PPL = R / (4 * WG3_LOADERS);                        // 1-KiB pieces per operand, stage and loader wave
     const int steps = (int)(pa.m_pad / R);
     const int s_begin = (int)((int64_t)steps * split / pa.splitk);
     const int s_end = (int)((int64_t)steps * (split + 1) / pa.splitk);
