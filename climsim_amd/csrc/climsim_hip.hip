@@ -551,9 +551,9 @@ int run_backward(cs_mlp* h, int64_t n, bool atomics_needed, hipStream_t st) {
     }
     {   // weight/bias gradients of ALL layers in one grouped launch
         const bool atomics_needed_plain = false;   // k_wgrad3 always accumulates atomically into the zeroed buffer
-        // 256x256 tiles + LDS-DMA ring from 20480 columns (measured, cfg-MLP: 16384 columns 77 us on the 128x128 kernel vs 88;
-        // 24576: 129 vs 105)
-        const bool big = h->wgrad2_mode == 1 || (h->wgrad2_mode < 0 && n >= 20480);
+        // 256x256 tiles + LDS-DMA ring from ~22k columns (measured, cfg-MLP, 128x128 loader-wave kernel vs 256x256: 20480 columns
+        // 71.2 vs 85.8 us; 24576: 111.3 vs 98.2; 32768: 144.9 vs 119.8; 65536: 276.7 vs 215.5)
+        const bool big = h->wgrad2_mode == 1 || (h->wgrad2_mode < 0 && n >= 22528);
         const int tdim = big ? 256 : 128;
         const bool dma_small = !big && tr && h->wgrad3 && !atomics_needed_plain;
         const int msteps = (big || dma_small) ? (int)(m_pad / WG2_ROWS) : steps;

@@ -4,7 +4,7 @@ the engine picks by batch size are the ones under test:
 
   cfg-MLP   8192  k_chain_fb<32> + k_wgrad3 (5 row splits)            - the bench.py workload
   cfg-MLP  16384  k_chain_fb<64> + k_wgrad3 with >= 7 row splits
-  cfg-MLP  24576  k_chain_fb<128> + k_wgrad2 (256x256 LDS-DMA tiles, n >= 20480)
+  cfg-MLP  24576  k_chain_fb<128> + k_wgrad2 (256x256 LDS-DMA tiles, n >= 22528)
   cfg-MLP  65536  k_chain_fb<128>, two rounds of workgroups + k_wgrad2
   pub-MLP   3072  k_chainw_fb at the published model's batch (step1_results.csv:170)
   pub-MLP  16384  k_chainw_fb + k_wgrad2-free wide path
