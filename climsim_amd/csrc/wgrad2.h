@@ -248,8 +248,17 @@ __device__ __forceinline__ void wgrad3_body(const WgradArgs& pa, const int work,
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    float bsum[2] = {0.f, 0.f};
-    const bool do_bias = (k0 == 0) && (wk == 0);
+    // Bias gradient sum_m dZ[m][n] of this tile's columns (tiles with k0 == 0): by the MFMAs, against a fragment of ONES - wave
+    // (wk, wn) takes the 32 columns j = wk of its 64.  (Summing the fragments' eight values per lane with VALU adds - 16
+    // dependent adds and 16 conversions per k16-step on two of the four waves - made exactly those workgroups, a quarter of
+    // them, the slow ones of the launch: every stage ends in a barrier.)
+    f32x16_t accb;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accb[r] = 0.f;
+    const bool do_bias = (k0 == 0);
+    bf16x8_t ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
 
     for (int s = 0; s < nst; ++s) {
         __builtin_amdgcn_s_barrier();
@@ -263,20 +272,12 @@ __device__ __forceinline__ void wgrad3_body(const WgradArgs& pa, const int work,
             for (int i = 0; i < 2; ++i) fh[i] = frag_w3(Hs, kk * 16, wk * 64 + i * 32, lane);
 #pragma unroll
             for (int j = 0; j < 2; ++j) fz[j] = frag_w3(Zs, kk * 16, wn * 64 + j * 32, lane);
-            if (do_bias) {
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    union { bf16x8_t v; u16 s[8]; } u;
-                    u.v = fz[j];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) bsum[j] += bf2f(u.s[e]);
-                }
-            }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[i], fz[j], acc[i][j], 0, 0, 0);
+            if (do_bias) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, wk ? fz[1] : fz[0], accb, 0, 0, 0);
         }
     }
     if (nst > 0) __builtin_amdgcn_s_barrier();                        // pairs with the loaders' last barrier
@@ -330,15 +331,9 @@ __device__ __forceinline__ void wgrad3_body(const WgradArgs& pa, const int work,
                 }
             }
     }
-    if (do_bias) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const float v = bsum[j] + __shfl_xor(bsum[j], 32, 64);
-            if (lane < 32) {
-                float* dst = db + n0 + wn * 64 + j * 32 + lane;
-                if (pa.use_atomics) atomicAdd(dst, v); else *dst = v;
-            }
-        }
+    if (do_bias && lane < 32) {                                       // row 0 of the ones product: lanes 0..31, element 0
+        float* dst = db + n0 + wn * 64 + wk * 32 + lane;
+        if (pa.use_atomics) atomicAdd(dst, accb[0]); else *dst = accb[0];
     }
 }
 
