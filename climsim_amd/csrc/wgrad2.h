@@ -80,8 +80,15 @@ __global__ __launch_bounds__(512) void k_wgrad2(const WgradArgs pa) {
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
-    const bool do_bias = (k0 == 0) && (wk == 0);
+    // bias gradient of this tile's columns (k0 == 0): by the MFMAs against a fragment of ones, wave (wk, wn) takes the 32
+    // columns j = wk of its 128 (a VALU add chain over the fragments on the wk == 0 waves made those workgroups the slow ones)
+    f32x16_t accb;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accb[r] = 0.f;
+    const bool do_bias = (k0 == 0);
+    bf16x8_t ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
     const bool k_live = (k0 + wk * 64) < ((p.k_real + 63) & ~63), n_live = (n0 + wn * 128) < p.N;
 
     if (nst > 0) {
@@ -112,25 +119,27 @@ __global__ __launch_bounds__(512) void k_wgrad2(const WgradArgs pa) {
                     for (int i = 0; i < 2; ++i) fh[i] = frag_w2(Hs, kk * 16, wk * 64 + i * 32, lane);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) fz[j] = frag_w2(Zs, kk * 16, wn * 128 + j * 32, lane);
-                    if (do_bias) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            union { bf16x8_t v; u16 s[8]; } u;
-                            u.v = fz[j];
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) bsum[j] += bf2f(u.s[e]);
-                        }
-                    }
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[i], fz[j], acc[i][j], 0, 0, 0);
+                    if (do_bias) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, wk == 0 ? fz[0] : wk == 1 ? fz[1] : wk == 2 ? fz[2] : fz[3], accb, 0, 0, 0);
+                }
+            } else if (do_bias && n_live) {                      // a wave whose k rows lie beyond the layer's K still owes its bias columns
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const bf16x8_t fzb = frag_w2(Zs, kk * 16, wn * 128 + wk * 32, lane);
+                    accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, fzb, accb, 0, 0, 0);
                 }
             }
         }
 #undef WG2_ISSUE
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // tail re-loads
+    }
+    if (do_bias && n_live) {
+        const int n = n0 + wn * 128 + wk * 32 + lane;
+        if (lane < 32 && n < p.N) atomicAdd(p.db + n, accb[0]);       // row 0 of the ones product
     }
     if (!(k_live && n_live)) return;
     // D[i = k][j = n]: lane owns column n = ..+(lane&31), rows k = ..+(r&3)+8*(r>>2)+4*(lane>>5)
@@ -146,14 +155,6 @@ __global__ __launch_bounds__(512) void k_wgrad2(const WgradArgs pa) {
                 if (k < p.k_real) atomicAdd(p.dW + (int64_t)k * p.N + n, acc[i][j][r]);
             }
         }
-    if (do_bias) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float v = bsum[j] + __shfl_xor(bsum[j], 32, 64);
-            const int n = n0 + wn * 128 + j * 32 + lane;
-            if (lane < 32 && n < p.N) atomicAdd(p.db + n, v);
-        }
-    }
 }
 
 // ---------------------------------------------------------------------------------------------------
