@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libclimsim_hip.so")
+# CLIMSIM_HIP_LIB: another build of the same library (tools/sanitize_host.sh points it at the host-only ASan/UBSan build)
+LIB_PATH = os.environ.get("CLIMSIM_HIP_LIB") or os.path.join(HERE, "libclimsim_hip.so")
 CS_MAX_HIDDEN = 16
 CS_FLAG_NO_TR_READ = 1
 CS_FLAG_NO_CHAIN = 2
@@ -56,10 +57,13 @@ SIGNATURES = {
     "cs_mlp_destroy": (None, [_P]),
     "cs_mlp_num_params": (_I64, [_P]),
     "cs_mlp_device_bytes": (_I64, [_P]),
+    "cs_mlp_check": (C.c_int, [_P, _P]),
+    "cs_mlp_coop_timeouts": (_I64, [_P]),
     "cs_dp_unique_id": (C.c_int, [C.c_char_p, _P]),
     "cs_dp_init": (C.c_int, [C.POINTER(_P), C.c_char_p, _P, C.c_int, C.c_int, C.c_int]),
     "cs_dp_allreduce": (C.c_int, [_P, _P, C.c_int64, _P]),
     "cs_dp_allreduce_bf16": (C.c_int, [_P, _P, C.c_int64, _P]),
+    "cs_dp_comm_info": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "cs_dp_destroy": (None, [_P]),
     "cs_mlp_set_norm": (C.c_int, [_P, _P, _P]),
     "cs_mlp_set_head_options": (C.c_int, [_P, C.c_int, _P, C.c_int64]),
@@ -86,6 +90,7 @@ SIGNATURES = {
     "cs_mlp_group_destroy": (None, [_P]),
     "cs_mlp_group_size": (_I32, [_P]),
     "cs_mlp_group_train_step": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_I64), C.c_int, C.POINTER(_F), _P, _P]),
+    "cs_mlp_group_forward": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_I64), C.c_int, C.POINTER(_P), C.POINTER(_P), _P, C.c_int, _P]),
     "cs_mlp_group_profile_step": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_I64), C.c_int, C.POINTER(_F), _P, _P,
                                             C.POINTER(CsKernelTimes)]),
     "cs_categorical_accuracy": (C.c_int, [_P, _P, _I64, _I32, _P, C.c_int, _P]),

@@ -75,8 +75,9 @@ struct ChainArgs {
 // What changes from step to step (and, in a grouped launch, from member to member) apart from the weights: the batch.
 struct ChainDyn {
     const float* x; const float* y; const int64_t* row_idx; float* loss; int64_t n_rows; int normalise;
+    float* yhat;             // predictions [n][output width] fp32 or null (prediction / evaluation passes)
 };
-__device__ __forceinline__ ChainDyn chain_dyn_of(const ChainArgs& p) { return ChainDyn{p.x, p.y, p.row_idx, p.loss, p.n_rows, p.normalise}; }
+__device__ __forceinline__ ChainDyn chain_dyn_of(const ChainArgs& p) { return ChainDyn{p.x, p.y, p.row_idx, p.loss, p.n_rows, p.normalise, p.yhat}; }
 
 // Grouped launches (GroupTable, kernels.h): `bid` / `ngrid` below are the workgroup index and grid size WITHIN a member
 // (blockIdx.x / gridDim.x for an ordinary launch).
@@ -311,7 +312,7 @@ __device__ __forceinline__ void chain_heads(const float* __restrict__ bias_lds, 
             const bool valid = m < d_.n_rows;
             float d[4];
             head4(v, d, n >= p.n_lin, p.keep, n, (have_y && valid) ? &tgt[a][q] : nullptr, p.loss_kind, sq, ab);
-            if (valid && p.yhat) *reinterpret_cast<float4*>(p.yhat + m * S.Nc + n) = make_float4(v[0], v[1], v[2], v[3]);
+            if (valid && d_.yhat) *reinterpret_cast<float4*>(d_.yhat + m * S.Nc + n) = make_float4(v[0], v[1], v[2], v[3]);
             const uint2 dpk = make_uint2(cvt_pk_bf16(d[0], d[1]), cvt_pk_bf16(d[2], d[3]));
             if (p.dz_out) *reinterpret_cast<uint2*>(p.dz_out + m * p.ld_dz_out + n) = dpk;
             if (Xdz) *reinterpret_cast<uint2*>(Xdz + chain_lds_off(mrow0 + a * 32 + (lane & 31), n)) = dpk;   // k_chain_fb: the backward half starts from here
@@ -582,4 +583,22 @@ __global__ __launch_bounds__(512) void k_chain_fb_group(const ChainPair* __restr
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     chain_body<BM, true, ELU>(P.pb, d, bid, Q, q, X, bias_lds, rows_lds);
+}
+
+// Forward pass only (prediction / evaluation: the validation pass of model.fit, hpo_baseline_v1.py:139-150 runs
+// `validation_data` every epoch for every trial) of K members in ONE launch: `members` holds forward arguments built
+// without activation copies, sign masks or dz; predictions and loss sums go where the member's ChainDyn points.
+template <int BM, bool ELU>
+__global__ __launch_bounds__(512) void k_chain_group(const ChainArgs* __restrict__ members, const GroupTable tab, const ChainDynTable dyn) {
+    extern __shared__ __attribute__((aligned(16))) u16 X[];
+    float* bias_lds = reinterpret_cast<float*>(X + BM * CHAIN_PITCH);
+    int64_t* rows_lds = reinterpret_cast<int64_t*>(bias_lds + CHAIN_MAX_BIAS);
+    const int T = (int)gridDim.x, w = xcd_work_id((int)blockIdx.x, T);
+    const int m = group_member(tab, w);
+    const int bid = w - tab.begin[m];
+    const int x8 = (int)blockIdx.x & 7, q8 = T >> 3, r8 = T & 7;
+    const int run_lo = x8 < r8 ? x8 * (q8 + 1) : r8 * (q8 + 1) + (x8 - r8) * q8, run_hi = run_lo + (x8 < r8 ? q8 + 1 : q8);
+    const int lo = max(run_lo, tab.begin[m]), hi = min(run_hi, tab.begin[m + 1]);
+    const int Q = min(32, max(1, hi - lo)), q = (w - lo) % Q;
+    chain_body<BM, false, ELU>(members[tab.idx[m]], dyn.d[m], bid, Q, q, X, bias_lds, rows_lds);
 }

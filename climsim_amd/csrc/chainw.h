@@ -84,7 +84,7 @@ __device__ __forceinline__ void chainw_body(const ChainArgs& p, const ChainDyn& 
                     float4 t4;
                     if (d_.y && valid) t4 = *reinterpret_cast<const float4*>(d_.y + yrow * p.n_real + n);
                     head4(v, d, n >= p.n_lin, p.keep, n, (d_.y && valid) ? &t4 : nullptr, p.loss_kind, sq, ab);
-                    if (valid && p.yhat) *reinterpret_cast<float4*>(p.yhat + m * p.n_real + n) = make_float4(v[0], v[1], v[2], v[3]);
+                    if (valid && d_.yhat) *reinterpret_cast<float4*>(d_.yhat + m * p.n_real + n) = make_float4(v[0], v[1], v[2], v[3]);
                     if (p.dz_out) *reinterpret_cast<uint2*>(p.dz_out + m * p.ld_dz_out + n) = make_uint2(cvt_pk_bf16(d[0], d[1]), cvt_pk_bf16(d[2], d[3]));
                 }
             }
@@ -181,4 +181,12 @@ __global__ __launch_bounds__(512) void k_chainw_fb_group(const ChainPair* __rest
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     chainw_body<true>(P.pb, d, bid, XW);
+}
+
+// forward pass only of K members in one launch (see k_chain_group, chain.h)
+__global__ __launch_bounds__(512) void k_chainw_group(const ChainArgs* __restrict__ members, const GroupTable tab, const ChainDynTable dyn) {
+    extern __shared__ __attribute__((aligned(16))) u16 XW[];
+    const int w = xcd_work_id((int)blockIdx.x, (int)gridDim.x);
+    const int m = group_member(tab, w);
+    chainw_body<false>(members[tab.idx[m]], dyn.d[m], w - tab.begin[m], XW);
 }

@@ -120,6 +120,7 @@ struct cs_mlp {
     double dropout = 0.0;          // cs_mlp_set_dropout: nn.Dropout(p) on the hidden layers while training (wide chain only)
     unsigned long long drop_seed = 0;
     int loss_kind = CS_LOSS_MSE;   // cs_mlp_set_head_options
+    int cfg_gen = 0;               // bumped by set_head_options / set_dropout: groups rebuild their member tables when it moves
     float* keep = nullptr;         // [n_outp] 1/0 per output column, or null (no output pruning)
     float* keep_store = nullptr;   // the arena slot `keep` points to when pruning is on
     int64_t m_pad_max = 0;
@@ -151,7 +152,9 @@ struct cs_mlp {
     // cooperative chain (coop.h): C workgroups per 32-row tile for batches of up to 4096 columns
     int coop_mode = 0;         // 0 off (default), -1 members by batch size (CS_FLAG_COOP / CS_COOP=1), 2 / 4 / 8 forced (CS_COOP=2|4|8)
     unsigned* coop_arrive = nullptr;   // [tiles] roll-call counters + [tiles][2 * CHAIN_MAX_STAGES][8] arrival flags behind them
-    unsigned* coop_error = nullptr;    // set by a bounded wait that ran out
+    unsigned* coop_error = nullptr;    // device address of coop_error_host
+    unsigned* coop_error_host = nullptr;   // pinned, host-mapped, coherent: bounded waits of cooperative launches that ran out (counted by the kernel)
+    int coop_spin_limit = COOP_SPIN_LIMIT;
     unsigned* coop_xcc = nullptr;      // [tiles] XCC ids seen per tile (roll call of the members)
     unsigned coop_epoch = 0;
     int coop_c_last = 0; int64_t coop_tiles_last = 0;
@@ -412,7 +415,6 @@ int run_forward(cs_mlp* h, const float* x, const int64_t* row_idx, int64_t n, in
             if (h->coop_c_last != coop_c || h->coop_tiles_last != m_pad / 32) {     // another launch shape: the counters start over
                 HIP_TRY(hipMemsetAsync(h->coop_arrive, 0, sizeof(unsigned) * 256 * (1 + 2 * CHAIN_MAX_STAGES * 8), st));
                 HIP_TRY(hipMemsetAsync(h->coop_xcc, 0, sizeof(unsigned) * 256, st));
-                if (!h->coop_used) HIP_TRY(hipMemsetAsync(h->coop_error, 0, 256, st));
                 h->coop_epoch = 0; h->coop_c_last = coop_c; h->coop_tiles_last = m_pad / 32;
             }
             if (h->coop_epoch >= 0x0fffffffu) {                                      // far from wrapping epoch * 8
@@ -420,7 +422,7 @@ int run_forward(cs_mlp* h, const float* x, const int64_t* row_idx, int64_t n, in
                 h->coop_epoch = 0;
             }
             static const int warm = getenv("CS_COOP_WARM") ? atoi(getenv("CS_COOP_WARM")) : 0;
-            CoopArgs co{coop_c, ++h->coop_epoch, h->coop_arrive, h->coop_arrive + 256, h->coop_xcc, h->coop_error, warm, h->dbg};
+            CoopArgs co{coop_c, ++h->coop_epoch, h->coop_arrive, h->coop_arrive + 256, h->coop_xcc, h->coop_error, h->coop_spin_limit, warm, h->dbg};
             h->coop_used = true;
             ProfScope ps(CS_K_CHAIN_FB, st);
             const dim3 cg((unsigned)((m_pad / 32) * coop_c));
@@ -615,6 +617,9 @@ int run_backward(cs_mlp* h, int64_t n, bool atomics_needed, hipStream_t st) {
 int check_batch(const cs_mlp* h, int64_t n) {
     if (!h) return fail(CS_ERR_INVALID, "null handle");
     if (n <= 0 || n > h->cfg.max_batch) return fail(CS_ERR_INVALID, "n=%lld outside 1..max_batch=%d", (long long)n, h->cfg.max_batch);
+    if (h->coop_error_host && *reinterpret_cast<const volatile unsigned*>(h->coop_error_host))      // coop_poll, defined below
+        return fail(CS_ERR_STATE, "the cooperative layer chain timed out waiting for a member workgroup in an earlier call: the state of this handle "
+                                  "(weights, optimiser slots) is invalid; CS_FLAG_COOP needs the device to itself");
     return CS_OK;
 }
 
@@ -744,10 +749,10 @@ int cs_mlp_create(cs_mlp_t** out, const cs_mlp_cfg* cfg) {
     A((void**)&h->seg_dev, sizeof(Segment) * 2 * h->L);
     if (h->use_chain) {
         A((void**)&h->coop_arrive, sizeof(unsigned) * 256 * (1 + 2 * CHAIN_MAX_STAGES * 8));
-        A((void**)&h->coop_error, 256);
         A((void**)&h->coop_xcc, sizeof(unsigned) * 256);
     }
-    if (getenv("CS_CHAIN_DBG")) A((void**)&h->dbg, (size_t)2 * (h->m_pad_max / 32) * 64 * 8);
+    // stamps: the chain kernels write [fwd|bwd][workgroup][64], the cooperative chain [workgroup][128] for up to 256 workgroups
+    if (getenv("CS_CHAIN_DBG")) A((void**)&h->dbg, (size_t)std::max<int64_t>(2 * (h->m_pad_max / 32) * 64, 256 * 128) * 8);
     if (h->use_chain)
         for (int l = 0; l + 1 < h->L; ++l) A((void**)&h->layers[l].mask, (size_t)(h->m_pad_max / 32) * 512 * 16);
     for (int l = 0; l < h->L; ++l) {       // activations last: the big, streamed part
@@ -781,6 +786,14 @@ int cs_mlp_create(cs_mlp_t** out, const cs_mlp_cfg* cfg) {
     if (rc == CS_OK && hipMemcpy(h->seg_dev, segs.data(), sizeof(Segment) * segs.size(), hipMemcpyHostToDevice) != hipSuccess)
         rc = fail(CS_ERR_HIP, "segment table upload failed");
     if (rc != CS_OK) return rc;
+    if (h->use_chain) {
+        // the cooperative chain's time-out counter lives in host memory the device can write (fine-grained, coherent): the host
+        // reads it on entry of every call - no copy, no synchronisation, nothing on the stream
+        HIP_TRY(hipHostMalloc((void**)&h->coop_error_host, 64, hipHostMallocMapped | hipHostMallocCoherent));
+        memset(h->coop_error_host, 0, 64);
+        HIP_TRY(hipHostGetDevicePointer((void**)&h->coop_error, h->coop_error_host, 0));
+        if (const char* e = getenv("CS_COOP_SPIN_LIMIT")) h->coop_spin_limit = atoi(e);
+    }
     guard.p = nullptr;
     *out = h;
     return CS_OK;
@@ -789,6 +802,7 @@ int cs_mlp_create(cs_mlp_t** out, const cs_mlp_cfg* cfg) {
 void cs_mlp_destroy(cs_mlp_t* h) {
     if (!h) return;
     for (void* p : h->allocs) (void)hipFree(p);
+    if (h->coop_error_host) (void)hipHostFree(h->coop_error_host);
     delete h;
 }
 
@@ -816,6 +830,7 @@ int cs_mlp_set_head_options(cs_mlp_t* h, int loss_kind, const float* keep_host, 
         h->keep = nullptr;
     }
     h->loss_kind = loss_kind;
+    h->cfg_gen += 1;
     return CS_OK;
 }
 
@@ -833,6 +848,7 @@ int cs_mlp_set_dropout(cs_mlp_t* h, double rate, uint64_t seed) {
     }
     h->dropout = rate;
     h->drop_seed = seed;
+    h->cfg_gen += 1;
     return CS_OK;
 }
 
@@ -848,39 +864,50 @@ int cs_mlp_set_weights(cs_mlp_t* h, const float* host, int64_t n, void* stream) 
 }
 
 namespace {
-// A bounded wait of the cooperative chain ran out (a member of a tile was not resident in time): the results since then are
-// wrong.  Reported at the points where the host reads the model back.
-int coop_check(cs_mlp* h, hipStream_t st) {
-    if (!h->coop_used) return CS_OK;
-    unsigned flag = 0;
-    HIP_TRY(hipMemcpyAsync(&flag, h->coop_error, sizeof flag, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    if (flag) return fail(CS_ERR_STATE, "the cooperative layer chain timed out waiting for a member workgroup (results since then are invalid); "
-                                        "CS_FLAG_COOP needs the device to itself: one cooperative launch at a time");
+// A bounded wait of the cooperative chain ran out (a member of a tile was not resident in time): everything computed since
+// then is wrong, including the optimiser state.  The kernel counts such waits in host-mapped memory, so this test costs a
+// host load: every compute entry point makes it on entry (a time-out of launch k fails the first call issued after launch k
+// has run), cs_mlp_check makes it behind a stream synchronisation.  The error is sticky: the handle's state is not trustworthy.
+int coop_poll(const cs_mlp* h) {
+    if (!h->coop_error_host) return CS_OK;
+    const unsigned n = *reinterpret_cast<const volatile unsigned*>(h->coop_error_host);
+    if (n) return fail(CS_ERR_STATE, "the cooperative layer chain timed out %u time(s) waiting for a member workgroup (results since then are invalid, "
+                                     "optimiser state included); CS_FLAG_COOP needs the device to itself: no other kernel - another stream, another "
+                                     "process - may occupy compute units while a cooperative launch runs", n);
     return CS_OK;
 }
 }  // namespace
 
+int cs_mlp_check(cs_mlp_t* h, void* stream) {
+    if (!h) return fail(CS_ERR_INVALID, "null handle");
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return coop_poll(h);
+}
+
+int64_t cs_mlp_coop_timeouts(const cs_mlp_t* h) {
+    return (h && h->coop_error_host) ? (int64_t)*reinterpret_cast<const volatile unsigned*>(h->coop_error_host) : 0;
+}
+
 int cs_mlp_get_weights(cs_mlp_t* h, float* host, int64_t n, void* stream) {
     if (!h || !host) return fail(CS_ERR_INVALID, "null argument");
-    if (int rc = coop_check(h, (hipStream_t)stream)) return rc;
     if (n != h->n_params_keras) return fail(CS_ERR_INVALID, "expected %lld floats, got %lld", (long long)h->n_params_keras, (long long)n);
     std::vector<float> tmp((size_t)h->n_params);
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipMemcpyAsync(tmp.data(), h->P, sizeof(float) * h->n_params, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    if (int rc = coop_poll(h)) return rc;
     internal_to_keras(h, tmp.data(), host);
     return CS_OK;
 }
 
 int cs_mlp_get_grads(cs_mlp_t* h, float* host, int64_t n, void* stream) {
     if (!h || !host) return fail(CS_ERR_INVALID, "null argument");
-    if (int rc = coop_check(h, (hipStream_t)stream)) return rc;
     if (n != h->n_params_keras) return fail(CS_ERR_INVALID, "expected %lld floats, got %lld", (long long)h->n_params_keras, (long long)n);
     std::vector<float> tmp((size_t)h->n_params);
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipMemcpyAsync(tmp.data(), h->G, sizeof(float) * h->n_params, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    if (int rc = coop_poll(h)) return rc;
     internal_to_keras(h, tmp.data(), host);
     return CS_OK;
 }
@@ -895,6 +922,7 @@ int cs_mlp_get_opt_state(cs_mlp_t* h, float* host_m, float* host_v, int64_t n, i
     internal_to_keras(h, tmp.data(), host_m);
     HIP_TRY(hipMemcpyAsync(tmp.data(), h->V, sizeof(float) * h->n_params, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    if (int rc = coop_poll(h)) return rc;
     internal_to_keras(h, tmp.data(), host_v);
     if (iterations) *iterations = h->iterations;
     return CS_OK;
@@ -966,6 +994,7 @@ int cs_mlp_set_grad_buffer(cs_mlp_t* h, void* dev_ptr) {
 
 int cs_mlp_apply(cs_mlp_t* h, float lr, float grad_scale, void* stream) {
     if (!h) return fail(CS_ERR_INVALID, "null handle");
+    if (int rc = coop_poll(h)) return rc;
     int rc = launch_optimizer(h, lr, grad_scale, false, (hipStream_t)stream);
     if (rc == CS_OK) { h->iterations += 1; h->grads_dirty = false; }
     return rc;
@@ -1139,6 +1168,9 @@ struct cs_mlp_group {
     bool wide = false, elu = false;
     int device = 0;
     ChainPair* pairs_dev = nullptr;      // [k] forward + backward chain arguments (everything but the batch)
+    ChainArgs* eval_dev = nullptr;       // [k] forward-only arguments (prediction / evaluation: no activation copies, masks or dz)
+    int fam = 0;                         // kernel family of every member at creation (cs_mlp_kernel_family)
+    std::vector<int> gen;                // cs_mlp::cfg_gen each member's entries of pairs_dev / eval_dev were built from
     WgradArgs* wg_dev = nullptr;         // [k] weight-gradient arguments for the batch sizes of `wg_n`
     OptArgs* opt_dev = nullptr;          // [k] optimiser arguments without the step's scalars
     std::vector<int64_t> wg_n;           // batch size each WgradArgs was built for (0 = never)
@@ -1173,6 +1205,43 @@ int wgrad_tiles128(const cs_mlp* h) {
     int t = 0;
     for (int l = 0; l < h->L; ++l) t += ((h->layers[l].Kp + 127) / 128) * ((h->layers[l].N + 127) / 128);
     return t;
+}
+
+// Member tables of the chain launches (everything but the batch).  Rebuilt when a member's head options change
+// (cs_mlp_set_head_options after the group was made: loss kind, output pruning); a member that LEFT the group's kernel
+// family meanwhile (cs_mlp_set_dropout moves a tuned-chain model to the wide chain) fails the step instead of silently
+// training without its dropout.
+int group_sync_members(cs_mlp_group* g, hipStream_t st) {
+    const int k = (int)g->m.size();
+    bool stale = false;
+    for (int i = 0; i < k; ++i) stale = stale || g->gen[(size_t)i] != g->m[(size_t)i]->cfg_gen;
+    if (!stale) return CS_OK;
+    for (int i = 0; i < k; ++i) {
+        const cs_mlp* h = g->m[(size_t)i];
+        if (cs_mlp_kernel_family(h) != g->fam)
+            return fail(CS_ERR_STATE, "member %d changed kernel family after the group was created (cs_mlp_set_dropout?): make a new group", i);
+        if (h->dropout > 0.0) return fail(CS_ERR_STATE, "member %d now trains with dropout: not built for grouped launches", i);
+    }
+    std::vector<ChainPair> pairs((size_t)k);
+    std::vector<ChainArgs> evals((size_t)k);
+    for (int i = 0; i < k; ++i) {
+        cs_mlp* h = g->m[(size_t)i];
+        ChainPair& P = pairs[(size_t)i];
+        P = ChainPair{};
+        chain_fwd_args(h, g->wide, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, true, true, P.pf);
+        if (g->wide) chainw_bwd_args(h, 0, P.pb); else chain_bwd_args(h, 0, P.pb);
+        P.pf.fused = 1; P.pb.fused = 1;
+        P.pf.dbg = nullptr; P.pb.dbg = nullptr;
+        ChainArgs& E = evals[(size_t)i];
+        E = ChainArgs{};
+        chain_fwd_args(h, g->wide, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, false, false, E);
+        E.dbg = nullptr;
+    }
+    HIP_TRY(hipStreamSynchronize(st));                   // launches in flight still read the old tables
+    HIP_TRY(hipMemcpy(g->pairs_dev, pairs.data(), sizeof(ChainPair) * k, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(g->eval_dev, evals.data(), sizeof(ChainArgs) * k, hipMemcpyHostToDevice));
+    for (int i = 0; i < k; ++i) g->gen[(size_t)i] = g->m[(size_t)i]->cfg_gen;
+    return CS_OK;
 }
 
 template <typename K>
@@ -1221,20 +1290,20 @@ int cs_mlp_group_create(cs_mlp_group_t** out, cs_mlp_t* const* members, int32_t 
     HIP_TRY(hipMalloc((void**)&g->pairs_dev, sizeof(ChainPair) * k));
     HIP_TRY(hipMalloc((void**)&g->wg_dev, sizeof(WgradArgs) * k));
     HIP_TRY(hipMalloc((void**)&g->opt_dev, sizeof(OptArgs) * k));
-    std::vector<ChainPair> pairs((size_t)k);
-    for (int i = 0; i < k; ++i) {
-        cs_mlp* h = g->m[(size_t)i];
-        ChainPair& P = pairs[(size_t)i];
-        P = ChainPair{};
-        chain_fwd_args(h, g->wide, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, true, true, P.pf);
-        if (g->wide) chainw_bwd_args(h, 0, P.pb); else chain_bwd_args(h, 0, P.pb);
-        P.pf.fused = 1; P.pb.fused = 1;
-        P.pf.dbg = nullptr; P.pb.dbg = nullptr;
-    }
-    HIP_TRY(hipMemcpy(g->pairs_dev, pairs.data(), sizeof(ChainPair) * k, hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc((void**)&g->eval_dev, sizeof(ChainArgs) * k));
+    g->fam = fam;
+    g->gen.assign((size_t)k, -1);
+    if (int rc = group_sync_members(g, nullptr)) return rc;
     if (g->wide) {
         if (int rc = set_lds(k_chainw_fb_group, chainw_lds_bytes())) return rc;
+        if (int rc = set_lds(k_chainw_group, chainw_lds_bytes())) return rc;
     } else {
+        if (int rc = set_lds(k_chain_group<32, false>, chain_lds_bytes<32>())) return rc;
+        if (int rc = set_lds(k_chain_group<32, true>, chain_lds_bytes<32>())) return rc;
+        if (int rc = set_lds(k_chain_group<64, false>, chain_lds_bytes<64>())) return rc;
+        if (int rc = set_lds(k_chain_group<64, true>, chain_lds_bytes<64>())) return rc;
+        if (int rc = set_lds(k_chain_group<128, false>, chain_lds_bytes<128>())) return rc;
+        if (int rc = set_lds(k_chain_group<128, true>, chain_lds_bytes<128>())) return rc;
         if (int rc = set_lds(k_chain_fb_group<32, false>, chain_lds_bytes<32>())) return rc;
         if (int rc = set_lds(k_chain_fb_group<32, true>, chain_lds_bytes<32>())) return rc;
         if (int rc = set_lds(k_chain_fb_group<64, false>, chain_lds_bytes<64>())) return rc;
@@ -1251,6 +1320,7 @@ int cs_mlp_group_create(cs_mlp_group_t** out, cs_mlp_t* const* members, int32_t 
 void cs_mlp_group_destroy(cs_mlp_group_t* g) {
     if (!g) return;
     if (g->pairs_dev) (void)hipFree(g->pairs_dev);
+    if (g->eval_dev) (void)hipFree(g->eval_dev);
     if (g->wg_dev) (void)hipFree(g->wg_dev);
     if (g->opt_dev) (void)hipFree(g->opt_dev);
     delete g;
@@ -1278,6 +1348,7 @@ int cs_mlp_group_train_step(cs_mlp_group_t* g, const float* const* x_dev, const 
         total_rows += round_up(n[i], 128);
     }
     if (na == 0) return CS_OK;
+    if (int rc = group_sync_members(g, st)) return rc;
     bool tables_stale = false;
     for (int a = 0; a < na; ++a) {
         cs_mlp* h = g->m[(size_t)act[a]];
@@ -1329,7 +1400,7 @@ int cs_mlp_group_train_step(cs_mlp_group_t* g, const float* const* x_dev, const 
         tab.idx[a] = i;
         tab.begin[a + 1] = tab.begin[a] + (int)(round_up(n[i], 128) / bm);
         float* slot = h->loss_ring + LOSS_STRIPES * LOSS_STRIPE_FLOATS * h->loss_cur;
-        dyn.d[a] = ChainDyn{x_dev[i], y_dev[i], row_idx_dev ? row_idx_dev[i] : nullptr, slot, n[i], normalise};
+        dyn.d[a] = ChainDyn{x_dev[i], y_dev[i], row_idx_dev ? row_idx_dev[i] : nullptr, slot, n[i], normalise, nullptr};
         h->opt_loss_src = slot; h->opt_loss_dst = loss_dev + 2 * i;
         h->opt_loss_zero = h->loss_ring + LOSS_STRIPES * LOSS_STRIPE_FLOATS * (h->loss_cur ^ 1);
         h->loss_cur ^= 1;
@@ -1384,6 +1455,58 @@ int cs_mlp_group_train_step(cs_mlp_group_t* g, const float* const* x_dev, const 
     return CS_OK;
 }
 
+int cs_mlp_group_forward(cs_mlp_group_t* g, const float* const* x_dev, const int64_t* const* row_idx_dev, const int64_t* n, int normalise,
+                         float* const* yhat_dev, const float* const* y_dev, float* loss_dev, int accumulate, void* stream) {
+    if (!g || !x_dev || !n) return fail(CS_ERR_INVALID, "null argument");
+    if (y_dev && !loss_dev) return fail(CS_ERR_INVALID, "targets given without loss_dev");
+    const int k = (int)g->m.size();
+    hipStream_t st = (hipStream_t)stream;
+    int act[CS_GROUP_MAX], na = 0;
+    int64_t total_rows = 0;
+    for (int i = 0; i < k; ++i) {
+        if (n[i] == 0) continue;
+        cs_mlp* h = g->m[(size_t)i];
+        if (int rc = check_batch(h, n[i])) return rc;
+        if (!x_dev[i]) return fail(CS_ERR_INVALID, "member %d: x_dev missing", i);
+        if (normalise && !h->have_norm) return fail(CS_ERR_STATE, "member %d: normalise requested before cs_mlp_set_norm", i);
+        if (g->wide && n[i] > h->chainw_max_n) return fail(CS_ERR_INVALID, "member %d: batch above the wide chain's limit", i);
+        act[na++] = i;
+        total_rows += round_up(n[i], 128);
+    }
+    if (na == 0) return CS_OK;
+    if (int rc = group_sync_members(g, st)) return rc;
+    if (y_dev && !accumulate) HIP_TRY(hipMemsetAsync(loss_dev, 0, sizeof(float) * 2 * k, st));
+    const int bm = group_bm(g, total_rows);
+    GroupTable tab{};
+    ChainDynTable dyn{};
+    tab.k = na;
+    for (int a = 0; a < na; ++a) {
+        const int i = act[a];
+        tab.idx[a] = i;
+        tab.begin[a + 1] = tab.begin[a] + (int)(round_up(n[i], 128) / bm);
+        const float* yi = y_dev ? y_dev[i] : nullptr;
+        dyn.d[a] = ChainDyn{x_dev[i], yi, row_idx_dev ? row_idx_dev[i] : nullptr, yi ? loss_dev + 2 * i : nullptr, n[i], normalise,
+                            yhat_dev ? yhat_dev[i] : nullptr};
+    }
+    {
+        ProfScope ps(CS_K_CHAIN_FWD, st);
+        const dim3 grid((unsigned)tab.begin[na]);
+        if (g->wide) CS_LAUNCH(k_chainw_group, grid, dim3(512), chainw_lds_bytes(), st, g->eval_dev, tab, dyn);
+        else if (bm == 32) {
+            if (g->elu) CS_LAUNCH((k_chain_group<32, true>), grid, dim3(512), chain_lds_bytes<32>(), st, g->eval_dev, tab, dyn);
+            else CS_LAUNCH((k_chain_group<32, false>), grid, dim3(512), chain_lds_bytes<32>(), st, g->eval_dev, tab, dyn);
+        } else if (bm == 64) {
+            if (g->elu) CS_LAUNCH((k_chain_group<64, true>), grid, dim3(512), chain_lds_bytes<64>(), st, g->eval_dev, tab, dyn);
+            else CS_LAUNCH((k_chain_group<64, false>), grid, dim3(512), chain_lds_bytes<64>(), st, g->eval_dev, tab, dyn);
+        } else {
+            if (g->elu) CS_LAUNCH((k_chain_group<128, true>), grid, dim3(512), chain_lds_bytes<128>(), st, g->eval_dev, tab, dyn);
+            else CS_LAUNCH((k_chain_group<128, false>), grid, dim3(512), chain_lds_bytes<128>(), st, g->eval_dev, tab, dyn);
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    return CS_OK;
+}
+
 int cs_mlp_group_profile_step(cs_mlp_group_t* g, const float* const* x_dev, const float* const* y_dev,
                               const int64_t* const* row_idx_dev, const int64_t* n, int normalise, const float* lr,
                               float* loss_dev, void* stream, cs_kernel_times* out) {
@@ -1423,6 +1546,8 @@ struct RcclApi {
     int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;   // ncclAllReduce
     int (*CommDestroy)(void*) = nullptr;                                              // ncclCommDestroy
     const char* (*GetErrorString)(int) = nullptr;                                     // ncclGetErrorString
+    int (*CommCount)(void*, int*) = nullptr;                                          // ncclCommCount
+    int (*CommUserRank)(void*, int*) = nullptr;                                       // ncclCommUserRank
 };
 RcclApi g_rccl;
 
@@ -1438,6 +1563,8 @@ int rccl_bind(const char* path) {
     a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(dlsym(lib, "ncclAllReduce"));
     a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
     a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+    a.CommCount = reinterpret_cast<decltype(a.CommCount)>(dlsym(lib, "ncclCommCount"));
+    a.CommUserRank = reinterpret_cast<decltype(a.CommUserRank)>(dlsym(lib, "ncclCommUserRank"));
     if (!a.GetUniqueId || !a.CommInitRank || !a.AllReduce || !a.CommDestroy)
         return fail(CS_ERR_STATE, "%s does not export the RCCL entry points", name);
     g_rccl = a;
@@ -1520,6 +1647,14 @@ int cs_dp_allreduce_bf16(cs_dp_t* c, float* buf, int64_t n, void* stream) {
         return rccl_fail("ncclAllReduce", rc);
     hipLaunchKernelGGL(k_dp_unpack_bf16, dim3(grid), dim3(256), 0, st, c->half, buf, n);
     HIP_TRY(hipGetLastError());
+    return CS_OK;
+}
+
+int cs_dp_comm_info(cs_dp_t* c, int* nranks, int* rank) {
+    if (!c || !c->comm || !nranks || !rank) return fail(CS_ERR_INVALID, "bad argument");
+    if (!g_rccl.CommCount || !g_rccl.CommUserRank) return fail(CS_ERR_STATE, "this RCCL exports no ncclCommCount / ncclCommUserRank");
+    if (int rc = g_rccl.CommCount(c->comm, nranks)) return rccl_fail("ncclCommCount", rc);
+    if (int rc = g_rccl.CommUserRank(c->comm, rank)) return rccl_fail("ncclCommUserRank", rc);
     return CS_OK;
 }
 

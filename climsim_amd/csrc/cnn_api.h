@@ -363,7 +363,9 @@ int cs_cnn_create(cs_cnn_t** out, const cs_cnn_cfg* cfg) {
         h->opt_blocks += sg.kind == 0 ? sg.taps * ((sg.cin + 31) / 32) * ((sg.cout + 31) / 32) : (int)((sg.size + 255) / 256);
         sg.blk_begin2 = h->opt_blocks2;
         h->opt_blocks2 += sg.kind == 0 ? sg.taps * ((sg.cin + 31) / 32) : (int)((sg.size + 255) / 256);
-        if (sg.kind == 0) h->opt_pitch = std::max(h->opt_pitch, (int)round_up(sg.cout, 32) + 8);
+        // the strip is copied out as kpd columns per row of the data-gradient pack: kpd may exceed round_up(c_out, 32)
+        // (CS_CNN_FLAG_TILE128 pads channels to 64: 448 against 416 for 406 channels) - the pitch covers both, pad columns stay zero
+        if (sg.kind == 0) h->opt_pitch = std::max(h->opt_pitch, std::max((int)round_up(sg.cout, 32), sg.Wd ? sg.kpd : 0) + 8);
     }
     if (const char* e = getenv("CS_CNN_OPT_TILES")) h->opt_tiles = atoi(e) != 0;
     if (!h->opt_tiles && hipFuncSetAttribute(reinterpret_cast<const void*>(k_cnn_optimizer2), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -334,7 +334,7 @@ __device__ __forceinline__ void cnn_opt_update4(const CnnOptArgs& a, int64_t i, 
 // 832-byte rows), and 64-byte pieces of the forward pack [c_out][tap*kpf + c_in]; the workgroup -> strip map gives every XCD a
 // contiguous run of strips so that the two halves of a forward-pack line meet in one L2.
 __global__ __launch_bounds__(256) void k_cnn_optimizer2(const CnnOptArgs a, int pitch) {
-    extern __shared__ __attribute__((aligned(16))) u16 strip[];            // [32][pitch], pitch = round_up(c_out, 32) + 8
+    extern __shared__ __attribute__((aligned(16))) u16 strip[];            // [32][pitch], pitch = max(round_up(c_out, 32), kpd) + 8
     const int tid = threadIdx.x;
     const int work = xcd_work_id(blockIdx.x, gridDim.x);
     int lo = 0, hi = a.n_seg - 1;

@@ -6,13 +6,13 @@
 // Why: one CU cannot pull the 4.65 MB of both weight sets through its vector-memory path in less than ~40 us (measured 80 us for
 // the whole fused chain, flat from 1024 to 8192 columns: DESIGN.md section 4 "Round 2").  With C members per tile a CU
 // streams 1/C of that; what it costs is one all-gather among the C members per layer.  Measured for exactly this pattern
-// (tests/handoff_probe.hip, profiles/r02_handoff_probe.txt): 1.7-1.9 us per layer boundary.  13 boundaries per step.
+// (tools/handoff_probe.hip, profiles/r02_handoff_probe.txt): 1.7-1.9 us per layer boundary.  13 boundaries per step.
 //
 // Protocol per stage (MI355X_MICROARCH.md "inter-workgroup visibility", form R1; placement-independent):
 //   producer: the slice is stored WRITE-THROUGH (global_store ... sc1), every storing wave drains (s_waitcnt vmcnt(0)),
 //             workgroup barrier, ONE lane stores the step's epoch into the member's flag word of the stage (agent scope);
 //   consumer: lane m of wave 0 polls member m's flag (relaxed agent loads, s_sleep, BOUNDED: on a time-out the error word is
-//             set and the kernel runs on - a wrong result that the host reports, never a hang), barrier, then the other
+//             counted and the kernel runs on - a wrong result that the host reports on its NEXT call, never a hang), barrier, then the other
 //             members' slices are read with sc1 loads (they bypass this CU's L1, which another CU's stores never refresh).
 // Epochs are monotonic (no flag is ever cleared inside a launch); the host clears them when the launch shape changes.  Members of a tile get consecutive work ids, i.e. sit on one XCD (speed only).
 //
@@ -32,7 +32,7 @@
 
 #define COOP_RED_PITCH 36                                   // floats per row of a wave's 32 x 32 partial tile (conflict-free b128 writes)
 #define COOP_RED_FLOATS (8 * 32 * COOP_RED_PITCH)
-#define COOP_SPIN_LIMIT (1 << 21)
+#define COOP_SPIN_LIMIT (1 << 21)                           // default bound of a wait (CoopArgs.spin_limit; CS_COOP_SPIN_LIMIT overrides: tests)
 
 struct CoopArgs {
     int C;                       // members per row tile: 2, 4 or 8
@@ -40,7 +40,9 @@ struct CoopArgs {
     unsigned* arrive;            // [tiles] roll-call counters (monotonic: C arrivals per step)
     unsigned* flags;             // [tiles][2 * CHAIN_MAX_STAGES][8] per-member arrival flags: the epoch of the last step that published
     unsigned* xcc_mask;          // [tiles] OR of (1 << XCC_ID) of the members that ever worked on the tile
-    unsigned* error;             // set to 1 when a bounded wait ran out
+    unsigned* error;             // HOST-MAPPED word (hipHostMalloc): counts the bounded waits that ran out; system-scope atomic, so the
+                                 // host sees it without a copy or a synchronisation (cs_mlp_* calls test it on entry, cs_mlp_check at a sync)
+    int spin_limit;              // polls before a wait gives up
     int warm;                    // development (CS_COOP_WARM): 4 = take the write-through (sc1) path even when the members share an XCD
     unsigned long long* dbg;     // development (CS_CHAIN_DBG): [workgroup][128] s_memtime stamps, null in production
 };
@@ -111,7 +113,7 @@ __device__ __forceinline__ void coop_exchange(const CoopArgs& co, int tile, int 
             if (lane == 0) {
                 int spins = 0;
                 while ((int)(__hip_atomic_load(flags + mslot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - co.epoch) < 0) {
-                    if (++spins > COOP_SPIN_LIMIT) { __hip_atomic_store(co.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                    if (++spins > co.spin_limit) { __hip_atomic_fetch_add(co.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
                     __builtin_amdgcn_s_sleep(1);
                 }
             }
@@ -331,7 +333,7 @@ __global__ __launch_bounds__(512) void k_chain_coop_fb(const ChainArgs pf, const
         const unsigned want = co.epoch * (unsigned)C;
         int spins = 0;
         while ((int)(__hip_atomic_load(roll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
-            if (++spins > COOP_SPIN_LIMIT) { __hip_atomic_store(co.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            if (++spins > co.spin_limit) { __hip_atomic_fetch_add(co.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
             __builtin_amdgcn_s_sleep(1);
         }
         const unsigned mask = __hip_atomic_load(co.xcc_mask + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -67,6 +67,12 @@ class RcclComm:
         fn = self._lib.cs_dp_allreduce_bf16 if payload == "bf16" else self._lib.cs_dp_allreduce
         self._check(fn(self._c, self._C.c_void_p(tensor.data_ptr()), tensor.numel(), st))
 
+    def info(self):
+        """(nranks, rank) as RCCL reports them for this communicator (ncclCommCount / ncclCommUserRank)."""
+        n, r = self._C.c_int(-1), self._C.c_int(-1)
+        self._check(self._lib.cs_dp_comm_info(self._c, self._C.byref(n), self._C.byref(r)))
+        return int(n.value), int(r.value)
+
     def close(self):
         if getattr(self, "_c", None) is not None and self._c.value:
             self._lib.cs_dp_destroy(self._c)

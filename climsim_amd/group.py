@@ -88,6 +88,43 @@ class MLPGroup:
                 m.iterations += 1
         return loss
 
+    def forward_batch(self, x, yhat=None, y=None, row_idx=None, n=None, normalise: bool = False, loss=None, accumulate: bool = False,
+                      active=None):
+        """Prediction / evaluation of every (active) member on one batch in ONE launch (cs_mlp_group_forward).  `x`, `y`,
+        `row_idx`, `yhat`: one tensor for all members or a list with one entry per member (a shared `yhat` tensor would be
+        written by every member: pass a list, or a (k, n, n_out) tensor).  With `y`, the (k, 2) tensor `loss` receives
+        [sum sq err, sum abs err] per member (added to when `accumulate`)."""
+        import torch
+        k = self.k
+        if yhat is not None and not isinstance(yhat, (list, tuple)):
+            if yhat.ndim != 3 or yhat.shape[0] != k:
+                raise ValueError("yhat must be a list of k tensors or one (k, n, n_out) tensor")
+            yhat = [yhat[i] for i in range(k)]
+        loss = self._loss if (loss is None and y is not None) else loss
+        ax, ay, ai, an, _, act = self._args(x, y, 0.0, row_idx, n, active)
+        P = C.c_void_p
+        ah = (P * k)(*[t.data_ptr() if t is not None else None for t in yhat]) if yhat is not None else None
+        st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        _lib.check(self.lib.cs_mlp_group_forward(self._g, ax, ai, an, int(normalise), ah, ay if y is not None else None,
+                                                 C.c_void_p(loss.data_ptr()) if loss is not None else None, int(accumulate), st))
+        return loss
+
+    def evaluate(self, x, y, batch_size: Optional[int] = None, normalise: bool = False):
+        """model.evaluate of every member on the same held-out split, one launch per batch for the whole group:
+        [{'loss', 'mse', 'mae'}] per member (loss = mse; a member trained with 'mae' / 'huber' reports that loss in 'loss')."""
+        import torch
+        bs = min(batch_size or min(m.max_batch for m in self.models), min(m.max_batch for m in self.models))
+        tot = torch.zeros((self.k, 2), dtype=torch.float32, device=self.device)
+        for i, lo in enumerate(range(0, x.shape[0], bs)):
+            hi = min(lo + bs, x.shape[0])
+            self.forward_batch(x[lo:hi], y=y[lo:hi], normalise=normalise, loss=tot, accumulate=i > 0)
+        s = tot.cpu().numpy().astype("float64")
+        out = []
+        for i, m in enumerate(self.models):
+            d = s[i] / (m.output_length * x.shape[0])
+            out.append({"loss": float(d[0]), "mse": float(d[0]), "mae": float(d[1])})
+        return out
+
     def profile_step(self, x, y, lrs, row_idx=None, n=None, normalise: bool = False, active=None):
         """One grouped step with an event pair around each of its launches: {kind: (milliseconds, launches)}."""
         import torch

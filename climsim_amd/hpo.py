@@ -106,16 +106,20 @@ class TrialPool:
                             for j, (k, a) in enumerate(zip(members, live)):
                                 if a:
                                     ep_sum[k] += out[j]
-            bucket_of = {k: b for b, members in enumerate(self.buckets) for k in members}
-            for k, m in enumerate(self.models):
-                with torch.cuda.stream(self.streams[bucket_of[k]]):
+            # epoch end: validation pass (the reference runs `validation_data` every epoch for every trial,
+            # hpo_baseline_v1.py:139-150) - ONE launch per batch for a whole bucket (cs_mlp_group_forward), like the steps
+            for b, (members, grp) in enumerate(zip(self.buckets, self.groups)):
+                with torch.cuda.stream(self.streams[b]):
                     if val is not None:
-                        ev = m.evaluate(val[0], val[1])
-                        hist[k]["val_loss"].append(ev["loss"])
-                        hist[k]["val_mae"].append(ev["mae"])
-                    tr = ep_sum[k].cpu().numpy().astype(np.float64) / (m.output_length * bss[k] * steps[k])
-                    hist[k]["loss"].append(float(tr[0]))
-                    hist[k]["mae"].append(float(tr[1]))
+                        evs = grp.evaluate(val[0], val[1]) if grp is not None else [self.models[members[0]].evaluate(val[0], val[1])]
+                        for k, ev in zip(members, evs):
+                            hist[k]["val_loss"].append(ev["loss"])
+                            hist[k]["val_mae"].append(ev["mae"])
+                    for k in members:
+                        m = self.models[k]
+                        tr = ep_sum[k].cpu().numpy().astype(np.float64) / (m.output_length * bss[k] * steps[k])
+                        hist[k]["loss"].append(float(tr[0]))
+                        hist[k]["mae"].append(float(tr[1]))
             for s in self.streams:
                 cur.wait_stream(s)
             if verbose:

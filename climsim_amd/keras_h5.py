@@ -6,15 +6,16 @@ The reference checkpoints with `keras.callbacks.ModelCheckpoint(filepath=...h5, 
 step2_lot-147_trial_0027.best.h5`.  Such a file is HDF5 written by h5py in Keras' "legacy H5" layout:
 
     /  (attrs keras_version, backend, model_config, training_config)
-    /model_weights             attrs layer_names = [b'input_1', b'dense', b'leaky_re_lu', ...]   (creation order)
+    /model_weights             attrs layer_names = [b'input', b'dense', b'leaky_re_lu', ...]   (creation order)
     /model_weights/<layer>     attrs weight_names = [b'<layer>/kernel:0', b'<layer>/bias:0'] (empty for weight-less layers)
     /model_weights/<layer>/<layer>/kernel:0 (in, out) float32,  bias:0 (out,) float32
     /optimizer_weights/...
 
 (`model.save_weights(x.h5)` writes the content of /model_weights at the root.)  `load_keras_h5` returns the weight list in
 the order Keras' `model.get_weights()` has - the order `MLPEmulator.set_weights` takes - by following `layer_names` and
-`weight_names`; `save_keras_h5` writes that layout for the layer sequence of `step2_retrain.build_model` (:95-126) with
-Keras' automatic layer names, so `model.load_weights(path)` of a reference-built model finds every tensor where it looks
+`weight_names`; `save_keras_h5` writes that layout for the layer sequence of `step2_retrain.build_model` (:95-128): the
+input layer 'input' and the model name 'retrained_model' as the reference names them, Keras' automatic names for every other
+layer, so `model.load_weights(path)` of a reference-built model finds every tensor where it looks
 (keras/saving/legacy/hdf5_format.py `load_weights_from_hdf5_group`: layers with weights are matched in order, tensors by
 `weight_names`).  Pinned by files the HDF5 C library wrote in this layout (tests/golden/hdf5/make_keras_h5_fixture.c) and by
 reading our own files back with `h5dump`; NOT verified against a running Keras (TensorFlow is not installable here).
@@ -32,6 +33,12 @@ _ACT_LAYER = {"relu": "re_lu", "elu": "elu", "leakyrelu": "leaky_re_lu"}
 _ACT_CLASS = {"relu": "ReLU", "elu": "ELU", "leakyrelu": "LeakyReLU"}
 
 
+# step2_retrain.build_model names exactly two things itself: `keras.layers.Input(..., name='input')` (:96) and
+# `keras.Model(..., name='retrained_model')` (:128); every other layer gets Keras' automatic name.
+INPUT_LAYER = "input"
+MODEL_NAME = "retrained_model"
+
+
 def _numbered(base: str, i: int) -> str:
     return base if i == 0 else f"{base}_{i}"
 
@@ -40,7 +47,7 @@ def keras_layer_sequence(n_hidden: int, activation: str):
     """[(layer name, has weights)] in creation order for build_model (step2_retrain.py:95-126): Input, n_hidden x (Dense,
     activation), Dense(output_length), activation, Dense(n_lin), Dense(n_relu, relu), Concatenate."""
     act = _ACT_LAYER[activation]
-    seq = [("input_1", False)]
+    seq = [(INPUT_LAYER, False)]
     for i in range(n_hidden + 1):
         seq += [(_numbered("dense", i), True), (_numbered(act, i), False)]
     seq += [(_numbered("dense", n_hidden + 1), True), (_numbered("dense", n_hidden + 2), True), ("concatenate", False)]
@@ -53,9 +60,9 @@ def model_config_json(weights: Sequence[np.ndarray], activation: str, alpha: flo
     n_hidden = len(weights) // 2 - 3
     seq = keras_layer_sequence(n_hidden, activation)
     n_in = int(weights[0].shape[0])
-    layers = [{"class_name": "InputLayer", "name": "input_1", "inbound_nodes": [],
-               "config": {"batch_input_shape": [None, n_in], "dtype": "float32", "sparse": False, "ragged": False, "name": "input_1"}}]
-    prev, wi = "input_1", 0
+    layers = [{"class_name": "InputLayer", "name": INPUT_LAYER, "inbound_nodes": [],
+               "config": {"batch_input_shape": [None, n_in], "dtype": "float32", "sparse": False, "ragged": False, "name": INPUT_LAYER}}]
+    prev, wi = INPUT_LAYER, 0
     dense_names = [n for n, w in seq if w]
     for name, has_w in seq[1:-3]:
         if has_w:
@@ -75,7 +82,7 @@ def model_config_json(weights: Sequence[np.ndarray], activation: str, alpha: flo
                        "config": {"name": name, "trainable": True, "dtype": "float32", "units": int(w.shape[1]), "activation": act_name, "use_bias": True}})
     layers.append({"class_name": "Concatenate", "name": "concatenate", "config": {"name": "concatenate", "trainable": True, "dtype": "float32", "axis": -1},
                    "inbound_nodes": [[[lin, 0, 0, {}], [rel, 0, 0, {}]]]})
-    return json.dumps({"class_name": "Functional", "config": {"name": "model", "layers": layers, "input_layers": [["input_1", 0, 0]],
+    return json.dumps({"class_name": "Functional", "config": {"name": MODEL_NAME, "layers": layers, "input_layers": [[INPUT_LAYER, 0, 0]],
                                                               "output_layers": [["concatenate", 0, 0]]}})
 
 
@@ -84,7 +91,12 @@ def save_keras_h5(path: str, weights: Sequence[np.ndarray], activation: str = "l
     """Write `weights` (Keras order [W0, b0, ..., W_lin, b_lin, W_relu, b_relu], kernels (in, out)) in Keras' legacy-H5 layout.
     `full_model`: the layout of `model.save(path)` (root attrs + /model_weights), else that of `model.save_weights(path)`.
     `optimizer_state` = {'m': [...], 'v': [...], 'iterations': int} goes to /optimizer_weights/climsim_amd (this package's own
-    slot layout; Keras ignores it when it loads weights)."""
+    slot layout; Keras ignores it when it loads weights).
+    Intended compatibility: `model.load_weights(path)` on a model built by the reference's `build_model`.  NOT supported:
+    resuming through `keras.models.load_model(path)` (the reference's sw_continue branch, step2_retrain.py:134-136) - the
+    `model_config` JSON is unverified against Keras and the optimiser slots are not in Keras' `optimizer_weights` naming
+    ('Adam/dense/kernel/m:0', ..., 'iter'), so a Keras resume would start Adam from zero.  Resume with this package instead
+    (`MLPEmulator.load_weights` restores weights, both moments and the iteration count)."""
     if len(weights) < 8 or len(weights) % 2:
         raise ValueError("expected the Keras weight list of the baseline MLP: >= 1 hidden layer, the 128-wide layer and two heads")
     n_hidden = len(weights) // 2 - 3

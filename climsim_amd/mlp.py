@@ -85,9 +85,12 @@ class MLPEmulator:
                  direct_head: bool = False, loss: str = "mse", output_keep=None, cooperative: bool = False):
         """`direct_head`, `loss` ('mse' | 'mae' | 'huber'), `output_keep` (1/0 per output column) and optimizer
         'AdamTorch' are the pieces of the online-testing MLP (climsim_amd/online_mlp.py); the baseline models leave
-        them at their defaults.  `cooperative`: training steps of up to 4096 columns split every 32-row tile over 8 / 4 / 2
-        workgroups (CS_FLAG_COOP, csrc/coop.h: 1.4x at batch 1024) - only when this process is the one user of the GPU
-        for such launches (the workgroups of a cooperative launch wait for one another)."""
+        them at their defaults.  `cooperative`: training steps of up to 2048 columns split every 32-row tile over 8 / 4
+        workgroups (CS_FLAG_COOP, csrc/coop.h: 1.3x at batch 1024) - only when this process is the one user of the GPU
+        while such launches run (their workgroups wait for one another; a side-stream kernel or a second process can starve
+        them).  Opt-in for that reason: a library cannot know that it owns the device.  A wait that runs out is counted by
+        the kernel in host-mapped memory: every later call on the model raises EngineError, `check()` forces the test
+        behind a synchronisation (fit() calls it at the end of every epoch), `coop_timeouts` reads the counter."""
         torch = _torch()
         if not torch.cuda.is_available():
             raise _lib.EngineError("MLPEmulator needs a ROCm GPU (no CPU fallback)")
@@ -103,6 +106,7 @@ class MLPEmulator:
             flags |= _lib.FLAG_DIRECT_HEAD
         if cooperative:
             flags |= _lib.CS_FLAG_COOP
+        self.cooperative = bool(cooperative)
         self.units = tuple(int(u) for u in units)
         self.activation, self.optimizer_name = activation, optimizer
         self.input_length, self.output_length = input_length, output_length_lin + output_length_relu
@@ -146,6 +150,16 @@ class MLPEmulator:
 
     def _stream(self):
         return C.c_void_p(_torch().cuda.current_stream(self.device).cuda_stream)
+
+    def check(self):
+        """Synchronise the current stream and raise EngineError if a cooperative launch (CS_FLAG_COOP) has timed out
+        since the model was built - everything computed since then, optimiser state included, is invalid (cs_mlp_check)."""
+        _lib.check(self.lib.cs_mlp_check(self._h, self._stream()))
+
+    @property
+    def coop_timeouts(self) -> int:
+        """Bounded waits of cooperative launches that ran out so far (0 for a healthy model; no synchronisation)."""
+        return int(self.lib.cs_mlp_coop_timeouts(self._h))
 
     # ---- weights
     def count_params(self) -> int:
@@ -367,6 +381,8 @@ class MLPEmulator:
                 _lib.check(self.lib.cs_categorical_accuracy(_ptr(yhat), _ptr(y[lo:hi]), hi - lo, self.output_length,
                                                             _ptr(hits), 1, self._stream()))
         s = tot.cpu().numpy().astype(np.float64) / (self.output_length * x.shape[0])
+        if self.cooperative:
+            self.check()                 # the copy above synchronised: a time-out of an earlier training step surfaces here
         out = {"loss": float(s[0]), "mse": float(s[0]), "mae": float(s[1])}
         if accuracy:
             out["accuracy"] = float(hits.item()) / x.shape[0]
@@ -450,6 +466,8 @@ class MLPEmulator:
                 if distributed:
                     dist.all_reduce(epoch_sum)
                 tr = epoch_sum.cpu().numpy().astype(np.float64) / (self.output_length * batch_size * steps)
+                if self.cooperative:
+                    self.check()         # a cooperative launch that timed out during the epoch fails the epoch, not the next checkpoint
                 row = {"loss": float(tr[0]), "mse": float(tr[0]), "mae": float(tr[1]), "lr": float(lr)}
                 if val is not None:
                     ev = self.evaluate(val[0], val[1], normalise=normalise, accuracy=True)

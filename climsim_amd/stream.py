@@ -29,6 +29,10 @@ class StreamedTrainer:
             raise ValueError("need at least two chunk slots (one being produced while one is consumed)")
         if batch_size > model.max_batch:
             raise ValueError(f"batch {batch_size} exceeds the engine's max_batch {model.max_batch}")
+        if getattr(model, "cooperative", False):
+            # the loader kernel on the side stream occupies compute units while the step runs: a cooperative launch
+            # (CS_FLAG_COOP), whose workgroups wait for one another, could be starved into a time-out
+            raise ValueError("StreamedTrainer drives a side stream: build the model with cooperative=False")
         self.torch, self.model, self.loader, self.batch, self.slots = torch, model, loader, int(batch_size), int(slots)
         self.device = model.device
         self.side = torch.cuda.Stream(device=self.device)

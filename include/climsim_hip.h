@@ -76,7 +76,10 @@ typedef struct cs_mlp_cfg {
                                     * 8 / 4 / 2 workgroups that exchange layer outputs inside the launch (1.4x at 1024 columns).  The
                                     * workgroups of such a launch wait for one another, so it needs every one of them resident: the caller
                                     * guarantees that NO OTHER cooperative launch (another stream, another process) runs on the device
-                                    * at the same time.  A wait that runs out sets an error that cs_mlp_get_weights / get_grads report. */
+                                    * at the same time - and no other kernel that occupies compute units (a side-stream loader).  A wait
+                                    * that runs out is COUNTED in host-mapped memory and the kernel runs on (never a hang): every later
+                                    * cs_mlp_* compute call on the handle fails with CS_ERR_STATE as soon as the host sees the count,
+                                    * cs_mlp_check() forces the test behind a stream synchronisation.  The error is sticky. */
 #define CS_FLAG_NO_CHAIN_FB 256    /* forward and backward chain as two launches (default: one launch on 32-row tiles)  */
 #define CS_FLAG_CHAIN_BWD32_ON_FWD64 32   /* tests: 64-row forward tiles (with CHAIN_BM64), 32-row backward tiles    */
 
@@ -146,6 +149,14 @@ int cs_mlp_apply(cs_mlp_t* h, float lr, float grad_scale, void* stream);
 /* Model.train_step: loss_grads + apply(lr, 1/(128 n)). */
 int cs_mlp_train_step(cs_mlp_t* h, const float* x_dev, const float* y_dev, const int64_t* row_idx_dev,
                       int64_t n, int normalise, float lr, float* loss_dev, void* stream);
+
+/* Cooperative-chain health (CS_FLAG_COOP; the counterpart of nothing in Keras - a safety net of this engine):
+ * cs_mlp_check synchronises `stream` and returns CS_ERR_STATE if any bounded wait of a cooperative launch has run out
+ * since the handle was created (the results since then, optimiser state included, are invalid); call it where the host
+ * synchronises anyway (end of an epoch, end of a timed block, before a checkpoint).  cs_mlp_coop_timeouts reads the
+ * counter without synchronising (0 for a healthy handle and for handles without the cooperative chain). */
+int cs_mlp_check(cs_mlp_t* h, void* stream);
+int64_t cs_mlp_coop_timeouts(const cs_mlp_t* h);
 
 /* Diagnostics: bytes of device memory held by the handle. */
 int64_t cs_mlp_device_bytes(const cs_mlp_t* h);
@@ -223,6 +234,15 @@ int32_t cs_mlp_group_size(const cs_mlp_group_t* g);
 int cs_mlp_group_train_step(cs_mlp_group_t* g, const float* const* x_dev, const float* const* y_dev,
                             const int64_t* const* row_idx_dev, const int64_t* n, int normalise, const float* lr,
                             float* loss_dev, void* stream);
+/* model.predict / model.evaluate of every member i with n[i] > 0 in ONE launch (the validation pass of model.fit: the
+ * reference runs `validation_data` every epoch for every trial, hpo_baseline_v1.py:139-150, 223-245).  Arguments as
+ * cs_mlp_forward, one entry per member: yhat_dev[i] (n[i], n_out) float32 or NULL (the array itself may be NULL), y_dev[i]
+ * targets or NULL (the array may be NULL); with targets, loss_dev[2 i] += sum (yhat-y)^2 (or the member's loss terms),
+ * loss_dev[2 i + 1] += sum |yhat-y|; loss_dev (k x 2 floats) is zeroed first unless accumulate != 0.  Members built after a
+ * later cs_mlp_set_head_options are picked up; a member moved to another kernel family fails the call (CS_ERR_STATE). */
+int cs_mlp_group_forward(cs_mlp_group_t* g, const float* const* x_dev, const int64_t* const* row_idx_dev, const int64_t* n,
+                         int normalise, float* const* yhat_dev, const float* const* y_dev, float* loss_dev, int accumulate,
+                         void* stream);
 /* cs_mlp_profile_step for a group: event pairs around the three launches. */
 int cs_mlp_group_profile_step(cs_mlp_group_t* g, const float* const* x_dev, const float* const* y_dev,
                               const int64_t* const* row_idx_dev, const int64_t* n, int normalise, const float* lr,
@@ -308,6 +328,9 @@ int  cs_dp_allreduce(cs_dp_t* comm, float* buf_dev, int64_t n_floats, void* stre
  * the reference reduces float32 (train_mlp_h5loader.py:195-207); the reduced sums carry bf16 rounding (2^-9 relative per
  * hop), every rank still receives the SAME buffer.  buf_dev must be 16-byte aligned. */
 int  cs_dp_allreduce_bf16(cs_dp_t* comm, float* buf_dev, int64_t n_floats, void* stream);
+/* What RCCL itself says about the communicator: ncclCommCount / ncclCommUserRank (bench.py prints them beside the
+ * launcher's WORLD_SIZE, so a scaling figure cannot come from a group of the wrong size). */
+int  cs_dp_comm_info(cs_dp_t* comm, int* nranks, int* rank);
 void cs_dp_destroy(cs_dp_t* comm);
 
 const char* cs_last_error(void);

@@ -248,18 +248,20 @@ def test_cnn_kernel_families_agree(CNN):
         assert c >= 0.999 and abs(ratio - 1) <= 1e-2, (i, c, ratio)
 
 
-@pytest.mark.parametrize("depth,width", [(2, 406), (2, 64), (1, 200)])
-def test_cnn_optimizer_forms_agree(CNN, depth, width, monkeypatch):
+@pytest.mark.parametrize("depth,width,tile128", [(2, 406, False), (2, 64, False), (1, 200, False), (2, 406, True)])
+def test_cnn_optimizer_forms_agree(CNN, depth, width, tile128, monkeypatch):
     """k_cnn_optimizer2 (strips of one tap x 32 c_in x all c_out: the form that runs) against k_cnn_optimizer (32 x 32 tiles,
     CS_CNN_OPT_TILES=1): the same per-element arithmetic, so weights, Adam slots (through a second step) and both bf16 operand
-    packs (through predictions and the next step's gradients) must come out bit-identical, pad rows and columns included."""
+    packs (through predictions and the next step's gradients) must come out bit-identical, pad rows and columns included.
+    `tile128` (CS_CNN_FLAG_TILE128): channels padded to 64, so a row of the data-gradient pack (448 columns for 406 channels) is
+    wider than round_up(c_out, 32) - the strip's pitch must cover it (round-2 advisor finding)."""
     n = 8
     ws = CO.glorot_cnn(seed=9, bias_scale=0.05, depth=depth, channels=width)
     x3, y3 = make_xy(n, 12)
     res = []
     for tiles in ("1", "0"):
         monkeypatch.setenv("CS_CNN_OPT_TILES", tiles)
-        m = CNN.CNNEmulator(depth=depth, channel_width=width, max_batch=16, trainable=True, loss="mse", dropout=0.0, seed=3)
+        m = CNN.CNNEmulator(depth=depth, channel_width=width, max_batch=16, trainable=True, loss="mse", dropout=0.0, seed=3, tile128=tile128)
         m.set_weights(ws)
         p0 = m.predict(x3)                                    # packs written by the recast-only pass
         g = m.gradient_tensor()

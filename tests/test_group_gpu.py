@@ -23,6 +23,12 @@ def G():
     return group, mlp
 
 
+# Round 3: the bars of the solo tests (tests/test_mlp_gpu.py holds weight movement to 2e-2 and measures 2.7e-3; round 2 left
+# 5e-2 / 2e-2 here).  Measured on the GPU box for these cases: see profiles/r03_test_margins.txt.
+MOVE_TOL = 2e-2
+CURVE_TOL = 1e-2
+
+
 def rel(a, b):
     return float(np.linalg.norm(np.asarray(a, np.float64) - np.asarray(b, np.float64)) / (np.linalg.norm(b) + 1e-30))
 
@@ -67,12 +73,12 @@ def run_case(G, specs, steps, skip=None):
             curves_r[i].append(l)
     for i, m in enumerate(members):
         assert m.iterations == len(curves_r[i])
-        np.testing.assert_allclose(curves_g[i], curves_r[i], rtol=2e-2, err_msg=f"member {i}")
+        np.testing.assert_allclose(curves_g[i], curves_r[i], rtol=CURVE_TOL, err_msg=f"member {i}")
         assert curves_g[i][0] == pytest.approx(curves_r[i][0], rel=2e-3)           # first step: same weights on both sides
         w0 = O.glorot_init(cfgs[i], 3 + i)
         for a, b, z in zip(m.get_weights(), wref[i], w0):
             if z.ndim == 2:                                                            # (biases were re-drawn: compare kernels' movement)
-                assert rel(a - z, b - z) <= 5e-2, (i, rel(a - z, b - z))
+                assert rel(a - z, b - z) <= MOVE_TOL, (i, rel(a - z, b - z))
     g.close()
     for m in members:
         m.close()
@@ -135,3 +141,71 @@ def test_group_equals_solo_engine_run_and_rejects_mixed_families(G):
         with pytest.raises(_lib.EngineError):
             group.MLPGroup(bad)
     assert group.group_by_family([a, wide, c, elu, per_layer]) == [[4], [0, 2], [1], [3]]
+
+
+def test_group_evaluation_is_one_launch_and_matches_solo_and_oracle(G):
+    """cs_mlp_group_forward (round 3): the validation pass of a trial group as ONE launch per batch.  Every member against
+    (a) its own solo evaluate / predict - same kernel bodies, so losses to float-atomics order and predictions bit-identical -
+    and (b) the bf16-emulating oracle forward (2e-3 of max |ref|, as tests/test_mlp_gpu.py).  Ragged row counts, members
+    sitting out, several batches accumulated."""
+    group, mlp = G
+    specs = [((512, 512), "leakyrelu"), ((128, 256, 512), "relu"), ((256,), "leakyrelu")]
+    members, cfgs, wss = [], [], []
+    for i, (units, act) in enumerate(specs):
+        m, cfg, ws = make_member(mlp, units, act, "Adam", seed=61 + i, max_batch=1024)
+        members.append(m); cfgs.append(cfg); wss.append(ws)
+    g = group.MLPGroup(members)
+    x, y = O.synth_columns(2500, seed=71)                            # 3 batches of 1024: the last one ragged (452 rows)
+    xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    evs = g.evaluate(xd, yd)
+    for m, cfg, ws, ev in zip(members, cfgs, wss, evs):
+        solo = m.evaluate(x, y)
+        assert ev["mse"] == pytest.approx(solo["mse"], rel=1e-5) and ev["mae"] == pytest.approx(solo["mae"], rel=1e-5)
+        ref = O.forward(ws, x, cfg, bf16=True)
+        assert ev["mse"] == pytest.approx(float(np.mean((ref - y) ** 2)), rel=2e-3)
+    # predictions: a (k, n, 128) tensor, member 1 sits out and its slice must stay untouched
+    n = 700
+    yh = torch.full((3, n, 128), -7.0, device="cuda")
+    g.forward_batch(xd[:n], yhat=yh, active=[True, False, True])
+    assert float(yh[1].min()) == -7.0 and float(yh[1].max()) == -7.0
+    for i in (0, 2):
+        np.testing.assert_array_equal(yh[i].cpu().numpy(), members[i].predict(x[:n]))
+        ref = O.forward(wss[i], x[:n], cfgs[i], bf16=True)
+        assert np.max(np.abs(yh[i].cpu().numpy() - ref)) <= 2e-3 * np.max(np.abs(ref))
+    g.close()
+    for m in members:
+        m.close()
+
+
+def test_group_follows_head_options_and_refuses_a_member_that_left_its_family(G):
+    """a group snapshots its members' chain arguments.  cs_mlp_set_head_options on a member AFTER the group was
+    made must reach the grouped steps (config generation counter), and cs_mlp_set_dropout - which moves a tuned-chain model
+    to the wide chain - must fail the next grouped call instead of silently training without dropout."""
+    group, mlp = G
+    from climsim_amd import _lib
+    a, cfg_a, ws_a = make_member(mlp, (256, 256), "relu", "SGD", 81, max_batch=512)
+    b, _, _ = make_member(mlp, (128,), "relu", "SGD", 82, max_batch=512)
+    solo, _, _ = make_member(mlp, (256, 256), "relu", "SGD", 81, max_batch=512)
+    g = group.MLPGroup([a, b])
+    x, y = O.synth_columns(512, seed=83)
+    xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    keep = np.ones(128, np.float32)
+    keep[60:75] = 0                                                  # output pruning + mean-absolute-error loss, set AFTER grouping
+    a.set_head_options("mae", keep)
+    solo.set_head_options("mae", keep)
+    lg = g.train_on_batch(xd, yd, [1e-2, 1e-2]).cpu().numpy()
+    ls = solo.train_on_batch(xd, yd, 1e-2).cpu().numpy()
+    np.testing.assert_allclose(lg[0], ls, rtol=1e-4)                # the group used the member's NEW loss and pruning
+    for wa, wb in zip(a.get_weights(), solo.get_weights()):
+        np.testing.assert_allclose(wa, wb, rtol=0, atol=2e-4 * max(1.0, float(np.abs(wb).max())))
+    pg = torch.zeros((2, 512, 128), device="cuda")
+    g.forward_batch(xd, yhat=pg)
+    assert float(pg[0][:, 60:75].abs().max()) == 0.0                # pruned outputs read zero in the grouped prediction too
+    a.set_dropout(0.1, seed=5)                                       # tuned chain -> wide chain: another kernel family
+    with pytest.raises(_lib.EngineError, match="family"):
+        g.train_on_batch(xd, yd, [1e-2, 1e-2])
+    with pytest.raises(_lib.EngineError, match="family"):
+        g.forward_batch(xd, y=yd)
+    g.close()
+    for m in (a, b, solo):
+        m.close()

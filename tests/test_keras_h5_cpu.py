@@ -65,7 +65,8 @@ def test_round_trip_in_creation_order_with_many_layers(tmp_path):
         assert (opt is not None and opt["iterations"] == 7) == full
     cfg = __import__("json").loads(model_config_json(ws, "elu"))
     names = [l["name"] for l in cfg["config"]["layers"]]
-    assert names[0] == "input_1" and names[-1] == "concatenate" and names.count("dense_14") == 1
+    assert names[0] == "input" and names[-1] == "concatenate" and names.count("dense_14") == 1       # step2_retrain.py:96 names the input layer
+    assert cfg["config"]["name"] == "retrained_model"                                                 # step2_retrain.py:128
     with pytest.raises(ValueError):
         save_keras_h5(str(tmp_path / "bad.h5"), ws[:5])
     write_hdf5_tree(str(tmp_path / "plain.h5"), {"data": np.zeros(3, np.float32)})

@@ -10,7 +10,7 @@ pass() {  # name, counters...
   rm -rf /tmp/pmc_$name
   timeout 600 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d /tmp/pmc_$name -- python3 $REPO/bench.py --batch $B --steps 20 --warmup 5 --cpu-budget 0 --no-profile --no-extras --train-only > $REPO/gpurun_out/pmc_$name.log 2>&1
   find /tmp/pmc_$name -name "*counter_collection*" -exec cp {} $REPO/gpurun_out/pmc_${name}_b$B.csv \;
-  python3 $REPO/tests/pmc_summ.py $REPO/gpurun_out/pmc_${name}_b$B.csv
+  python3 $REPO/tools/pmc_summ.py $REPO/gpurun_out/pmc_${name}_b$B.csv
 }
 pass fetch FETCH_SIZE
 pass write WRITE_SIZE

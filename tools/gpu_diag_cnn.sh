@@ -9,7 +9,7 @@ pass() {  # tag, script, counters...
   rm -rf /tmp/pmc_$tag
   timeout 600 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d /tmp/pmc_$tag -- python3 $REPO/$script > $REPO/gpurun_out/pmc_$tag.log 2>&1
   find /tmp/pmc_$tag -name "*counter_collection*" -exec cp {} $REPO/gpurun_out/pmc_$tag.csv \;
-  echo "== $tag"; python3 $REPO/tests/pmc_summ.py $REPO/gpurun_out/pmc_$tag.csv
+  echo "== $tag"; python3 $REPO/tools/pmc_summ.py $REPO/gpurun_out/pmc_$tag.csv
 }
 pass cnn_fetch "bench_cnn.py 512 5" FETCH_SIZE
 pass cnn_write "bench_cnn.py 512 5" WRITE_SIZE

@@ -20,8 +20,8 @@ cd /tmp && rm -rf /tmp/prof && timeout 900 rocprofv3 --kernel-trace --stats --ou
 cd $REPO
 find /tmp/prof -name "*kernel_stats*" -exec cp {} gpurun_out/r02_rocprofv3_kernel_stats_b8192.csv \;
 grep -E "k_|rocclr" gpurun_out/r02_rocprofv3_kernel_stats_b8192.csv | cut -c1-170
-echo "== pmc"; bash tests/gpu_diag.sh 8192 2>&1 | tail -40 > gpurun_out/r02_pmc_mlp_b8192.txt; tail -40 gpurun_out/r02_pmc_mlp_b8192.txt
-python tests/pmc_traffic_json.py 8192 && cp profiles/r02_pmc_hbm_traffic.json gpurun_out/
+echo "== pmc"; bash tools/gpu_diag.sh 8192 2>&1 | tail -40 > gpurun_out/r02_pmc_mlp_b8192.txt; tail -40 gpurun_out/r02_pmc_mlp_b8192.txt
+python tools/pmc_traffic_json.py 8192 && cp profiles/r02_pmc_hbm_traffic.json gpurun_out/
 echo "== side benches"
 timeout 600 python bench_cnn.py 512 20 2>&1 | tail -1 > gpurun_out/r02_cnn_bench_b512.json
 timeout 600 python bench_loader.py 64 21600 2>&1 | tail -1 > gpurun_out/r02_loader_bench_highres.json
