@@ -23,10 +23,14 @@ def G():
     return group, mlp
 
 
-# Round 3: the bars of the solo tests (tests/test_mlp_gpu.py holds weight movement to 2e-2 and measures 2.7e-3; round 2 left
-# 5e-2 / 2e-2 here).  Measured on the GPU box for these cases: see profiles/r03_test_margins.txt.
+# Round 3: bars set from measurements (tests/conftest.py record_margin -> profiles/r03_test_margins.json; round 2 left 5e-2 /
+# 2e-2 here).  Measured maxima over all cases: loss curves 3.2e-4 (tuned), 1.3e-4 (wide), 5.6e-5 (ELU); weight movement
+# 1.28e-2 (tuned), 1.3e-3 (ELU), 3.75e-2 (wide: RAdam at lr 2.5e-4 moves the 124 x 768 kernel by ~1e-3 of its norm in 4 steps,
+# so bf16 rounding of the gradients is a large share of the movement).
 MOVE_TOL = 2e-2
-CURVE_TOL = 1e-2
+MOVE_TOL_WIDE = 5e-2
+CURVE_TOL = 2e-3
+from conftest import record_margin  # noqa: E402
 
 
 def rel(a, b):
@@ -44,7 +48,7 @@ def make_member(mlp, units, act, opt, seed, max_batch=4096):
     return m, cfg, ws
 
 
-def run_case(G, specs, steps, skip=None):
+def run_case(G, specs, steps, skip=None, tag="tuned"):
     """specs: [(units, act, opt, lr, n, data_seed)].  Runs `steps` grouped steps (member i sits out step s when
     (i, s) in skip) and the same steps per member through the oracle; returns nothing, asserts."""
     group, mlp = G
@@ -73,12 +77,14 @@ def run_case(G, specs, steps, skip=None):
             curves_r[i].append(l)
     for i, m in enumerate(members):
         assert m.iterations == len(curves_r[i])
+        record_margin(f"group_{tag}_loss_curve_rel", float(np.max(np.abs(np.asarray(curves_g[i]) / np.asarray(curves_r[i]) - 1.0))))
         np.testing.assert_allclose(curves_g[i], curves_r[i], rtol=CURVE_TOL, err_msg=f"member {i}")
         assert curves_g[i][0] == pytest.approx(curves_r[i][0], rel=2e-3)           # first step: same weights on both sides
         w0 = O.glorot_init(cfgs[i], 3 + i)
         for a, b, z in zip(m.get_weights(), wref[i], w0):
             if z.ndim == 2:                                                            # (biases were re-drawn: compare kernels' movement)
-                assert rel(a - z, b - z) <= MOVE_TOL, (i, rel(a - z, b - z))
+                record_margin(f"group_{tag}_weight_movement_rel", rel(a - z, b - z))
+                assert rel(a - z, b - z) <= (MOVE_TOL_WIDE if tag == "wide" else MOVE_TOL), (i, rel(a - z, b - z))
     g.close()
     for m in members:
         m.close()
@@ -101,10 +107,10 @@ def test_group_members_may_sit_out_steps(G):
 
 
 def test_group_elu_family_and_wide_family(G):
-    run_case(G, [((256, 128), "elu", "Adam", 1e-3, 500, 31), ((512, 512), "elu", "RMSprop", 1e-3, 384, 32)], steps=4)
+    run_case(G, [((256, 128), "elu", "Adam", 1e-3, 500, 31), ((512, 512), "elu", "RMSprop", 1e-3, 384, 32)], steps=4, tag="elu")
     # wide chain: the published lot-147/trial_0027 widths next to other search-space shapes (hpo_baseline_v1.py:66-74)
     run_case(G, [((768, 640, 512, 640, 640), "leakyrelu", "RAdam", 2.5e-4, 768, 41), ((1024, 896), "relu", "Adam", 1e-3, 200, 42),
-                 ((384, 384, 384), "leakyrelu", "SGD", 1e-2, 1000, 43)], steps=4)
+                 ((384, 384, 384), "leakyrelu", "SGD", 1e-2, 1000, 43)], steps=4, tag="wide")
 
 
 def test_group_large_total_uses_taller_tiles(G):
