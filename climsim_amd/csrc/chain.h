@@ -144,7 +144,9 @@ __device__ __forceinline__ void chain_prime_t(ChainQ& Q, const u16* __restrict__
 // One stage for one wave: acc[MT][NT] 32x32 tiles over contraction length Kc.
 // D = weight prefetch depth in k16-steps (4 or 8; 8 needs 32 more VGPRs).
 // (SELF_PRIME is always true: see the note in chain_stage.)
-template <int BMROWS, int MT, int NT, int D, bool SELF_PRIME, int PITCH = CHAIN_PITCH>
+__device__ __forceinline__ void chainw_copy_out(const u16* __restrict__ X, u16* __restrict__ out, int ldo, int width, int64_t m0, int tid);   // chainw.h
+
+template <int BMROWS, int MT, int NT, int D, bool SELF_PRIME, int PITCH = CHAIN_PITCH, bool WIDE_PEND = false>
 __device__ __forceinline__ void chain_mma(const u16* __restrict__ X, const u16* __restrict__ wfrag, int ks_total, int ntiles,
                                           int jt0, int mrow0, int tid, f32x16_t (&acc)[MT][NT], ChainPending& pend, int64_t m0) {
     const int lane = tid & 63;
@@ -217,7 +219,8 @@ __device__ __forceinline__ void chain_mma(const u16* __restrict__ X, const u16* 
     // the queue-priming loads: its stores are younger than every primed slot, so the counted waits never
     // wait for a store acknowledgement (waiting vmcnt(0) for them before priming cost ~1 us per stage).
     if (pend.out) {
-        chain_copy_out<BMROWS>(X, pend.out, pend.ldo, pend.width, m0, tid);
+        if constexpr (WIDE_PEND) chainw_copy_out(X, pend.out, pend.ldo, pend.width, m0, tid);      // wide chain: any width, this wave's share
+        else chain_copy_out<BMROWS>(X, pend.out, pend.ldo, pend.width, m0, tid);
         pend.out = nullptr;
     }
     const int arow = mrow0 + (lane & 31), ahalf = lane >> 5;

@@ -7,7 +7,9 @@
 //     a wide stage can be produced in several column passes without clobbering its input);
 //   * a wave owns the 32-column tile pairs (2w, 2w+1), (2w+16, 2w+17) of a stage, one pair per pass, through chain_mma
 //     (v_mfma 32x32x16, one row tile x two column tiles, inline-asm weight stream with counted vmcnt);
-//   * backward reads act'(h) from the global activation copies (no sign masks).
+//   * backward: act'(z) from 1-bit sign masks that the forward epilogue writes in the lane layout the backward epilogue uses
+//     (one 8-byte load per thread and stage; round 2 read the activation copies back as 8-byte pieces of 32 rows - 4096
+//     extra requests per stage on the vector-memory pipe that bounds the kernel); ELU keeps the activation path.
 // Against 13 separate GEMM launches of ~11 us each this removes the per-launch latency, which is what bounds the
 // per-layer path at the reference's batch sizes.
 #pragma once
@@ -15,10 +17,24 @@
 
 #define CWD_PITCH 1024
 #define CWD_BM 32
-constexpr int chainw_lds_bytes() { return 2 * CWD_BM * CWD_PITCH * 2 + CHAIN_MAX_BIAS * 4 + CWD_BM * 8; }
+#define CWD_MAX_BIAS 7936         // floats of bias staged in LDS (sum of layer widths): what is left of the 160 KiB beside the two activation
+                                  // buffers - e.g. 7 layers of 1024 + the two 128-wide ones (round 2 shared the tuned chain's 4096, which sent
+                                  // 5 x 896 and 5 x 1024 - inside the reference's search space - to the one-GEMM-per-layer path)
+constexpr int chainw_lds_bytes() { return 2 * CWD_BM * CWD_PITCH * 2 + CWD_MAX_BIAS * 4 + CWD_BM * 8; }
 
 __device__ __forceinline__ int cwd_off(int row, int col) {        // element offset of (row, col): 16-B chunks XOR (row & 15)
     return row * CWD_PITCH + ((((col >> 3) ^ (row & 15))) << 3) + (col & 7);
+}
+
+// This WAVE's share of a stage output's rows LDS -> global (the 8 waves of a workgroup call it independently - a wave with no
+// column tiles in a stage at once, the others behind their first weight loads -, together they cover all 32 rows): whole
+// 16-B chunks, row by row.
+__device__ __forceinline__ void chainw_copy_out(const u16* __restrict__ X, u16* __restrict__ out, int ldo, int width, int64_t m0, int tid) {
+    const int cpr = width >> 3;                                  // 16-B chunks per row
+    for (int g = tid; g < CWD_BM * cpr; g += 512) {
+        const int r = g / cpr, c = g - r * cpr;
+        *reinterpret_cast<uint4*>(out + (m0 + r) * ldo + c * 8) = *reinterpret_cast<const uint4*>(X + cwd_off(r, c * 8));
+    }
 }
 
 template <bool BWD>
@@ -26,7 +42,7 @@ __device__ __forceinline__ void chainw_body(const ChainArgs& p, const ChainDyn& 
     u16* Xin = XW;
     u16* Xout = XW + CWD_BM * CWD_PITCH;
     float* bias_lds = reinterpret_cast<float*>(XW + 2 * CWD_BM * CWD_PITCH);
-    int64_t* rows_lds = reinterpret_cast<int64_t*>(bias_lds + CHAIN_MAX_BIAS);
+    int64_t* rows_lds = reinterpret_cast<int64_t*>(bias_lds + CWD_MAX_BIAS);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int64_t m0 = (int64_t)bid * CWD_BM;
 
@@ -62,14 +78,15 @@ __device__ __forceinline__ void chainw_body(const ChainArgs& p, const ChainDyn& 
 
     float sq = 0.f, ab = 0.f;
     const int mrow = lane & 31, hi4 = 4 * (lane >> 5);
+    ChainPending pend{nullptr, 0, 0};
     for (int i = 0; i < p.n_stages; ++i) {
         const ChainStage& S = p.st[i];
         const int ntiles = S.Nc >> 5, ks = S.Kc >> 4;
         if (!BWD && S.epi == EPI_OUT) {                          // heads: one column tile per wave and pass (128 wide: waves 0..3)
+            if (wid >= ntiles && pend.out) { chainw_copy_out(Xin, pend.out, pend.ldo, pend.width, m0, tid); pend.out = nullptr; }
             for (int tile = wid; tile < ntiles; tile += 8) {
                 f32x16_t acc1[1][1];
-                ChainPending none{nullptr, 0, 0};
-                chain_mma<CWD_BM, 1, 1, 4, true, CWD_PITCH>(Xin, S.wfrag, ks, ntiles, tile, 0, tid, acc1, none, m0);
+                chain_mma<CWD_BM, 1, 1, 4, true, CWD_PITCH, true>(Xin, S.wfrag, ks, ntiles, tile, 0, tid, acc1, pend, m0);
                 const f32x16_t& acc = acc1[0][0];
                 const int64_t m = m0 + mrow;
                 const bool row_ok = m < d_.n_rows;
@@ -90,58 +107,92 @@ __device__ __forceinline__ void chainw_body(const ChainArgs& p, const ChainDyn& 
             }
             continue;                                            // last stage of the forward pass
         }
-        for (int tile0 = 2 * wid; tile0 < ntiles; tile0 += 16) { // a pass: column tiles tile0, tile0 + 1 (widths are multiples of 128)
-            f32x16_t acc2[1][2];
-            ChainPending none{nullptr, 0, 0};
-            uint2 hh[2][4];                                      // backward: the activations to differentiate through, in flight during the k-loop
-            if (BWD) {
+        // Column tiles are dealt to the waves in contiguous, BALANCED runs (ntiles / 8 each, the first ntiles % 8 waves one more)
+        // and a wave goes through its run in passes of two tiles (one for an odd rest): 24 tiles (768 wide) are 3 per wave
+        // = a pass of 2 + a pass of 1 on EVERY wave.  (Round 2 dealt pairs (2w, 2w+1), (2w+16, 2w+17): 768 wide = a full pass +
+        // a pass on four waves only, 640 wide = a full pass + a pass on two waves, 128 wide = two waves out of eight.)
+        const int t_base = ntiles >> 3, t_rem = ntiles & 7;
+        const int t_cnt = t_base + (wid < t_rem ? 1 : 0), t_lo = wid * t_base + min(wid, t_rem);
+        // The previous stage's output (this stage's input, intact in Xin) goes to global memory BEHIND the first weight
+        // loads of this stage (chain_mma, `pend`): its stores are then younger than every primed slot and the counted waits
+        // never wait for a store acknowledgement.  A wave without tiles in this stage copies its share right away.
+        if (t_cnt == 0 && pend.out) {
+            chainw_copy_out(Xin, pend.out, pend.ldo, pend.width, m0, tid);
+            pend.out = nullptr;
+        }
+        // sign bits of this thread's (up to four) column tiles: tile slot k of the wave's run -> 16 bits at 16 k; element
+        // 4 q + e of a tile at bit 4 q + e.  Forward and backward deal the tiles of a layer width identically, so the
+        // backward stage of layer l + 1 finds the bits of layer l's output where the forward stage of layer l put them.
+        const bool use_mask = S.mask != nullptr && p.act != ACT_ELU;
+        unsigned mk0 = 0u, mk1 = 0u;
+        const float bsc = p.drop_thr ? p.bwd_scale : 1.f;         // dropout: the kept activations were scaled by 1 / (1 - rate)
+        uint2* mptr = use_mask ? reinterpret_cast<uint2*>(S.mask) + (int64_t)bid * 512 + tid : nullptr;
+        if (BWD && use_mask && t_cnt > 0) { const uint2 mv = *mptr; mk0 = mv.x; mk1 = mv.y; }      // lands during the first k-loop
+        auto epilogue = [&](int tile, int slot, const f32x16_t& acc, const uint2 (&hq)[4]) {
+            unsigned bits16 = BWD ? ((slot < 2 ? mk0 : mk1) >> ((slot & 1) * 16)) : 0u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = tile * 32 + 8 * q + hi4;
+                float v[4] = {acc[4 * q + 0], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+                if (!BWD) {
+                    const float4 b4 = *reinterpret_cast<const float4*>(bias_lds + S.bias_off + n);
+                    v[0] = act_fwd(v[0] + b4.x, p.act, p.slope); v[1] = act_fwd(v[1] + b4.y, p.act, p.slope);
+                    v[2] = act_fwd(v[2] + b4.z, p.act, p.slope); v[3] = act_fwd(v[3] + b4.w, p.act, p.slope);
+                    if (p.drop_thr) {                            // training-mode nn.Dropout: relu(dropout(z)) == dropout(relu(z))
+                        const unsigned h0 = mlp_drop_hash2(m0 + mrow, n, S.drop_key), h1 = mlp_drop_hash2(m0 + mrow, n + 2, S.drop_key);
+                        v[0] = (h0 & 0xffffu) >= p.drop_thr ? v[0] * p.drop_scale : 0.f;
+                        v[1] = (h0 >> 16) >= p.drop_thr ? v[1] * p.drop_scale : 0.f;
+                        v[2] = (h1 & 0xffffu) >= p.drop_thr ? v[2] * p.drop_scale : 0.f;
+                        v[3] = (h1 >> 16) >= p.drop_thr ? v[3] * p.drop_scale : 0.f;
+                    }
+                    if (use_mask)
+                        bits16 |= ((v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u)) << (4 * q);
+                } else if (use_mask) {
+                    const unsigned b4 = bits16 >> (4 * q);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= (b4 & (1u << e)) ? bsc : p.slope * bsc;
+                } else {
+                    const uint2 h2 = hq[q];
+                    v[0] *= act_bwd_from_h(bf2f((u16)(h2.x & 0xffff)), p.act, p.slope);
+                    v[1] *= act_bwd_from_h(bf2f((u16)(h2.x >> 16)), p.act, p.slope);
+                    v[2] *= act_bwd_from_h(bf2f((u16)(h2.y & 0xffff)), p.act, p.slope);
+                    v[3] *= act_bwd_from_h(bf2f((u16)(h2.y >> 16)), p.act, p.slope);
+                    if (p.drop_thr) { v[0] *= p.bwd_scale; v[1] *= p.bwd_scale; v[2] *= p.bwd_scale; v[3] *= p.bwd_scale; }
+                }
+                *reinterpret_cast<uint2*>(Xout + cwd_off(mrow, n)) = make_uint2(cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3]));
+            }
+            if (!BWD && use_mask) { if (slot < 2) mk0 |= bits16 << ((slot & 1) * 16); else mk1 |= bits16 << ((slot & 1) * 16); }
+        };
+        for (int tile0 = t_lo; tile0 < t_lo + t_cnt; tile0 += 2) {
+            const bool two = tile0 + 1 < t_lo + t_cnt;
+            const int slot0 = tile0 - t_lo;
+            uint2 hh[2][4];                                      // backward, ELU: the activations to differentiate through, in flight during the k-loop
+            if (BWD && !use_mask) {
 #pragma unroll
                 for (int b = 0; b < 2; ++b)
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
-                        hh[b][q] = *reinterpret_cast<const uint2*>(S.hprev + (m0 + mrow) * S.ldh + (tile0 + b) * 32 + 8 * q + hi4);
+                        hh[b][q] = *reinterpret_cast<const uint2*>(S.hprev + (m0 + mrow) * S.ldh + (tile0 + (two ? b : 0)) * 32 + 8 * q + hi4);
             }
             // the weight stream of chain.h: inline-asm loads, counted vmcnt, 8 (or 4) k16-steps in flight
-            if ((S.Kc & 127) == 0) chain_mma<CWD_BM, 1, 2, 8, true, CWD_PITCH>(Xin, S.wfrag, ks, ntiles, tile0, 0, tid, acc2, none, m0);
-            else chain_mma<CWD_BM, 1, 2, 4, true, CWD_PITCH>(Xin, S.wfrag, ks, ntiles, tile0, 0, tid, acc2, none, m0);
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                const int tile = tile0 + b;
-                const f32x16_t& acc = acc2[0][b];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int n = tile * 32 + 8 * q + hi4;
-                    float v[4] = {acc[4 * q + 0], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
-                    if (!BWD) {
-                        const float4 b4 = *reinterpret_cast<const float4*>(bias_lds + S.bias_off + n);
-                        v[0] = act_fwd(v[0] + b4.x, p.act, p.slope); v[1] = act_fwd(v[1] + b4.y, p.act, p.slope);
-                        v[2] = act_fwd(v[2] + b4.z, p.act, p.slope); v[3] = act_fwd(v[3] + b4.w, p.act, p.slope);
-                        if (p.drop_thr) {                            // training-mode nn.Dropout: relu(dropout(z)) == dropout(relu(z))
-                            const unsigned h0 = mlp_drop_hash2(m0 + mrow, n, S.drop_key), h1 = mlp_drop_hash2(m0 + mrow, n + 2, S.drop_key);
-                            v[0] = (h0 & 0xffffu) >= p.drop_thr ? v[0] * p.drop_scale : 0.f;
-                            v[1] = (h0 >> 16) >= p.drop_thr ? v[1] * p.drop_scale : 0.f;
-                            v[2] = (h1 & 0xffffu) >= p.drop_thr ? v[2] * p.drop_scale : 0.f;
-                            v[3] = (h1 >> 16) >= p.drop_thr ? v[3] * p.drop_scale : 0.f;
-                        }
-                    } else {
-                        const uint2 h2 = hh[b][q];
-                        v[0] *= act_bwd_from_h(bf2f((u16)(h2.x & 0xffff)), p.act, p.slope);
-                        v[1] *= act_bwd_from_h(bf2f((u16)(h2.x >> 16)), p.act, p.slope);
-                        v[2] *= act_bwd_from_h(bf2f((u16)(h2.y & 0xffff)), p.act, p.slope);
-                        v[3] *= act_bwd_from_h(bf2f((u16)(h2.y >> 16)), p.act, p.slope);
-                        if (p.drop_thr) { v[0] *= p.bwd_scale; v[1] *= p.bwd_scale; v[2] *= p.bwd_scale; v[3] *= p.bwd_scale; }
-                    }
-                    *reinterpret_cast<uint2*>(Xout + cwd_off(mrow, n)) = make_uint2(cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3]));
-                }
+            if (two) {
+                f32x16_t acc2[1][2];
+                if ((S.Kc & 127) == 0) chain_mma<CWD_BM, 1, 2, 8, true, CWD_PITCH, true>(Xin, S.wfrag, ks, ntiles, tile0, 0, tid, acc2, pend, m0);
+                else chain_mma<CWD_BM, 1, 2, 4, true, CWD_PITCH, true>(Xin, S.wfrag, ks, ntiles, tile0, 0, tid, acc2, pend, m0);
+                epilogue(tile0, slot0, acc2[0][0], hh[0]);
+                epilogue(tile0 + 1, slot0 + 1, acc2[0][1], hh[1]);
+            } else {
+                f32x16_t acc1[1][1];
+                if ((S.Kc & 127) == 0) chain_mma<CWD_BM, 1, 1, 8, true, CWD_PITCH, true>(Xin, S.wfrag, ks, ntiles, tile0, 0, tid, acc1, pend, m0);
+                else chain_mma<CWD_BM, 1, 1, 4, true, CWD_PITCH, true>(Xin, S.wfrag, ks, ntiles, tile0, 0, tid, acc1, pend, m0);
+                epilogue(tile0, slot0, acc1[0][0], hh[0]);
             }
         }
+        if (!BWD && use_mask && t_cnt > 0) *mptr = make_uint2(mk0, mk1);
         __syncthreads();                                         // Xout complete, nobody reads Xin any more
-        if (S.out) {                                             // global copy (next layer's wgrad / the backward pass), coalesced
-            const int cpr = S.Nc >> 3;
-            for (int g = tid; g < CWD_BM * cpr; g += 512) {
-                const int r = g / cpr, c = g - r * cpr;
-                *reinterpret_cast<uint4*>(S.out + (m0 + r) * S.ldo + c * 8) = *reinterpret_cast<const uint4*>(Xout + cwd_off(r, c * 8));
-            }
+        if (S.out) {                                             // global copy (next layer's wgrad / the backward pass), coalesced:
+            if (i + 1 == p.n_stages) chainw_copy_out(Xout, S.out, S.ldo, S.Nc, m0, tid);   // nobody comes after: now
+            else pend = ChainPending{S.out, S.ldo, S.Nc};                                  // the next stage copies it behind its first weight loads
         }
         u16* t = Xin; Xin = Xout; Xout = t;
     }

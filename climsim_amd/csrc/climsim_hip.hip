@@ -329,7 +329,7 @@ void chainw_bwd_args(const cs_mlp* h, int64_t n, ChainArgs& c) {
     for (int l = h->L - 1, i = 0; l >= 1; --l, ++i) {
         const Layer& ly = h->layers[l];
         ChainStage& S = c.st[i];
-        S.wfrag = ly.Wb; S.bias_off = 0; S.Kc = ly.N; S.Nc = ly.Kp;
+        S.wfrag = ly.Wb; S.bias_off = 0; S.Kc = ly.N; S.Nc = ly.Kp; S.mask = h->layers[l - 1].mask;
         S.out = h->layers[l - 1].dZ; S.ldo = h->layers[l - 1].N;
         S.hprev = ly.H; S.ldh = ly.Kp; S.epi = EPI_DGRAD;
     }
@@ -364,7 +364,7 @@ void chain_fwd_args(const cs_mlp* h, bool wide, const float* x, const int64_t* r
         S.wfrag = ly.Wf; S.bias_off = ly.bias_off; S.Kc = ly.Kp; S.Nc = ly.N;
         c.bias_src[l] = h->P + ly.b_off; c.bias_len[l] = ly.N;
         // prediction / evaluation keeps nothing for a backward pass: no activation copies, no sign masks
-        if (l + 1 < h->L) { S.out = want_dz ? h->layers[l + 1].H : nullptr; S.ldo = h->layers[l + 1].Kp; S.epi = EPI_HIDDEN; S.mask = (want_dz && !wide) ? ly.mask : nullptr; }
+        if (l + 1 < h->L) { S.out = want_dz ? h->layers[l + 1].H : nullptr; S.ldo = h->layers[l + 1].Kp; S.epi = EPI_HIDDEN; S.mask = want_dz ? ly.mask : nullptr; }      // (null for ELU models on the wide chain: never allocated)
         else { S.out = nullptr; S.ldo = 0; S.epi = EPI_OUT; S.mask = nullptr; }
     }
     if (!wide) { c.ablate = h->chain_ablate; c.dbg = h->dbg; }
@@ -687,7 +687,8 @@ int cs_mlp_create(cs_mlp_t** out, const cs_mlp_cfg* cfg) {
     {
         int boff = 0;
         for (int l = 0; l < h->L; ++l) { h->layers[l].bias_off = boff; boff += h->layers[l].N; }
-        if (boff > CHAIN_MAX_BIAS) { h->use_chain = false; h->use_chainw = false; }
+        if (boff > CHAIN_MAX_BIAS) h->use_chain = false;       // LDS bias block of the tuned chain / of the wide chain
+        if (boff > CWD_MAX_BIAS) h->use_chainw = false;
     }
     if (h->use_chain) h->use_chainw = false;               // the tuned kernels take the 128/256/512 models
     if (const char* e = getenv("CS_CHAINW_MAX_N")) h->chainw_max_n = atoll(e);
@@ -753,7 +754,9 @@ int cs_mlp_create(cs_mlp_t** out, const cs_mlp_cfg* cfg) {
     }
     // stamps: the chain kernels write [fwd|bwd][workgroup][64], the cooperative chain [workgroup][128] for up to 256 workgroups
     if (getenv("CS_CHAIN_DBG")) A((void**)&h->dbg, (size_t)std::max<int64_t>(2 * (h->m_pad_max / 32) * 64, 256 * 128) * 8);
-    if (h->use_chain)
+    // sign masks of the hidden activations: tuned chain (16 B per thread and 32..128-row tile) and wide chain (8 B per thread and
+    // 32-row tile; ReLU / LeakyReLU - ELU differentiates through the stored activations)
+    if (h->use_chain || (h->use_chainw && cfg->act != CS_ACT_ELU))
         for (int l = 0; l + 1 < h->L; ++l) A((void**)&h->layers[l].mask, (size_t)(h->m_pad_max / 32) * 512 * 16);
     for (int l = 0; l < h->L; ++l) {       // activations last: the big, streamed part
         Layer& ly = h->layers[l];
