@@ -47,25 +47,64 @@ __device__ __forceinline__ void chainw_body(const ChainArgs& p, const ChainDyn& 
     const int64_t m0 = (int64_t)bid * CWD_BM;
 
     if (!BWD) {
-        for (int i = 0; i < p.n_stages; ++i)
-            for (int t = tid; t < p.bias_len[i]; t += 512) bias_lds[p.st[i].bias_off + t] = p.bias_src[i][t];
-        if (tid < CWD_BM) rows_lds[tid] = (m0 + tid < d_.n_rows) ? (d_.row_idx ? d_.row_idx[m0 + tid] : m0 + tid) : -1;
+        {   // all bias loads and the row-index load in flight together (one memory latency, not one per stage)
+            float bv[CHAIN_MAX_STAGES][2];
+            int64_t rv = -1;
+            if (tid < CWD_BM && m0 + tid < d_.n_rows) rv = d_.row_idx ? d_.row_idx[m0 + tid] : m0 + tid;
+#pragma unroll
+            for (int i = 0; i < CHAIN_MAX_STAGES; ++i)
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    bv[i][u] = (i < p.n_stages && tid + 512 * u < p.bias_len[i]) ? p.bias_src[i][tid + 512 * u] : 0.f;
+#pragma unroll
+            for (int i = 0; i < CHAIN_MAX_STAGES; ++i)
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    if (i < p.n_stages && tid + 512 * u < p.bias_len[i]) bias_lds[p.st[i].bias_off + tid + 512 * u] = bv[i][u];
+            if (tid < CWD_BM) rows_lds[tid] = rv;
+        }
         __syncthreads();
         const int groups = p.kp0 >> 2;                           // 4 features per item
-        for (int g = tid; g < CWD_BM * groups; g += 512) {
-            const int ml = g / groups, c = (g - ml * groups) * 4;
-            const int64_t src = rows_lds[ml];
-            float v[4] = {0.f, 0.f, 0.f, 0.f};
-            if (src >= 0) {
-                for (int j = 0; j < 4 && c + j < p.n_in; ++j) {
-                    float t = d_.x[src * p.n_in + c + j];
-                    if (d_.normalise) { t = (t - p.sub[c + j]) / p.div[c + j]; t = (fabsf(t) <= 3.402823466e38f) ? t : 0.f; }
-                    v[j] = t;
+        const int items = CWD_BM * groups;
+        const bool vec = (p.n_in & 3) == 0;
+        for (int g0 = tid; g0 < items; g0 += 4 * 512) {          // 4 independent items per thread in flight (one 16-B load each)
+            float4 xv[4];
+            int mlv[4], cv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int g = g0 + u * 512;
+                mlv[u] = g / groups; cv[u] = (g - mlv[u] * groups) * 4;
+                xv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (g < items) {
+                    const int64_t src = rows_lds[mlv[u]];
+                    if (src >= 0 && cv[u] < p.n_in) {
+                        const float* xr = d_.x + src * p.n_in + cv[u];
+                        if (vec && cv[u] + 3 < p.n_in) xv[u] = *reinterpret_cast<const float4*>(xr);
+                        else {
+                            float t[4] = {0.f, 0.f, 0.f, 0.f};
+                            for (int j = 0; j < 4 && cv[u] + j < p.n_in; ++j) t[j] = xr[j];
+                            xv[u] = make_float4(t[0], t[1], t[2], t[3]);
+                        }
+                    }
                 }
             }
-            const uint2 pk = pack4(v[0], v[1], v[2], v[3]);
-            *reinterpret_cast<uint2*>(Xin + cwd_off(ml, c)) = pk;
-            if (p.h0) *reinterpret_cast<uint2*>(p.h0 + (m0 + ml) * p.ldh0 + c) = pk;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int g = g0 + u * 512;
+                if (g >= items) continue;
+                float v[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
+                if (d_.normalise && rows_lds[mlv[u]] >= 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (cv[u] + j < p.n_in) {
+                            const float t = (v[j] - p.sub[cv[u] + j]) / p.div[cv[u] + j];
+                            v[j] = (fabsf(t) <= 3.402823466e38f) ? t : 0.f;
+                        }
+                }
+                const uint2 pk = pack4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<uint2*>(Xin + cwd_off(mlv[u], cv[u])) = pk;
+                if (p.h0) *reinterpret_cast<uint2*>(p.h0 + (m0 + mlv[u]) * p.ldh0 + cv[u]) = pk;
+            }
         }
     } else {
         const int chunks = p.w_in >> 3;                          // 16-B chunks per row
