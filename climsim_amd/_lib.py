@@ -65,6 +65,13 @@ SIGNATURES = {
     "cs_dp_allreduce_bf16": (C.c_int, [_P, _P, C.c_int64, _P]),
     "cs_dp_comm_info": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "cs_dp_destroy": (None, [_P]),
+    "cs_dp_ipc_create": (C.c_int, [C.POINTER(_P), C.c_int, C.c_int, C.c_int, _I64]),
+    "cs_dp_ipc_export": (C.c_int, [_P, _P]),
+    "cs_dp_ipc_connect": (C.c_int, [_P, _P]),
+    "cs_dp_ipc_buffer": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_I64)]),
+    "cs_dp_ipc_allreduce": (C.c_int, [_P, _I64, _P]),
+    "cs_dp_ipc_timeouts": (_I64, [_P]),
+    "cs_dp_ipc_destroy": (None, [_P]),
     "cs_mlp_set_norm": (C.c_int, [_P, _P, _P]),
     "cs_mlp_set_head_options": (C.c_int, [_P, C.c_int, _P, C.c_int64]),
     "cs_mlp_set_dropout": (C.c_int, [_P, C.c_double, C.c_uint64]),

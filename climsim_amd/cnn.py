@@ -251,6 +251,15 @@ class CNNEmulator:
             _lib.check(self.lib.cs_cnn_set_grad_buffer(self._h, _ptr(self._grad_tensor), self._n_params))
         return self._grad_tensor
 
+    def bind_gradient_tensor(self, tensor):
+        """Make `tensor` the engine's flat gradient buffer (the exchange buffer of the one-shot all-reduce, dp.py: IpcComm)."""
+        import torch
+        if tensor.numel() < self._n_params or tensor.dtype != torch.float32 or not tensor.is_cuda:
+            raise ValueError("gradient buffer must be a float32 device tensor of at least %d elements" % self._n_params)
+        tensor.zero_()
+        self._grad_tensor = tensor[:self._n_params]
+        _lib.check(self.lib.cs_cnn_set_grad_buffer(self._h, _ptr(self._grad_tensor), self._n_params))
+
     def get_gradients(self, grad_scale: float = 1.0) -> List[np.ndarray]:
         return self._split(self.gradient_tensor().detach().cpu().numpy() * np.float32(grad_scale))
 

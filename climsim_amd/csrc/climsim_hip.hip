@@ -1653,6 +1653,191 @@ int cs_dp_allreduce_bf16(cs_dp_t* c, float* buf, int64_t n, void* stream) {
     return CS_OK;
 }
 
+// ---- one-shot all-reduce over peer-mapped buffers (an OPTION beside RCCL) ---------------------------------
+// The gradient of these models is small (4.8 MB fp32) and a ring collective over 8 GPUs is latency-dominated (14 hops).  On one
+// node every GPU can address every other GPU's HBM over xGMI, so the all-reduce can be ONE kernel per rank:
+//   (0) every rank tells every peer "my gradients of step e are in memory" (a flag word in the peer's flag array) and waits
+//       for the same word from every peer;
+//   (1) reduce-scatter by PULL: rank r sums slice r of all W gradient buffers (fixed rank order: every rank would compute the
+//       same bits, and each slice is computed exactly once) ...
+//   (2) ... and all-gather by PUSH: writes the sum into slice r of every rank's buffer (slices are disjoint: no rank reads
+//       what another writes);
+//   (3) the last workgroup to finish tells every peer "my pushes of step e are done" and waits for every peer's word: when the
+//       kernel ends, this rank's buffer holds the complete sum.
+// The buffers are hipMalloc'ed by the library and exported / opened with hipIpc* handles (the handles travel through the
+// launcher's rendezvous); the engine's gradient buffer is REBOUND to the exchange buffer (cs_mlp_set_grad_buffer), so there
+// is no copy.  Peer accesses are system-scope (sc0 sc1: no stale line in a local cache across steps), every wait is bounded
+// (a time-out is counted in `err` and reported by the call that follows, never a hang).  Correctness is tested with two
+// processes on one device (tests/test_dp_ipc_gpu.py); over real xGMI links it has NOT run (one GPU per box in this pool), which
+// is why RCCL stays the default.
+#define CS_DP_IPC_MAX 8
+struct IpcArgs {
+    float* buf[CS_DP_IPC_MAX];          // gradient exchange buffer of every rank (peer-mapped; [rank] is the local one)
+    unsigned* flags[CS_DP_IPC_MAX];     // [2][CS_DP_IPC_MAX] words per rank: phase x source rank -> last epoch signalled
+    unsigned* arrive;                   // local: workgroups of this launch that finished their share
+    unsigned* err;                      // local, host-mapped: bounded waits that ran out
+    int world, rank;
+    unsigned epoch;
+    int64_t n;
+    int spin_limit;
+};
+__device__ __forceinline__ void sys_store_u32(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ unsigned sys_load_u32(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ float4 sys_load_f4(const float* p) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void sys_store_f4(float* p, float4 x) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4 v = {x.x, x.y, x.z, x.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+__global__ __launch_bounds__(256) void k_dp_oneshot(const IpcArgs a) {
+    const int tid = threadIdx.x;
+    // (0) my gradients are complete (the kernels that wrote them ended before this launch: their lines are in memory)
+    if (blockIdx.x == 0 && tid < a.world) sys_store_u32(a.flags[tid] + a.rank, a.epoch);
+    if (tid < a.world) {
+        int spins = 0;
+        while ((int)(sys_load_u32(a.flags[a.rank] + tid) - a.epoch) < 0) {
+            if (++spins > a.spin_limit) { __hip_atomic_fetch_add(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+            __builtin_amdgcn_s_sleep(4);
+        }
+    }
+    __syncthreads();
+    // (1) + (2): slice `rank` in 16-byte pieces
+    const int64_t q = a.n >> 2;                                     // float4 pieces (n is a multiple of 4)
+    const int64_t per = (q + a.world - 1) / a.world;
+    const int64_t lo = per * a.rank, hi = min(q, lo + per);
+    for (int64_t i = lo + (int64_t)blockIdx.x * 256 + tid; i < hi; i += (int64_t)gridDim.x * 256) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int r = 0; r < a.world; ++r) {
+            const float4 v = sys_load_f4(a.buf[r] + 4 * i);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        for (int r = 0; r < a.world; ++r) sys_store_f4(a.buf[r] + 4 * i, s);
+    }
+    // (3) every push of this workgroup has been acknowledged; the last workgroup signals the peers and waits for theirs
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __threadfence_system();
+    __syncthreads();
+    __shared__ unsigned last;
+    if (tid == 0) last = (__hip_atomic_fetch_add(a.arrive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) ? 1u : 0u;
+    __syncthreads();
+    if (!last) return;
+    if (tid == 0) __hip_atomic_store(a.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < a.world) {
+        sys_store_u32(a.flags[tid] + CS_DP_IPC_MAX + a.rank, a.epoch);
+        int spins = 0;
+        while ((int)(sys_load_u32(a.flags[a.rank] + CS_DP_IPC_MAX + tid) - a.epoch) < 0) {
+            if (++spins > a.spin_limit) { __hip_atomic_fetch_add(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+            __builtin_amdgcn_s_sleep(4);
+        }
+    }
+    __threadfence_system();
+}
+
+struct cs_dp_ipc {
+    int world = 1, rank = 0, device = 0;
+    int64_t n = 0;
+    float* buf = nullptr; unsigned* flags = nullptr; unsigned* arrive = nullptr;
+    unsigned* err_host = nullptr; unsigned* err_dev = nullptr;
+    float* peer_buf[CS_DP_IPC_MAX] = {}; unsigned* peer_flags[CS_DP_IPC_MAX] = {};
+    bool opened[CS_DP_IPC_MAX] = {};
+    bool connected = false;
+    unsigned epoch = 0;
+    int spin_limit = 1 << 22;
+};
+
+int cs_dp_ipc_create(cs_dp_ipc_t** out, int world, int rank, int device, int64_t n_floats) {
+    if (!out) return fail(CS_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (world < 1 || world > CS_DP_IPC_MAX || rank < 0 || rank >= world) return fail(CS_ERR_INVALID, "rank %d of %d (at most %d ranks)", rank, world, CS_DP_IPC_MAX);
+    if (n_floats <= 0 || (n_floats & 3)) return fail(CS_ERR_INVALID, "the exchange buffer holds a positive multiple of 4 floats (got %lld)", (long long)n_floats);
+    HIP_TRY(hipSetDevice(device));
+    cs_dp_ipc* c = new cs_dp_ipc();
+    struct Guard { cs_dp_ipc* p; ~Guard() { if (p) cs_dp_ipc_destroy(p); } } guard{c};
+    c->world = world; c->rank = rank; c->device = device; c->n = n_floats;
+    HIP_TRY(hipMalloc((void**)&c->buf, sizeof(float) * n_floats));
+    HIP_TRY(hipMemset(c->buf, 0, sizeof(float) * n_floats));
+    HIP_TRY(hipMalloc((void**)&c->flags, 4096));
+    HIP_TRY(hipMemset(c->flags, 0, 4096));
+    c->arrive = c->flags + 512;                                     // same allocation, never touched by a peer
+    HIP_TRY(hipHostMalloc((void**)&c->err_host, 64, hipHostMallocMapped | hipHostMallocCoherent));
+    memset(c->err_host, 0, 64);
+    HIP_TRY(hipHostGetDevicePointer((void**)&c->err_dev, c->err_host, 0));
+    if (const char* e = getenv("CS_DP_IPC_SPIN_LIMIT")) c->spin_limit = atoi(e);
+    HIP_TRY(hipDeviceSynchronize());
+    c->peer_buf[rank] = c->buf; c->peer_flags[rank] = c->flags;
+    guard.p = nullptr;
+    *out = c;
+    return CS_OK;
+}
+
+int cs_dp_ipc_export(cs_dp_ipc_t* c, void* handles_out) {
+    if (!c || !handles_out) return fail(CS_ERR_INVALID, "null argument");
+    static_assert(2 * sizeof(hipIpcMemHandle_t) <= CS_DP_IPC_HANDLE_BYTES, "two HIP IPC handles fit the exported record");
+    hipIpcMemHandle_t h[2];
+    HIP_TRY(hipIpcGetMemHandle(&h[0], c->buf));
+    HIP_TRY(hipIpcGetMemHandle(&h[1], c->flags));
+    memset(handles_out, 0, CS_DP_IPC_HANDLE_BYTES);
+    memcpy(handles_out, h, sizeof h);
+    return CS_OK;
+}
+
+int cs_dp_ipc_connect(cs_dp_ipc_t* c, const void* all_handles) {
+    if (!c || !all_handles) return fail(CS_ERR_INVALID, "null argument");
+    if (c->connected) return fail(CS_ERR_STATE, "already connected");
+    HIP_TRY(hipSetDevice(c->device));
+    for (int r = 0; r < c->world; ++r) {
+        if (r == c->rank) continue;
+        hipIpcMemHandle_t h[2];
+        memcpy(h, (const char*)all_handles + (size_t)r * CS_DP_IPC_HANDLE_BYTES, sizeof h);
+        HIP_TRY(hipIpcOpenMemHandle((void**)&c->peer_buf[r], h[0], hipIpcMemLazyEnablePeerAccess));
+        c->opened[r] = true;
+        HIP_TRY(hipIpcOpenMemHandle((void**)&c->peer_flags[r], h[1], hipIpcMemLazyEnablePeerAccess));
+    }
+    c->connected = true;
+    return CS_OK;
+}
+
+int cs_dp_ipc_buffer(cs_dp_ipc_t* c, void** dev_ptr, int64_t* n_floats) {
+    if (!c || !dev_ptr || !n_floats) return fail(CS_ERR_INVALID, "null argument");
+    *dev_ptr = c->buf; *n_floats = c->n;
+    return CS_OK;
+}
+
+int cs_dp_ipc_allreduce(cs_dp_ipc_t* c, int64_t n_floats, void* stream) {
+    if (!c) return fail(CS_ERR_INVALID, "null handle");
+    if (!c->connected && c->world > 1) return fail(CS_ERR_STATE, "cs_dp_ipc_connect has not run");
+    if (n_floats <= 0 || n_floats > c->n || (n_floats & 3)) return fail(CS_ERR_INVALID, "n_floats=%lld outside the exchange buffer (%lld, multiples of 4)", (long long)n_floats, (long long)c->n);
+    if (*reinterpret_cast<const volatile unsigned*>(c->err_host))
+        return fail(CS_ERR_STATE, "a peer did not arrive in time in an earlier one-shot all-reduce (%u waits ran out): the gradients since then are invalid",
+                    *reinterpret_cast<const volatile unsigned*>(c->err_host));
+    IpcArgs a{};
+    for (int r = 0; r < c->world; ++r) { a.buf[r] = c->peer_buf[r]; a.flags[r] = c->peer_flags[r]; }
+    a.arrive = c->arrive; a.err = c->err_dev; a.world = c->world; a.rank = c->rank; a.epoch = ++c->epoch; a.n = n_floats; a.spin_limit = c->spin_limit;
+    const int64_t pieces = (n_floats / 4 + c->world - 1) / c->world;
+    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(64, (pieces + 1023) / 1024));
+    hipLaunchKernelGGL(k_dp_oneshot, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return CS_OK;
+}
+
+int64_t cs_dp_ipc_timeouts(const cs_dp_ipc_t* c) { return (c && c->err_host) ? (int64_t)*reinterpret_cast<const volatile unsigned*>(c->err_host) : 0; }
+
+void cs_dp_ipc_destroy(cs_dp_ipc_t* c) {
+    if (!c) return;
+    (void)hipDeviceSynchronize();
+    for (int r = 0; r < CS_DP_IPC_MAX; ++r)
+        if (c->opened[r]) { if (c->peer_buf[r]) (void)hipIpcCloseMemHandle(c->peer_buf[r]); if (c->peer_flags[r]) (void)hipIpcCloseMemHandle(c->peer_flags[r]); }
+    if (c->buf) (void)hipFree(c->buf);
+    if (c->flags) (void)hipFree(c->flags);
+    if (c->err_host) (void)hipHostFree(c->err_host);
+    delete c;
+}
+
 int cs_dp_comm_info(cs_dp_t* c, int* nranks, int* rank) {
     if (!c || !c->comm || !nranks || !rank) return fail(CS_ERR_INVALID, "bad argument");
     if (!g_rccl.CommCount || !g_rccl.CommUserRank) return fail(CS_ERR_STATE, "this RCCL exports no ncclCommCount / ncclCommUserRank");

@@ -85,6 +85,91 @@ class RcclComm:
             pass
 
 
+class _DevicePointer:
+    """A raw device allocation of the library as an object torch can wrap without copying (`torch.as_tensor`)."""
+
+    def __init__(self, ptr: int, n_floats: int):
+        self.__cuda_array_interface__ = {"shape": (n_floats,), "typestr": "<f4", "data": (ptr, False), "version": 2, "strides": None}
+
+
+class IpcComm:
+    """The one-shot all-reduce of the C ABI (`cs_dp_ipc_*`): every rank's gradient buffer is an exchange buffer the other
+    ranks of the node map through HIP IPC; one kernel per rank pulls + sums its slice and pushes the sum back to everyone.
+    The ENGINE'S gradient buffer is rebound to the exchange buffer, so the collective works in place.  An option
+    (`DataParallel(collective="oneshot")`, CS_DP_COLLECTIVE=oneshot): it has run with two processes on one device only."""
+
+    def __init__(self, dist, device, engine):
+        import ctypes as C
+        import torch
+        from . import _lib
+        self._lib, self._check, self._C, self._torch = _lib.load(), _lib.check, C, torch
+        world, rank = dist.get_world_size(), dist.get_rank()
+        n = int(engine.gradient_tensor().numel())
+        n4 = (n + 3) // 4 * 4
+        self._c = C.c_void_p()
+        self.n, self._engine, self._n_grad = n4, engine, n
+        # as in RcclComm: every local step's outcome is agreed on, so that no rank raises alone
+        ok, err = 1, ""
+        rec = C.create_string_buffer(128)
+        with torch.cuda.device(device):
+            if self._lib.cs_dp_ipc_create(C.byref(self._c), world, rank, device.index if device.index is not None else torch.cuda.current_device(), n4) != 0 \
+                    or self._lib.cs_dp_ipc_export(self._c, rec) != 0:
+                ok, err = 0, self._lib.cs_last_error().decode()
+        self._agree(dist, device, ok, "exchange buffer setup failed", err)
+        import numpy as np
+        xdev = device if dist.get_backend() == "nccl" else "cpu"          # the handle records travel through the rendezvous' own medium
+        mine = torch.from_numpy(np.frombuffer(rec.raw, dtype=np.uint8).copy()).to(xdev)
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        allrec = C.create_string_buffer(b"".join(p.cpu().numpy().tobytes() for p in parts), 128 * world)
+        with torch.cuda.device(device):
+            rc = self._lib.cs_dp_ipc_connect(self._c, allrec)
+        self._agree(dist, device, 1 if rc == 0 else 0, "opening the peers' buffers failed", self._lib.cs_last_error().decode() if rc else "")
+        ptr, nn = C.c_void_p(), C.c_int64()
+        self._check(self._lib.cs_dp_ipc_buffer(self._c, C.byref(ptr), C.byref(nn)))
+        self.tensor = torch.as_tensor(_DevicePointer(ptr.value, n4), device=device)[:n]      # a view of the library's allocation
+        engine.bind_gradient_tensor(self.tensor)
+        dist.barrier()                                            # nobody starts a step before every rank has opened every buffer
+
+    def _agree(self, dist, device, ok, what, err):
+        t = self._torch.tensor([ok], dtype=self._torch.int32, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        if int(t.item()) == 0:
+            self.close()
+            raise self._lib_error(f"one-shot all-reduce: {what} on some rank" + (": " + err if err else ""))
+
+    @staticmethod
+    def _lib_error(msg):
+        from ._lib import EngineError
+        return EngineError(msg)
+
+    def all_reduce(self, tensor, payload: str = "fp32"):
+        if payload != "fp32":
+            raise ValueError("the one-shot all-reduce sums float32")
+        st = self._C.c_void_p(self._torch.cuda.current_stream(tensor.device).cuda_stream)
+        self._check(self._lib.cs_dp_ipc_allreduce(self._c, self.n, st))
+
+    @property
+    def timeouts(self) -> int:
+        return int(self._lib.cs_dp_ipc_timeouts(self._c))
+
+    def close(self):
+        if getattr(self, "_c", None) is not None and self._c.value:
+            if getattr(self, "tensor", None) is not None:
+                # the engine must not keep pointing into an allocation that is about to be freed: give it a torch tensor again
+                self._torch.cuda.synchronize()
+                self._engine.bind_gradient_tensor(self._torch.zeros(self._n_grad, dtype=self._torch.float32, device=self.tensor.device))
+                self.tensor = None
+            self._lib.cs_dp_ipc_destroy(self._c)
+            self._c = self._C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def shard_of_batch(perm, step: int, global_batch: int, rank: int, world: int):
     """Rows of global batch `step` owned by `rank`: a strided view of the epoch permutation."""
     sl = perm[step * global_batch + rank:(step + 1) * global_batch:world]
@@ -92,12 +177,14 @@ def shard_of_batch(perm, step: int, global_batch: int, rank: int, world: int):
 
 
 class DataParallel:
-    def __init__(self, engine, dist=None, output_length: int = 128, grad_payload: str | None = None):
+    def __init__(self, engine, dist=None, output_length: int = 128, grad_payload: str | None = None, collective: str | None = None):
         """`grad_payload`: "fp32" (default; what DDP in the reference sends) or "bf16" - the gradient sums cross the links
         as bf16 (half the bytes: 2.39 MB for the 5x512 MLP, 26.4 MB for the CNN) and are widened back before the optimiser,
         whose moments and master weights stay float32.  Every rank receives the same reduced buffer either way, so the
         replicas stay bit-identical to each other; against fp32 sums the update carries bf16 rounding of the gradient.
-        Environment default: CS_DP_PAYLOAD."""
+        Environment default: CS_DP_PAYLOAD.
+        `collective`: "rccl" (default) or "oneshot" - the one-kernel all-reduce over peer-mapped buffers (IpcComm; one node,
+        at most 8 ranks, fp32 payload; an option until a measured scaling curve says otherwise).  Environment: CS_DP_COLLECTIVE."""
         self.engine, self.dist = engine, dist
         self.payload = grad_payload or os.environ.get("CS_DP_PAYLOAD", "fp32")
         if self.payload not in ("fp32", "bf16"):
@@ -109,7 +196,15 @@ class DataParallel:
         # GPU runs take the engine's own RCCL communicator (collective on the compute stream); torch.distributed's
         # all_reduce remains for CPU tensors (gloo tests), on request (CS_DP_NATIVE=0) and if the native setup fails
         self.native = None
-        if dist is not None and getattr(self.grad, "is_cuda", False) and os.environ.get("CS_DP_NATIVE", "1") != "0":
+        self.collective = collective or os.environ.get("CS_DP_COLLECTIVE", "rccl")
+        if self.collective not in ("rccl", "oneshot"):
+            raise ValueError(f"collective must be 'rccl' or 'oneshot', not {self.collective!r}")
+        if self.collective == "oneshot" and dist is not None and getattr(self.grad, "is_cuda", False):
+            if self.payload != "fp32":
+                raise ValueError("collective='oneshot' sums float32 (grad_payload='fp32')")
+            self.native = IpcComm(dist, self.grad.device, engine)     # raises on EVERY rank or on none
+            self.grad = engine.gradient_tensor()                      # now the exchange buffer
+        elif dist is not None and getattr(self.grad, "is_cuda", False) and os.environ.get("CS_DP_NATIVE", "1") != "0":
             from ._lib import EngineError
             try:
                 self.native = RcclComm(dist, self.grad.device)

@@ -345,6 +345,16 @@ class MLPEmulator:
             _lib.check(self.lib.cs_mlp_set_grad_buffer(self._h, _ptr(self._grad_tensor)))
         return self._grad_tensor
 
+    def bind_gradient_tensor(self, tensor):
+        """Make `tensor` (float32, device, at least gradient_tensor().numel() elements, 16-byte aligned) the engine's flat
+        gradient buffer - e.g. the exchange buffer of the one-shot all-reduce (climsim_amd/dp.py: IpcComm)."""
+        n = self.gradient_tensor().numel()
+        if tensor.numel() < n or tensor.dtype != _torch().float32 or not tensor.is_cuda:
+            raise ValueError("gradient buffer must be a float32 device tensor of at least %d elements" % n)
+        tensor.zero_()
+        _lib.check(self.lib.cs_mlp_set_grad_buffer(self._h, _ptr(tensor)))
+        self._grad_tensor = tensor[:n]
+
     def get_gradients(self, grad_scale: float = 1.0) -> List[np.ndarray]:
         """Gradients of the last loss_grads call, Keras order (testing / inspection)."""
         self.gradient_tensor()

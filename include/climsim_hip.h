@@ -333,6 +333,28 @@ int  cs_dp_allreduce_bf16(cs_dp_t* comm, float* buf_dev, int64_t n_floats, void*
 int  cs_dp_comm_info(cs_dp_t* comm, int* nranks, int* rank);
 void cs_dp_destroy(cs_dp_t* comm);
 
+/* ---- one-shot all-reduce over peer-mapped buffers: an OPTION beside cs_dp_allreduce (same role: the one gradient
+ * all-reduce of a DDP step, train_mlp_h5loader.py:195-207).  Every rank owns an exchange buffer that the other ranks of the
+ * NODE map through HIP IPC handles; one kernel per rank pulls + sums its 1/world slice from all buffers and pushes the sum
+ * into every buffer (two flag exchanges, every wait bounded).  The engine's gradient buffer is rebound to the exchange
+ * buffer (cs_mlp_set_grad_buffer / cs_cnn_set_grad_buffer), so nothing is copied.
+ *   every rank: cs_dp_ipc_create(&c, world, rank, device, n_floats)        n_floats = gradient length rounded up to 4
+ *               cs_dp_ipc_export(c, record)                                CS_DP_IPC_HANDLE_BYTES opaque bytes
+ *               ... all-gather the records through the launcher's rendezvous ...
+ *               cs_dp_ipc_connect(c, records_of_all_ranks)                 world x CS_DP_IPC_HANDLE_BYTES, rank order
+ *               cs_dp_ipc_buffer(c, &ptr, &n)  ->  cs_mlp_set_grad_buffer(h, ptr)
+ *   every step: cs_dp_ipc_allreduce(c, n_floats, stream)                   in place on the exchange buffer
+ * At most 8 ranks, one node.  Tested with two processes on one device; NOT yet run over xGMI links: RCCL stays the default. */
+typedef struct cs_dp_ipc cs_dp_ipc_t;
+#define CS_DP_IPC_HANDLE_BYTES 128
+int  cs_dp_ipc_create(cs_dp_ipc_t** out, int world, int rank, int device, int64_t n_floats);
+int  cs_dp_ipc_export(cs_dp_ipc_t* c, void* record_out);
+int  cs_dp_ipc_connect(cs_dp_ipc_t* c, const void* all_records);
+int  cs_dp_ipc_buffer(cs_dp_ipc_t* c, void** dev_ptr, int64_t* n_floats);
+int  cs_dp_ipc_allreduce(cs_dp_ipc_t* c, int64_t n_floats, void* stream);
+int64_t cs_dp_ipc_timeouts(const cs_dp_ipc_t* c);
+void cs_dp_ipc_destroy(cs_dp_ipc_t* c);
+
 const char* cs_last_error(void);
 const char* cs_version(void);
 

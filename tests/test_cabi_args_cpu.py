@@ -95,6 +95,17 @@ def test_group_loader_metrics_dp_and_cnn_entries(lib):
     i0, i1 = C.c_int(), C.c_int()
     bad(lib, lib.cs_dp_comm_info(None, C.byref(i0), C.byref(i1)))
     lib.cs_dp_destroy(None)
+    ic = C.c_void_p()
+    bad(lib, lib.cs_dp_ipc_create(None, 2, 0, 0, 1024))
+    bad(lib, lib.cs_dp_ipc_create(C.byref(ic), 9, 0, 0, 1024), b"at most 8")
+    bad(lib, lib.cs_dp_ipc_create(C.byref(ic), 2, 2, 0, 1024))
+    bad(lib, lib.cs_dp_ipc_create(C.byref(ic), 2, 0, 0, 1023), b"multiple of 4")
+    bad(lib, lib.cs_dp_ipc_export(None, None))
+    bad(lib, lib.cs_dp_ipc_connect(None, None))
+    bad(lib, lib.cs_dp_ipc_buffer(None, None, None))
+    bad(lib, lib.cs_dp_ipc_allreduce(None, 4, None))
+    assert lib.cs_dp_ipc_timeouts(None) == 0
+    lib.cs_dp_ipc_destroy(None)
     h = C.c_void_p()
     bad(lib, lib.cs_cnn_create(C.byref(h), None))
     bad(lib, lib.cs_cnn_create(None, None))
