@@ -215,10 +215,11 @@ __device__ __forceinline__ void chain_mma(const u16* __restrict__ X, const u16* 
     // Older compiler-issued memory ops need no explicit drain: completion is in order, so the first counted
     // wait below also covers them.
     if (SELF_PRIME) chain_prime_t<NT, D>(Q, wfrag, ks_total, ntiles, jt0, lane);
-    // The previous stage's output (= this stage's input, still intact in X) goes to global memory NOW, behind
-    // the queue-priming loads: its stores are younger than every primed slot, so the counted waits never
-    // wait for a store acknowledgement (waiting vmcnt(0) for them before priming cost ~1 us per stage).
-    if (pend.out) {
+    // The previous stage's output (= this stage's input, intact in X until the barrier behind this k-loop) still has to go to
+    // global memory.  32-row tiles: NOW, behind the queue-priming loads (in front of them a vmcnt(0) for the stores cost ~1 us
+    // per stage).  Taller tiles: behind the LAST weight load of the stage (below).
+    constexpr bool LATE_COPY = BMROWS >= 64;
+    if (!LATE_COPY && pend.out) {
         if constexpr (WIDE_PEND) chainw_copy_out(X, pend.out, pend.ldo, pend.width, m0, tid);      // wide chain: any width, this wave's share
         else chain_copy_out<BMROWS>(X, pend.out, pend.ldo, pend.width, m0, tid);
         pend.out = nullptr;
@@ -230,6 +231,18 @@ __device__ __forceinline__ void chain_mma(const u16* __restrict__ X, const u16* 
     int s0 = 0;
     for (; s0 + D < ks_total; s0 += D) {     // contraction lengths are multiples of 64 = 4 steps; D=8 needs 128
         CHAIN_BLOCK(false)
+    }
+    // Taller tiles copy out HERE.  Memory operations of a wave retire in order, so a counted wait for a weight load also
+    // waits for every older store: behind the priming loads the stores sit in front of every refill, and the first
+    // refilled slot - D steps later - waits for their acknowledgements.  With 64 / 128 KiB per stage and workgroup that is what
+    // the chain spent a quarter of its time on at 65536 columns (no stores at all: 399.6 -> 301.8 us).  Behind the last load
+    // nothing in this stage waits for them: they drain under the tail MFMAs, the epilogue and the barrier.  Same-box A/B
+    // (us, fused chain; priming / here / here in one piece per tail step): 65536 columns 411.7 / 377.6 / 384.5, 16384 (64-row
+    // tiles) 117.4 / 113.4 / 115.7; 32-row tiles lose: 8192 columns 79.7 / 79.3 / 79.7, 3072: 71.9 / 73.2 / 73.5, published
+    // model (wide chain) 105.7 / 107.3 / 110.6 - there the copy is 32 KiB and the tail is where the wave is busiest.
+    if (LATE_COPY && pend.out) {
+        chain_copy_out<BMROWS>(X, pend.out, pend.ldo, pend.width, m0, tid);
+        pend.out = nullptr;
     }
     CHAIN_BLOCK(true)                        // last D steps: the final wait is vmcnt(0), every slot is consumed
 #undef CHAIN_AF

@@ -153,8 +153,7 @@ __device__ __forceinline__ void chainw_body(const ChainArgs& p, const ChainDyn& 
         const int t_base = ntiles >> 3, t_rem = ntiles & 7;
         const int t_cnt = t_base + (wid < t_rem ? 1 : 0), t_lo = wid * t_base + min(wid, t_rem);
         // The previous stage's output (this stage's input, intact in Xin) goes to global memory BEHIND the first weight
-        // loads of this stage (chain_mma, `pend`): its stores are then younger than every primed slot and the counted waits
-        // never wait for a store acknowledgement.  A wave without tiles in this stage copies its share right away.
+        // loads of this stage (chain_mma, `pend`; 32-row tiles: behind the priming loads, measured better than behind the last load).  A wave without tiles in this stage copies its share right away.
         if (t_cnt == 0 && pend.out) {
             chainw_copy_out(Xin, pend.out, pend.ldo, pend.width, m0, tid);
             pend.out = nullptr;
