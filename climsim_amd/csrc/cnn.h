@@ -32,7 +32,7 @@ struct ConvArgs {
     // k_conv2 only, forward modes: second pass accumulated on top of the activated first one -
     // out = [dropout](act(conv(A) + bias)) + (A2nd * B2nd + bias2)   (conv b + the block's 1-tap projection in one launch)
     const u16* A2nd; int lda2; const u16* B2nd; int ldb2, kpt2; const float* bias2;
-    int ablate;                                      // development (CS_CONV_ABLATE): 1 no DMA in the loop, 2 no MFMA, 4 no epilogue
+    int ablate;                                      // development (CS_CONV_ABLATE): 1 no DMA in the loop, 2 no MFMA, 4 no epilogue, 8 epilogue without its global stores
 };
 
 // (lowbias32: kernels.h)

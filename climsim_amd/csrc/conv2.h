@@ -181,7 +181,8 @@ __global__ __launch_bounds__(512) void k_conv2(const ConvArgs p) {
         if ((lane & 15) < 14) {                                                                          \
             _Pragma("unroll") for (int it = 0; it < 16; ++it) {                                          \
                 const uint4 v_ = *reinterpret_cast<const uint4*>(l_ + it * 960);                         \
-                *reinterpret_cast<uint4*>(g_ + (int64_t)it * 4 * (ld)) = v_;                              \
+                if (!(p.ablate & 8)) *reinterpret_cast<uint4*>(g_ + (int64_t)it * 4 * (ld)) = v_;         \
+                else asm volatile("" ::"v"(v_.x), "v"(v_.w));                                             \
             }                                                                                            \
         }                                                                                                \
     }
