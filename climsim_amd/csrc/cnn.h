@@ -32,6 +32,10 @@ struct ConvArgs {
     // k_conv2 only, forward modes: second pass accumulated on top of the activated first one -
     // out = [dropout](act(conv(A) + bias)) + (A2nd * B2nd + bias2)   (conv b + the block's 1-tap projection in one launch)
     const u16* A2nd; int lda2; const u16* B2nd; int ldb2, kpt2; const float* bias2;
+    // k_conv2 only: 1 bit per element of the activated (and dropped-out) tensor, in the kernel's own lane layout - [work id][512
+    // threads] x 128 bits (112 used: bit (i * 7 + j) * 4 + e of the thread's 4 x 7 result quads).  Written by the TRAIN_FWD epilogue
+    // (bits_out), read by the BWD launch that masks with that tensor (bits_in, instead of 28 eight-byte loads of `mask` per lane).
+    uint4* bits_out; const uint4* bits_in;
     int ablate;                                      // development (CS_CONV_ABLATE): 1 no DMA in the loop, 2 no MFMA, 4 no epilogue, 8 epilogue without its global stores
 };
 

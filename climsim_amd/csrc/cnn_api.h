@@ -12,7 +12,7 @@ struct CnnConv {
     int64_t w_off, b_off;              // offsets of kernel / bias in the flat Keras-order buffers
     u16* Wd; int ldd, kpd, slot0;      // data-gradient pack this kernel is written into (training), or null
 };
-struct CnnBlockBufs { u16 *A1, *A2, *XS, *DZ1, *DZ2, *GG; };
+struct CnnBlockBufs { u16 *A1, *A2, *XS, *DZ1, *DZ2, *GG; uint4 *B1 = nullptr, *B2 = nullptr; };   // B1 / B2: mask bits of A1 / A2 (k_conv2 lane layout)
 
 struct cs_cnn {
     cs_cnn_cfg cfg;
@@ -157,8 +157,9 @@ void launch_conv(const cs_cnn* h, const CnnConv& c, const u16* in, int ld_in, in
 // training-mode conv: out2 = dropout(act(conv(in))), out = out2 + add
 void launch_conv_train(const cs_cnn* h, const CnnConv& c, const u16* in, int ld_in, int layer, unsigned seed, const u16* add,
                        u16* out, u16* out2, int64_t m_rows, int64_t m_pad, hipStream_t st, const CnnConv* c2 = nullptr,
-                       const u16* in2 = nullptr, int ld_in2 = 0) {
+                       const u16* in2 = nullptr, int ld_in2 = 0, uint4* bits_out = nullptr) {
     ConvArgs p{};
+    p.bits_out = bits_out;
     cnn_fill_conv(h, p, c, in, ld_in, m_rows);
     cnn_second_pass(p, c2, in2, ld_in2);
     p.act = CACT_RELU; p.add = add; p.ldadd = CNN_CP; p.out = out; p.ldo = CNN_CP; p.out2 = out2; p.ldo2 = CNN_CP;
@@ -170,8 +171,9 @@ void launch_conv_train(const cs_cnn* h, const CnnConv& c, const u16* in, int ld_
 
 // data gradient: g = sum_slots A_s[m+sh_s] * Wd ; out (raw g, optional) ; out2 = g * (mask != 0) * mscale
 void launch_conv_bwd(const cs_cnn* h, const u16* dz3, const u16* g1, int lda, int kpt, const u16* Wd, int slots, const u16* mask,
-                     u16* out, u16* out2, int64_t m_rows, int64_t m_pad, hipStream_t st) {
+                     u16* out, u16* out2, int64_t m_rows, int64_t m_pad, hipStream_t st, const uint4* bits_in = nullptr) {
     ConvArgs p{};
+    p.bits_in = bits_in;
     p.A0 = p.A1 = p.A2 = dz3; p.A3 = g1;
     if (slots == 1) { p.sh0 = p.sh1 = p.sh2 = p.sh3 = 0; } else { p.sh0 = -1; p.sh1 = 0; p.sh2 = 1; p.sh3 = 0; }
     p.lda = lda; p.B = Wd; p.ldb = slots * kpt; p.kpt = kpt; p.taps = slots; p.seq = h->cfg.seq; p.m_rows = m_rows;
@@ -311,6 +313,11 @@ int cs_cnn_create(cs_cnn_t** out, const cs_cnn_cfg* cfg) {
         for (int b = 0; b < depth; ++b) {
             for (u16** t : {&h->blk[b].A1, &h->blk[b].A2, &h->blk[b].XS, &h->blk[b].DZ1, &h->blk[b].DZ2, &h->blk[b].GG})
                 A((void**)t, sizeof(u16) * h->m_pad_max * CNN_CP);
+            if (!h->tile128 && !(getenv("CS_CNN_MASK_BITS") && atoi(getenv("CS_CNN_MASK_BITS")) == 0)) {
+                const size_t wgs = (size_t)(h->m_pad_max / CV2_BM) * ((cfg->channels + CV2_BN - 1) / CV2_BN);
+                A((void**)&h->blk[b].B1, wgs * 512 * sizeof(uint4));
+                A((void**)&h->blk[b].B2, wgs * 512 * sizeof(uint4));
+            }
             if (b > 0) A((void**)&h->Wd_a[b], sizeof(u16) * CNN_CP * 4 * cp);
             A((void**)&h->Wd_b[b], sizeof(u16) * CNN_CP * 3 * cp);
         }
@@ -489,12 +496,12 @@ int cs_cnn_loss_grads(cs_cnn_t* h, const float* x_dev, int x3d, const float* y_d
     for (int b = 0; b < depth; ++b) {
         const CnnConv &ca = h->convs[3 * b], &cb = h->convs[3 * b + 1], &cr = h->convs[3 * b + 2];
         CnnBlockBufs& B = h->blk[b];
-        launch_conv_train(h, ca, x, ldx, 2 * b, seed, nullptr, B.A1, nullptr, m_rows, m_pad, st);
+        launch_conv_train(h, ca, x, ldx, 2 * b, seed, nullptr, B.A1, nullptr, m_rows, m_pad, st, nullptr, nullptr, 0, B.B1);
         if (h->tile128) {
             launch_conv(h, cr, x, ldx, CACT_NONE, nullptr, h->R, CNN_CP, m_rows, m_pad, st);
             launch_conv_train(h, cb, B.A1, CNN_CP, 2 * b + 1, seed, h->R, B.XS, B.A2, m_rows, m_pad, st);
         } else {
-            launch_conv_train(h, cb, B.A1, CNN_CP, 2 * b + 1, seed, nullptr, B.XS, B.A2, m_rows, m_pad, st, &cr, x, ldx);
+            launch_conv_train(h, cb, B.A1, CNN_CP, 2 * b + 1, seed, nullptr, B.XS, B.A2, m_rows, m_pad, st, &cr, x, ldx, B.B2);
         }
         x = B.XS; ldx = CNN_CP;
     }
@@ -507,12 +514,12 @@ int cs_cnn_loss_grads(cs_cnn_t* h, const float* x_dev, int x3d, const float* y_d
                        h->G + h->off_wr, h->G + h->off_br);
     // ---- data gradients, last block to first
     launch_conv_bwd(h, h->DZO, h->DZO, 128, kgran, h->Wd_o, 1, h->blk[depth - 1].A2, h->blk[depth - 1].GG, h->blk[depth - 1].DZ2,
-                    m_rows, m_pad, st);
+                    m_rows, m_pad, st, h->blk[depth - 1].B2);
     for (int b = depth - 1; b >= 0; --b) {
         CnnBlockBufs& B = h->blk[b];
-        launch_conv_bwd(h, B.DZ2, B.DZ2, CNN_CP, cp, h->Wd_b[b], 3, B.A1, nullptr, B.DZ1, m_rows, m_pad, st);
+        launch_conv_bwd(h, B.DZ2, B.DZ2, CNN_CP, cp, h->Wd_b[b], 3, B.A1, nullptr, B.DZ1, m_rows, m_pad, st, B.B1);
         if (b > 0) launch_conv_bwd(h, B.DZ1, B.GG, CNN_CP, cp, h->Wd_a[b], 4, h->blk[b - 1].A2, h->blk[b - 1].GG, h->blk[b - 1].DZ2,
-                                   m_rows, m_pad, st);
+                                   m_rows, m_pad, st, h->blk[b - 1].B2);
     }
     // ---- weight gradients: stream-K over every conv of the step (conv_wgrad2.h) + the 10-channel conv
     if (h->n_cw_tiles > 0) {

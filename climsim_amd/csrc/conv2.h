@@ -158,8 +158,12 @@ __global__ __launch_bounds__(512) void k_conv2(const ConvArgs p) {
     for (int j = 0; j < 7; ++j)
         bq[j] = MODE != CONV_BWD ? *reinterpret_cast<const float4*>(p.bias + n0 + wn * 112 + j * 16 + 4 * (lane >> 4))
                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+    // BWD: the mask bits of this thread's 112 results (one 16-byte load, in flight during the main loop)
+    uint4 mbits = make_uint4(0u, 0u, 0u, 0u);
+    if (MODE == CONV_BWD && p.bits_in) mbits = p.bits_in[(int64_t)work * 512 + tid];
     CV2_SETUP()
     CV2_PIPELINE(12)
+    if (MODE == CONV_BWD) asm volatile("" : "+v"(mbits.x), "+v"(mbits.y), "+v"(mbits.z), "+v"(mbits.w));   // retired with the pipeline's vmcnt(0): hipcc must not wait for it behind the stores below
 
     if (p.ablate & 4) return;
     // ---- epilogue.  D[channel][row]: lane owns row ..+(lane&15), channels ..+4*(lane>>4)+{0..3}.
@@ -189,6 +193,20 @@ __global__ __launch_bounds__(512) void k_conv2(const ConvArgs p) {
 
     if (MODE == CONV_BWD) {
         if (p.out) CV2_STORE_TILE(p.out, p.ldo)
+        if (p.bits_in) {
+            // mask from the forward pass's bits: no memory operation between the two store tiles (the eight-byte mask loads
+            // below sit BEHIND the first tile's stores and retire after them: a second round trip per launch)
+            const unsigned mw[4] = {mbits.x, mbits.y, mbits.z, mbits.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 7; ++j) {
+                    const int t = (i * 7 + j) * 4;
+                    const unsigned b4 = mw[t >> 5] >> (t & 31);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[i][j][e] = (b4 & (1u << e)) ? acc[i][j][e] * p.mscale : 0.f;
+                }
+        } else {
 #pragma unroll
         for (int jh = 0; jh < 7; jh += 4) {                 // all loads of a half first, then their uses
             uint2 k2[4][4];
@@ -207,6 +225,7 @@ __global__ __launch_bounds__(512) void k_conv2(const ConvArgs p) {
                     acc[i][j][2] = (k.y & 0x7fffu) ? acc[i][j][2] * p.mscale : 0.f;
                     acc[i][j][3] = (k.y & 0x7fff0000u) ? acc[i][j][3] * p.mscale : 0.f;
                 }
+        }
         }
         CV2_STORE_TILE(p.out2, p.ldo2)
     } else {
@@ -233,6 +252,21 @@ __global__ __launch_bounds__(512) void k_conv2(const ConvArgs p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[i][j][e] = v[e];
             }
+        }
+        if (MODE == CONV_TRAIN_FWD && p.bits_out) {
+            // acc now holds the activated, dropped-out tensor the backward pass masks with (>= 0 everywhere: ReLU): one bit
+            // per element, this thread's 112 in one 16-byte store
+            unsigned mw[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 7; ++j) {
+                    const int t = (i * 7 + j) * 4;
+                    const unsigned b4 = (acc[i][j][0] > 0.f ? 1u : 0u) | (acc[i][j][1] > 0.f ? 2u : 0u) | (acc[i][j][2] > 0.f ? 4u : 0u) |
+                                        (acc[i][j][3] > 0.f ? 8u : 0u);
+                    mw[t >> 5] |= b4 << (t & 31);
+                }
+            p.bits_out[(int64_t)work * 512 + tid] = make_uint4(mw[0], mw[1], mw[2], mw[3]);
         }
         if (MODE == CONV_TRAIN_FWD && p.out2) CV2_STORE_TILE(p.out2, p.ldo2)
         if (p.A2nd) {
