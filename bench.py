@@ -422,7 +422,8 @@ def main():
                     "the one-kernel all-reduce over peer-mapped buffers (cs_dp_ipc_*); the other one is timed on its own and reported in `comm`")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU-baseline timing (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event pass")
-    ap.add_argument("--no-extras", action="store_true", help="skip the CNN / loader side figures")
+    ap.add_argument("--no-extras", action="store_true", help="skip the side figures")
+    ap.add_argument("--extras", default="pub_mlp,cnn,loader,stream", help="which side figures to take (comma-separated)")
     ap.add_argument("--train-only", action="store_true", help="counter runs: nothing but the training steps (no held-out "
                     "evaluation, no prediction pass), so that per-kernel averages are averages over training launches")
     args = ap.parse_args()
@@ -684,10 +685,15 @@ def main():
     if rank == 0 and world == 1 and not args.no_extras:
         model.close()
         torch.cuda.empty_cache()
-        extras["pub_mlp"] = side_bench(lambda: pub_mlp_side_bench(torch, device, args.cpu_budget / 3))
-        extras["cnn"] = side_bench(cnn_side_bench)
-        extras["loader"] = side_bench(loader_side_bench)
-        extras["stream"] = side_bench(stream_side_bench)
+        want = set(args.extras.split(","))
+        if "pub_mlp" in want:
+            extras["pub_mlp"] = side_bench(lambda: pub_mlp_side_bench(torch, device, args.cpu_budget / 3))
+        if "cnn" in want:
+            extras["cnn"] = side_bench(cnn_side_bench)
+        if "loader" in want:
+            extras["loader"] = side_bench(loader_side_bench)
+        if "stream" in want:
+            extras["stream"] = side_bench(stream_side_bench)
 
     if rank == 0:
         out = {"metric": "training columns/sec", "value": round(value, 1), "unit": "columns/s",

@@ -45,7 +45,7 @@ def test_one_gpu_line():
 def test_one_gpu_line_with_the_cpu_legs():
     """The acceptance leg (engine against the fp32 CPU restatement after the same steps on the same batches) and the
     published-model side figure with its own CPU baseline."""
-    d = run(["--steps", "5", "--warmup", "2", "--min-seconds", "0.05", "--rows", "65536", "--cpu-budget", "3", "--no-profile"])
+    d = run(["--steps", "5", "--warmup", "2", "--min-seconds", "0.05", "--rows", "65536", "--cpu-budget", "3", "--no-profile", "--extras", "pub_mlp"])
     a = d["heldout"]["against_cpu_restatement"]
     assert "error" not in a, a
     # a REPORT, not the parity bar (tests/test_mlp_gpu.py::test_heldout_per_variable_mae_r2_match_cpu_training holds 2 % / 5 %
