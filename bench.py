@@ -420,6 +420,8 @@ def main():
                     "bf16 = half the bytes, cs_dp_allreduce_bf16); both are timed and reported in `comm` either way")
     ap.add_argument("--collective", choices=("rccl", "oneshot"), default="rccl", help="N>1: the gradient all-reduce of the timed steps: RCCL (default) or "
                     "the one-kernel all-reduce over peer-mapped buffers (cs_dp_ipc_*); the other one is timed on its own and reported in `comm`")
+    ap.add_argument("--time-oneshot", action="store_true", help="N>1 with --collective rccl: also time the one-shot all-reduce on its own (`comm.allreduce_us_oneshot_ipc`). "
+                    "Off by default: that path has only run with two processes on ONE device, and a fault in it must not take a scaling run down")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU-baseline timing (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event pass")
     ap.add_argument("--no-extras", action="store_true", help="skip the side figures")
@@ -560,7 +562,7 @@ def main():
         # the OTHER collective on its own, same 20 steps (the one-shot all-reduce rebinds the engine's gradient buffer to its
         # exchange buffer while it exists; RCCL's communicator works on whatever buffer the engine holds)
         other_us, other_err = None, None
-        if dp.collective == "rccl":
+        if dp.collective == "rccl" and args.time_oneshot:
             from climsim_amd._lib import EngineError
             try:
                 dpo = DataParallel(model, dist, collective="oneshot")

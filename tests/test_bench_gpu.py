@@ -59,7 +59,7 @@ def test_one_gpu_line_with_the_cpu_legs():
 
 
 def test_two_ranks_start_themselves_and_report_weak_strong_and_comm():
-    d = run(["--gpus", "2", *FAST, "--no-profile", "--batch", "2048", "--weak-large-batch", "8192"], {"CS_BENCH_SHARE_GPU": "1"})
+    d = run(["--gpus", "2", *FAST, "--no-profile", "--batch", "2048", "--weak-large-batch", "8192", "--time-oneshot"], {"CS_BENCH_SHARE_GPU": "1"})
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 4096
     assert d["value"] == pytest.approx(4096 / (d["ms_per_step"] * 1e-3), rel=1e-3)          # whole-job columns / max-over-ranks time
     s = d["strong"]
