@@ -558,7 +558,12 @@ def main():
         n_grad = int(model.gradient_tensor().numel())
         us = {pl: collective_us(pl) for pl in (("fp32", "bf16") if dp.collective == "rccl" else ("fp32",))}
         us.setdefault("bf16", None)
-        rccl_n, rccl_r = dp.native.info() if (dp.native is not None and dp.collective == "rccl") else (None, None)
+        rccl_n, rccl_r = None, None
+        if dp.native is not None and dp.collective == "rccl":
+            try:
+                rccl_n, rccl_r = dp.native.info()
+            except Exception:                                        # an RCCL without ncclCommCount: report nothing rather than fail the run
+                pass
         # the OTHER collective on its own, same 20 steps (the one-shot all-reduce rebinds the engine's gradient buffer to its
         # exchange buffer while it exists; RCCL's communicator works on whatever buffer the engine holds)
         other_us, other_err = None, None
