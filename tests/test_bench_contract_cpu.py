@@ -24,6 +24,25 @@ def test_committed_bench_line_has_the_contract_keys():
     assert abs(d["value"] - d["config"]["global_batch"] / (d["ms_per_step"] * 1e-3)) <= 0.01 * d["value"]
 
 
+def test_round3_bench_line_carries_the_repaired_fields():
+    """The line committed at the end of round 3 (profiles/r03_bench_b8192.json): per-kernel times that add up to the step, the
+    acceptance leg against the CPU restatement, the published model with its own CPU baseline, no dead ReLU head."""
+    d = json.loads(open(os.path.join(REPO, "profiles", "r03_bench_b8192.json")).read().strip().splitlines()[-1])
+    assert d["metric"] == "training columns/sec" and d["n_gpus"] == 1 and d["vs_baseline"] is None and d["dtype"] == "bf16"
+    assert sum(k["ms_per_step"] for k in d["kernels"].values()) <= d["ms_per_step"] * 1.001
+    assert 0 < d["kernels_note"]["scaled_by"] <= 1.0
+    assert d["coop_timeouts"] == 0
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["traffic"] > 0 and r["traffic_source"].startswith("profiles/r03_")
+    a = d["heldout"]["against_cpu_restatement"]
+    assert a["rel_diff_mae_all_outputs"] < 0.02 and a["min_R2"]["engine_bf16"] > 0.5 and a["min_R2"]["cpu_fp32"] > 0.5
+    assert all(v is None or v > 0 for v in d["heldout"]["per_variable"]["R2"].values())        # no variable lost to a dead unit
+    p = d["pub_mlp"]
+    assert p["columns_per_s"] > 2e7 and p["cpu_baseline"]["kind"] == "port" and p["cpu_baseline"]["cores"] >= 1
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["value"] > 0 and c["unit"] == d["unit"]
+
+
 def test_bench_defaults_and_flags():
     src = open(os.path.join(REPO, "bench.py")).read()
     for flag in ("--gpus", "--steps", "--warmup"):

@@ -306,7 +306,7 @@ def test_heldout_per_variable_mae_r2_match_cpu_training(M, lowres_assets):
     the evaluation pipeline of data_utils (set_pressure_grid -> output_weighting -> calc_MAE / RMSE / R2 ->
     create_metrics_df; golden-pinned on the CPU).
     Tolerance: MAE and RMSE within 2 % relative for the two 60-level variables and 5 % for the eight single-output
-    variables (one output is noisier than the mean of 60), R2 within 0.02 absolute.  Measured (tests/accept_dbg.py):
+    variables (one output is noisier than the mean of 60), R2 within 0.02 absolute.  Measured (a development script, since removed):
     aggregate MAE engine 0.01219 vs CPU 0.01210 (0.75 %), single outputs within 2.1 %, and the engine against itself with
     another batch order 0.01219 - the bar is the run-to-run spread of a chaotic optimisation.  The learning-rate drop
     matters: with a constant 1e-3 the final iterate of EITHER implementation moves by 10-35 % on single outputs from one
