@@ -25,7 +25,8 @@
 #define CV2_BN 224
 #define CV2_A_BYTES (CV2_BM * 64)
 #define CV2_STAGE_BYTES ((CV2_BM + CV2_BN) * 64)
-#define CV2_LDS_BYTES (CV2_STAGES * CV2_STAGE_BYTES)
+#define CV2_RING_BYTES (CV2_STAGES * CV2_STAGE_BYTES)
+#define CV2_LDS_BYTES (CV2_RING_BYTES + 2048)      // + the two bias vectors of this channel tile (2 x 224 floats)
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
@@ -151,13 +152,14 @@ __global__ __launch_bounds__(512) void k_conv2(const ConvArgs p) {
         __builtin_amdgcn_s_barrier();                                  /* ... and nobody reads the ring any more */ \
     }
 
-    // bias of this lane's 7 channel quads, fetched before the pipeline: a load issued in the epilogue costs a full L2
-    // round trip per dependent use, and there is nothing left to hide it behind
-    float4 bq[7];
-#pragma unroll
-    for (int j = 0; j < 7; ++j)
-        bq[j] = MODE != CONV_BWD ? *reinterpret_cast<const float4*>(p.bias + n0 + wn * 112 + j * 16 + 4 * (lane >> 4))
-                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+    // Biases of this channel tile (and of the second pass) wait in LDS behind the ring: a load issued in the epilogue costs a full
+    // L2 round trip per dependent use, and held in registers (round 2: 28 VGPRs across the main loop) they pushed the forward
+    // variants to 256 VGPRs + 92-104 bytes of scratch per lane.
+    float* bias_lds = reinterpret_cast<float*>(cv2_ring + CV2_RING_BYTES);
+    if (MODE != CONV_BWD && tid < CV2_BN) {
+        bias_lds[tid] = p.bias[n0 + tid];
+        if (p.A2nd) bias_lds[CV2_BN + tid] = p.bias2[n0 + tid];
+    }
     // BWD: the mask bits of this thread's 112 results (one 16-byte load, in flight during the main loop)
     uint4 mbits = make_uint4(0u, 0u, 0u, 0u);
     if (MODE == CONV_BWD && p.bits_in) mbits = p.bits_in[(int64_t)work * 512 + tid];
@@ -235,7 +237,7 @@ __global__ __launch_bounds__(512) void k_conv2(const ConvArgs p) {
 #pragma unroll
         for (int j = 0; j < 7; ++j) {
             const int n = nw + j * 16 + 4 * (lane >> 4);
-            const float4 b4 = bq[j];
+            const float4 b4 = *reinterpret_cast<const float4*>(bias_lds + wn * 112 + j * 16 + 4 * (lane >> 4));
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int64_t m = mw + i * 16 + (lane & 15);
@@ -274,7 +276,7 @@ __global__ __launch_bounds__(512) void k_conv2(const ConvArgs p) {
             // (x_next = dropout(relu(conv_b(a1))) + conv_r(x): one launch, no R tensor, no extra epilogue)
 #pragma unroll
             for (int j = 0; j < 7; ++j) {
-                const float4 b4 = *reinterpret_cast<const float4*>(p.bias2 + nw + j * 16 + 4 * (lane >> 4));
+                const float4 b4 = *reinterpret_cast<const float4*>(bias_lds + CV2_BN + wn * 112 + j * 16 + 4 * (lane >> 4));
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { acc[i][j][0] += b4.x; acc[i][j][1] += b4.y; acc[i][j][2] += b4.z; acc[i][j][3] += b4.w; }
             }
