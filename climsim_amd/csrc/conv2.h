@@ -20,7 +20,12 @@
 #ifndef CV2_SWZ_EXPR
 #define CV2_SWZ_EXPR (((q & 1) << 1) ^ ((q >> 1) * 3))
 #endif
-#define CV2_STAGES 4             // a 5-slot ring (four slabs in flight, 150 KiB) measured 1 % / 4 % SLOWER (train / predict, same box)
+#ifndef CV2_ASM_LOOP
+#define CV2_ASM_LOOP 1
+#endif
+#ifndef CV2_STAGES
+#define CV2_STAGES (CV2_ASM_LOOP ? 5 : 4)   // builtin loop: a 5-slot ring with FOUR slabs in flight measured 1 % / 4 % slower; the asm loop keeps
+#endif                                      // three in flight and uses the fifth slot to take `lgkmcnt(0)` out of the barrier's way
 #define CV2_BM 256
 #define CV2_BN 224
 #define CV2_A_BYTES (CV2_BM * 64)
@@ -82,27 +87,56 @@ __global__ __launch_bounds__(512) void k_conv2(const ConvArgs p) {
         kc = qkpt >> 5; nt = qtaps * kc;                                                                \
     }
 
-    // Slab `st` (clamped past the end: identical bytes, uniform vmcnt count): CV2_SRC derives the wave-uniform part of
-    // the four piece sources (SGPRs), CV2_PIECE(k) forms the per-lane address right where the piece is issued - holding
-    // four 64-bit lane addresses across the MFMA groups cost 22-31 spilled VGPRs in the two-pass kernels.
-#define CV2_SRC(st)                                                                                    \
-        const int sc_ = min((st), nt - 1);                                                              \
-        const int tap_ = sc_ / kc, c0_ = (sc_ - tap_ * kc) * 32;                                        \
-        const int sh_ = tap_ == 0 ? qs0 : tap_ == 1 ? qs1 : tap_ == 2 ? qs2 : qs3;                      \
-        const u16* S_ = tap_ == 0 ? qA0 : tap_ == 1 ? qA1 : tap_ == 2 ? qA2 : qA3;                      \
-        const char* Sb_ = reinterpret_cast<const char*>(S_) + ((int64_t)sh_ * qlda + c0_) * 2;          \
-        const int boff_ = sc_ * 64;                                                                     \
-        const unsigned base_ = lds0 + (unsigned)((st) & (CV2_STAGES - 1)) * CV2_STAGE_BYTES;
-#define CV2_PIECE(k)                                                                                   \
-        dma16((k) == 0 ? (((ok0 >> tap_) & 1u) ? Sb_ + arow0 : zsrc)                                    \
-              : (k) == 1 ? (((ok1 >> tap_) & 1u) ? Sb_ + arow1 : zsrc)                                  \
-              : (k) == 2 ? bsrc0 + boff_ : bsrc1 + boff_,                                               \
-              base_ + ((k) == 0 ? a_piece0 : (k) == 1 ? a_piece0 + 8192u : (k) == 2 ? CV2_A_BYTES + a_piece0 : CV2_A_BYTES + b_piece1));
-#define CV2_ISSUE(st)                                                                                  \
+    // Slab sources: CV2_SRCX derives the wave-uniform part of the four piece sources of slab (tap, chunk) (SGPRs, names suffixed X),
+    // CV2_PIECEX(X, k) forms the per-lane address right where the piece is issued - holding four 64-bit lane addresses across the
+    // MFMA groups cost 22-31 spilled VGPRs in the two-pass kernels.  Pieces past the last slab re-fetch it (identical bytes,
+    // uniform vmcnt count).
+#define CV2_SRCX(X, tap, ch, slot)                                                                      \
+        const int tap_##X = (tap), c0_##X = (ch) * 32;                                                  \
+        const int sh_##X = tap_##X == 0 ? qs0 : tap_##X == 1 ? qs1 : tap_##X == 2 ? qs2 : qs3;          \
+        const u16* S_##X = tap_##X == 0 ? qA0 : tap_##X == 1 ? qA1 : tap_##X == 2 ? qA2 : qA3;          \
+        const char* Sb_##X = reinterpret_cast<const char*>(S_##X) + ((int64_t)sh_##X * qlda + c0_##X) * 2; \
+        const int boff_##X = (tap_##X * kc + (ch)) * 64;                                                \
+        const unsigned base_##X = lds0 + (unsigned)(slot) * CV2_STAGE_BYTES;
+#ifndef CV2_ABL
+#define CV2_ABL 0            // development (results are garbage): 1 = no DMA in the loop, 2 = no fragment reads in the loop, 4 = no MFMAs,
+#endif                       // 16 = row-operand pieces of taps > 0 come from the zero page, 32 = weight pieces always from slab 0 (L1 hits)
+#define CV2_PIECEX(X, k)                                                                               \
+        dma16((k) == 0 ? ((((ok0 >> tap_##X) & 1u) && !((CV2_ABL & 16) && tap_##X)) ? Sb_##X + arow0 : zsrc)                              \
+              : (k) == 1 ? ((((ok1 >> tap_##X) & 1u) && !((CV2_ABL & 16) && tap_##X)) ? Sb_##X + arow1 : zsrc)                            \
+              : (k) == 2 ? bsrc0 + ((CV2_ABL & 32) ? 0 : boff_##X) : bsrc1 + ((CV2_ABL & 32) ? 0 : boff_##X),                                         \
+              base_##X + ((k) == 0 ? a_piece0 : (k) == 1 ? a_piece0 + 8192u : (k) == 2 ? CV2_A_BYTES + a_piece0 : CV2_A_BYTES + b_piece1));
+#if CV2_ASM_LOOP
+    // The contraction runs over (tap, 32-channel chunk) in an order that puts the two 64-byte halves of every 128-byte line of
+    // the operands into CONSECUTIVE slabs (2m, 2m+1 of one tap; the odd last chunk of each tap at the end): the two halves are
+    // then requested back to back by the same lanes and the second is served from the L1 line the first brought in.  Issued a
+    // slab apart (round 2: slab s+4 per iteration) every line travelled L2 -> L1 twice and the main loop ran at the pace of
+    // that fill (64 B/clk per CU): 20 us of DMA against 15.4 us of MFMA per 39-slab launch (`tools/conv2_loop_ablate.sh`).
+    // State of the next slab to issue, advanced by CV2_ADV and held at the last slab: no division in the loop.
+    int isl, itap, ich, kpair, lone;
+#define CV2_ADV()                                                        /* selects, no branches: scalar work between the MFMAs */ \
     {                                                                                                   \
-        CV2_SRC(st)                                                                                     \
+        const int go_ = isl + 1 < nt ? 1 : 0;                                                           \
+        const int wrap_ = (lone ^ 1) & (ich + 1 == kpair ? 1 : 0);      /* pair region: last chunk of this tap */ \
+        const int ntap_ = itap + (lone | wrap_);                                                        \
+        const int tolone_ = wrap_ & (ntap_ == qtaps ? 1 : 0);           /* pairs of every tap done: the odd chunks */ \
+        const int nich_ = lone ? ich : wrap_ ? 0 : ich + 1;                                             \
+        isl += go_;                                                                                     \
+        ich = go_ ? (tolone_ ? kc - 1 : nich_) : ich;                                                   \
+        itap = go_ ? (tolone_ ? 0 : ntap_) : itap;                                                      \
+        lone = go_ ? (lone | tolone_) : lone;                                                           \
+    }
+#else
+#define CV2_SRC(st, slot)                                                                              \
+        const int scl_ = min((st), nt - 1);                                                             \
+        CV2_SRCX(_, scl_ / kc, scl_ - (scl_ / kc) * kc, slot)
+#define CV2_PIECE(k) CV2_PIECEX(_, k)
+#define CV2_ISSUE(st, slot)                                                                            \
+    {                                                                                                   \
+        CV2_SRC(st, slot)                                                                               \
         CV2_PIECE(0) CV2_PIECE(1) CV2_PIECE(2) CV2_PIECE(3)                                             \
     }
+#endif
 
     f32x4_t acc[4][7];
 #pragma unroll
@@ -115,14 +149,89 @@ __global__ __launch_bounds__(512) void k_conv2(const ConvArgs p) {
     const unsigned a_off = (unsigned)((wm * 64 + (lane & 15)) * 64) + sw;
     const unsigned b_off = (unsigned)(CV2_A_BYTES + (wn * 112 + (lane & 15)) * 64) + sw;
 
-    // One pass of the software pipeline over the current operands, accumulating into acc: DMA three slabs ahead; the
-    // fragments of slab s+1 are read from LDS between the MFMAs of slab s, each fragment register reloaded in place
-    // right after its last use; the four DMA pieces of slab s+4 are issued one at a time between MFMA groups (all
-    // eight waves leave the barrier together, and a wave that issues its pieces back to back stalls while its SIMD
-    // partner does the same).  Ends with the ring drained and free.
+    // One pass of the software pipeline over the current operands, accumulating into acc.  The loop body is written out in
+    // `asm volatile` pieces (MFMAs, fragment reads, counted waits) so that its order is the one below (hipcc's own schedule of
+    // the builtin form, kept under CV2_ASM_LOOP=0, regrouped the fragment reads and waited `lgkmcnt(0)` right behind a read four
+    // to five times per slab).
+    //   * row-major over the 4 x 7 tiles: fa[i] is re-read (slab s+1) behind its seventh MFMA, fw[j] behind the MFMAs of the
+    //     last row; the next slab's first MFMA needs fw[0], issued seven MFMAs earlier, and waits with a COUNT (LDS returns in order);
+    //   * 5-slot ring, slabs issued in PAIRS (see CV2_ADV above): iteration s even issues slabs s+4 (slot of slab s-1) and s+5
+    //     (slot of slab s: every wave's reads of it have retired - `lgkmcnt(0)` in front of the barrier), piece by piece with
+    //     the two halves of a line adjacent, two pieces per row of tiles; odd iterations issue nothing.  Per wave 8 or 16 pieces
+    //     are outstanding at a barrier; `vmcnt(8)` (even) / `vmcnt(9)` (odd: all of the older pair but its last piece, which
+    //     belongs to slab s+2) says slab s+1 has landed.
+    // Ends with the ring drained and free.
+#if CV2_ASM_LOOP
+#define CV2_MFMA(i, j) if (!(CV2_ABL & 4)) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(fw[j]), "v"(fa[i]));
+#define CV2_LDA(i) if (!(CV2_ABL & 2) || !inloop) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[i]) : "v"(va), "n"((i) * 1024));
+#define CV2_LDW(j) if (!(CV2_ABL & 2) || !inloop) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fw[j]) : "v"(vb), "n"((j) * 1024));
+#define CV2_LGKM(n) asm volatile("s_waitcnt lgkmcnt(" #n ")");
+#define CV2_PAIR(k) if (EVEN_ && !(CV2_ABL & 1)) { CV2_PIECEX(P, k) CV2_PIECEX(Q, k) }
+    // one slab: MFMAs on the fragments in registers, fragments of the next slab (slot sl_r) read in place
+#define CV2_SLAB(EVEN)                                                                                 \
+    {                                                                                                   \
+        constexpr bool EVEN_ = EVEN;                                                                    \
+        if (EVEN_) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");   /* slab s+1 landed (mine); my reads of slab s retired */ \
+        else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");                                           \
+        __builtin_amdgcn_s_barrier();                                            /* ... everyone's */      \
+        const int slp_ = sl_r + 3 >= CV2_STAGES ? sl_r + 3 - CV2_STAGES : sl_r + 3;   /* slot of slab s+4 = of slab s-1 */ \
+        const int slq_ = sl_r == 0 ? CV2_STAGES - 1 : sl_r - 1;                        /* slot of slab s+5 = of slab s */ \
+        CV2_SRCX(P, itap, ich, slp_)                                                                    \
+        if (EVEN_) CV2_ADV()                                                                            \
+        CV2_SRCX(Q, itap, ich, slq_)                                                                    \
+        if (EVEN_) CV2_ADV()                                                                            \
+        va = lds0 + (unsigned)sl_r * CV2_STAGE_BYTES + a_off;                                           \
+        vb = lds0 + (unsigned)sl_r * CV2_STAGE_BYTES + b_off;                                           \
+        CV2_LGKM(7) CV2_MFMA(0, 0) CV2_LGKM(6) CV2_MFMA(0, 1) CV2_LGKM(5) CV2_MFMA(0, 2) CV2_LGKM(4) CV2_MFMA(0, 3) \
+        CV2_LGKM(3) CV2_MFMA(0, 4) CV2_LGKM(2) CV2_MFMA(0, 5) CV2_LGKM(1) CV2_MFMA(0, 6)                \
+        CV2_LDA(0) CV2_PAIR(0)                                                                          \
+        CV2_MFMA(1, 0) CV2_MFMA(1, 1) CV2_MFMA(1, 2) CV2_MFMA(1, 3) CV2_MFMA(1, 4) CV2_MFMA(1, 5) CV2_MFMA(1, 6) \
+        CV2_LDA(1) CV2_PAIR(1)                                                                          \
+        CV2_MFMA(2, 0) CV2_MFMA(2, 1) CV2_MFMA(2, 2) CV2_MFMA(2, 3) CV2_MFMA(2, 4) CV2_MFMA(2, 5) CV2_MFMA(2, 6) \
+        CV2_LDA(2) CV2_PAIR(2)                                                                          \
+        CV2_LGKM(3)                                 /* fa[3] of this slab: three younger reads */        \
+        CV2_MFMA(3, 0) CV2_LDW(0) CV2_MFMA(3, 1) CV2_LDW(1) CV2_MFMA(3, 2) CV2_LDW(2) CV2_MFMA(3, 3) CV2_LDW(3) \
+        CV2_MFMA(3, 4) CV2_LDW(4) CV2_MFMA(3, 5) CV2_LDW(5) CV2_MFMA(3, 6) CV2_LDW(6)                   \
+        CV2_LDA(3) CV2_PAIR(3)                                                                          \
+        sl_r = sl_r + 1 == CV2_STAGES ? 0 : sl_r + 1;                                                   \
+    }
 #define CV2_PIPELINE(NOLDR)                                                                            \
     {                                                                                                   \
-        CV2_ISSUE(0) CV2_ISSUE(1) CV2_ISSUE(2) CV2_ISSUE(3)                                             \
+        isl = 0; itap = 0; ich = 0; kpair = kc & ~1; lone = kpair == 0 ? 1 : 0;                                 \
+        if (lone) ich = kc - 1;                                                                         \
+        {                                                                                               \
+            CV2_SRCX(P, itap, ich, 0) CV2_ADV() CV2_SRCX(Q, itap, ich, 1) CV2_ADV()                     \
+            CV2_PIECEX(P, 0) CV2_PIECEX(Q, 0) CV2_PIECEX(P, 1) CV2_PIECEX(Q, 1)                         \
+            CV2_PIECEX(P, 2) CV2_PIECEX(Q, 2) CV2_PIECEX(P, 3) CV2_PIECEX(Q, 3)                         \
+        }                                                                                               \
+        {                                                                                               \
+            CV2_SRCX(P, itap, ich, 2) CV2_ADV() CV2_SRCX(Q, itap, ich, 3) CV2_ADV()                     \
+            CV2_PIECEX(P, 0) CV2_PIECEX(Q, 0) CV2_PIECEX(P, 1) CV2_PIECEX(Q, 1)                         \
+            CV2_PIECEX(P, 2) CV2_PIECEX(Q, 2) CV2_PIECEX(P, 3) CV2_PIECEX(Q, 3)                         \
+        }                                                                                               \
+        bf16x8_t fa[4], fw[7];                                                                          \
+        asm volatile("s_waitcnt vmcnt(9)" ::: "memory");            /* slab 0 has landed */               \
+        __builtin_amdgcn_s_barrier();                                                                   \
+        unsigned va = lds0 + a_off, vb = lds0 + b_off; bool inloop = false;                             \
+        CV2_LDA(0) CV2_LDA(1) CV2_LDA(2)                                                                \
+        CV2_LDW(0) CV2_LDW(1) CV2_LDW(2) CV2_LDW(3) CV2_LDW(4) CV2_LDW(5) CV2_LDW(6)                    \
+        CV2_LDA(3)                                  /* the loop's own reload order: its counts hold from s = 0 */ \
+        int sl_r = 1; inloop = true;                                                                    \
+        for (int s = 0; s < nt; s += 2) {                                                               \
+            CV2_SLAB(true)                                                                              \
+            if (s + 1 < nt) CV2_SLAB(false)                                                             \
+        }                                                                                               \
+        /* the clamped tail pieces and reads have landed; the last MFMA's result is written (no hazard check sees an asm MFMA) */ \
+        /* the fragments read past the last slab are never used: they are operands here so that their registers stay theirs until the reads have retired */ \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7"                     \
+                     : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fw[0]), "+v"(fw[1]), "+v"(fw[2]), "+v"(fw[3]), "+v"(fw[4]), "+v"(fw[5]), "+v"(fw[6]) \
+                     :: "memory");                                                                      \
+        __builtin_amdgcn_s_barrier();                                  /* ... and nobody reads the ring any more */ \
+    }
+#else
+#define CV2_PIPELINE(NOLDR)                                                                            \
+    {                                                                                                   \
+        CV2_ISSUE(0, 0) CV2_ISSUE(1, 1) CV2_ISSUE(2, 2) CV2_ISSUE(3, 3)                                 \
         bf16x8_t fa[4], fw[7];                                                                          \
         asm volatile("s_waitcnt vmcnt(" #NOLDR ")" ::: "memory");   /* slab 0 has landed */               \
         __builtin_amdgcn_s_barrier();                                                                   \
@@ -131,8 +240,8 @@ __global__ __launch_bounds__(512) void k_conv2(const ConvArgs p) {
         for (int s = 0; s < nt; ++s) {                                                                  \
             asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");   /* slab s+1 landed; my reads of slab s done */ \
             __builtin_amdgcn_s_barrier();                                 /* ... everyone's: slot s&3 is free */ \
-            CV2_SRC(s + 4)                                                                              \
-            const unsigned char* nx = cv2_ring + ((s + 1) & (CV2_STAGES - 1)) * CV2_STAGE_BYTES;        \
+            CV2_SRC(s + 4, (s + 4) & 3)                                                                 \
+            const unsigned char* nx = cv2_ring + ((s + 1) & 3) * CV2_STAGE_BYTES;                       \
             _Pragma("unroll") for (int j = 0; j < 6; ++j) {                                             \
                 _Pragma("unroll") for (int i = 0; i < 4; ++i)                                           \
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0); \
@@ -151,6 +260,7 @@ __global__ __launch_bounds__(512) void k_conv2(const ConvArgs p) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   /* the clamped tail pieces have landed ... */ \
         __builtin_amdgcn_s_barrier();                                  /* ... and nobody reads the ring any more */ \
     }
+#endif
 
     // Biases of this channel tile (and of the second pass) wait in LDS behind the ring: a load issued in the epilogue costs a full
     // L2 round trip per dependent use, and held in registers (round 2: 28 VGPRs across the main loop) they pushed the forward
@@ -309,8 +419,17 @@ __global__ __launch_bounds__(512) void k_conv2(const ConvArgs p) {
     }
 #undef CV2_STORE_TILE
 #undef CV2_PIPELINE
+#undef CV2_MFMA
+#undef CV2_LDA
+#undef CV2_LDW
+#undef CV2_LGKM
 #undef CV2_ISSUE
 #undef CV2_SRC
+#undef CV2_SRCX
+#undef CV2_PIECEX
+#undef CV2_ADV
+#undef CV2_SLAB
+#undef CV2_PAIR
 #undef CV2_PIECE
 #undef CV2_SETUP
 }
