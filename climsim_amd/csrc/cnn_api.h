@@ -132,7 +132,7 @@ void cnn_dispatch(const cs_cnn* h, ConvArgs& p, bool wide, int n_pad, int64_t m_
         p.zeros = h->zeros;
         p.ablate = h->conv_ablate;
         p.n_tiles = (h->cfg.channels + CV2_BN - 1) / CV2_BN;
-        hipLaunchKernelGGL((k_conv2<MODE>), dim3((unsigned)(m_pad / CV2_BM) * p.n_tiles), dim3(512), CV2_LDS_BYTES, st, p);
+        hipLaunchKernelGGL((k_conv2<MODE>), dim3((unsigned)(m_pad / CV2_BM) * p.n_tiles), dim3(CV2_THREADS), CV2_LDS_BYTES, st, p);
     } else {
         hipLaunchKernelGGL((k_conv<MODE>), dim3((unsigned)(m_pad / 128), (unsigned)(n_pad / 128)), dim3(256), 0, st, p);
     }
