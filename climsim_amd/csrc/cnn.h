@@ -28,7 +28,8 @@ struct ConvArgs {
     u16* out; int ldo;           // PREDICT/TRAIN_FWD: result ; BWD: raw sum g (may be null)
     u16* out2; int ldo2;         // TRAIN_FWD: value before the residual add (may be null) ; BWD: masked gradient
     const u16* mask; int ldmask; float mscale;       // BWD: out2 = acc * (mask != 0) * mscale
-    const u16* zeros; int n_tiles;                   // k_conv2 only: zero page for out-of-column rows, channel tiles
+    const u16* zeros; int n_tiles;                   // k_conv2 only: zero page for rows past the batch, channel tiles
+    int64_t m_store;                                 // k_conv2 only: rows the output tensors hold (its 240-row tiles do not divide it)
     // k_conv2 only, forward modes: second pass accumulated on top of the activated first one -
     // out = [dropout](act(conv(A) + bias)) + (A2nd * B2nd + bias2)   (conv b + the block's 1-tap projection in one launch)
     const u16* A2nd; int lda2; const u16* B2nd; int ldb2, kpt2; const float* bias2;

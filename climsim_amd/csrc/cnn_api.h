@@ -126,13 +126,18 @@ void cnn_fill_conv(const cs_cnn* h, ConvArgs& p, const CnnConv& c, const u16* in
     p.m_rows = m_rows; p.bias = c.bias;
 }
 
+// Rows the trunk buffers hold for m_rows real ones (every kernel's row tile divides 256 except k_conv2's 240: its last tile
+// stops storing at m_pad)
+inline int64_t cnn_m_pad(int64_t m_rows) { return round_up(m_rows, 256); }
+
 template <int MODE>
 void cnn_dispatch(const cs_cnn* h, ConvArgs& p, bool wide, int n_pad, int64_t m_pad, hipStream_t st) {
     if (wide && !h->tile128) {
         p.zeros = h->zeros;
         p.ablate = h->conv_ablate;
         p.n_tiles = (h->cfg.channels + CV2_BN - 1) / CV2_BN;
-        hipLaunchKernelGGL((k_conv2<MODE>), dim3((unsigned)(m_pad / CV2_BM) * p.n_tiles), dim3(CV2_THREADS), CV2_LDS_BYTES, st, p);
+        p.m_store = m_pad;
+        hipLaunchKernelGGL((k_conv2<MODE>), dim3((unsigned)((m_pad + CV2_BM - 1) / CV2_BM) * p.n_tiles), dim3(CV2_THREADS), CV2_LDS_BYTES, st, p);
     } else {
         hipLaunchKernelGGL((k_conv<MODE>), dim3((unsigned)(m_pad / 128), (unsigned)(n_pad / 128)), dim3(256), 0, st, p);
     }
@@ -191,7 +196,7 @@ int cnn_check_batch(const cs_cnn* h, int64_t n) {
 // inference-mode trunk: leaves the ELU'd 10-channel rows in O10
 void cnn_trunk_predict(cs_cnn* h, const float* x_dev, const int64_t* row_idx, int layout3d, int64_t n, hipStream_t st) {
     const int seq = h->cfg.seq;
-    const int64_t m_rows = n * seq, m_pad = round_up(m_rows, 256);
+    const int64_t m_rows = n * seq, m_pad = cnn_m_pad(m_rows);
     hipLaunchKernelGGL(k_cnn_input, dim3((unsigned)((m_pad + 255) / 256)), dim3(256), 0, st, x_dev, row_idx, layout3d, m_rows, m_pad,
                        seq, h->A0, CNN_A0_LD);
     const u16* x = h->A0;
@@ -242,8 +247,9 @@ int cs_cnn_create(cs_cnn_t** out, const cs_cnn_cfg* cfg) {
     HIP_TRY(hipSetDevice(cfg->device));
     cs_cnn* h = new cs_cnn();
     h->cfg = *cfg;
-    h->m_pad_max = round_up((int64_t)cfg->max_batch * cfg->seq, 256);
-    h->tile128 = (cfg->flags & CS_CNN_FLAG_TILE128) != 0;
+    h->m_pad_max = cnn_m_pad((int64_t)cfg->max_batch * cfg->seq);
+    // k_conv2's row tiles are whole columns (240 % seq == 0, kernel width 3); anything else runs on the 128 x 128 kernels
+    h->tile128 = (cfg->flags & CS_CNN_FLAG_TILE128) != 0 || CV2_BM % cfg->seq != 0;
     if (const char* e = getenv("CS_CONV_ABLATE")) h->conv_ablate = atoi(e);
     if (const char* e = getenv("CS_CNN_WGRAD_SPLITS")) h->cw_splits = atoi(e);
     const int kgran = h->tile128 ? 64 : 32;                       // contraction slab of the trunk kernels
@@ -314,7 +320,7 @@ int cs_cnn_create(cs_cnn_t** out, const cs_cnn_cfg* cfg) {
             for (u16** t : {&h->blk[b].A1, &h->blk[b].A2, &h->blk[b].XS, &h->blk[b].DZ1, &h->blk[b].DZ2, &h->blk[b].GG})
                 A((void**)t, sizeof(u16) * h->m_pad_max * CNN_CP);
             if (!h->tile128 && !(getenv("CS_CNN_MASK_BITS") && atoi(getenv("CS_CNN_MASK_BITS")) == 0)) {
-                const size_t wgs = (size_t)(h->m_pad_max / CV2_BM) * ((cfg->channels + CV2_BN - 1) / CV2_BN);
+                const size_t wgs = (size_t)((h->m_pad_max + CV2_BM - 1) / CV2_BM) * ((cfg->channels + CV2_BN - 1) / CV2_BN);
                 A((void**)&h->blk[b].B1, wgs * 512 * sizeof(uint4));
                 A((void**)&h->blk[b].B2, wgs * 512 * sizeof(uint4));
             }
@@ -482,7 +488,7 @@ int cs_cnn_loss_grads(cs_cnn_t* h, const float* x_dev, int x3d, const float* y_d
     if (rc != CS_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     const int seq = h->cfg.seq, depth = h->cfg.depth, cp = h->cpw, kgran = h->tile128 ? 64 : 32;
-    const int64_t m_rows = n * seq, m_pad = round_up(m_rows, 256);
+    const int64_t m_rows = n * seq, m_pad = cnn_m_pad(m_rows);
     const unsigned seed = (unsigned)((h->cfg.seed + (uint64_t)h->drop_calls) & 0xffffffffu);
     h->drop_calls++;
     HIP_TRY(hipMemsetAsync(loss_dev, 0, 4 * sizeof(float), st));

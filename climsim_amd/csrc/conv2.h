@@ -1,15 +1,19 @@
 // Wide tap-GEMM of the level-axis CNN (all convs whose output is the C-channel trunk: forward a/b/projection,
 // both data-gradient forms).  Same contract as k_conv<MODE> in cnn.h (ConvArgs), different machine mapping:
 //
-//   * 256(rows) x 224(channels) output tile per workgroup: two channel tiles cover the 448-channel pad of the
-//     406-wide trunk exactly (the 128x128 kernel computed 512), 240 workgroups at batch 512 = one round on
-//     256 CUs.  8 waves of 64 x 112, v_mfma_f32_16x16x32_bf16: 4 x 7 tiles = 112 accumulator VGPRs,
-//     11 LDS fragment reads per 28 MFMAs (the 2x2 32x32 arrangement needed 16 per 16).
-//   * contraction in slabs of 32 (channel pad 416 instead of 448), operands stream global -> LDS with
-//     `global_load_lds_dwordx4` into a 4-slot ring (30 KiB per slot), three slabs in flight, counted `vmcnt` +
-//     raw `s_barrier`; the fragments of the next slab are read between the MFMAs of the current one.  Rows that fall outside their column (tap shift at level 0 / 59) or past
-//     the batch fetch from a zero page instead of being predicated, so every wave issues the same number
-//     of DMA pieces per slab.
+//   * 240(rows) x 224(channels) output tile per workgroup: 240 rows = whole columns (240 % seq == 0: the host takes the 128x128
+//     kernel otherwise), two channel tiles cover the 448-channel pad of the 406-wide trunk exactly, 256 workgroups at batch
+//     512 = one per CU.  8 compute waves of 64 x 112 (the fourth row group starts at row 176 and recomputes 16 rows of
+//     the third: same values, not stored twice), v_mfma_f32_16x16x32_bf16: 4 x 7 tiles = 112 accumulator VGPRs.
+//   * contraction in slabs of 32 channels, CHUNK-major: for every 32-channel chunk the taps that read one tensor (the three
+//     taps of a conv; the fourth "tap" of the block data gradient is another tensor) share ONE row tile in LDS - the unshifted
+//     240 rows - and their fragments are read at row +-1; a lane whose shifted row leaves its column reads 16 zero bytes
+//     instead.  58 KiB of operands per three slabs instead of 90: the loop runs at the pace of the LDS-DMA pieces
+//     (~27 B/clk per CU whatever their source - round-3 ablations), so pieces are what had to go.
+//   * operands stream global -> LDS with `global_load_lds_dwordx4`, issued by four LOADER waves (waves 8-11; an LDS-DMA
+//     piece costs a wave that also computes 100-190 clocks, a loader ~20); two rings of five slots (row tiles 16 KiB, weight
+//     slabs 14 KiB), the items of slab s+4 requested behind barrier s, raw `s_barrier` + counted `vmcnt` in the loaders,
+//     counted `lgkmcnt` in the compute waves.  Rows past the batch fetch from a zero page instead of being predicated.
 //   * LDS image is lane-linear per 1-KiB piece (16 rows x 64 B); the bank swizzle (16-B chunk ^ cv2_swz(row>>2))
 //     is applied on the per-lane SOURCE address and again on the ds_read_b128 address.
 //   * consecutive work ids = the two channel tiles of one row tile, and the XCD remap keeps them on one L2.
@@ -20,18 +24,17 @@
 #ifndef CV2_SWZ_EXPR
 #define CV2_SWZ_EXPR (((q & 1) << 1) ^ ((q >> 1) * 3))
 #endif
-#define CV2_STAGES 5             // slab s+4 goes to the slot of slab s-1 (see the compute pass): three slabs in flight
-#ifndef CV2_ABL
-#define CV2_ABL 0                // development (garbage results): 64 = row-operand pieces only for tap 0 (the piece count of a shared row tile)
-#endif
-#define CV2_THREADS 768          // 8 compute waves + 4 loader waves
-#define CV2_BM 256
+#define CV2_THREADS 768          // 8 compute waves + 4 loader waves: 168 VGPRs per lane
+#define CV2_BM 240
 #define CV2_BN 224
-#define CV2_A_BYTES (CV2_BM * 64)
-#define CV2_STAGE_BYTES ((CV2_BM + CV2_BN) * 64)
-#define CV2_RING_BYTES (CV2_STAGES * CV2_STAGE_BYTES)
-#define CV2_BITS_OFF (CV2_RING_BYTES + 2048)
-#define CV2_LDS_BYTES (CV2_RING_BYTES + 2048 + 8192)   // + the two bias vectors of this channel tile (2 x 224 floats) + the mask bits (CONV_BWD): 160 KiB
+#define CV2_NSLOT 5              // the items of slab s+4 go to the slots of slab s-1 (see the compute pass): three slabs in flight
+#define CV2_A_SLOT 16384         // row tile: 15 pieces of 16 rows x 64 B
+#define CV2_B_SLOT 14336         // weight slab: 14 pieces
+#define CV2_B_RING (CV2_NSLOT * CV2_A_SLOT)
+#define CV2_BIAS_OFF (CV2_B_RING + CV2_NSLOT * CV2_B_SLOT)     // the two bias vectors of this channel tile (2 x 224 floats) ...
+#define CV2_ZERO_OFF (CV2_BIAS_OFF + 1792)                     // ... and 16 zero bytes for the lanes outside their column
+#define CV2_BITS_OFF (CV2_BIAS_OFF + 2048)                     // the mask bits of the compute threads (CONV_BWD)
+#define CV2_LDS_BYTES (CV2_BITS_OFF + 8192)                    // = 160 KiB
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
@@ -54,21 +57,23 @@ __global__ __launch_bounds__(CV2_THREADS) void k_conv2(const ConvArgs p) {
     const bool loader = wid >= 8;
     const int lw = wid - 8;
     const int wm = (wid >> 1) & 3, wn = wid & 1;
+    const int r0w = wm < 3 ? wm * 64 : CV2_BM - 64;          // first tile row of this compute wave
     const int work = xcd_work_id(blockIdx.x, gridDim.x);
     const int64_t m0 = (int64_t)(work / p.n_tiles) * CV2_BM;
     const int n0 = (work % p.n_tiles) * CV2_BN;
 
     // ---- DMA geometry (loaders): lane -> (row prow, physical chunk pos) of a 16-row piece; it fetches logical chunk
-    // pos ^ cv2_swz(prow>>2).  Loader lw owns pieces 4lw..4lw+3 of the row operand (16 per slab) and of the weights
-    // (14 per slab: loader 3 re-fetches piece 13 twice, identical bytes, uniform vmcnt count).
+    // pos ^ cv2_swz(prow>>2).  Loader lw owns pieces 4lw..4lw+3 of a row tile (15: loader 3 fetches piece 14 twice) and of
+    // a weight slab (14: loader 3 fetches piece 13 three times) - identical bytes, uniform vmcnt count.
     const int prow = lane >> 2, pos = lane & 3;
     const int cl = (pos ^ cv2_swz((prow >> 2) & 3)) * 8;
     typedef unsigned char __attribute__((address_space(3))) * lds_b;
     const unsigned lds0 = (unsigned)(uintptr_t)((lds_b)cv2_ring);
     const char* zsrc = reinterpret_cast<const char*>(p.zeros);
 
-    // The operands of the running pass (a kernel runs one pass, or two for "conv b + projection", see below).
-    const u16 *qA0 = p.A0, *qA1 = p.A1, *qA2 = p.A2, *qA3 = p.A3, *qB = p.B;
+    // The operands of the running pass (a kernel runs one pass, or two for "conv b + projection", see below).  Taps 0-2 read
+    // qA0 (at shifts qs0-qs2), tap 3 reads qA3: cnn_api.h fills ConvArgs that way for every launch of this kernel.
+    const u16 *qA0 = p.A0, *qA3 = p.A3, *qB = p.B;
     int qs0 = p.sh0, qs1 = p.sh1, qs2 = p.sh2, qs3 = p.sh3, qlda = p.lda, qldb = p.ldb, qkpt = p.kpt, qtaps = p.taps;
     int kc, nt;
 
@@ -78,58 +83,70 @@ __global__ __launch_bounds__(CV2_THREADS) void k_conv2(const ConvArgs p) {
 #pragma unroll
         for (int j = 0; j < 7; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-    // fragment addresses: row (..+(lane&15)), chunk lane>>4, swizzled by cv2_swz((row>>2)&3)
-    const unsigned sw = (unsigned)(((lane >> 4) ^ cv2_swz((lane & 15) >> 2)) << 4);
-    const unsigned a_off = (unsigned)((wm * 64 + (lane & 15)) * 64) + sw;
-    const unsigned b_off = (unsigned)(CV2_A_BYTES + (wn * 112 + (lane & 15)) * 64) + sw;
+    // fragment addresses (compute waves): weight rows wn*112 + 16j + (lane&15), 16-byte chunk lane>>4, swizzled by
+    // cv2_swz((row>>2)&3); tile rows r0w + 16i + (lane&15) + shift for the three shifts a tap can have.
+    const int l15 = lane & 15;
+    const unsigned b_off = (unsigned)((wn * 112 + l15) * 64) + (unsigned)(((lane >> 4) ^ cv2_swz(l15 >> 2)) << 4);
+    unsigned aoff[3];
+    unsigned lanebits = 0u;       // bit 2i: row i's lane sits at the first level of its column (no row above), bit 2i+1: at the last
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const int x = l15 + d - 1, xr = x & 15;            // x = -1 .. 16: the neighbouring piece for -1 and 16
+        aoff[d] = (unsigned)((r0w + (x - xr)) * 64 + xr * 64) + (unsigned)(((lane >> 4) ^ cv2_swz(xr >> 2)) << 4);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int lev = (r0w + 16 * i + l15) % p.seq;      // the tile starts at a column start
+        if (lev == 0) lanebits |= 1u << (2 * i);
+        if (lev == p.seq - 1) lanebits |= 2u << (2 * i);
+    }
 
-    // ---- One pass of the pipeline over the current operands.  Barrier protocol, the same count in both roles:
-    // [slab 0 landed] (one per slab s: [slab s+1 landed, slot of slab s-1 free]) [ring drained].
+    // ---- One pass of the pipeline over the current operands.  Slab s = (chunk s / T, tap s % T), T = taps.  Barrier protocol,
+    // the same count in both roles: [slab 0 landed] (one per slab s: [slab s+1 landed, slots of slab s-1 free]) [rings drained].
     //
-    // Loader: slabs 0-3 up front, then slab s+4 (clamped to the last: identical bytes) into the slot of slab s-1 behind
-    // barrier s; its own `vmcnt` in front of a barrier says that its pieces of the slab have landed.
+    // Loader: the items of slabs 0-3 up front, then those of slab s+4 behind barrier s - its weight slab (4 pieces per loader)
+    // and, when the slab is the first that reads a tensor in its chunk (tap 0, tap 3), the row tile (4 pieces).  Its own
+    // `vmcnt` in front of a barrier says that its pieces of slab s+1 have landed: the count is that of the pieces issued for
+    // slabs s+2 and s+3 (16 with one tap; 8 to 16 otherwise - 8 waits for a little more than needed, never less).
 #define CV2_LOAD_PASS()                                                                                \
     {                                                                                                   \
         kc = qkpt >> 5; nt = qtaps * kc;                                                                \
-        const char* bsrc[4]; int64_t arow[4]; unsigned okb[4];                                          \
+        const char* bsrc[4]; int64_t arow[4]; unsigned adst[4], bdst[4], oka = 0u;                      \
         _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                                 \
-            const int pb = min(4 * lw + k, 13);                                                         \
+            const int pa = min(4 * lw + k, 14), pb = min(4 * lw + k, 13);                               \
             bsrc[k] = reinterpret_cast<const char*>(qB + (int64_t)(n0 + pb * 16 + prow) * qldb + cl);   \
-            const int64_t am = m0 + (4 * lw + k) * 16 + prow;                                           \
+            bdst[k] = lds0 + CV2_B_RING + (unsigned)pb * 1024u;                                         \
+            const int64_t am = m0 + pa * 16 + prow;                                                     \
             arow[k] = (am * qlda + cl) * 2;                                                             \
-            const int lev = (int)(am % p.seq);                                                          \
-            const int shs_[4] = {qs0, qs1, qs2, qs3};                                                   \
-            okb[k] = 0u;                                                                                \
-            _Pragma("unroll") for (int t = 0; t < 4; ++t)                                               \
-                if (am < p.m_rows && lev + shs_[t] >= 0 && lev + shs_[t] < p.seq) okb[k] |= 1u << t;    \
+            adst[k] = lds0 + (unsigned)pa * 1024u;                                                      \
+            if (am < p.m_rows) oka |= 1u << k;                                                          \
         }                                                                                               \
-        int isl = 0, itap = 0, ich = 0, slot = 0;                                                       \
+        int it = 0, ic = 0, as = CV2_NSLOT - 1, bs = 0;                                                 \
         auto issue = [&]() {                                                                            \
-            const int sh_ = itap == 0 ? qs0 : itap == 1 ? qs1 : itap == 2 ? qs2 : qs3;                  \
-            const u16* S_ = itap == 0 ? qA0 : itap == 1 ? qA1 : itap == 2 ? qA2 : qA3;                  \
-            const char* Sb_ = reinterpret_cast<const char*>(S_) + ((int64_t)sh_ * qlda + ich * 32) * 2; \
-            const int boff_ = isl * 64;                                                                 \
-            const unsigned base_ = lds0 + (unsigned)slot * CV2_STAGE_BYTES + (unsigned)lw * 4096u;      \
-            if (!(CV2_ABL & 64) || itap == 0)                                                           \
-            _Pragma("unroll") for (int k = 0; k < 4; ++k)                                               \
-                dma16(((okb[k] >> itap) & 1u) ? Sb_ + arow[k] : zsrc, base_ + (unsigned)k * 1024u);     \
-            _Pragma("unroll") for (int k = 0; k < 4; ++k)                                               \
-                dma16(bsrc[k] + boff_, base_ + CV2_A_BYTES + (lw == 3 && k >= 2 ? 1024u : (unsigned)k * 1024u)); \
-            const int go_ = isl + 1 < nt ? 1 : 0;                     /* selects, no branches */          \
-            const int wrap_ = ich + 1 == kc ? 1 : 0;                                                    \
-            isl += go_;                                                                                 \
-            ich = go_ ? (wrap_ ? 0 : ich + 1) : ich;                                                    \
-            itap += go_ & wrap_;                                                                        \
-            slot = slot + 1 == CV2_STAGES ? 0 : slot + 1;                                               \
+            if ((it == 0) | (it == 3)) {                                                                \
+                as = as + 1 == CV2_NSLOT ? 0 : as + 1;                                                  \
+                const char* Sb_ = reinterpret_cast<const char*>(it == 3 ? qA3 : qA0) + ic * 64;         \
+                _Pragma("unroll") for (int k = 0; k < 4; ++k)                                           \
+                    dma16(((oka >> k) & 1u) ? Sb_ + arow[k] : zsrc, adst[k] + (unsigned)as * CV2_A_SLOT); \
+            }                                                                                           \
+            const int boff_ = (it * kc + ic) * 64;                                                      \
+            _Pragma("unroll") for (int k = 0; k < 4; ++k) dma16(bsrc[k] + boff_, bdst[k] + (unsigned)bs * CV2_B_SLOT); \
+            bs = bs + 1 == CV2_NSLOT ? 0 : bs + 1;                                                      \
+            const int wrap_ = it + 1 == qtaps ? 1 : 0;                                                  \
+            it = wrap_ ? 0 : it + 1;                                                                    \
+            ic += wrap_;                                                                                \
         };                                                                                              \
-        issue(); issue(); issue(); issue();                                                             \
-        asm volatile("s_waitcnt vmcnt(24)" ::: "memory");                                               \
+        _Pragma("unroll") for (int s = 0; s < 4; ++s) if (s < nt) issue();                              \
+        if (nt < 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                    \
+        else if (qtaps == 1) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");                          \
+        else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                                          \
         __builtin_amdgcn_s_barrier();                                                                   \
         for (int s = 0; s < nt; ++s) {                                                                  \
-            if (CV2_ABL & 64) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                          \
-            else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");                                      \
+            if (s + 4 > nt) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      /* the tail: nothing younger to count */ \
+            else if (qtaps == 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");                      \
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                       \
             __builtin_amdgcn_s_barrier();                                                               \
-            issue();                                                                                    \
+            if (s + 4 < nt) issue();                                                                    \
         }                                                                                               \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                \
         __builtin_amdgcn_s_barrier();                                                                   \
@@ -141,47 +158,66 @@ __global__ __launch_bounds__(CV2_THREADS) void k_conv2(const ConvArgs p) {
     // weight fragments of the slab in registers and TWO row-operand fragments in rotation (36 fragment VGPRs, not 44:
     // twelve waves per CU leave 168 VGPRs per lane): row i's fragment register takes row i+2 behind the row's seventh
     // MFMA, fw[j] takes the next slab's behind the MFMAs of row 3; LDS returns in order, so every wait is a COUNT of
-    // younger reads and nothing waits for a read it has just issued.  The five-slot ring keeps `lgkmcnt(0)` away from the
-    // barrier: the slot refilled behind barrier s held slab s-1, whose fragments the MFMAs of iteration s-1 consumed.
+    // younger reads and nothing waits for a read it has just issued.  The five-slot rings keep `lgkmcnt(0)` away from the
+    // barrier: the slots refilled behind barrier s held slab s-1, whose fragments the MFMAs of iteration s-1 consumed (a row
+    // tile is refilled five tiles later still).  (va, lb) address the row tile of a slab at its tap's shift: lb holds, for
+    // that shift, the lanes that have no such row in their column - they read the zero bytes.
 #define CV2_MFMA(A, i, j) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(fw[j]), "v"(A));
-#define CV2_LDA(A, i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(A) : "v"(va), "n"((i) * 1024));
+#define CV2_LDA(A, i, VA, LB)                                                                          \
+    {                                                                                                   \
+        const unsigned vr_ = ((LB) & (3u << (2 * (i)))) ? lds0 + CV2_ZERO_OFF - (unsigned)(i) * 1024u : (VA);   \
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(A) : "v"(vr_), "n"((i) * 1024));            \
+    }
 #define CV2_LDW(j) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fw[j]) : "v"(vb), "n"((j) * 1024));
 #define CV2_LGKM(n) asm volatile("s_waitcnt lgkmcnt(" #n ")");
 #define CV2_ROW(A, i) CV2_MFMA(A, i, 0) CV2_MFMA(A, i, 1) CV2_MFMA(A, i, 2) CV2_MFMA(A, i, 3) CV2_MFMA(A, i, 4) CV2_MFMA(A, i, 5) CV2_MFMA(A, i, 6)
+#define CV2_SLAB_STATE(VA, LB)                              /* (VA, LB, vb) of slab (n_it, n_as, n_bs); selects, no branches */ \
+    {                                                                                                   \
+        const int sh1_ = (shpack >> (2 * n_it)) & 3;            /* shift + 1 */                           \
+        const unsigned t_ = sh1_ == 0 ? aoff[0] : aoff[1];                                              \
+        VA = lds0 + (unsigned)n_as * CV2_A_SLOT + (sh1_ == 2 ? aoff[2] : t_);                           \
+        LB = lanebits & ((0xaa0055u >> (8 * sh1_)) & 0xffu);                                            \
+        vb = lds0 + CV2_B_RING + (unsigned)n_bs * CV2_B_SLOT + b_off;                                   \
+    }
 #define CV2_COMPUTE_PASS()                                                                             \
     {                                                                                                   \
         kc = qkpt >> 5; nt = qtaps * kc;                                                                \
         bf16x8_t fa0, fa1, fw[7];                                                                       \
+        int n_it = 0, n_as = 0, n_bs = 0;                                                               \
+        const int shpack = (qs0 + 1) | ((qs1 + 1) << 2) | ((qs2 + 1) << 4) | ((qs3 + 1) << 6);          \
+        unsigned va, lb, van, lbn, vb;                                                                  \
+        CV2_SLAB_STATE(va, lb)                                                                          \
         __builtin_amdgcn_s_barrier();                               /* slab 0 has landed */               \
-        unsigned va = lds0 + a_off, vb = lds0 + b_off;                                                  \
-        CV2_LDA(fa0, 0)                                                                                 \
+        CV2_LDA(fa0, 0, va, lb)                                                                         \
         CV2_LDW(0) CV2_LDW(1) CV2_LDW(2) CV2_LDW(3) CV2_LDW(4) CV2_LDW(5) CV2_LDW(6)                    \
-        CV2_LDA(fa1, 1)                             /* the loop's own order: its counts hold from s = 0 */ \
-        int sl_r = 1;                                                                                   \
+        CV2_LDA(fa1, 1, va, lb)                     /* the loop's own order: its counts hold from s = 0 */ \
         for (int s = 0; s < nt; ++s) {                                                                  \
             __builtin_amdgcn_s_barrier();           /* slab s+1 has landed */                             \
             CV2_LGKM(7) CV2_MFMA(fa0, 0, 0) CV2_LGKM(6) CV2_MFMA(fa0, 0, 1) CV2_LGKM(5) CV2_MFMA(fa0, 0, 2)   \
             CV2_LGKM(4) CV2_MFMA(fa0, 0, 3) CV2_LGKM(3) CV2_MFMA(fa0, 0, 4) CV2_LGKM(2) CV2_MFMA(fa0, 0, 5)   \
             CV2_LGKM(1) CV2_MFMA(fa0, 0, 6)                                                             \
-            CV2_LDA(fa0, 2)                         /* row 2 of this slab (va still points at it) */      \
+            CV2_LDA(fa0, 2, va, lb)                 /* row 2 of this slab */                              \
             CV2_LGKM(1) CV2_ROW(fa1, 1)                                                                 \
-            CV2_LDA(fa1, 3)                                                                             \
-            va = lds0 + (unsigned)sl_r * CV2_STAGE_BYTES + a_off;                                       \
-            vb = lds0 + (unsigned)sl_r * CV2_STAGE_BYTES + b_off;                                       \
+            CV2_LDA(fa1, 3, va, lb)                                                                     \
+            n_it = n_it + 1 == qtaps ? 0 : n_it + 1;                /* slab s+1 */                        \
+            n_as += (0x9 >> n_it) & 1;                              /* taps 0 and 3 open a row tile */    \
+            n_as = n_as == CV2_NSLOT ? 0 : n_as;                                                        \
+            n_bs = n_bs + 1 == CV2_NSLOT ? 0 : n_bs + 1;                                                \
+            CV2_SLAB_STATE(van, lbn)                                                                    \
             CV2_LGKM(1) CV2_ROW(fa0, 2)                                                                 \
-            CV2_LDA(fa0, 0)                         /* row 0 of slab s+1 */                               \
+            CV2_LDA(fa0, 0, van, lbn)               /* row 0 of slab s+1 */                               \
             CV2_LGKM(1)                                                                                 \
             CV2_MFMA(fa1, 3, 0) CV2_LDW(0) CV2_MFMA(fa1, 3, 1) CV2_LDW(1) CV2_MFMA(fa1, 3, 2) CV2_LDW(2) CV2_MFMA(fa1, 3, 3) CV2_LDW(3) \
             CV2_MFMA(fa1, 3, 4) CV2_LDW(4) CV2_MFMA(fa1, 3, 5) CV2_LDW(5) CV2_MFMA(fa1, 3, 6) CV2_LDW(6) \
-            CV2_LDA(fa1, 1)                         /* row 1 of slab s+1 */                               \
-            sl_r = sl_r + 1 == CV2_STAGES ? 0 : sl_r + 1;                                               \
+            CV2_LDA(fa1, 1, van, lbn)               /* row 1 of slab s+1 */                               \
+            va = van; lb = lbn;                                                                         \
         }                                                                                               \
         /* the fragments read past the last slab are never used: they are operands here so that their registers stay  \
            theirs until the reads have retired; the last MFMA's result is written (no hazard check sees an asm MFMA) */ \
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7"                             \
                      : "+v"(fa0), "+v"(fa1), "+v"(fw[0]), "+v"(fw[1]), "+v"(fw[2]), "+v"(fw[3]), "+v"(fw[4]), "+v"(fw[5]), "+v"(fw[6]) \
                      :: "memory");                                                                      \
-        __builtin_amdgcn_s_barrier();               /* the ring is drained and nobody reads it any more */ \
+        __builtin_amdgcn_s_barrier();               /* the rings are drained and nobody reads them any more */ \
     }
 
     if (loader) {
@@ -193,7 +229,7 @@ __global__ __launch_bounds__(CV2_THREADS) void k_conv2(const ConvArgs p) {
         CV2_LOAD_PASS()
         if (MODE != CONV_BWD && p.A2nd && !(p.ablate & 4)) {
             __builtin_amdgcn_s_barrier();           // the compute waves are done with their LDS staging regions
-            qA0 = qA1 = qA2 = qA3 = p.A2nd; qs0 = qs1 = qs2 = qs3 = 0; qlda = p.lda2;
+            qA0 = qA3 = p.A2nd; qs0 = qs1 = qs2 = qs3 = 0; qlda = p.lda2;
             qB = p.B2nd; qldb = p.ldb2; qkpt = p.kpt2; qtaps = 1;
             CV2_LOAD_PASS()
         }
@@ -203,7 +239,8 @@ __global__ __launch_bounds__(CV2_THREADS) void k_conv2(const ConvArgs p) {
     // Biases of this channel tile (and of the second pass) wait in LDS behind the ring: a load issued in the epilogue costs a full
     // L2 round trip per dependent use, and held in registers (round 2: 28 VGPRs across the main loop) they pushed the forward
     // variants to 256 VGPRs + 92-104 bytes of scratch per lane.
-    float* bias_lds = reinterpret_cast<float*>(cv2_ring + CV2_RING_BYTES);
+    float* bias_lds = reinterpret_cast<float*>(cv2_ring + CV2_BIAS_OFF);
+    if (tid < 4) *reinterpret_cast<unsigned*>(cv2_ring + CV2_ZERO_OFF + tid * 4) = 0u;
     if (MODE != CONV_BWD && tid < CV2_BN) {
         bias_lds[tid] = p.bias[n0 + tid];
         if (p.A2nd) bias_lds[CV2_BN + tid] = p.bias2[n0 + tid];
@@ -211,7 +248,7 @@ __global__ __launch_bounds__(CV2_THREADS) void k_conv2(const ConvArgs p) {
     // One copy of the pipeline for both passes of a two-pass launch (a loop, not two expansions: the accumulators keep ONE
     // register assignment - with two, hipcc moved 64 of them through scratch between the passes at 168 VGPRs).
     unsigned char* reg = cv2_ring + wid * (64 * 240);
-    const int64_t mw = m0 + wm * 64;
+    const int64_t mw = m0 + r0w;
     const int nw = n0 + wn * 112;
     bool second = false;
     for (;;) {
@@ -239,17 +276,19 @@ __global__ __launch_bounds__(CV2_THREADS) void k_conv2(const ConvArgs p) {
         __builtin_amdgcn_sched_barrier(0);                                                               \
         /* 4 rows per instruction, 14 of 16 lanes per row carry one 16-B chunk: no division by 14.  A running pointer and   \
            four rows in flight: sixteen precomputed 64-bit addresses do not fit beside the accumulators at 168 VGPRs */       \
-        u16* g_ = (dst) + (mw + (lane >> 4)) * (ld) + nw + (lane & 15) * 8;                              \
+        const int it0_ = wm == 3 ? 4 : 0;      /* the fourth row group's first 16 rows are the third's last: stored there */ \
+        u16* g_ = (dst) + (mw + (lane >> 4) + 4 * it0_) * (ld) + nw + (lane & 15) * 8;                   \
         const unsigned char* l_ = reg + (lane >> 4) * 240 + (lane & 15) * 16;                            \
         const int64_t gstep_ = (int64_t)4 * (ld);                                                        \
+        int64_t row_ = mw + (lane >> 4) + 4 * it0_;                                                      \
         if ((lane & 15) < 14) {                                                                          \
-            _Pragma("unroll 1") for (int it = 0; it < 16; it += 4) {                                     \
+            _Pragma("unroll 1") for (int it = it0_; it < 16; it += 4) {                                      \
                 uint4 v_[4];                                                                             \
                 _Pragma("unroll") for (int u = 0; u < 4; ++u) v_[u] = *reinterpret_cast<const uint4*>(l_ + (it + u) * 960); \
                 _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                          \
-                    if (!(p.ablate & 8)) *reinterpret_cast<uint4*>(g_) = v_[u];                           \
+                    if (!(p.ablate & 8)) { if (row_ < p.m_store) *reinterpret_cast<uint4*>(g_) = v_[u]; }  \
                     else asm volatile("" ::"v"(v_[u].x), "v"(v_[u].w));                                   \
-                    g_ += gstep_;                                                                        \
+                    g_ += gstep_; row_ += 4;                                                             \
                 }                                                                                        \
             }                                                                                            \
         }                                                                                                \
@@ -282,7 +321,7 @@ __global__ __launch_bounds__(CV2_THREADS) void k_conv2(const ConvArgs p) {
             for (int j = jh; j < jh + 4 && j < 7; ++j)
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    k2[j - jh][i] = *reinterpret_cast<const uint2*>(p.mask + (mw + i * 16 + (lane & 15)) * p.ldmask + nw + j * 16 + 4 * (lane >> 4));
+                    k2[j - jh][i] = *reinterpret_cast<const uint2*>(p.mask + min(mw + i * 16 + (lane & 15), p.m_store - 1) * p.ldmask + nw + j * 16 + 4 * (lane >> 4));
 #pragma unroll
             for (int j = jh; j < jh + 4 && j < 7; ++j)
 #pragma unroll
@@ -353,7 +392,7 @@ __global__ __launch_bounds__(CV2_THREADS) void k_conv2(const ConvArgs p) {
             }
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                   // every wave is done with its LDS staging region
-            qkpt = p.kpt2; qtaps = 1; second = true;
+            qkpt = p.kpt2; qtaps = 1; qs0 = qs1 = qs2 = qs3 = 0; second = true;
         }
     }
     }
@@ -366,7 +405,7 @@ __global__ __launch_bounds__(CV2_THREADS) void k_conv2(const ConvArgs p) {
                 for (int j = jh; j < jh + 4 && j < 7; ++j)
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
-                        r2[j - jh][i] = *reinterpret_cast<const uint2*>(p.add + (mw + i * 16 + (lane & 15)) * p.ldadd + nw + j * 16 + 4 * (lane >> 4));
+                        r2[j - jh][i] = *reinterpret_cast<const uint2*>(p.add + min(mw + i * 16 + (lane & 15), p.m_store - 1) * p.ldadd + nw + j * 16 + 4 * (lane >> 4));
 #pragma unroll
                 for (int j = jh; j < jh + 4 && j < 7; ++j)
 #pragma unroll
@@ -389,4 +428,5 @@ __global__ __launch_bounds__(CV2_THREADS) void k_conv2(const ConvArgs p) {
 #undef CV2_LDW
 #undef CV2_LGKM
 #undef CV2_ROW
+#undef CV2_SLAB_STATE
 }
