@@ -319,7 +319,7 @@ int cs_cnn_create(cs_cnn_t** out, const cs_cnn_cfg* cfg) {
         for (int b = 0; b < depth; ++b) {
             for (u16** t : {&h->blk[b].A1, &h->blk[b].A2, &h->blk[b].XS, &h->blk[b].DZ1, &h->blk[b].DZ2, &h->blk[b].GG})
                 A((void**)t, sizeof(u16) * h->m_pad_max * CNN_CP);
-            if (!h->tile128 && !(getenv("CS_CNN_MASK_BITS") && atoi(getenv("CS_CNN_MASK_BITS")) == 0)) {
+            if (!h->tile128) {          // k_conv2 masks with these (it has no other form)
                 const size_t wgs = (size_t)((h->m_pad_max + CV2_BM - 1) / CV2_BM) * ((cfg->channels + CV2_BN - 1) / CV2_BN);
                 A((void**)&h->blk[b].B1, wgs * 512 * sizeof(uint4));
                 A((void**)&h->blk[b].B2, wgs * 512 * sizeof(uint4));

@@ -122,7 +122,7 @@ __global__ __launch_bounds__(CV2_THREADS) void k_conv2(const ConvArgs p) {
             if (am < p.m_rows) oka |= 1u << k;                                                          \
         }                                                                                               \
         int it = 0, ic = 0, as = CV2_NSLOT - 1, bs = 0;                                                 \
-        auto issue = [&]() {                                                                            \
+        auto issue = [&]() __attribute__((always_inline)) {                                                                            \
             if ((it == 0) | (it == 3)) {                                                                \
                 as = as + 1 == CV2_NSLOT ? 0 : as + 1;                                                  \
                 const char* Sb_ = reinterpret_cast<const char*>(it == 3 ? qA3 : qA0) + ic * 64;         \
@@ -253,7 +253,6 @@ __global__ __launch_bounds__(CV2_THREADS) void k_conv2(const ConvArgs p) {
     bool second = false;
     for (;;) {
     CV2_COMPUTE_PASS()
-    if (second) break;
     // BWD: the mask bits of this thread's 112 results wait in LDS (the loaders fetched them with slab 0)
     uint4 mbits = make_uint4(0u, 0u, 0u, 0u);
     if (MODE == CONV_BWD && p.bits_in) mbits = *reinterpret_cast<const uint4*>(cv2_ring + CV2_BITS_OFF + tid * 16);
@@ -263,34 +262,43 @@ __global__ __launch_bounds__(CV2_THREADS) void k_conv2(const ConvArgs p) {
     // The accumulators are transformed in place; each output tensor then goes wave-tile by wave-tile through
     // a private LDS region (64 rows x 240-B pitch) so that the global stores are 16 B per lane along 224-B row
     // segments instead of row-per-lane 8-B pieces.
+#ifndef CV2_STORE_G
+#define CV2_STORE_G 4            // row groups (of 16 rows) packed into the staging region before their rows are stored: 4 = the whole wave tile
+#endif
 #define CV2_STORE_TILE_X(dst, ld, XF)                                                                       \
     {                                                                                                    \
-        _Pragma("unroll") for (int j = 0; j < 7; ++j)                                                    \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                \
-            {                                                                                            \
-                const f32x4_t x_ = XF(i, j);                                                             \
-                *reinterpret_cast<uint2*>(reg + (i * 16 + (lane & 15)) * 240 + (j * 16 + 4 * (lane >> 4)) * 2) = \
-                    pack4_hw(x_[0], x_[1], x_[2], x_[3]);                                                \
-                __builtin_amdgcn_sched_barrier(0);                                                       \
-            }                                                                                            \
-        __builtin_amdgcn_sched_barrier(0);                                                               \
-        /* 4 rows per instruction, 14 of 16 lanes per row carry one 16-B chunk: no division by 14.  A running pointer and   \
-           four rows in flight: sixteen precomputed 64-bit addresses do not fit beside the accumulators at 168 VGPRs */       \
-        const int it0_ = wm == 3 ? 4 : 0;      /* the fourth row group's first 16 rows are the third's last: stored there */ \
-        u16* g_ = (dst) + (mw + (lane >> 4) + 4 * it0_) * (ld) + nw + (lane & 15) * 8;                   \
-        const unsigned char* l_ = reg + (lane >> 4) * 240 + (lane & 15) * 16;                            \
+        /* XF(i, j) yields the tiles (and may transform the accumulators in place on the way); they are packed into the wave's   \
+           staging region, read back along the rows - 4 rows per instruction, 14 of 16 lanes per row carry one 16-B chunk: no     \
+           division by 14 - and stored.  A running pointer and four rows in flight: sixteen precomputed 64-bit addresses do not    \
+           fit beside the accumulators at 168 VGPRs. */                                                                          \
+        u16* g_ = (dst) + (mw + (lane >> 4)) * (ld) + nw + (lane & 15) * 8;                              \
+        const unsigned char* l_ = reinterpret_cast<const unsigned char*>(__builtin_assume_aligned(reg + (lane >> 4) * 240 + (lane & 15) * 16, 16)); \
         const int64_t gstep_ = (int64_t)4 * (ld);                                                        \
-        int64_t row_ = mw + (lane >> 4) + 4 * it0_;                                                      \
-        if ((lane & 15) < 14) {                                                                          \
-            _Pragma("unroll 1") for (int it = it0_; it < 16; it += 4) {                                      \
-                uint4 v_[4];                                                                             \
-                _Pragma("unroll") for (int u = 0; u < 4; ++u) v_[u] = *reinterpret_cast<const uint4*>(l_ + (it + u) * 960); \
-                _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                          \
-                    if (!(p.ablate & 8)) { if (row_ < p.m_store) *reinterpret_cast<uint4*>(g_) = v_[u]; }  \
-                    else asm volatile("" ::"v"(v_[u].x), "v"(v_[u].w));                                   \
-                    g_ += gstep_; row_ += 4;                                                             \
+        int row_ = (int)(mw - m0) + (lane >> 4);                                                         \
+        const int lim_ = (p.ablate & 8) ? 0 : (int)min((int64_t)CV2_BM, p.m_store - m0);   /* tile rows the tensors hold */ \
+        _Pragma("unroll") for (int i0 = 0; i0 < 4; i0 += CV2_STORE_G) {                                  \
+            _Pragma("unroll") for (int i = i0; i < i0 + CV2_STORE_G; ++i)                                \
+                _Pragma("unroll") for (int j = 0; j < 7; ++j) {                                          \
+                    const f32x4_t x_ = XF(i, j);                                                         \
+                    if (dst)                                                                             \
+                        *reinterpret_cast<uint2*>(reg + (i * 16 + (lane & 15)) * 240 + (j * 16 + 4 * (lane >> 4)) * 2) = \
+                            pack4_hw(x_[0], x_[1], x_[2], x_[3]);                                        \
+                    __builtin_amdgcn_sched_barrier(0);                                                   \
+                }                                                                                        \
+            if ((dst) && (lane & 15) < 14) {                                                             \
+                _Pragma("unroll 1") for (int it = 4 * i0; it < 4 * (i0 + CV2_STORE_G); it += 4) {        \
+                    const uint4 va_ = *reinterpret_cast<const uint4*>(l_ + it * 960), vb_ = *reinterpret_cast<const uint4*>(l_ + (it + 1) * 960), \
+                                vc_ = *reinterpret_cast<const uint4*>(l_ + (it + 2) * 960), vd_ = *reinterpret_cast<const uint4*>(l_ + (it + 3) * 960); \
+                    /* the fourth row group's first 16 rows are the third's last: stored there */        \
+                    const int lo_ = (wm == 3 ? 16 : 0) + (int)(mw - m0);                                 \
+                    if (row_ < lim_ && row_ >= lo_) *reinterpret_cast<uint4*>(g_) = va_;                 \
+                    if (row_ + 4 < lim_ && row_ + 4 >= lo_) *reinterpret_cast<uint4*>(g_ + gstep_) = vb_; \
+                    if (row_ + 8 < lim_ && row_ + 8 >= lo_) *reinterpret_cast<uint4*>(g_ + 2 * gstep_) = vc_; \
+                    if (row_ + 12 < lim_ && row_ + 12 >= lo_) *reinterpret_cast<uint4*>(g_ + 3 * gstep_) = vd_; \
+                    g_ += 4 * gstep_; row_ += 16;                                                        \
                 }                                                                                        \
             }                                                                                            \
+            __builtin_amdgcn_sched_barrier(0);                                                           \
         }                                                                                                \
     }
 
@@ -302,7 +310,7 @@ __global__ __launch_bounds__(CV2_THREADS) void k_conv2(const ConvArgs p) {
             // mask from the forward pass's bits, applied where the tile is packed for the second tensor (nothing holds 112 masked
             // values beside the accumulators: 168 VGPRs): no memory operation between the two store tiles
             const unsigned mwb[4] = {mbits.x, mbits.y, mbits.z, mbits.w};
-            auto masked = [&](int i, int j) {
+            auto masked = [&](int i, int j) __attribute__((always_inline)) {
                 const int t = (i * 7 + j) * 4;
                 const unsigned b4 = mwb[t >> 5] >> (t & 31);
                 f32x4_t r;
@@ -313,73 +321,55 @@ __global__ __launch_bounds__(CV2_THREADS) void k_conv2(const ConvArgs p) {
             CV2_STORE_TILE_X(p.out2, p.ldo2, masked)
             return;
         }
-        {
-#pragma unroll
-        for (int jh = 0; jh < 7; jh += 4) {                 // all loads of a half first, then their uses
-            uint2 k2[4][4];
-#pragma unroll
-            for (int j = jh; j < jh + 4 && j < 7; ++j)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    k2[j - jh][i] = *reinterpret_cast<const uint2*>(p.mask + min(mw + i * 16 + (lane & 15), p.m_store - 1) * p.ldmask + nw + j * 16 + 4 * (lane >> 4));
-#pragma unroll
-            for (int j = jh; j < jh + 4 && j < 7; ++j)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const uint2 k = k2[j - jh][i];
-                    acc[i][j][0] = (k.x & 0x7fffu) ? acc[i][j][0] * p.mscale : 0.f;
-                    acc[i][j][1] = (k.x & 0x7fff0000u) ? acc[i][j][1] * p.mscale : 0.f;
-                    acc[i][j][2] = (k.y & 0x7fffu) ? acc[i][j][2] * p.mscale : 0.f;
-                    acc[i][j][3] = (k.y & 0x7fff0000u) ? acc[i][j][3] * p.mscale : 0.f;
-                }
-        }
-        }
+        // without the forward pass's bits (no such launch exists: cnn_api.h allocates them with the kernel) nothing is masked
         CV2_STORE_TILE(p.out2, p.ldo2)
         return;
     } else {
         // trunk convs are ReLU or linear (the ELU conv has 10 channels and runs on k_conv): one max against
-        // 0 or -inf instead of a per-element switch (which unrolled into ~8k instructions of cold code)
+        // 0 or -inf instead of a per-element switch (which unrolled into ~8k instructions of cold code).
+        // transform(i, j): bias, activation, dropout of one tile, IN PLACE (the second pass accumulates on top), and its bit of the
+        // mask the backward pass uses (>= 0 everywhere after ReLU: one bit per element, this thread's 112 in one 16-byte store).
         const float act_floor = p.act == CACT_RELU ? 0.f : -__builtin_huge_valf();
-#pragma unroll
-        for (int j = 0; j < 7; ++j) {
+        unsigned mwb[4] = {0u, 0u, 0u, 0u};
+        auto transform = [&](int i, int j) __attribute__((always_inline)) {
             const int n = nw + j * 16 + 4 * (lane >> 4);
-            const float4 b4 = *reinterpret_cast<const float4*>(bias_lds + wn * 112 + j * 16 + 4 * (lane >> 4));
+            unsigned bo = (unsigned)(wn * 112 + j * 16 + 4 * (lane >> 4)) * 4u;
+            asm volatile("" : "+v"(bo));        // re-read per tile: seven bias quads held across the row groups are 28 VGPRs this kernel does not have
+            const float4 b4 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(bias_lds) + bo);
+            const int64_t m = mw + i * 16 + (lane & 15);
+            float v[4] = {acc[i][j][0] + b4.x, acc[i][j][1] + b4.y, acc[i][j][2] + b4.z, acc[i][j][3] + b4.w};
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int64_t m = mw + i * 16 + (lane & 15);
-                float v[4] = {acc[i][j][0] + b4.x, acc[i][j][1] + b4.y, acc[i][j][2] + b4.z, acc[i][j][3] + b4.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], act_floor);      // ReLU | identity, branch-free
-                if (MODE == CONV_TRAIN_FWD && p.drop_thr) {
-                    const unsigned h0 = drop_hash2(m, n, p.drop_key), h1 = drop_hash2(m, n + 2, p.drop_key);
-                    v[0] = (h0 & 0xffffu) >= p.drop_thr ? v[0] * p.drop_scale : 0.f;
-                    v[1] = (h0 >> 16) >= p.drop_thr ? v[1] * p.drop_scale : 0.f;
-                    v[2] = (h1 & 0xffffu) >= p.drop_thr ? v[2] * p.drop_scale : 0.f;
-                    v[3] = (h1 >> 16) >= p.drop_thr ? v[3] * p.drop_scale : 0.f;
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[i][j][e] = v[e];
-                __builtin_amdgcn_sched_barrier(0);
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], act_floor);      // ReLU | identity, branch-free
+            if (MODE == CONV_TRAIN_FWD && p.drop_thr) {
+                const unsigned h0 = drop_hash2(m, n, p.drop_key), h1 = drop_hash2(m, n + 2, p.drop_key);
+                v[0] = (h0 & 0xffffu) >= p.drop_thr ? v[0] * p.drop_scale : 0.f;
+                v[1] = (h0 >> 16) >= p.drop_thr ? v[1] * p.drop_scale : 0.f;
+                v[2] = (h1 & 0xffffu) >= p.drop_thr ? v[2] * p.drop_scale : 0.f;
+                v[3] = (h1 >> 16) >= p.drop_thr ? v[3] * p.drop_scale : 0.f;
             }
-        }
-        if (MODE == CONV_TRAIN_FWD && p.bits_out) {
-            // acc now holds the activated, dropped-out tensor the backward pass masks with (>= 0 everywhere: ReLU): one bit
-            // per element, this thread's 112 in one 16-byte store
-            unsigned mw[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 7; ++j) {
-                    const int t = (i * 7 + j) * 4;
-                    const unsigned b4 = (acc[i][j][0] > 0.f ? 1u : 0u) | (acc[i][j][1] > 0.f ? 2u : 0u) | (acc[i][j][2] > 0.f ? 4u : 0u) |
-                                        (acc[i][j][3] > 0.f ? 8u : 0u);
-                    mw[t >> 5] |= b4 << (t & 31);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            p.bits_out[(int64_t)work * 512 + tid] = make_uint4(mw[0], mw[1], mw[2], mw[3]);
-        }
-        if (MODE == CONV_TRAIN_FWD && p.out2) CV2_STORE_TILE(p.out2, p.ldo2)
-        if (!p.A2nd) break;
+            for (int e = 0; e < 4; ++e) acc[i][j][e] = v[e];
+            if (MODE == CONV_TRAIN_FWD) {
+                const int t = (i * 7 + j) * 4;
+                const unsigned b4m = (v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u);
+                mwb[t >> 5] |= b4m << (t & 31);
+            }
+            return acc[i][j];
+        };
+        // ONE copy of the store code for both epilogues of a two-pass launch (as for the pipeline): after the first pass the
+        // tiles are transformed on their way into the first tensor this launch stores - the block's second output (training,
+        // conv b), the result itself when there is no second pass, nothing (inference, conv b) - after the second they go out as
+        // they are.
+        const bool two = p.A2nd != nullptr;
+        u16* dst_ = second ? p.out : (MODE == CONV_TRAIN_FWD && p.out2) ? p.out2 : two ? nullptr : p.out;
+        const int ldd_ = (second || !(MODE == CONV_TRAIN_FWD && p.out2)) ? p.ldo : p.ldo2;
+        auto hook = [&](int i, int j) __attribute__((always_inline)) {
+            if (!second) transform(i, j);
+            return acc[i][j];
+        };
+        CV2_STORE_TILE_X(dst_, ldd_, hook)
+        if (MODE == CONV_TRAIN_FWD && !second && p.bits_out) p.bits_out[(int64_t)work * 512 + tid] = make_uint4(mwb[0], mwb[1], mwb[2], mwb[3]);
+        if (second || !two) return;
         {
             // second pass: the block's projection of its input, accumulated on top of the activated conv output
             // (x_next = dropout(relu(conv_b(a1))) + conv_r(x): one launch, no R tensor, no extra epilogue)
@@ -395,28 +385,6 @@ __global__ __launch_bounds__(CV2_THREADS) void k_conv2(const ConvArgs p) {
             qkpt = p.kpt2; qtaps = 1; qs0 = qs1 = qs2 = qs3 = 0; second = true;
         }
     }
-    }
-    if (MODE != CONV_BWD) {
-        if (!second && p.add) {
-#pragma unroll
-            for (int jh = 0; jh < 7; jh += 4) {
-                uint2 r2[4][4];
-#pragma unroll
-                for (int j = jh; j < jh + 4 && j < 7; ++j)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        r2[j - jh][i] = *reinterpret_cast<const uint2*>(p.add + min(mw + i * 16 + (lane & 15), p.m_store - 1) * p.ldadd + nw + j * 16 + 4 * (lane >> 4));
-#pragma unroll
-                for (int j = jh; j < jh + 4 && j < 7; ++j)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const uint2 r = r2[j - jh][i];
-                        acc[i][j][0] += bf2f((u16)(r.x & 0xffff)); acc[i][j][1] += bf2f((u16)(r.x >> 16));
-                        acc[i][j][2] += bf2f((u16)(r.y & 0xffff)); acc[i][j][3] += bf2f((u16)(r.y >> 16));
-                    }
-            }
-        }
-        CV2_STORE_TILE(p.out, p.ldo)
     }
 #undef CV2_STORE_TILE
 #undef CV2_STORE_TILE_X
