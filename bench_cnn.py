@@ -44,4 +44,4 @@ print(json.dumps({"metric": "CNN training columns/sec", "value": round(B / dt_tr
                   "ms_per_step": round(dt_train * 1e3, 3), "train_tflops_algorithmic": round(3 * fwd * B / dt_train / 1e12, 1),
                   "predict_columns_per_s": round(B / dt_pred, 1), "predict_tflops_algorithmic": round(fwd * B / dt_pred / 1e12, 1),
                   "loss_after": first, "dtype": "bf16 operands, fp32 accumulate/master/Adam",
-                  "note": "trunk convs 256x224 LDS-DMA tap-GEMMs (K pad 416, N pad 448), conv wgrad 256x224 with taps folded into one axis; dropout 0.175, mae_adjusted, Adam"}))
+                  "note": "trunk convs 240x224 LDS-DMA tap-GEMMs (whole columns, one row tile per chunk shared by the taps, loader waves; K pad 416, N pad 448), conv wgrad 256x224 with taps folded into one axis; dropout 0.175, mae_adjusted, Adam"}))

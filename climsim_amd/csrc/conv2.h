@@ -263,7 +263,7 @@ __global__ __launch_bounds__(CV2_THREADS) void k_conv2(const ConvArgs p) {
     // a private LDS region (64 rows x 240-B pitch) so that the global stores are 16 B per lane along 224-B row
     // segments instead of row-per-lane 8-B pieces.
 #ifndef CV2_STORE_G
-#define CV2_STORE_G 4            // row groups (of 16 rows) packed into the staging region before their rows are stored: 4 = the whole wave tile
+#define CV2_STORE_G 1            // row groups (of 16 rows) packed into the staging region before their rows are stored: 4 = the whole wave tile
 #endif
 #define CV2_STORE_TILE_X(dst, ld, XF)                                                                       \
     {                                                                                                    \

@@ -225,7 +225,7 @@ def test_cnn_full_depth_gradients(CNN):
 
 
 def test_cnn_kernel_families_agree(CNN):
-    """The 256x224 LDS-DMA kernels (default) against the 128x128 register-staged kernels (CS_CNN_FLAG_TILE128):
+    """The 240x224 LDS-DMA kernels (default) against the 128x128 register-staged kernels (CS_CNN_FLAG_TILE128):
     two independent implementations of the same tap-GEMMs (different tiling, MFMA shape, contraction padding,
     weight-gradient decomposition).  They differ by accumulation order and by ONE rounding point: the 128-tile family
     stores the block's projection as a bf16 tensor before adding it, the default family accumulates it in fp32 on top
