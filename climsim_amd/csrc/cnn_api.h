@@ -37,6 +37,11 @@ struct cs_cnn {
     int64_t iterations = 0, drop_calls = 0;
     bool grads_dirty = false;
     std::vector<void*> allocs;
+    // k_conv2 programs (conv2.h): trunk convs on the same row tiles are chained into one launch, flushed when another kernel follows
+    ConvProg prog{}; int prog_mode = -1; unsigned prog_grid = 0;
+    int fuse_max = CV2_MAX_STAGES;       // CS_CNN_FUSE (1 = one conv per launch)
+    unsigned* pair_flags = nullptr; unsigned gen = 0; int flag_tiles = 0;
+    unsigned *err_host = nullptr, *err_dev = nullptr;      // pinned, host-mapped: bounded waits that ran out / partners on another XCD
 };
 
 namespace {
@@ -130,15 +135,34 @@ void cnn_fill_conv(const cs_cnn* h, ConvArgs& p, const CnnConv& c, const u16* in
 // stops storing at m_pad)
 inline int64_t cnn_m_pad(int64_t m_rows) { return round_up(m_rows, 256); }
 
+// Launch the pending program of trunk convs (no-op when none is pending).  Every kernel that reads what they wrote comes behind a flush.
+void cnn_flush(cs_cnn* h, hipStream_t st) {
+    ConvProg& P = h->prog;
+    if (P.n == 0) return;
+    P.gen0 = h->gen; h->gen += (unsigned)P.n;
+    P.flags = h->pair_flags; P.error = h->err_dev; P.n_row_tiles = h->flag_tiles;
+    static const int spin = getenv("CS_CNN_SPIN_LIMIT") ? atoi(getenv("CS_CNN_SPIN_LIMIT")) : (1 << 22);
+    P.spin_limit = spin;
+    P.tiles = (int)h->prog_grid;
+    const dim3 grid((unsigned)round_up((int64_t)h->prog_grid, 8) * P.st[0].n_tiles), block(CV2_THREADS);
+    if (h->prog_mode == CONV_PREDICT) hipLaunchKernelGGL((k_conv2<CONV_PREDICT>), grid, block, CV2_LDS_BYTES, st, P);
+    else if (h->prog_mode == CONV_TRAIN_FWD) hipLaunchKernelGGL((k_conv2<CONV_TRAIN_FWD>), grid, block, CV2_LDS_BYTES, st, P);
+    else hipLaunchKernelGGL((k_conv2<CONV_BWD>), grid, block, CV2_LDS_BYTES, st, P);
+    P.n = 0;
+}
+
 template <int MODE>
-void cnn_dispatch(const cs_cnn* h, ConvArgs& p, bool wide, int n_pad, int64_t m_pad, hipStream_t st) {
+void cnn_dispatch(cs_cnn* h, ConvArgs& p, bool wide, int n_pad, int64_t m_pad, hipStream_t st) {
     if (wide && !h->tile128) {
         p.zeros = h->zeros;
         p.ablate = h->conv_ablate;
         p.n_tiles = (h->cfg.channels + CV2_BN - 1) / CV2_BN;
         p.m_store = m_pad;
-        hipLaunchKernelGGL((k_conv2<MODE>), dim3((unsigned)((m_pad + CV2_BM - 1) / CV2_BM) * p.n_tiles), dim3(CV2_THREADS), CV2_LDS_BYTES, st, p);
+        const unsigned grid = (unsigned)((m_pad + CV2_BM - 1) / CV2_BM);                   // row tiles (cnn_flush pads and multiplies)
+        if (h->prog.n && (h->prog_mode != MODE || h->prog.n >= h->fuse_max || h->prog_grid != grid)) cnn_flush(h, st);
+        h->prog.st[h->prog.n++] = p; h->prog_mode = MODE; h->prog_grid = grid;
     } else {
+        cnn_flush(h, st);
         hipLaunchKernelGGL((k_conv<MODE>), dim3((unsigned)(m_pad / 128), (unsigned)(n_pad / 128)), dim3(256), 0, st, p);
     }
 }
@@ -149,7 +173,7 @@ void cnn_second_pass(ConvArgs& p, const CnnConv* c2, const u16* in2, int ld_in2)
 }
 
 // inference-mode conv (dropout is identity): out = act(conv(in)) (+ add | + conv2nd(in2))
-void launch_conv(const cs_cnn* h, const CnnConv& c, const u16* in, int ld_in, int act, const u16* add, u16* out,
+void launch_conv(cs_cnn* h, const CnnConv& c, const u16* in, int ld_in, int act, const u16* add, u16* out,
                  int ld_out, int64_t m_rows, int64_t m_pad, hipStream_t st, const CnnConv* c2 = nullptr, const u16* in2 = nullptr,
                  int ld_in2 = 0) {
     ConvArgs p{};
@@ -160,7 +184,7 @@ void launch_conv(const cs_cnn* h, const CnnConv& c, const u16* in, int ld_in, in
 }
 
 // training-mode conv: out2 = dropout(act(conv(in))), out = out2 + add
-void launch_conv_train(const cs_cnn* h, const CnnConv& c, const u16* in, int ld_in, int layer, unsigned seed, const u16* add,
+void launch_conv_train(cs_cnn* h, const CnnConv& c, const u16* in, int ld_in, int layer, unsigned seed, const u16* add,
                        u16* out, u16* out2, int64_t m_rows, int64_t m_pad, hipStream_t st, const CnnConv* c2 = nullptr,
                        const u16* in2 = nullptr, int ld_in2 = 0, uint4* bits_out = nullptr) {
     ConvArgs p{};
@@ -175,7 +199,7 @@ void launch_conv_train(const cs_cnn* h, const CnnConv& c, const u16* in, int ld_
 }
 
 // data gradient: g = sum_slots A_s[m+sh_s] * Wd ; out (raw g, optional) ; out2 = g * (mask != 0) * mscale
-void launch_conv_bwd(const cs_cnn* h, const u16* dz3, const u16* g1, int lda, int kpt, const u16* Wd, int slots, const u16* mask,
+void launch_conv_bwd(cs_cnn* h, const u16* dz3, const u16* g1, int lda, int kpt, const u16* Wd, int slots, const u16* mask,
                      u16* out, u16* out2, int64_t m_rows, int64_t m_pad, hipStream_t st, const uint4* bits_in = nullptr) {
     ConvArgs p{};
     p.bits_in = bits_in;
@@ -187,8 +211,19 @@ void launch_conv_bwd(const cs_cnn* h, const u16* dz3, const u16* g1, int lda, in
     cnn_dispatch<CONV_BWD>(h, p, true, CNN_CP, m_pad, st);
 }
 
+// A stage wait of a chained conv launch that ran out, or channel tiles of one row tile found on different XCDs (conv2.h): counted by the
+// kernel in host-mapped memory; every later call on the model fails (what such a launch computed is not trusted).
+int cnn_poll(const cs_cnn* h) {
+    if (!h || !h->err_host) return CS_OK;
+    const unsigned e = *reinterpret_cast<const volatile unsigned*>(h->err_host);
+    if (e) return fail(CS_ERR_STATE, "a chained conv launch failed its stage hand-off (%u waits ran out, %u partners on another XCD): "
+                       "recreate the model with CS_CNN_FUSE=1", e & 0xffffu, e >> 16);
+    return CS_OK;
+}
+
 int cnn_check_batch(const cs_cnn* h, int64_t n) {
     if (!h) return fail(CS_ERR_INVALID, "null handle");
+    if (int rc = cnn_poll(h)) return rc;
     if (n <= 0 || n > h->cfg.max_batch) return fail(CS_ERR_INVALID, "n=%lld outside 1..max_batch=%d", (long long)n, h->cfg.max_batch);
     return CS_OK;
 }
@@ -299,6 +334,8 @@ int cs_cnn_create(cs_cnn_t** out, const cs_cnn_cfg* cfg) {
     A((void**)&h->wd, sizeof(float) * 100);
     A((void**)&h->bd, sizeof(float) * 16);
     A((void**)&h->zeros, 4096);
+    h->flag_tiles = (int)((h->m_pad_max + CV2_BM - 1) / CV2_BM);
+    A((void**)&h->pair_flags, sizeof(unsigned) * 8 * (size_t)h->flag_tiles);     // [tiles][4] stage words + [tiles][4] XCC ids (conv2.h)
     A((void**)&h->A0, sizeof(u16) * h->m_pad_max * CNN_A0_LD);
     A((void**)&h->O10, sizeof(u16) * h->m_pad_max * 128);
     for (u16** b : {&h->X, &h->A1, &h->R, &h->XN}) A((void**)b, sizeof(u16) * h->m_pad_max * CNN_CP);
@@ -338,6 +375,13 @@ int cs_cnn_create(cs_cnn_t** out, const cs_cnn_cfg* cfg) {
     size_t at = 0;
     for (auto& r : req) { *r.first = arena + at; at += r.second; }
     h->G = h->G_own;
+    {
+        const char* e = getenv("CS_CNN_FUSE");
+        h->fuse_max = e ? std::max(1, std::min(atoi(e), CV2_MAX_STAGES)) : CV2_MAX_STAGES;
+        if (hipHostMalloc((void**)&h->err_host, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { cs_cnn_destroy(h); return fail(CS_ERR_NOMEM, "hipHostMalloc failed"); }
+        memset(h->err_host, 0, 64);
+        if (hipHostGetDevicePointer((void**)&h->err_dev, h->err_host, 0) != hipSuccess) { cs_cnn_destroy(h); return fail(CS_ERR_HIP, "hipHostGetDevicePointer failed"); }
+    }
     {
         const u16 one = 0x3f80;                                   // bf16 1.0 at byte 64 of the zero page: the "ones chunk"
         if (hipMemcpy(reinterpret_cast<char*>(h->zeros) + 64, &one, sizeof one, hipMemcpyHostToDevice) != hipSuccess) {
@@ -398,6 +442,7 @@ int cs_cnn_create(cs_cnn_t** out, const cs_cnn_cfg* cfg) {
 void cs_cnn_destroy(cs_cnn_t* h) {
     if (!h) return;
     for (void* p : h->allocs) (void)hipFree(p);
+    if (h->err_host) (void)hipHostFree(h->err_host);
     delete h;
 }
 
@@ -527,6 +572,7 @@ int cs_cnn_loss_grads(cs_cnn_t* h, const float* x_dev, int x3d, const float* y_d
         if (b > 0) launch_conv_bwd(h, B.DZ1, B.GG, CNN_CP, cp, h->Wd_a[b], 4, h->blk[b - 1].A2, h->blk[b - 1].GG, h->blk[b - 1].DZ2,
                                    m_rows, m_pad, st, h->blk[b - 1].B2);
     }
+    cnn_flush(h, st);
     // ---- weight gradients: stream-K over every conv of the step (conv_wgrad2.h) + the 10-channel conv
     if (h->n_cw_tiles > 0) {
         CwArgs ca{};

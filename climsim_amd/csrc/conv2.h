@@ -38,6 +38,16 @@
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
+// LDS-DMA piece that does not look in this CU's L1 (sc1: served by L2): the row operands of a chained launch were written by this
+// and by another CU earlier in the same launch, and the L1 may still hold lines of a tensor an earlier stage read before a later one
+// rewrote it (inference ping-pongs three tensors).  `buffer_inv sc1` between stages would do the same job - and measured +4.7 us per
+// stage: it also drops what the L2 holds of the weights.  The weights take the plain path (nothing writes them during a launch).
+__device__ __forceinline__ void dma16_sc1(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off sc1\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
 // Bank swizzle of the 16-B chunks of a 64-B LDS row: chunk' = chunk ^ cv2_swz((row >> 2) & 3), cv2_swz = {0,2,3,1}.
 // ds_read_b128 is served in four groups of 16 lanes that are NOT contiguous ({0-3,12-15,20-27}, {4-11,16-19,28-31},
 // and the same +32): with lane = (chunk, row) a group holds rows {0-3,12-15} at chunk c and rows {4-11} at chunk c^1
@@ -45,8 +55,30 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 // plain chunk ^ quad puts quads 0/1 and 2/3 on the same banks (measured: SQ_LDS_BANK_CONFLICT = half of all LDS cycles).
 __device__ __forceinline__ int cv2_swz(int q) { return CV2_SWZ_EXPR; }
 
+// A launch runs a PROGRAM of up to CV2_MAX_STAGES convs on the same row tiles (cnn_api.h chains the trunk's convs: stage s+1 reads
+// what stage s wrote).  240-row tiles are whole columns, so a workgroup's next conv needs nothing but its own rows - in every channel:
+// the other channel tile(s) of the row tile, written by the workgroup(s) with the adjacent work id on the same XCD (one L2).  Between
+// stages: every wave's stores retired (`vmcnt(0)` = they are in L2), workgroup barrier, one thread publishes the stage in the row tile's
+// flag word and polls the partners' (agent-scope atomics, served by L2), barrier, the loaders invalidate the CU's L1 (`buffer_inv sc1`:
+// it may hold lines of a tensor an earlier stage read and a later one rewrote) and request the next conv's slabs.  What a launch
+// boundary cost instead: ~6 us of launch + prologue and ~7 us of store drain per conv (27.5 MB per tensor to memory before the next
+// kernel may start; inside a launch the consumers read it from L2 and the write-back happens behind their main loops).
+// A wait is bounded (spin_limit polls); one that runs out, or a partner found on another XCD, is counted in `error` (host-mapped):
+// the host fails the next call on the model (cs_cnn: CS_ERR_STATE) - the result of such a launch is not trusted.
+#define CV2_MAX_STAGES 12
+struct ConvProg {
+    ConvArgs st[CV2_MAX_STAGES];
+    int n;                       // stages of this launch
+    unsigned gen0;               // a workgroup publishes gen0 + s + 1 behind stage s (one counter per model, never reset)
+    unsigned* flags;             // [row tile][4]: flag word of each channel tile ; [row tile][4] XCC ids behind them (+ 4 * tiles)
+    unsigned* error;             // host-mapped
+    int spin_limit, n_row_tiles;
+    int tiles;                   // row tiles of this launch; the grid is round_up(tiles, 8) * n_tiles workgroups
+};
+
 template <int MODE>
-__global__ __launch_bounds__(CV2_THREADS) void k_conv2(const ConvArgs p) {
+__global__ __launch_bounds__(CV2_THREADS) void k_conv2(const ConvProg P) {
+    const ConvArgs& p0 = P.st[0];      // geometry (row tiles, channel tiles, seq, zero page) is that of every stage
     extern __shared__ __attribute__((aligned(16))) unsigned char cv2_ring[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -58,9 +90,14 @@ __global__ __launch_bounds__(CV2_THREADS) void k_conv2(const ConvArgs p) {
     const int lw = wid - 8;
     const int wm = (wid >> 1) & 3, wn = wid & 1;
     const int r0w = wm < 3 ? wm * 64 : CV2_BM - 64;          // first tile row of this compute wave
-    const int work = xcd_work_id(blockIdx.x, gridDim.x);
-    const int64_t m0 = (int64_t)(work / p.n_tiles) * CV2_BM;
-    const int n0 = (work % p.n_tiles) * CV2_BN;
+    // Block b runs on XCD b % 8 (the hardware deals block ids round-robin): the channel tiles of a row tile are CONSECUTIVE blocks
+    // of one XCD, whatever the grid size (the grid is padded to 8 row tiles; the stage hand-off needs one L2 and checks it).
+    const int xcd_ = blockIdx.x & 7, li_ = blockIdx.x >> 3;
+    const int row_tile = (li_ / p0.n_tiles) * 8 + xcd_, my_half = li_ % p0.n_tiles;
+    if (row_tile >= P.tiles) return;                         // padding: the whole workgroup leaves before any barrier
+    const int work = row_tile * p0.n_tiles + my_half;
+    const int64_t m0 = (int64_t)row_tile * CV2_BM;
+    const int n0 = my_half * CV2_BN;
 
     // ---- DMA geometry (loaders): lane -> (row prow, physical chunk pos) of a 16-row piece; it fetches logical chunk
     // pos ^ cv2_swz(prow>>2).  Loader lw owns pieces 4lw..4lw+3 of a row tile (15: loader 3 fetches piece 14 twice) and of
@@ -69,36 +106,38 @@ __global__ __launch_bounds__(CV2_THREADS) void k_conv2(const ConvArgs p) {
     const int cl = (pos ^ cv2_swz((prow >> 2) & 3)) * 8;
     typedef unsigned char __attribute__((address_space(3))) * lds_b;
     const unsigned lds0 = (unsigned)(uintptr_t)((lds_b)cv2_ring);
-    const char* zsrc = reinterpret_cast<const char*>(p.zeros);
+    const char* zsrc = reinterpret_cast<const char*>(p0.zeros);
 
     // The operands of the running pass (a kernel runs one pass, or two for "conv b + projection", see below).  Taps 0-2 read
     // qA0 (at shifts qs0-qs2), tap 3 reads qA3: cnn_api.h fills ConvArgs that way for every launch of this kernel.
-    const u16 *qA0 = p.A0, *qA3 = p.A3, *qB = p.B;
-    int qs0 = p.sh0, qs1 = p.sh1, qs2 = p.sh2, qs3 = p.sh3, qlda = p.lda, qldb = p.ldb, qkpt = p.kpt, qtaps = p.taps;
+    const u16 *qA0, *qA3, *qB;
+    int qs0, qs1, qs2, qs3, qlda, qldb, qkpt, qtaps;
     int kc, nt;
+#define CV2_STAGE_OPERANDS()                                                                           \
+    {                                                                                                   \
+        qA0 = p.A0; qA3 = p.A3; qB = p.B; qs0 = p.sh0; qs1 = p.sh1; qs2 = p.sh2; qs3 = p.sh3;           \
+        qlda = p.lda; qldb = p.ldb; qkpt = p.kpt; qtaps = p.taps;                                       \
+    }
 
     f32x4_t acc[4][7];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 7; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
     // fragment addresses (compute waves): weight rows wn*112 + 16j + (lane&15), 16-byte chunk lane>>4, swizzled by
     // cv2_swz((row>>2)&3); tile rows r0w + 16i + (lane&15) + shift for the three shifts a tap can have.
     const int l15 = lane & 15;
     const unsigned b_off = (unsigned)((wn * 112 + l15) * 64) + (unsigned)(((lane >> 4) ^ cv2_swz(l15 >> 2)) << 4);
-    unsigned aoff[3];
+    unsigned aoff_m = 0u, aoff_0 = 0u, aoff_p = 0u;       // three scalars: an array captured by the stage lambda went to scratch, indexed in the loop
     unsigned lanebits = 0u;       // bit 2i: row i's lane sits at the first level of its column (no row above), bit 2i+1: at the last
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         const int x = l15 + d - 1, xr = x & 15;            // x = -1 .. 16: the neighbouring piece for -1 and 16
-        aoff[d] = (unsigned)((r0w + (x - xr)) * 64 + xr * 64) + (unsigned)(((lane >> 4) ^ cv2_swz(xr >> 2)) << 4);
+        const unsigned ao = (unsigned)((r0w + (x - xr)) * 64 + xr * 64) + (unsigned)(((lane >> 4) ^ cv2_swz(xr >> 2)) << 4);
+        if (d == 0) aoff_m = ao; else if (d == 1) aoff_0 = ao; else aoff_p = ao;
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int lev = (r0w + 16 * i + l15) % p.seq;      // the tile starts at a column start
+        const int lev = (r0w + 16 * i + l15) % p0.seq;      // the tile starts at a column start
         if (lev == 0) lanebits |= 1u << (2 * i);
-        if (lev == p.seq - 1) lanebits |= 2u << (2 * i);
+        if (lev == p0.seq - 1) lanebits |= 2u << (2 * i);
     }
 
     // ---- One pass of the pipeline over the current operands.  Slab s = (chunk s / T, tap s % T), T = taps.  Barrier protocol,
@@ -127,7 +166,7 @@ __global__ __launch_bounds__(CV2_THREADS) void k_conv2(const ConvArgs p) {
                 as = as + 1 == CV2_NSLOT ? 0 : as + 1;                                                  \
                 const char* Sb_ = reinterpret_cast<const char*>(it == 3 ? qA3 : qA0) + ic * 64;         \
                 _Pragma("unroll") for (int k = 0; k < 4; ++k)                                           \
-                    dma16(((oka >> k) & 1u) ? Sb_ + arow[k] : zsrc, adst[k] + (unsigned)as * CV2_A_SLOT); \
+                    dma16_sc1(((oka >> k) & 1u) ? Sb_ + arow[k] : zsrc, adst[k] + (unsigned)as * CV2_A_SLOT); \
             }                                                                                           \
             const int boff_ = (it * kc + ic) * 64;                                                      \
             _Pragma("unroll") for (int k = 0; k < 4; ++k) dma16(bsrc[k] + boff_, bdst[k] + (unsigned)bs * CV2_B_SLOT); \
@@ -174,8 +213,8 @@ __global__ __launch_bounds__(CV2_THREADS) void k_conv2(const ConvArgs p) {
 #define CV2_SLAB_STATE(VA, LB)                              /* (VA, LB, vb) of slab (n_it, n_as, n_bs); selects, no branches */ \
     {                                                                                                   \
         const int sh1_ = (shpack >> (2 * n_it)) & 3;            /* shift + 1 */                           \
-        const unsigned t_ = sh1_ == 0 ? aoff[0] : aoff[1];                                              \
-        VA = lds0 + (unsigned)n_as * CV2_A_SLOT + (sh1_ == 2 ? aoff[2] : t_);                           \
+        const unsigned t_ = sh1_ == 0 ? aoff_m : aoff_0;                                                \
+        VA = lds0 + (unsigned)n_as * CV2_A_SLOT + (sh1_ == 2 ? aoff_p : t_);                            \
         LB = lanebits & ((0xaa0055u >> (8 * sh1_)) & 0xffu);                                            \
         vb = lds0 + CV2_B_RING + (unsigned)n_bs * CV2_B_SLOT + b_off;                                   \
     }
@@ -221,17 +260,27 @@ __global__ __launch_bounds__(CV2_THREADS) void k_conv2(const ConvArgs p) {
     }
 
     if (loader) {
-        if (MODE == CONV_BWD && p.bits_in) {        // the mask bits of the compute threads' results: 8 KiB, 2 pieces per loader
-            const char* bsrc_ = reinterpret_cast<const char*>(p.bits_in + (int64_t)work * 512) + lw * 2048 + lane * 16;
-            dma16(bsrc_, lds0 + CV2_BITS_OFF + (unsigned)lw * 2048u);
-            dma16(bsrc_ + 1024, lds0 + CV2_BITS_OFF + (unsigned)lw * 2048u + 1024u);
-        }
-        CV2_LOAD_PASS()
-        if (MODE != CONV_BWD && p.A2nd && !(p.ablate & 4)) {
-            __builtin_amdgcn_s_barrier();           // the compute waves are done with their LDS staging regions
-            qA0 = qA3 = p.A2nd; qs0 = qs1 = qs2 = qs3 = 0; qlda = p.lda2;
-            qB = p.B2nd; qldb = p.ldb2; qkpt = p.kpt2; qtaps = 1;
+        for (int stage = 0; stage < P.n; ++stage) {
+            const ConvArgs& p = P.st[stage];
+            CV2_STAGE_OPERANDS()
+#ifndef CV2_INV
+#define CV2_INV 0                // development: 1 = `buffer_inv sc1` between stages instead of relying on the sc1 pieces (measured, see dma16_sc1)
+#endif
+            if (stage && CV2_INV == 1) asm volatile("buffer_inv sc1" ::: "memory");
+            if (stage && CV2_INV == 2) asm volatile("buffer_inv sc0" ::: "memory");      // behind the stage barrier pair: this CU's L1 forgets what earlier stages read
+            if (MODE == CONV_BWD && p.bits_in) {        // the mask bits of the compute threads' results: 8 KiB, 2 pieces per loader
+                const char* bsrc_ = reinterpret_cast<const char*>(p.bits_in + (int64_t)work * 512) + lw * 2048 + lane * 16;
+                dma16(bsrc_, lds0 + CV2_BITS_OFF + (unsigned)lw * 2048u);
+                dma16(bsrc_ + 1024, lds0 + CV2_BITS_OFF + (unsigned)lw * 2048u + 1024u);
+            }
             CV2_LOAD_PASS()
+            if (MODE != CONV_BWD && p.A2nd && !(p.ablate & 4)) {
+                __builtin_amdgcn_s_barrier();           // the compute waves are done with their LDS staging regions
+                qA0 = qA3 = p.A2nd; qs0 = qs1 = qs2 = qs3 = 0; qlda = p.lda2;
+                qB = p.B2nd; qldb = p.ldb2; qkpt = p.kpt2; qtaps = 1;
+                CV2_LOAD_PASS()
+            }
+            if (stage + 1 < P.n) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); }     // the stage barrier pair (see below)
         }
         return;
     }
@@ -241,15 +290,22 @@ __global__ __launch_bounds__(CV2_THREADS) void k_conv2(const ConvArgs p) {
     // variants to 256 VGPRs + 92-104 bytes of scratch per lane.
     float* bias_lds = reinterpret_cast<float*>(cv2_ring + CV2_BIAS_OFF);
     if (tid < 4) *reinterpret_cast<unsigned*>(cv2_ring + CV2_ZERO_OFF + tid * 4) = 0u;
+    unsigned char* reg = cv2_ring + wid * (64 * 240);
+    const int64_t mw = m0 + r0w;
+    const int nw = n0 + wn * 112;
+    // one stage = one conv (the body returns where the conv is done)
+    auto run_stage = [&](const ConvArgs& p) __attribute__((always_inline)) {
+    CV2_STAGE_OPERANDS()
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 7; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     if (MODE != CONV_BWD && tid < CV2_BN) {
         bias_lds[tid] = p.bias[n0 + tid];
         if (p.A2nd) bias_lds[CV2_BN + tid] = p.bias2[n0 + tid];
     }
     // One copy of the pipeline for both passes of a two-pass launch (a loop, not two expansions: the accumulators keep ONE
     // register assignment - with two, hipcc moved 64 of them through scratch between the passes at 168 VGPRs).
-    unsigned char* reg = cv2_ring + wid * (64 * 240);
-    const int64_t mw = m0 + r0w;
-    const int nw = n0 + wn * 112;
     bool second = false;
     for (;;) {
     CV2_COMPUTE_PASS()
@@ -258,10 +314,15 @@ __global__ __launch_bounds__(CV2_THREADS) void k_conv2(const ConvArgs p) {
     if (MODE == CONV_BWD && p.bits_in) mbits = *reinterpret_cast<const uint4*>(cv2_ring + CV2_BITS_OFF + tid * 16);
 
     if (p.ablate & 4) return;
-    // ---- epilogue.  D[channel][row]: lane owns row ..+(lane&15), channels ..+4*(lane>>4)+{0..3}.
+    // The epilogue's view of the thread index: recomputed behind the main loop (opaque to hipcc) - lane constants kept across the
+    // loop were parked in scratch at 168 VGPRs and reloaded before every use, each reload waiting for every store in flight.
+    int te = threadIdx.x;
+    asm volatile("" : "+v"(te));
+    const int le = te & 63;
+    // ---- epilogue.  D[channel][row]: le owns row ..+(le&15), channels ..+4*(le>>4)+{0..3}.
     // The accumulators are transformed in place; each output tensor then goes wave-tile by wave-tile through
-    // a private LDS region (64 rows x 240-B pitch) so that the global stores are 16 B per lane along 224-B row
-    // segments instead of row-per-lane 8-B pieces.
+    // a private LDS region (64 rows x 240-B pitch) so that the global stores are 16 B per le along 224-B row
+    // segments instead of row-per-le 8-B pieces.
 #ifndef CV2_STORE_G
 #define CV2_STORE_G 1            // row groups (of 16 rows) packed into the staging region before their rows are stored: 4 = the whole wave tile
 #endif
@@ -271,21 +332,21 @@ __global__ __launch_bounds__(CV2_THREADS) void k_conv2(const ConvArgs p) {
            staging region, read back along the rows - 4 rows per instruction, 14 of 16 lanes per row carry one 16-B chunk: no     \
            division by 14 - and stored.  A running pointer and four rows in flight: sixteen precomputed 64-bit addresses do not    \
            fit beside the accumulators at 168 VGPRs. */                                                                          \
-        u16* g_ = (dst) + (mw + (lane >> 4)) * (ld) + nw + (lane & 15) * 8;                              \
-        const unsigned char* l_ = reinterpret_cast<const unsigned char*>(__builtin_assume_aligned(reg + (lane >> 4) * 240 + (lane & 15) * 16, 16)); \
+        u16* g_ = (dst) + (mw + (le >> 4)) * (ld) + nw + (le & 15) * 8;                              \
+        const unsigned char* l_ = reinterpret_cast<const unsigned char*>(__builtin_assume_aligned(reg + (le >> 4) * 240 + (le & 15) * 16, 16)); \
         const int64_t gstep_ = (int64_t)4 * (ld);                                                        \
-        int row_ = (int)(mw - m0) + (lane >> 4);                                                         \
+        int row_ = (int)(mw - m0) + (le >> 4);                                                         \
         const int lim_ = (p.ablate & 8) ? 0 : (int)min((int64_t)CV2_BM, p.m_store - m0);   /* tile rows the tensors hold */ \
         _Pragma("unroll") for (int i0 = 0; i0 < 4; i0 += CV2_STORE_G) {                                  \
             _Pragma("unroll") for (int i = i0; i < i0 + CV2_STORE_G; ++i)                                \
                 _Pragma("unroll") for (int j = 0; j < 7; ++j) {                                          \
                     const f32x4_t x_ = XF(i, j);                                                         \
                     if (dst)                                                                             \
-                        *reinterpret_cast<uint2*>(reg + (i * 16 + (lane & 15)) * 240 + (j * 16 + 4 * (lane >> 4)) * 2) = \
+                        *reinterpret_cast<uint2*>(reg + (i * 16 + (le & 15)) * 240 + (j * 16 + 4 * (le >> 4)) * 2) = \
                             pack4_hw(x_[0], x_[1], x_[2], x_[3]);                                        \
                     __builtin_amdgcn_sched_barrier(0);                                                   \
                 }                                                                                        \
-            if ((dst) && (lane & 15) < 14) {                                                             \
+            if ((dst) && (le & 15) < 14) {                                                             \
                 _Pragma("unroll 1") for (int it = 4 * i0; it < 4 * (i0 + CV2_STORE_G); it += 4) {        \
                     const uint4 va_ = *reinterpret_cast<const uint4*>(l_ + it * 960), vb_ = *reinterpret_cast<const uint4*>(l_ + (it + 1) * 960), \
                                 vc_ = *reinterpret_cast<const uint4*>(l_ + (it + 2) * 960), vd_ = *reinterpret_cast<const uint4*>(l_ + (it + 3) * 960); \
@@ -332,11 +393,13 @@ __global__ __launch_bounds__(CV2_THREADS) void k_conv2(const ConvArgs p) {
         const float act_floor = p.act == CACT_RELU ? 0.f : -__builtin_huge_valf();
         unsigned mwb[4] = {0u, 0u, 0u, 0u};
         auto transform = [&](int i, int j) __attribute__((always_inline)) {
-            const int n = nw + j * 16 + 4 * (lane >> 4);
-            unsigned bo = (unsigned)(wn * 112 + j * 16 + 4 * (lane >> 4)) * 4u;
+            const int n = nw + j * 16 + 4 * (le >> 4);
+            unsigned bo = (unsigned)(wn * 112 + j * 16 + 4 * (le >> 4)) * 4u;
             asm volatile("" : "+v"(bo));        // re-read per tile: seven bias quads held across the row groups are 28 VGPRs this kernel does not have
             const float4 b4 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(bias_lds) + bo);
-            const int64_t m = mw + i * 16 + (lane & 15);
+            int mi = i * 16 + (le & 15);
+            asm volatile("" : "+v"(mi));        // per tile, per stage: hoisted out of the stage loop the 56 hash seeds of a thread live in scratch
+            const int64_t m = mw + mi;
             float v[4] = {acc[i][j][0] + b4.x, acc[i][j][1] + b4.y, acc[i][j][2] + b4.z, acc[i][j][3] + b4.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], act_floor);      // ReLU | identity, branch-free
@@ -368,14 +431,14 @@ __global__ __launch_bounds__(CV2_THREADS) void k_conv2(const ConvArgs p) {
             return acc[i][j];
         };
         CV2_STORE_TILE_X(dst_, ldd_, hook)
-        if (MODE == CONV_TRAIN_FWD && !second && p.bits_out) p.bits_out[(int64_t)work * 512 + tid] = make_uint4(mwb[0], mwb[1], mwb[2], mwb[3]);
+        if (MODE == CONV_TRAIN_FWD && !second && p.bits_out) p.bits_out[(int64_t)work * 512 + te] = make_uint4(mwb[0], mwb[1], mwb[2], mwb[3]);
         if (second || !two) return;
         {
             // second pass: the block's projection of its input, accumulated on top of the activated conv output
             // (x_next = dropout(relu(conv_b(a1))) + conv_r(x): one launch, no R tensor, no extra epilogue)
 #pragma unroll
             for (int j = 0; j < 7; ++j) {
-                const float4 b4 = *reinterpret_cast<const float4*>(bias_lds + CV2_BN + wn * 112 + j * 16 + 4 * (lane >> 4));
+                const float4 b4 = *reinterpret_cast<const float4*>(bias_lds + CV2_BN + wn * 112 + j * 16 + 4 * (le >> 4));
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { acc[i][j][0] += b4.x; acc[i][j][1] += b4.y; acc[i][j][2] += b4.z; acc[i][j][3] += b4.w; }
                 __builtin_amdgcn_sched_barrier(0);
@@ -385,6 +448,42 @@ __global__ __launch_bounds__(CV2_THREADS) void k_conv2(const ConvArgs p) {
             qkpt = p.kpt2; qtaps = 1; qs0 = qs1 = qs2 = qs3 = 0; second = true;
         }
     }
+    }
+    };
+    for (int stage = 0; stage < P.n; ++stage) {
+        run_stage(P.st[stage]);
+        if (stage + 1 < P.n) {
+            // stage barrier pair: my stores are in L2 / everyone's; publish, wait for the other channel tiles of my rows
+#ifndef CV2_NOSYNC
+#define CV2_NOSYNC 0
+#endif
+            if (CV2_NOSYNC != 2) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+#ifndef CV2_NOSYNC
+#define CV2_NOSYNC 0
+#endif
+            if (tid == 0 && !CV2_NOSYNC) {
+                const unsigned gen = P.gen0 + (unsigned)stage + 1u;
+                unsigned* fl = P.flags + (int64_t)row_tile * 4;
+                unsigned* xc = fl + (int64_t)P.n_row_tiles * 4;
+                const unsigned xcc = (__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 15u) + 1u;      // HW_REG_XCC_ID[3:0]
+                if (stage == 0) __hip_atomic_store(xc + my_half, xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(fl + my_half, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int h = 0; h < p0.n_tiles; ++h) {
+                    if (h == my_half) continue;
+                    int spins = 0;
+                    while ((int)(__hip_atomic_load(fl + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - gen) < 0) {
+                        if (++spins > P.spin_limit) { __hip_atomic_fetch_add(P.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    // one L2 is what makes the partner's plain stores visible here
+                    if (stage == 0 && __hip_atomic_load(xc + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != xcc)
+                        __hip_atomic_fetch_add(P.error, 1u << 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
+            __builtin_amdgcn_s_barrier();
+        }
     }
 #undef CV2_STORE_TILE
 #undef CV2_STORE_TILE_X
@@ -397,4 +496,5 @@ __global__ __launch_bounds__(CV2_THREADS) void k_conv2(const ConvArgs p) {
 #undef CV2_LGKM
 #undef CV2_ROW
 #undef CV2_SLAB_STATE
+#undef CV2_STAGE_OPERANDS
 }

@@ -247,6 +247,31 @@ def test_cnn_kernel_families_agree(CNN):
         c, ratio = cos_rel(a, b)
         assert c >= 0.999 and abs(ratio - 1) <= 1e-2, (i, c, ratio)
 
+def test_cnn_chained_launches_match_one_conv_per_launch(CNN, monkeypatch):
+    """The trunk's convs run as programs of up to 12 convs per launch (csrc/conv2.h: stage hand-off between the channel tiles of
+    a row tile through L2 + flags); CS_CNN_FUSE=1 launches every conv on its own.  The arithmetic is the same, so predictions,
+    loss sums and every gradient tensor must be bit-identical - depth 12 (two programs forward, three backward), a batch whose
+    last row tile is partial, dropout on."""
+    depth, width, n = 12, 406, 37
+    ws = CO.glorot_cnn(seed=6, bias_scale=0.05, depth=depth, channels=width)
+    x3, y3 = make_xy(n, 21)
+    res = []
+    for fuse in ("1", "12", "5"):
+        monkeypatch.setenv("CS_CNN_FUSE", fuse)
+        m = CNN.CNNEmulator(depth=depth, channel_width=width, max_batch=64, trainable=True, loss="mse", dropout=0.175, seed=3)
+        m.set_weights(ws)
+        pred = m.predict(x3)
+        sums = m.loss_grads(x3, y3).cpu().numpy()
+        res.append((pred, sums, m.get_gradients(1.0 / (n * 60))))
+        m.close()
+    for other in res[1:]:
+        np.testing.assert_array_equal(res[0][0], other[0])
+        for a, b in zip(res[0][2], other[2]):
+            # the weight-gradient kernel adds its partial sums with float atomics: only its inputs are bit-identical
+            c, ratio = cos_rel(a, b)
+            assert c >= 0.999999 and abs(ratio - 1) <= 1e-5
+        np.testing.assert_allclose(res[0][1], other[1], rtol=1e-6)
+
 
 @pytest.mark.parametrize("depth,width,tile128", [(2, 406, False), (2, 64, False), (1, 200, False), (2, 406, True)])
 def test_cnn_optimizer_forms_agree(CNN, depth, width, tile128, monkeypatch):
