@@ -355,6 +355,8 @@ int cs_cnn_create(cs_cnn_t** out, const cs_cnn_cfg* cfg) {
         h->Wd_b.assign(depth, nullptr);
         for (int b = 0; b < depth; ++b) {
             for (u16** t : {&h->blk[b].A1, &h->blk[b].A2, &h->blk[b].XS, &h->blk[b].DZ1, &h->blk[b].DZ2, &h->blk[b].GG})
+                if (t == &h->blk[b].A2 && !h->tile128) continue;     // only the 128 x 128 kernels keep a2 (their masks)
+                else
                 A((void**)t, sizeof(u16) * h->m_pad_max * CNN_CP);
             if (!h->tile128) {          // k_conv2 masks with these (it has no other form)
                 const size_t wgs = (size_t)((h->m_pad_max + CV2_BM - 1) / CV2_BM) * ((cfg->channels + CV2_BN - 1) / CV2_BN);
@@ -552,7 +554,8 @@ int cs_cnn_loss_grads(cs_cnn_t* h, const float* x_dev, int x3d, const float* y_d
             launch_conv(h, cr, x, ldx, CACT_NONE, nullptr, h->R, CNN_CP, m_rows, m_pad, st);
             launch_conv_train(h, cb, B.A1, CNN_CP, 2 * b + 1, seed, h->R, B.XS, B.A2, m_rows, m_pad, st);
         } else {
-            launch_conv_train(h, cb, B.A1, CNN_CP, 2 * b + 1, seed, nullptr, B.XS, B.A2, m_rows, m_pad, st, &cr, x, ldx, B.B2);
+            // no a2 tensor: the backward pass masks with its bits (B2) and no weight gradient reads it (27.5 MB less to store per block)
+            launch_conv_train(h, cb, B.A1, CNN_CP, 2 * b + 1, seed, nullptr, B.XS, nullptr, m_rows, m_pad, st, &cr, x, ldx, B.B2);
         }
         x = B.XS; ldx = CNN_CP;
     }
