@@ -69,6 +69,7 @@ struct ChainArgs {
                              // backward half: no prologue load (dz is in X) and no L2 warm-up (a prefetch of Wb issued during
                              // the forward half would sit in front of that half's weight stream: memory operations complete in order)
     int ablate;              // timing experiments only (CS_CHAIN_ABLATE): 4 no global stores, 8 no warm-up
+    int store_nt;            // activations / gradients leave with the non-temporal policy (host: batches the L2s cannot hold anyway)
     unsigned long long* dbg; // optional [grid][64] s_memtime stamps (CS_CHAIN_DBG), null in production
 };
 
@@ -92,20 +93,25 @@ __device__ __forceinline__ unsigned bf_pos(unsigned h16) { return (unsigned)((h1
 // Stage output rows LDS -> global, fully coalesced (one wave-instruction = 1 KiB of one row).  The MFMA
 // result layout gives every lane 4 columns of ONE row, so storing from registers touches 32 rows per
 // instruction with 16-byte pieces - 8x the write requests for the same bytes.
+// `nt`: non-temporal stores.  Same-box A/B (us, chain / weight gradients / step): 8192 columns 77.6 / 32.4 / 127.4 plain, 75.2 / 36.5 /
+// 127.4 nt (the weight-gradient kernel then misses them in L2); 16384: 184.3 -> 189.6 per step; 65536: 363.4 / 210.6 / 590.6 plain,
+// 354.9 / 203.2 / 577.0 nt - at that size the L2s keep none of the 704 MB anyway, and what they keep instead is the weights.
+// Second box, step only: 24576 columns 283.5 -> 281.1, 32768: 328.4 -> 320.8, 49152: 517.4 -> 513.2, 65536: 614.4 -> 595.3: on from 24576 (CS_CHAIN_NT_MIN).
 template <int BM>
 __device__ __forceinline__ void chain_copy_out(const u16* __restrict__ X, u16* __restrict__ out, int ldo, int width,
-                                               int64_t m0, int tid) {
+                                               int64_t m0, int tid, bool nt = false) {
     const int cpr_shift = (width == 512) ? 6 : (width == 256 ? 5 : 4);       // 16-B chunks per row
     const int total = BM << cpr_shift;
     for (int g = tid; g < total; g += 512) {
         const int r = g >> cpr_shift, c = g & ((1 << cpr_shift) - 1);
         const uint4 v = *reinterpret_cast<const uint4*>(X + r * CHAIN_PITCH + ((c ^ (r & 15)) << 3));
-        *reinterpret_cast<uint4*>(out + (m0 + r) * ldo + c * 8) = v;
+        if (nt) __builtin_nontemporal_store((u32x4_t){v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4_t*>(out + (m0 + r) * ldo + c * 8));
+        else *reinterpret_cast<uint4*>(out + (m0 + r) * ldo + c * 8) = v;
     }
 }
 
 struct ChainPending {          // stage output still to be copied LDS -> global (done by the NEXT stage, see chain_mma)
-    u16* out; int ldo; int width;
+    u16* out; int ldo; int width; int nt;
 };
 
 // The weight queue of a wave: 8 (or 4) k16-steps x up to 2 column tiles of 1 KiB wave-loads in flight.  Named scalars
@@ -221,7 +227,7 @@ __device__ __forceinline__ void chain_mma(const u16* __restrict__ X, const u16* 
     constexpr bool LATE_COPY = BMROWS >= 64;
     if (!LATE_COPY && pend.out) {
         if constexpr (WIDE_PEND) chainw_copy_out(X, pend.out, pend.ldo, pend.width, m0, tid);      // wide chain: any width, this wave's share
-        else chain_copy_out<BMROWS>(X, pend.out, pend.ldo, pend.width, m0, tid);
+        else chain_copy_out<BMROWS>(X, pend.out, pend.ldo, pend.width, m0, tid, pend.nt != 0);
         pend.out = nullptr;
     }
     const int arow = mrow0 + (lane & 31), ahalf = lane >> 5;
@@ -241,7 +247,7 @@ __device__ __forceinline__ void chain_mma(const u16* __restrict__ X, const u16* 
     // tiles) 117.4 / 113.4 / 115.7; 32-row tiles lose: 8192 columns 79.7 / 79.3 / 79.7, 3072: 71.9 / 73.2 / 73.5, published
     // model (wide chain) 105.7 / 107.3 / 110.6 - there the copy is 32 KiB and the tail is where the wave is busiest.
     if (LATE_COPY && pend.out) {
-        chain_copy_out<BMROWS>(X, pend.out, pend.ldo, pend.width, m0, tid);
+        chain_copy_out<BMROWS>(X, pend.out, pend.ldo, pend.width, m0, tid, pend.nt != 0);
         pend.out = nullptr;
     }
     CHAIN_BLOCK(true)                        // last D steps: the final wait is vmcnt(0), every slot is consumed
@@ -398,8 +404,8 @@ __device__ __forceinline__ void chain_stage(u16* X, const float* bias_lds, const
     }
     __syncthreads();                         // X now holds this stage's output
     if (EPI != EPI_OUT && S.out && !(p.ablate & (4 | 16))) {
-        if (last) chain_copy_out<BMROWS>(X, S.out, S.ldo, S.Nc, m0, tid);     // nobody comes after: copy now
-        else pend = ChainPending{S.out, S.ldo, S.Nc};                         // the next stage copies it
+        if (last) chain_copy_out<BMROWS>(X, S.out, S.ldo, S.Nc, m0, tid, p.store_nt != 0);     // nobody comes after: copy now
+        else pend = ChainPending{S.out, S.ldo, S.Nc, p.store_nt};                         // the next stage copies it
     }
     chain_stamp(p, bid, tid, slot);
 }
@@ -513,7 +519,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const ChainDyn& d
     chain_stamp(p, bid, tid, slot);
 
     float sq = 0.f, ab = 0.f;
-    ChainPending pend{nullptr, 0, 0};
+    ChainPending pend{nullptr, 0, 0, 0};
     for (int i = 0; i < p.n_stages; ++i) {
         const ChainStage& S = p.st[i];
         const bool last = (i + 1 == p.n_stages);

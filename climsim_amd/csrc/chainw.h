@@ -117,7 +117,7 @@ __device__ __forceinline__ void chainw_body(const ChainArgs& p, const ChainDyn& 
 
     float sq = 0.f, ab = 0.f;
     const int mrow = lane & 31, hi4 = 4 * (lane >> 5);
-    ChainPending pend{nullptr, 0, 0};
+    ChainPending pend{nullptr, 0, 0, 0};
     for (int i = 0; i < p.n_stages; ++i) {
         const ChainStage& S = p.st[i];
         const int ntiles = S.Nc >> 5, ks = S.Kc >> 4;
@@ -230,7 +230,7 @@ __device__ __forceinline__ void chainw_body(const ChainArgs& p, const ChainDyn& 
         __syncthreads();                                         // Xout complete, nobody reads Xin any more
         if (S.out) {                                             // global copy (next layer's wgrad / the backward pass), coalesced:
             if (i + 1 == p.n_stages) chainw_copy_out(Xout, S.out, S.ldo, S.Nc, m0, tid);   // nobody comes after: now
-            else pend = ChainPending{S.out, S.ldo, S.Nc};                                  // the next stage copies it behind its first weight loads
+            else pend = ChainPending{S.out, S.ldo, S.Nc, 0};                               // the next stage copies it behind its first weight loads
         }
         u16* t = Xin; Xin = Xout; Xout = t;
     }

@@ -146,6 +146,7 @@ struct cs_mlp {
     bool grads_dirty = true;   // G may hold non-zero values (cleared by cs_mlp_apply)
     unsigned long long* dbg = nullptr;   // CS_CHAIN_DBG: [2][grid_max][64] stamps (fwd, bwd)
     int chain_ablate = 0;      // CS_CHAIN_ABLATE env, timing experiments only
+    int64_t chain_nt_min = 24576;   // CS_CHAIN_NT_MIN: batch from which the tuned chain's activation / gradient stores are non-temporal (chain.h)
     bool wgrad3 = true;        // small-batch wgrad through the LDS-DMA ring (CS_WGRAD3=0: register-staged k_wgrad)
     int wgrad2_mode = -1;      // CS_WGRAD2 env: 0 never, 1 always, -1 by batch size
     int wgrad_splitk = 0;      // 0 = automatic (CS_WGRAD_SPLITK env overrides, for tuning runs)
@@ -349,6 +350,7 @@ void chain_bwd_args(const cs_mlp* h, int64_t n, ChainArgs& c) {
         S.hprev = ly.H; S.ldh = ly.Kp; S.epi = EPI_DGRAD;
     }
     c.ablate = h->chain_ablate; c.dbg = h->dbg ? h->dbg + (h->m_pad_max / 32) * 64 : nullptr;
+    c.store_nt = n >= h->chain_nt_min ? 1 : 0;
     c.dz_in = h->layers[h->L - 1].dZ; c.ld_dz_in = 128; c.w_in = 128;
     c.n_rows = n; c.act = h->cfg.act; c.slope = (h->cfg.act == CS_ACT_RELU) ? 0.f : h->cfg.alpha;
 }
@@ -367,7 +369,7 @@ void chain_fwd_args(const cs_mlp* h, bool wide, const float* x, const int64_t* r
         if (l + 1 < h->L) { S.out = want_dz ? h->layers[l + 1].H : nullptr; S.ldo = h->layers[l + 1].Kp; S.epi = EPI_HIDDEN; S.mask = want_dz ? ly.mask : nullptr; }      // (null for ELU models on the wide chain: never allocated)
         else { S.out = nullptr; S.ldo = 0; S.epi = EPI_OUT; S.mask = nullptr; }
     }
-    if (!wide) { c.ablate = h->chain_ablate; c.dbg = h->dbg; }
+    if (!wide) { c.ablate = h->chain_ablate; c.dbg = h->dbg; c.store_nt = n >= h->chain_nt_min ? 1 : 0; }
     c.x = x; c.row_idx = row_idx; c.n_in = h->cfg.n_in; c.kp0 = l0.Kp; c.sub = h->sub; c.div = h->div;
     c.normalise = normalise; c.h0 = want_dz ? l0.H : nullptr; c.ldh0 = l0.Kp; c.n_rows = n;
     c.act = h->cfg.act; c.slope = (h->cfg.act == CS_ACT_RELU) ? 0.f : h->cfg.alpha;
@@ -700,6 +702,7 @@ int cs_mlp_create(cs_mlp_t** out, const cs_mlp_cfg* cfg) {
     if (h->L > WGRAD_MAX_LAYERS) return fail(CS_ERR_INVALID, "too many layers");
     if (const char* e = getenv("CS_WGRAD_SPLITK")) h->wgrad_splitk = atoi(e);
     if (const char* e = getenv("CS_CHAIN_ABLATE")) h->chain_ablate = atoi(e);
+    if (const char* e = getenv("CS_CHAIN_NT_MIN")) h->chain_nt_min = atoll(e);
     if (const char* e = getenv("CS_WGRAD2")) h->wgrad2_mode = atoi(e);
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad2), hipFuncAttributeMaxDynamicSharedMemorySize, WG2_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad3<4, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, WG3_LDS_BYTES));
