@@ -323,6 +323,14 @@ __global__ __launch_bounds__(CV2_THREADS) void k_conv2(const ConvProg P) {
     // The accumulators are transformed in place; each output tensor then goes wave-tile by wave-tile through
     // a private LDS region (64 rows x 240-B pitch) so that the global stores are 16 B per le along 224-B row
     // segments instead of row-per-le 8-B pieces.
+#ifndef CV2_STORE_NT
+#define CV2_STORE_NT 0
+#endif
+#if CV2_STORE_NT
+#define CV2_ST(ptr, v) __builtin_nontemporal_store((u32x4_t){(v).x, (v).y, (v).z, (v).w}, reinterpret_cast<u32x4_t*>(ptr));
+#else
+#define CV2_ST(ptr, v) *reinterpret_cast<uint4*>(ptr) = (v);
+#endif
 #ifndef CV2_STORE_G
 #define CV2_STORE_G 1            // row groups (of 16 rows) packed into the staging region before their rows are stored: 4 = the whole wave tile
 #endif
@@ -352,10 +360,10 @@ __global__ __launch_bounds__(CV2_THREADS) void k_conv2(const ConvProg P) {
                                 vc_ = *reinterpret_cast<const uint4*>(l_ + (it + 2) * 960), vd_ = *reinterpret_cast<const uint4*>(l_ + (it + 3) * 960); \
                     /* the fourth row group's first 16 rows are the third's last: stored there */        \
                     const int lo_ = (wm == 3 ? 16 : 0) + (int)(mw - m0);                                 \
-                    if (row_ < lim_ && row_ >= lo_) *reinterpret_cast<uint4*>(g_) = va_;                 \
-                    if (row_ + 4 < lim_ && row_ + 4 >= lo_) *reinterpret_cast<uint4*>(g_ + gstep_) = vb_; \
-                    if (row_ + 8 < lim_ && row_ + 8 >= lo_) *reinterpret_cast<uint4*>(g_ + 2 * gstep_) = vc_; \
-                    if (row_ + 12 < lim_ && row_ + 12 >= lo_) *reinterpret_cast<uint4*>(g_ + 3 * gstep_) = vd_; \
+                    if (row_ < lim_ && row_ >= lo_) CV2_ST(g_, va_)                 \
+                    if (row_ + 4 < lim_ && row_ + 4 >= lo_) CV2_ST(g_ + gstep_, vb_) \
+                    if (row_ + 8 < lim_ && row_ + 8 >= lo_) CV2_ST(g_ + 2 * gstep_, vc_) \
+                    if (row_ + 12 < lim_ && row_ + 12 >= lo_) CV2_ST(g_ + 3 * gstep_, vd_) \
                     g_ += 4 * gstep_; row_ += 16;                                                        \
                 }                                                                                        \
             }                                                                                            \
