@@ -303,7 +303,7 @@ def pub_mlp_side_bench(torch, device, cpu_budget, batch=3072, steps=200):
     return out
 
 
-def cnn_side_bench(batch=512, steps=10):
+def cnn_side_bench(batch=512, steps=30):
     """Level-axis CNN (depth 12, width 406; hpo_train.py): training step and prediction, columns/s."""
     import torch
     from climsim_amd.cnn import CNNEmulator
@@ -313,7 +313,7 @@ def cnn_side_bench(batch=512, steps=10):
     y = (torch.rand((batch, 128), device="cuda", generator=g) * 0.1).contiguous()
 
     def timed(fn, reps):
-        for _ in range(3):
+        for _ in range(5):
             fn()
         torch.cuda.synchronize()
         t0 = time.perf_counter()

@@ -15,7 +15,7 @@ build.build()
 from climsim_amd.cnn import CNNEmulator  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
-K = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+K = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 N = 16 * B
 m = CNNEmulator(depth=12, channel_width=406, max_batch=B, trainable=True, init_seed=0, seed=1)
 g = torch.Generator(device="cuda").manual_seed(0)
@@ -26,7 +26,7 @@ loss = torch.zeros(4, device="cuda")
 
 
 def timed(fn, reps):
-    for _ in range(3):
+    for _ in range(5):
         fn(0)
     torch.cuda.synchronize()
     t0 = time.perf_counter()

@@ -595,7 +595,8 @@ int cs_cnn_loss_grads(cs_cnn_t* h, const float* x_dev, int x3d, const float* y_d
     ConvWgradArgs wa{};
     wa.items = h->items_dev; wa.n_items = h->n_items; wa.m_rows = m_rows; wa.m_pad = m_pad; wa.seq = seq;
     const int steps = (int)(m_pad / 64);
-    int splitk = ((h->tile128 ? 1024 : 64) + h->total_tiles - 1) / h->total_tiles;
+    static const int cw_wgs = getenv("CS_CNN_WGRAD_SMALL_WGS") ? atoi(getenv("CS_CNN_WGRAD_SMALL_WGS")) : 256;
+    int splitk = ((h->tile128 ? 1024 : cw_wgs) + h->total_tiles - 1) / h->total_tiles;
     if (splitk > steps) splitk = steps;
     if (splitk < 1) splitk = 1;
     wa.splitk = splitk; wa.use_atomics = 1;
