@@ -1122,7 +1122,16 @@ int cs_loader_stack(const void* mli_dev, const void* mlo_dev, int32_t src_f64, i
     if (n_steps <= 0 || n_steps > 65535 || ncol <= 0 || n_in <= 0 || n_out < 0) return fail(CS_ERR_INVALID, "bad sizes");
     const dim3 grid((unsigned)((ncol + 64 * LD_CPL - 1) / (64 * LD_CPL)), (unsigned)n_steps);
     hipStream_t st = (hipStream_t)stream;
-    if (src_f64)
+    // whole rows staged in LDS, 16-byte contiguous stores (loader.h, round 3): widths that are multiples of 4 and 16-byte aligned outputs
+    static const bool v3_off = getenv("CS_LOADER_V3") && atoi(getenv("CS_LOADER_V3")) == 0;
+    const bool v3 = !v3_off && n_in % 4 == 0 && (n_out % 4 == 0 || !y_out_dev) && ((uintptr_t)x_out_dev % 16 == 0) && ((uintptr_t)y_out_dev % 16 == 0);
+    if (v3 && src_f64)
+        CS_LAUNCH((k_loader_stack3<double>), grid, dim3(256), 0, st, (const double*)mli_dev,
+                           (const double*)mlo_dev, ncol, n_in, in_sub_dev, in_div_dev, n_out, tend_src_dev, out_scale_dev, x_out_dev, y_out_dev);
+    else if (v3)
+        CS_LAUNCH((k_loader_stack3<float>), grid, dim3(256), 0, st, (const float*)mli_dev,
+                           (const float*)mlo_dev, ncol, n_in, in_sub_dev, in_div_dev, n_out, tend_src_dev, out_scale_dev, x_out_dev, y_out_dev);
+    else if (src_f64)
         CS_LAUNCH((k_loader_stack2<double, LD_CPL, LD_FCH, LD_U>), grid, dim3(256), 0, st, (const double*)mli_dev,
                            (const double*)mlo_dev, ncol, n_in, in_sub_dev, in_div_dev, n_out, tend_src_dev, out_scale_dev, x_out_dev, y_out_dev);
     else

@@ -12,11 +12,14 @@
 // features and writes the training rows in 256-byte pieces.  HBM-bound: 3,024 B per column with f64 sources (2,016 with f32).
 #pragma once
 #include "kernels.h"
+#ifndef LD_ABL
+#define LD_ABL 0             // development (timing only): 1 = no global stores, 2 = no global loads
+#endif
 
 template <typename T, bool TARGET>
 __device__ __forceinline__ float loader_value(const T* __restrict__ src, const T* __restrict__ mli, int64_t off, int f, int ncol,
                                               const double* __restrict__ p0, const double* __restrict__ p1, const int* __restrict__ tend_src) {
-    double v = (double)src[off];
+    double v = (LD_ABL & 2) ? (double)(off & 1023) : (double)src[off];
     if (TARGET) {
         const int ts = tend_src[f];
         if (ts >= 0) v = (v - (double)mli[(int64_t)ts * ncol + (off - (int64_t)f * ncol)]) / 1200.0;
@@ -40,7 +43,7 @@ __device__ __forceinline__ void loader_pass2(float* tile, const T* __restrict__ 
                                              const double* __restrict__ p0, const double* __restrict__ p1,
                                              const int* __restrict__ tend_src, float* __restrict__ out_rows) {
     constexpr int COLS = 64 * CPL, PITCH = COLS + 1;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: sub / div / tend_src become scalar loads
     const int c = c0 + CPL * lane;
     const int ncols = min(COLS, ncol - c0);
     for (int fc = 0; fc < nf; fc += FCH) {
@@ -66,7 +69,7 @@ __device__ __forceinline__ void loader_pass2(float* tile, const T* __restrict__ 
         __syncthreads();
         for (int cc = w; cc < ncols; cc += 4) {
             float* row = out_rows + (int64_t)cc * nf + fc;
-            for (int f = lane; f < nfc; f += 64) row[f] = tile[f * PITCH + cc];
+            for (int f = lane; f < nfc; f += 64) { if (!(LD_ABL & 1)) row[f] = tile[f * PITCH + cc]; else asm volatile("" :: "v"(tile[f * PITCH + cc])); }
         }
         __syncthreads();
     }
@@ -84,4 +87,76 @@ __global__ __launch_bounds__(256) void k_loader_stack2(const T* __restrict__ mli
     if (x_out) loader_pass2<T, false, CPL, FCH, U>(tile, a, a, n_in, ncol, c0, sub, div, nullptr, x_out + (t * ncol + c0) * (int64_t)n_in);
     if (y_out) loader_pass2<T, true, CPL, FCH, U>(tile, mlo + t * (int64_t)n_out * ncol, a, n_out, ncol, c0, scale, nullptr, tend_src,
                                                y_out + (t * ncol + c0) * (int64_t)n_out);
+}
+
+// ---- round 3: the same pass with the WHOLE output rows of the tile staged in LDS and written as one contiguous stream.
+// Ablations of k_loader_stack2 on 64 x 21,600 float64 columns (LD_ABL): 1.19 ms as built, 0.90 ms without its global stores, 1.05 ms
+// without its global LOADS - the stores alone ran at 1.3 TB/s: 4 bytes per lane, 256-byte pieces that start at every multiple of
+// 496 bytes.  Here a workgroup's output (64 columns x nf floats) is ONE contiguous block when nf <= 128 (v1 shapes: 124 / 128), so
+// it leaves as 16 bytes per lane, 1 KiB per wave instruction, whole 128-byte lines.  LDS tile [64 columns][128 floats]: a lane packs
+// the four consecutive features it converts into one ds_write_b128 (chunk index XOR column & 7: eight lanes of a write cycle, eight bank
+// groups); the copy-out thread i takes the i-th float4 of the block = (column i / (nf/4), chunk i % (nf/4)).  Needs nf % 4 == 0;
+// nf > 128 goes in feature chunks of 128 (512-byte pieces per column); anything else takes k_loader_stack2.
+#ifndef LD3_U
+#define LD3_U 2
+#endif
+template <typename T, bool TARGET>
+__device__ __forceinline__ void loader_pass3(float* tile, const T* __restrict__ src, const T* __restrict__ mli, int nf, int ncol, int c0,
+                                             const double* __restrict__ p0, const double* __restrict__ p1,
+                                             const int* __restrict__ tend_src, float* __restrict__ out_rows) {
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: sub / div / tend_src become scalar loads
+    const int c = c0 + lane;
+    const int ncols = min(64, ncol - c0);
+    for (int fc = 0; fc < nf; fc += 128) {
+        const int nfc = min(128, nf - fc), cpc = nfc >> 2;            // float4 chunks per column in this pass
+        for (int q0 = w; q0 < cpc; q0 += 4 * LD3_U) {                  // LD3_U float4s per lane and trip: 4 LD3_U loads in flight
+            float4 r[LD3_U];
+#pragma unroll
+            for (int u = 0; u < LD3_U; ++u) {
+                const int q = q0 + 4 * u, f = fc + 4 * q;
+                float v[4] = {0.f, 0.f, 0.f, 0.f};
+                if (q < cpc && c < ncol) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = loader_value<T, TARGET>(src, mli, (int64_t)(f + e) * ncol + c, f + e, ncol, p0, p1, tend_src);
+                }
+                r[u] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+#pragma unroll
+            for (int u = 0; u < LD3_U; ++u) {
+                const int q = q0 + 4 * u;
+                if (q < cpc) *reinterpret_cast<float4*>(tile + lane * 128 + ((q ^ (lane & 7)) << 2)) = r[u];
+            }
+        }
+        __syncthreads();
+        const int total = ncols * cpc;
+        if (nfc == nf) {
+            float4* dst = reinterpret_cast<float4*>(out_rows);        // the tile's rows are one block
+            for (int i = tid; i < total; i += 256) {
+                const int cc = i / cpc, q = i - cc * cpc;
+                const float4 v = *reinterpret_cast<const float4*>(tile + cc * 128 + ((q ^ (cc & 7)) << 2));
+                if (!(LD_ABL & 1)) dst[i] = v; else asm volatile("" :: "v"(v.x), "v"(v.w));
+            }
+        } else {
+            for (int i = tid; i < total; i += 256) {
+                const int cc = i / cpc, q = i - cc * cpc;
+                const float4 v = *reinterpret_cast<const float4*>(tile + cc * 128 + ((q ^ (cc & 7)) << 2));
+                *reinterpret_cast<float4*>(out_rows + (int64_t)cc * nf + fc + 4 * q) = v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_loader_stack3(const T* __restrict__ mli, const T* __restrict__ mlo, int ncol, int n_in,
+                                                       const double* __restrict__ sub, const double* __restrict__ div, int n_out,
+                                                       const int* __restrict__ tend_src, const double* __restrict__ scale,
+                                                       float* __restrict__ x_out, float* __restrict__ y_out) {
+    __shared__ __attribute__((aligned(16))) float tile[64 * 128];
+    const int c0 = blockIdx.x * 64;
+    const int64_t t = blockIdx.y;
+    const T* a = mli + t * (int64_t)n_in * ncol;
+    if (x_out) loader_pass3<T, false>(tile, a, a, n_in, ncol, c0, sub, div, nullptr, x_out + (t * ncol + c0) * (int64_t)n_in);
+    if (y_out) loader_pass3<T, true>(tile, mlo + t * (int64_t)n_out * ncol, a, n_out, ncol, c0, scale, nullptr, tend_src,
+                                     y_out + (t * ncol + c0) * (int64_t)n_out);
 }
