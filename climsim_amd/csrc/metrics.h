@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256) void k_metrics_partial(const float* __restrict
                                                          double* __restrict__ acc /*[ncol][n_out][6], zeroed*/) {
     __shared__ double red[128][6];
     const int c = blockIdx.x;
-    const int fl = threadIdx.x & 127, h = threadIdx.x >> 7;
+    const int fl = threadIdx.x & 127, h = __builtin_amdgcn_readfirstlane(threadIdx.x >> 7);      // wave-uniform: the time step and ps[n] stay scalar
     const int f = blockIdx.y * 128 + fl;
     const bool live = f < n_out;
     const int t0 = (int)((int64_t)T * blockIdx.z / gridDim.z), t1 = (int)((int64_t)T * (blockIdx.z + 1) / gridDim.z);
