@@ -416,7 +416,7 @@ constexpr int chain_lds_bytes() { return BM * CHAIN_PITCH * 2 + CHAIN_MAX_BIAS *
 
 template <int BM, bool BWD, bool ELU>
 __device__ __forceinline__ void chain_body(const ChainArgs& p, const ChainDyn& d_, int bid, int wQ, int wq, u16* X, float* bias_lds, int64_t* rows_lds) {
-    const int tid = threadIdx.x, wid = tid >> 6;
+    const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t m0 = (int64_t)bid * BM;
     int slot = 0;
     chain_stamp(p, bid, tid, slot);

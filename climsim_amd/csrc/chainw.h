@@ -43,7 +43,7 @@ __device__ __forceinline__ void chainw_body(const ChainArgs& p, const ChainDyn& 
     u16* Xout = XW + CWD_BM * CWD_PITCH;
     float* bias_lds = reinterpret_cast<float*>(XW + 2 * CWD_BM * CWD_PITCH);
     int64_t* rows_lds = reinterpret_cast<int64_t*>(bias_lds + CWD_MAX_BIAS);
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t m0 = (int64_t)bid * CWD_BM;
 
     if (!BWD) {

@@ -15,6 +15,9 @@
 // HBM-bound: 2 * 4 B per (row, output).
 #pragma once
 #include "kernels.h"
+#ifndef MT_U
+#define MT_U 4
+#endif
 
 __global__ __launch_bounds__(256) void k_metrics_partial(const float* __restrict__ pred, const float* __restrict__ target, int T, int ncol,
                                                          int n_out, const double* __restrict__ ps, const double* __restrict__ wa,
@@ -30,17 +33,17 @@ __global__ __launch_bounds__(256) void k_metrics_partial(const float* __restrict
     double s_abs = 0, s_sq = 0, s_p = 0, s_t = 0, s_ts = 0, s_tss = 0;
     if (live) {
         const double shift = (double)target[(int64_t)c * n_out + f] * ((a + b * ps[c]) * ar);      // sample t = 0 of this (c, f)
-        for (int tb = t0 + h; tb < t1; tb += 8) {                  // 4 time steps (stride 2) in flight
-            double w[4]; float pv[4], tv[4];
+        for (int tb = t0 + h; tb < t1; tb += 2 * MT_U) {           // MT_U time steps (stride 2) in flight
+            double w[MT_U]; float pv[MT_U], tv[MT_U];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < MT_U; ++u) {
                 const int t = tb + 2 * u;
                 const int64_t n = (int64_t)(t < t1 ? t : t0) * ncol + c;
                 w[u] = t < t1 ? (a + b * ps[n]) * ar : 0.0;
                 pv[u] = pred[n * n_out + f]; tv[u] = target[n * n_out + f];
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < MT_U; ++u) {
                 if (tb + 2 * u >= t1) continue;
                 const double pw = (double)pv[u] * w[u], tw = (double)tv[u] * w[u];
                 const double d = pw - tw, ts = tw - shift;
