@@ -16,6 +16,9 @@
 #pragma once
 #include "cnn_train.h"
 #include "wgrad2.h"
+#ifndef CW_ABL
+#define CW_ABL 0                 // development (timing only): 1 = no LDS-DMA requests, 2 = no fragment reads in the loop, 4 = no MFMAs, 8 = no flush
+#endif
 
 struct CwTile {                  // one output tile of one conv
     const u16* H; const u16* Z;
@@ -130,8 +133,8 @@ __global__ __launch_bounds__(NW * 64) void k_conv_wgrad2(const CwArgs pa) {
         _Pragma("unroll") for (int j = 0; j < PP; ++j) {                                                \
             const char *hs_, *zs_;                                                                      \
             CW2_SRC(j, hs_, zs_)                                                                        \
-            dma16(hs_, base_ + 1024u * j);                                                              \
-            dma16(zs_, base_ + 1024u * j + 16384u);                                                     \
+            if (!(CW_ABL & 1)) { dma16(hs_, base_ + 1024u * j);                                         \
+            dma16(zs_, base_ + 1024u * j + 16384u); }                                                   \
         }                                                                                               \
     }
 
@@ -299,8 +302,8 @@ __global__ __launch_bounds__(512 + 64 * CW2L_LOADERS) void k_conv_wgrad2l(const 
             const char* zs_ = in_ ? zp[j] : zpage;                                                      \
             hp[j] += 32 * ldh2; zp[j] += 32 * ldz2; mi[j] += 32;                                        \
             lv[j] += linc; if (lv[j] >= lvhi[j]) lv[j] -= pa.seq;                                       \
-            dma16(hs_, base_ + 1024u * j);                                                              \
-            dma16(zs_, base_ + 1024u * j + 16384u);                                                     \
+            if (!(CW_ABL & 1)) { dma16(hs_, base_ + 1024u * j);                                         \
+            dma16(zs_, base_ + 1024u * j + 16384u); }                                                   \
         }                                                                                               \
     }
         CW2L_ISSUE(0) CW2L_ISSUE(1) CW2L_ISSUE(2) CW2L_ISSUE(3)
@@ -350,17 +353,62 @@ __global__ __launch_bounds__(512 + 64 * CW2L_LOADERS) void k_conv_wgrad2l(const 
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
 #pragma unroll
-            for (int i = 0; i < IT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[i], fz[j], acc[i][j], 0, 0, 0);
-            CW2_FRAG(fz[j], nx, fo_z[j])
+            for (int i = 0; i < IT; ++i) if (!(CW_ABL & 4)) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[i], fz[j], acc[i][j], 0, 0, 0);
+            if (!(CW_ABL & 2)) CW2_FRAG(fz[j], nx, fo_z[j])
         }
 #pragma unroll
         for (int i = 0; i < IT; ++i) {
-            acc[i][6] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[i], fz[6], acc[i][6], 0, 0, 0);
-            CW2_FRAG(fh[i], nx, fo_h[i])
+            if (!(CW_ABL & 4)) acc[i][6] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[i], fz[6], acc[i][6], 0, 0, 0);
+            if (!(CW_ABL & 2)) CW2_FRAG(fh[i], nx, fo_h[i])
         }
-        CW2_FRAG(fz[6], nx, fo_z[6])
+        if (!(CW_ABL & 2)) CW2_FRAG(fz[6], nx, fo_z[6])
     }
 #undef CW2_FRAG
+    if (CW_ABL & 8) {
+#pragma unroll
+        for (int i = 0; i < IT; ++i)
+#pragma unroll
+            for (int j = 0; j < 7; ++j) asm volatile("" :: "v"(acc[i][j]));
+        return;
+    }
+    // ---- flush.  Through LDS, one 16-row group at a time, so that an atomic instruction adds 64 CONSECUTIVE floats of one row
+    // (two whole 128-byte lines) instead of 16 floats of four rows (four half lines): the flush was 0.18 ms of the kernel's 1.1
+    // (CW_ABL=8; 247 MB of partial sums per step in 64-byte pieces).
+#ifndef CW_FLUSH_LDS
+#define CW_FLUSH_LDS 1
+#endif
+#if CW_FLUSH_LDS
+    __builtin_amdgcn_s_barrier();                                       // every compute wave is done with the ring (the loaders have left)
+    float* stg = reinterpret_cast<float*>(cw_ring) + wid * (16 * 112);  // 7 KiB per wave
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int kf = T.k0 + wm * (16 * IT) + i * 16;                  // first kk row of the group: one tap (kpt is a multiple of 16)
+        const int tap = kf / T.kpt, c0 = kf - tap * T.kpt;
+        if (tap < T.taps) {
+#pragma unroll
+            for (int j = 0; j < 7; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) stg[(4 * (lane >> 4) + r) * 112 + j * 16 + (lane & 15)] = acc[i][j][r];
+            // (a wave reads back what it wrote itself: LDS operations of one wave complete in order, no barrier)
+            float* row = T.dW + ((int64_t)tap * T.cin + c0) * T.cout + T.n0 + wn * 112;
+            const int nmax = T.cout - (T.n0 + wn * 112);                // columns of this wave that exist
+            for (int rr = 0; rr < 16 && c0 + rr < T.cin; ++rr) {
+                const float v0 = stg[rr * 112 + lane];
+                if (lane < nmax) atomicAdd(row + (int64_t)rr * T.cout + lane, v0);
+                if (lane < 48) {
+                    const float v1 = stg[rr * 112 + 64 + lane];
+                    if (64 + lane < nmax) atomicAdd(row + (int64_t)rr * T.cout + 64 + lane, v1);
+                }
+            }
+        } else if (kf == T.taps * T.kpt && T.db && (lane >> 4) == 0) {  // the ones row: bias gradient
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                const int n = T.n0 + wn * 112 + j * 16 + (lane & 15);
+                if (n < T.cout) atomicAdd(T.db + n, acc[i][j][0]);
+            }
+        }
+    }
+#else
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
         const int kb = T.k0 + wm * (16 * IT) + i * 16 + 4 * (lane >> 4);
@@ -384,4 +432,5 @@ __global__ __launch_bounds__(512 + 64 * CW2L_LOADERS) void k_conv_wgrad2l(const 
             }
         }
     }
+#endif
 }
