@@ -96,6 +96,10 @@ __global__ __launch_bounds__(256) void k_loader_stack2(const T* __restrict__ mli
 // it leaves as 16 bytes per lane, 1 KiB per wave instruction, whole 128-byte lines.  LDS tile [64 columns][128 floats]: a lane packs
 // the four consecutive features it converts into one ds_write_b128 (chunk index XOR column & 7: eight lanes of a write cycle, eight bank
 // groups); the copy-out thread i takes the i-th float4 of the block = (column i / (nf/4), chunk i % (nf/4)).  Needs nf % 4 == 0;
+// (Tried on top: multiplying by a per-feature reciprocal wherever that provably rounds to the same float32 - low 29 mantissa bits away
+// from a float32 rounding boundary - and dividing otherwise; bit-identical on tests/test_loader_gpu.py::test_device_loader_rounding_boundaries,
+// but 1.06-1.16 ms against 0.90-0.92 for the plain divisions on the same box: the reciprocal has to come from LDS or be formed per wave,
+// and either costs more than the dozen float64 instructions it replaces.)
 // nf > 128 goes in feature chunks of 128 (512-byte pieces per column); anything else takes k_loader_stack2.
 #ifndef LD3_U
 #define LD3_U 2

@@ -73,6 +73,47 @@ def test_device_loader_edge_cases(L, raw_tree, lowres_assets):
     with pytest.raises(ValueError):
         ld.stack_raw(a[:, :100], b)
 
+def test_device_loader_rounding_boundaries(L, raw_tree, lowres_assets):
+    """Bit-identity where it is hardest (written for a reciprocal-multiply variant of k_loader_stack3 that measured slower and was
+    dropped; kept as the guard for any such attempt): values built so that (x - sub) / div lands on or next to float32 rounding boundaries (midpoints between two floats, the
+    ties included), in float32's subnormal range, at zero and at +-inf, and tendencies whose (b - a) / 1200 * scale does the same."""
+    root, _ = raw_tree
+    du = make(lowres_assets, "pytorch", root)
+    ld = L.GpuColumnLoader(du)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        sub, div, scale = du.save_norm()
+    sub, div, scale = np.asarray(sub, np.float64), np.asarray(div, np.float64), np.asarray(scale, np.float64)
+    rng = np.random.default_rng(11)
+    T, ncol = 2, 1024
+    # float32 midpoints m (exact in float64) and their float64 neighbours, scaled back through div and sub
+    f = rng.normal(0, 3, (T, 124, ncol)).astype(np.float32)
+    up = np.nextafter(f, np.float32(np.inf))
+    mid = (f.astype(np.float64) + up.astype(np.float64)) / 2
+    k = rng.integers(-3, 4, mid.shape)
+    target = mid.view(np.int64) + k                                  # 0..3 float64 ulps off the boundary
+    target = target.view(np.float64)
+    target[:, :, :32] = rng.normal(0, 1, (T, 124, 32)) * 1e-41          # float32 subnormal range
+    target[:, :, 32:40] = 0.0
+    a = target * div[None, :, None] + sub[None, :, None]
+    a[0, 3, 50] = np.inf
+    a[1, 4, 51] = -np.inf
+    b = rng.normal(0, 1, (T, 128, ncol))
+    tend = ld._tend.cpu().numpy()
+    m = tend >= 0
+    g = rng.normal(0, 1e-4, (T, int(m.sum()), ncol)).astype(np.float32)
+    gm = (g.astype(np.float64) + np.nextafter(g, np.float32(np.inf)).astype(np.float64)) / 2
+    with np.errstate(divide="ignore", invalid="ignore"):
+        b[:, m] = a[:, tend[m]] + gm / np.where(scale[m] != 0, scale[m], 1.0)[None, :, None] * 1200
+        b[~np.isfinite(b)] = 0.0
+        x, y = ld.stack_raw(a, b)
+        xr = (a.transpose(0, 2, 1).reshape(-1, 124) - sub) / div
+        xr[~np.isfinite(xr)] = 0
+        yr = b.copy()
+        yr[:, m] = (b[:, m] - a[:, tend[m]]) / 1200
+        yr = yr.transpose(0, 2, 1).reshape(-1, 128) * scale
+    np.testing.assert_array_equal(x.cpu().numpy(), np.float32(xr))
+    np.testing.assert_array_equal(y.cpu().numpy(), np.float32(yr))
+
 
 def test_device_loader_from_netcdf4_files(L, lowres_assets, tmp_path):
     """NetCDF-4 (= HDF5) timestep files, read by the native reader (climsim_amd/hdf5.py), through the device loader:
