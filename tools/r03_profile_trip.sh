@@ -23,15 +23,11 @@ grep -E "k_|rocclr" gpurun_out/r03_rocprofv3_kernel_stats_b8192.csv | cut -c1-17
 echo "== pmc"; bash tools/gpu_diag.sh 8192 2>&1 | tail -40 > gpurun_out/r03_pmc_mlp_b8192.txt; tail -40 gpurun_out/r03_pmc_mlp_b8192.txt
 python tools/pmc_traffic_json.py 8192 && cp profiles/r03_pmc_hbm_traffic.json gpurun_out/
 echo "== side benches"
-timeout 600 python bench_cnn.py 512 20 2>&1 | tail -1 > gpurun_out/r03_cnn_bench_b512.json
 timeout 600 python bench_loader.py 64 21600 2>&1 | tail -1 > gpurun_out/r03_loader_bench_highres.json
 timeout 600 python bench_stream.py 2>&1 | tail -1 > gpurun_out/r03_stream_bench_highres.json
 timeout 600 python bench_metrics.py 2>&1 | tail -1 > gpurun_out/r03_metrics_bench_scoring.json
 timeout 600 python bench_online_mlp.py 2>&1 | tail -1 > gpurun_out/r03_online_mlp_bench.json
-for f in cnn_bench_b512 loader_bench_highres stream_bench_highres metrics_bench_scoring online_mlp_bench; do echo $f; cut -c1-300 gpurun_out/r03_$f.json; done
-echo "== pub-MLP / CNN rocprof"
+for f in loader_bench_highres stream_bench_highres metrics_bench_scoring online_mlp_bench; do echo $f; cut -c1-300 gpurun_out/r03_$f.json; done
+echo "== trial groups"
 timeout 300 python bench_hpo.py 2>&1 | tail -1 > gpurun_out/r03_hpo_bench.json; cut -c1-300 gpurun_out/r03_hpo_bench.json
-cd /tmp && rm -rf /tmp/profc && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/profc -- python3 $REPO/bench_cnn.py 512 20 > $REPO/gpurun_out/rocprof_cnn.log 2>&1
-cd $REPO
-find /tmp/profc -name "*kernel_stats*" -exec cp {} gpurun_out/r03_cnn_rocprofv3_kernel_stats_b512.csv \;
-head -8 gpurun_out/r03_cnn_rocprofv3_kernel_stats_b512.csv | cut -c1-150
+echo "== CNN"; bash tools/r03_cnn_trip.sh 2>&1 | tail -30
