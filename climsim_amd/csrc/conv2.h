@@ -76,6 +76,8 @@ struct ConvProg {
     int tiles;                   // row tiles of this launch; the grid is round_up(tiles, 8) * n_tiles workgroups
 };
 
+static_assert(sizeof(ConvProg) <= 4096, "ConvProg travels by value: kernel arguments are limited to 4 KiB");
+
 template <int MODE>
 __global__ __launch_bounds__(CV2_THREADS) void k_conv2(const ConvProg P) {
     const ConvArgs& p0 = P.st[0];      // geometry (row tiles, channel tiles, seq, zero page) is that of every stage
