@@ -601,7 +601,9 @@ int run_backward(cs_mlp* h, int64_t n, bool atomics_needed, hipStream_t st) {
             wg += d.tiles_k * d.tiles_n * splitk;
         }
         ProfScope ps(CS_K_WGRAD, st);
-        if (big) CS_LAUNCH(k_wgrad2, dim3((unsigned)wg), dim3(512), WG2_LDS_BYTES, st, w);
+        static const bool wg2_loaders = !(getenv("CS_WGRAD2_LOADERS") && atoi(getenv("CS_WGRAD2_LOADERS")) == 0);
+        if (big && wg2_loaders) CS_LAUNCH(k_wgrad2l, dim3((unsigned)wg), dim3(768), WG2L_LDS_BYTES, st, w);
+        else if (big) CS_LAUNCH(k_wgrad2, dim3((unsigned)wg), dim3(512), WG2_LDS_BYTES, st, w);
         else if (dma_small) {
             // one round of workgroups: 64-row stages (the whole LDS as ring); more: 32-row stages, two workgroups per CU
             static const int rows_env = getenv("CS_WGRAD3_ROWS") ? atoi(getenv("CS_WGRAD3_ROWS")) : 0;
@@ -705,6 +707,7 @@ int cs_mlp_create(cs_mlp_t** out, const cs_mlp_cfg* cfg) {
     if (const char* e = getenv("CS_CHAIN_NT_MIN")) h->chain_nt_min = atoll(e);
     if (const char* e = getenv("CS_WGRAD2")) h->wgrad2_mode = atoi(e);
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad2), hipFuncAttributeMaxDynamicSharedMemorySize, WG2_LDS_BYTES));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad2l), hipFuncAttributeMaxDynamicSharedMemorySize, WG2L_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad3<4, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, WG3_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad3<4, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, WG3_LDS_BYTES_64));
     if (const char* e = getenv("CS_WGRAD3")) h->wgrad3 = atoi(e) != 0;

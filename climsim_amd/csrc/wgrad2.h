@@ -157,6 +157,187 @@ __global__ __launch_bounds__(512) void k_wgrad2(const WgradArgs pa) {
         }
 }
 
+// k_wgrad2 with the operand requests on FOUR LOADER WAVES (waves 8-11), as k_wgrad3 and the CNN kernels: a 1-KiB LDS-DMA piece costs a
+// wave that also computes 100-190 clocks and a loader ~20, and this kernel issues 32 per 32-row stage.  Twelve waves leave 168 VGPRs
+// per lane: the bias product moves to the loaders and the compute loop is written out in asm (below).  Measured (us, weight gradients
+// of the cfg-MLP): 24576 columns 102.3 -> 97.4, 32768: 123.4 -> 118.6, 65536: 203.0 -> 194.0 - small, because at these sizes the kernel
+// is bound by re-reading H and dZ from memory (704 MB at 65536 columns; non-temporal pieces, for all or for the older half of the
+// rows, changed nothing).
+#define WG2L_SLOTS 5
+__global__ __launch_bounds__(768) void k_wgrad2l(const WgradArgs pa) {
+    extern __shared__ __attribute__((aligned(16))) u16 ring[];    // [stage][H|Z][32][256]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wk = (wid >> 1) & 3, wn = wid & 1;
+    const int work = xcd_work_id(blockIdx.x, gridDim.x);     // operand sharers on one XCD (kernels.h)
+    int li = 0;
+    while (li + 1 < pa.n_layers && work >= pa.L[li + 1].wg_begin) ++li;
+    const WgradLayer& p = pa.L[li];
+    const int rel = work - p.wg_begin;
+    const int ntile = p.tiles_k * p.tiles_n;
+    const int split = rel / ntile, tile = rel - split * ntile;
+    const int k0 = (tile % p.tiles_k) * 256, n0 = (tile / p.tiles_k) * 256;
+    const int steps = (int)(pa.m_pad / WG2_ROWS);
+    const int s_begin = (int)((int64_t)steps * split / pa.splitk);
+    const int s_end = (int)((int64_t)steps * (split + 1) / pa.splitk);
+    const int nst = s_end - s_begin;
+
+    typedef u16 __attribute__((address_space(3))) * lds_p;
+    const unsigned lds0 = (unsigned)(uintptr_t)((lds_p)ring);
+    if (wid >= 8) {
+        // ---- loader lw: pieces 4 lw .. 4 lw + 3 (2 rows of 512 B each) of both operands.  Lane i of a piece: row i>>5, physical
+        // 16-B chunk i&31 holds logical chunk (((p>>2) ^ (m&3)) << 2) | (p&3)
+        if (nst <= 0) return;
+        const int lw = wid - 8;
+        const int prow = lane >> 5, pch = lane & 31;
+        const u16* hsrc[4]; const u16* zsrc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ml = 2 * (4 * lw + j) + prow;                 // row inside the stage
+            const int c = ((((pch >> 2) ^ (ml & 3)) << 2) | (pch & 3)) * 8;
+            hsrc[j] = p.H + (int64_t)ml * p.ldh + k0 + c;
+            zsrc[j] = p.Z + (int64_t)ml * p.ldz + n0 + c;
+        }
+        const unsigned my_piece = __builtin_amdgcn_readfirstlane((unsigned)(4 * lw) * 1024u);
+#define WG2L_ISSUE(st)                                                                                 \
+    {                                                                                                   \
+        const int sc_ = min((st), nst - 1);                                                             \
+        const int64_t roff = (int64_t)(s_begin + sc_) * WG2_ROWS;                                       \
+        const unsigned base = lds0 + (unsigned)((st) % WG2L_SLOTS) * (WG2_STAGE_ELEMS * 2) + my_piece;  \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                 \
+            dma16(hsrc[j] + roff * p.ldh, base + 1024u * j);                                            \
+            dma16(zsrc[j] + roff * p.ldz, base + WG2_ROWS * 512u + 1024u * j);                          \
+        }                                                                                               \
+    }
+        // The bias gradient of this tile's columns (tiles with k0 == 0) is the loaders' too: the product of a fragment of ONES with the
+        // dZ fragments, 64 columns per loader - 16 accumulator and 4 fragment registers the compute waves do not have at 168 VGPRs.
+        const bool do_bias = (k0 == 0) && p.db != nullptr;
+        f32x16_t accb[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accb[t][r] = 0.f;
+        bf16x8_t ones;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+        // Barrier protocol (the same count in both roles): [stage 0 landed] then one per stage s: [stage s+1 landed; the slot of stage
+        // s-1 is free] - the compute waves read the fragments of stage s+1 during stage s, so a slot is refilled a stage later than it
+        // was last read and nothing has to wait for `lgkmcnt(0)` in front of a barrier.  Five slots = 160 KiB: three stages in flight.
+        WG2L_ISSUE(0)
+        WG2L_ISSUE(1)
+        WG2L_ISSUE(2)
+        WG2L_ISSUE(3)
+        asm volatile("s_waitcnt vmcnt(24)" ::: "memory");       // stage 0 has landed (mine)
+        __builtin_amdgcn_s_barrier();
+        for (int s = 0; s < nst; ++s) {
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // this wave's 8 pieces of stage s+1 have landed (stages s+2, s+3 in flight)
+            __builtin_amdgcn_s_barrier();
+            WG2L_ISSUE(s + 4)
+            if (do_bias) {
+                const u16* Zs = ring + (s % WG2L_SLOTS) * WG2_STAGE_ELEMS + WG2_ROWS * 256;
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+                        accb[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, frag_w2(Zs, kk * 16, lw * 64 + t * 32, lane), accb[t], 0, 0, 0);
+            }
+        }
+#undef WG2L_ISSUE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // tail re-loads must not outlive the kernel
+        if (do_bias && lane < 32) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int n = n0 + lw * 64 + t * 32 + lane;
+                if (n < p.N) atomicAdd(p.db + n, accb[t][0]);   // row 0 of the ones product
+            }
+        }
+        return;
+    }
+
+    f32x16_t acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const bool k_live = (k0 + wk * 64) < ((p.k_real + 63) & ~63), n_live = (n0 + wn * 128) < p.N;
+
+    // Compute loop, written out in `asm volatile` (order = as below; hipcc's schedule of the builtin form read all ten fragments of a
+    // 16-row step behind the barrier and waited for them, twice per stage, with both waves of a SIMD in the same phase).  Per 16-row
+    // step: fh0 x fz0..3, then fh0 takes the NEXT step's rows; fh1 x fz0..3 with each fz reloaded behind its MFMA, fh1 last.  A fragment is
+    // two transposing 64-bit reads (+2048 bytes: four rows on); LDS returns in order, so every wait is a count of younger reads.
+    if (nst > 0) {
+        typedef unsigned long long u64_t;
+        union Frag { bf16x8_t v; u64_t h[2]; };
+        Frag fh[2], fz[4];
+        unsigned ah[2], az[4];                          // byte addresses of this lane's fragment pieces in the slot being read
+        {
+            const int mrow = 8 * (lane >> 5) + ((lane & 15) >> 2);
+            const int col = 16 * ((lane >> 4) & 1) + (lane & 3) * 4;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) ah[i] = lds0 + 2u * (unsigned)swz_w2(mrow, wk * 64 + i * 32 + col);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) az[j] = lds0 + WG2_ROWS * 512u + 2u * (unsigned)swz_w2(mrow, wn * 128 + j * 32 + col);
+        }
+        const bool live = k_live && n_live;
+#define W2L_RD(F, A, OFF) asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4" \
+                                       : "=v"((F).h[0]), "=v"((F).h[1]) : "v"(A), "n"(OFF), "n"((OFF) + 2048));
+#define W2L_MM(i, j) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(fh[i].v), "v"(fz[j].v));
+#define W2L_LGKM(n) asm volatile("s_waitcnt lgkmcnt(" #n ")");
+        // one 16-row step on the fragments in registers; the reloads fetch rows NOFF of the slot the addresses point at
+#define W2L_STEP(NOFF)                                                                                 \
+        W2L_LGKM(8) W2L_MM(0, 0) W2L_LGKM(6) W2L_MM(0, 1) W2L_LGKM(4) W2L_MM(0, 2) W2L_LGKM(2) W2L_MM(0, 3)   \
+        W2L_RD(fh[0], ah[0], NOFF)                                                                      \
+        W2L_LGKM(2) W2L_MM(1, 0) W2L_RD(fz[0], az[0], NOFF) W2L_MM(1, 1) W2L_RD(fz[1], az[1], NOFF)     \
+        W2L_MM(1, 2) W2L_RD(fz[2], az[2], NOFF) W2L_MM(1, 3) W2L_RD(fz[3], az[3], NOFF)                 \
+        W2L_RD(fh[1], ah[1], NOFF)
+        __builtin_amdgcn_s_barrier();                       // stage 0 has landed
+        if (live) {                                         // the loop's own read order: its counts hold from the first step
+            W2L_RD(fh[0], ah[0], 0) W2L_RD(fz[0], az[0], 0) W2L_RD(fz[1], az[1], 0) W2L_RD(fz[2], az[2], 0) W2L_RD(fz[3], az[3], 0)
+            W2L_RD(fh[1], ah[1], 0)
+        }
+        int slot = 0;
+        for (int s = 0; s < nst; ++s) {
+            __builtin_amdgcn_s_barrier();                   // stage s+1 has landed
+            if (live) {
+                W2L_STEP(8192)                              // rows 0-15 of stage s; reloads: rows 16-31 of the same slot
+                const int nslot = slot + 1 == WG2L_SLOTS ? 0 : slot + 1;
+                const unsigned delta = (unsigned)((nslot - slot) * (WG2_STAGE_ELEMS * 2));
+#pragma unroll
+                for (int i = 0; i < 2; ++i) ah[i] += delta;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) az[j] += delta;
+                slot = nslot;
+                W2L_STEP(0)                                 // rows 16-31; reloads: rows 0-15 of stage s+1
+            }
+        }
+        // the fragments read past the last stage are never used: operands here so that their registers stay theirs until the reads have
+        // retired; the last MFMA's result is written (no hazard check sees an asm MFMA)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7"
+                     : "+v"(fh[0].v), "+v"(fh[1].v), "+v"(fz[0].v), "+v"(fz[1].v), "+v"(fz[2].v), "+v"(fz[3].v) :: "memory");
+#undef W2L_RD
+#undef W2L_MM
+#undef W2L_LGKM
+#undef W2L_STEP
+    }
+    if (!(k_live && n_live)) return;
+    // D[i = k][j = n]: lane owns column n = ..+(lane&31), rows k = ..+(r&3)+8*(r>>2)+4*(lane>>5)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 128 + j * 32 + (lane & 31);
+            if (n >= p.N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = k0 + wk * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (k < p.k_real) atomicAdd(p.dW + (int64_t)k * p.N + n, acc[i][j][r]);
+            }
+        }
+}
+
+
 // ---------------------------------------------------------------------------------------------------
 // Small-batch form with the same LDS-DMA pipeline: 128(k) x 128(n) tiles, 4 waves of 64 x 64, 32-row
 // stages of 16 KiB, 4-slot ring = 64 KiB -> two workgroups per CU, each with three stages in flight.
