@@ -164,6 +164,7 @@ __global__ __launch_bounds__(512) void k_wgrad2(const WgradArgs pa) {
 // is bound by re-reading H and dZ from memory (704 MB at 65536 columns; non-temporal pieces, for all or for the older half of the
 // rows, changed nothing).
 #define WG2L_SLOTS 5
+#define WG2L_LDS_BYTES (WG2L_SLOTS * WG2_STAGE_ELEMS * 2)
 __global__ __launch_bounds__(768) void k_wgrad2l(const WgradArgs pa) {
     extern __shared__ __attribute__((aligned(16))) u16 ring[];    // [stage][H|Z][32][256]
     const int tid = threadIdx.x, lane = tid & 63;
