@@ -23,13 +23,22 @@ import numpy as np
 
 
 class StreamedTrainer:
-    def __init__(self, model, loader, batch_size: int, slots: int = 2, dist=None):
+    def __init__(self, model, loader, batch_size: int, slots: int = 2, dist=None, loader_on: str | None = None):
+        """`loader_on`: "main" (default; CS_STREAM_LOADER overrides) runs the loader KERNEL on the training stream - host chunks are
+        still staged and copied on the side stream, the kernel waits for the copy - "side" runs it on the side stream too.  On one
+        GPU the two measure the same (round 3, bench_stream.py: 56.0 / 56.2 M columns/s; the loader is 1.3-1.6 G columns/s, 2 % of a
+        pass, and what separates the pass from loader + steps back to back, 59.6 M, is the short last batch of every chunk);
+        with the kernel on the training stream nothing ever runs beside a step, so a cooperative model is accepted."""
+        import os
         import torch
+        self.loader_on = loader_on or os.environ.get("CS_STREAM_LOADER", "main")
+        if self.loader_on not in ("main", "side"):
+            raise ValueError("loader_on must be 'main' or 'side'")
         if slots < 2:
             raise ValueError("need at least two chunk slots (one being produced while one is consumed)")
         if batch_size > model.max_batch:
             raise ValueError(f"batch {batch_size} exceeds the engine's max_batch {model.max_batch}")
-        if getattr(model, "cooperative", False):
+        if getattr(model, "cooperative", False) and self.loader_on == "side":
             # the loader kernel on the side stream occupies compute units while the step runs: a cooperative launch
             # (CS_FLAG_COOP), whose workgroups wait for one another, could be starved into a time-out
             raise ValueError("StreamedTrainer drives a side stream: build the model with cooperative=False")
@@ -51,20 +60,38 @@ class StreamedTrainer:
         mli, mlo = raw
         main = torch.cuda.current_stream(self.device)
         device_raw = [a for a in (mli, mlo) if not isinstance(a, np.ndarray) and a is not None]
-        if device_raw:
+        if device_raw and self.loader_on == "side":
             # raw chunks that already live in HBM were produced on the caller's stream: the loader kernel on the side
             # stream must not start before that work has finished (host arrays are copied on the side stream itself)
             self.side.wait_stream(main)
             for a in device_raw:
                 a.record_stream(self.side)
+        def dev(a):
+            if isinstance(a, np.ndarray):
+                a = torch.from_numpy(np.ascontiguousarray(a)).pin_memory()
+                return a.to(self.device, non_blocking=True)
+            return a
+        if self.loader_on == "main":
+            # copies on the side stream (they overlap the steps already queued), the kernel on the training stream behind them
+            host = any(isinstance(a, np.ndarray) for a in (mli, mlo))
+            if host:
+                with torch.cuda.stream(self.side):
+                    if free_event is not None:
+                        self.side.wait_event(free_event)
+                    mli, mlo = dev(mli), dev(mlo)
+                    copied = torch.cuda.Event()
+                    copied.record(self.side)
+                main.wait_event(copied)
+                for a in (mli, mlo):
+                    if a is not None:
+                        a.record_stream(main)
+            x, y = self.loader.stack_raw(mli, mlo)           # main-stream order: the slot's previous chunk has been consumed
+            ready = torch.cuda.Event()
+            ready.record(main)
+            return x, y, ready
         with torch.cuda.stream(self.side):
             if free_event is not None:
                 self.side.wait_event(free_event)             # the slot's previous chunk has been consumed
-            def dev(a):
-                if isinstance(a, np.ndarray):
-                    a = torch.from_numpy(np.ascontiguousarray(a)).pin_memory()
-                    return a.to(self.device, non_blocking=True)
-                return a
             x, y = self.loader.stack_raw(dev(mli), dev(mlo))
             ready = torch.cuda.Event()
             ready.record(self.side)

@@ -124,8 +124,10 @@ def test_a_timed_out_cooperative_launch_fails_the_next_call(M, monkeypatch):
 
 
 def test_streamed_trainer_refuses_a_cooperative_model(M):
-    """The side-stream loader occupies compute units while the step runs: exactly what can starve a cooperative launch."""
+    """A loader kernel on the side stream occupies compute units while the step runs: exactly what can starve a cooperative launch
+    (with the kernel on the training stream - the default since round 3 - nothing runs beside the step, and the model is accepted)."""
     from climsim_amd.stream import StreamedTrainer
     m, _, _ = make(M, (128, 128), "relu")
     with pytest.raises(ValueError, match="cooperative"):
-        StreamedTrainer(m, loader=None, batch_size=256)
+        StreamedTrainer(m, loader=None, batch_size=256, loader_on="side")
+    StreamedTrainer(m, loader=None, batch_size=256, loader_on="main")

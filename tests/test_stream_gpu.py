@@ -10,7 +10,8 @@ pytestmark = pytest.mark.gpu
 from test_loader_cpu import make, raw_tree  # noqa: E402,F401
 
 
-def test_streamed_training_equals_materialised_training(raw_tree, lowres_assets):
+@pytest.mark.parametrize("loader_on", ["main", "side"])
+def test_streamed_training_equals_materialised_training(raw_tree, lowres_assets, loader_on):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from climsim_amd import build
@@ -31,7 +32,7 @@ def test_streamed_training_equals_materialised_training(raw_tree, lowres_assets)
     B, LR = 128, 1e-3
 
     a = MLPEmulator(units=(128, 128), max_batch=B, seed=3)
-    st = StreamedTrainer(a, ld, batch_size=B, slots=2)
+    st = StreamedTrainer(a, ld, batch_size=B, slots=2, loader_on=loader_on)      # loader kernel on the training stream (default) / on the side stream
     out = st.fit_chunks(iter(chunks), learning_rate=LR, passes_per_chunk=2, seed=11)
     rows = sum(c[0].shape[0] * c[0].shape[2] for c in chunks)
     assert out["rows"] == 2 * rows and out["steps"] == 2 * sum(-(-c[0].shape[0] * 384 // B) for c in chunks) == a.iterations
