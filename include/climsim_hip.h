@@ -275,6 +275,10 @@ typedef struct cs_cnn_cfg {
     double beta1, beta2, eps;   /* keras.optimizers.Adam defaults 0.9, 0.999, 1e-7 */
     uint64_t seed;       /* dropout stream: call k of cs_cnn_loss_grads uses seed + k */
 } cs_cnn_cfg;
+/* The trunk's convolutions run as launches of up to 12 convs with an in-launch hand-off between the workgroups of a row tile (bounded
+ * waits; csrc/conv2.h, CS_CNN_FUSE).  A wait that runs out - or workgroups of a row tile found on different XCDs - is counted by the
+ * kernel in host-mapped memory: every later cs_cnn_predict / cs_cnn_loss_grads / cs_cnn_train_step on the handle fails with
+ * CS_ERR_STATE (what such a launch computed is not trusted); recreate the model, with CS_CNN_FUSE=1 for one conv per launch. */
 int  cs_cnn_create(cs_cnn_t** out, const cs_cnn_cfg* cfg);            /* CNNHyperModel().build()   */
 void cs_cnn_destroy(cs_cnn_t* h);
 int64_t cs_cnn_num_params(const cs_cnn_t* h);                          /* model.count_params()      */
