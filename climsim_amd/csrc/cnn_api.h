@@ -40,6 +40,7 @@ struct cs_cnn {
     // k_conv2 programs (conv2.h): trunk convs on the same row tiles are chained into one launch, flushed when another kernel follows
     ConvProg prog{}; int prog_mode = -1; unsigned prog_grid = 0;
     int fuse_max = CV2_MAX_STAGES;       // CS_CNN_FUSE (1 = one conv per launch)
+    int spin_limit = 1 << 22;            // CS_CNN_SPIN_LIMIT: polls before a stage hand-off gives up (read at creation)
     unsigned* pair_flags = nullptr; unsigned gen = 0; int flag_tiles = 0;
     unsigned *err_host = nullptr, *err_dev = nullptr;      // pinned, host-mapped: bounded waits that ran out / partners on another XCD
 };
@@ -141,8 +142,7 @@ void cnn_flush(cs_cnn* h, hipStream_t st) {
     if (P.n == 0) return;
     P.gen0 = h->gen; h->gen += (unsigned)P.n;
     P.flags = h->pair_flags; P.error = h->err_dev; P.n_row_tiles = h->flag_tiles;
-    static const int spin = getenv("CS_CNN_SPIN_LIMIT") ? atoi(getenv("CS_CNN_SPIN_LIMIT")) : (1 << 22);
-    P.spin_limit = spin;
+    P.spin_limit = h->spin_limit;
     P.tiles = (int)h->prog_grid;
     const dim3 grid((unsigned)round_up((int64_t)h->prog_grid, 8) * P.st[0].n_tiles), block(CV2_THREADS);
     if (h->prog_mode == CONV_PREDICT) hipLaunchKernelGGL((k_conv2<CONV_PREDICT>), grid, block, CV2_LDS_BYTES, st, P);
@@ -380,6 +380,7 @@ int cs_cnn_create(cs_cnn_t** out, const cs_cnn_cfg* cfg) {
     {
         const char* e = getenv("CS_CNN_FUSE");
         h->fuse_max = e ? std::max(1, std::min(atoi(e), CV2_MAX_STAGES)) : CV2_MAX_STAGES;
+        if (const char* sl = getenv("CS_CNN_SPIN_LIMIT")) h->spin_limit = atoi(sl);
         if (hipHostMalloc((void**)&h->err_host, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { cs_cnn_destroy(h); return fail(CS_ERR_NOMEM, "hipHostMalloc failed"); }
         memset(h->err_host, 0, 64);
         if (hipHostGetDevicePointer((void**)&h->err_dev, h->err_host, 0) != hipSuccess) { cs_cnn_destroy(h); return fail(CS_ERR_HIP, "hipHostGetDevicePointer failed"); }

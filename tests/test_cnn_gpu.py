@@ -272,6 +272,31 @@ def test_cnn_chained_launches_match_one_conv_per_launch(CNN, monkeypatch):
             assert c >= 0.999999 and abs(ratio - 1) <= 1e-5
         np.testing.assert_allclose(res[0][1], other[1], rtol=1e-6)
 
+def test_cnn_handoff_timeout_fails_the_next_call(CNN, monkeypatch):
+    """A stage hand-off of a chained conv launch that gives up (CS_CNN_SPIN_LIMIT=0: the first poll that finds the partner not
+    ready) is counted by the kernel in host-mapped memory; the NEXT call on the model fails - a healthy model never does."""
+    from climsim_amd._lib import EngineError
+    depth, width, n = 12, 406, 64
+    x3, _ = make_xy(n, 5)
+    monkeypatch.setenv("CS_CNN_SPIN_LIMIT", "0")
+    bad = CNN.CNNEmulator(depth=depth, channel_width=width, max_batch=64, init_seed=1)
+    monkeypatch.delenv("CS_CNN_SPIN_LIMIT")
+    good = CNN.CNNEmulator(depth=depth, channel_width=width, max_batch=64, init_seed=1)
+    failed = False
+    for _ in range(20):                      # 16 row tiles x 22 hand-offs per call: some poll comes too early within a few calls
+        try:
+            bad.predict(x3)
+        except EngineError as e:
+            assert "hand-off" in str(e)
+            failed = True
+            break
+    assert failed
+    with pytest.raises(EngineError):
+        bad.predict(x3)                      # sticky
+    for _ in range(3):
+        good.predict(x3)
+    bad.close(); good.close()
+
 
 @pytest.mark.parametrize("depth,width,tile128", [(2, 406, False), (2, 64, False), (1, 200, False), (2, 406, True)])
 def test_cnn_optimizer_forms_agree(CNN, depth, width, tile128, monkeypatch):
