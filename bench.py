@@ -57,29 +57,21 @@ def pmc_traffic(kernel, batch):
 
 
 class ClockSampler:
-    """Shader clock (MHz) and `gpu_busy_percent` of the GPU while the timed region runs, read from sysfs (pp_dpm_sclk: the
-    starred level is the current one) by a host thread every 20 ms - nothing is launched on the GPU.  None where sysfs is
-    not readable."""
+    """Shader clock (MHz) of the GPU while the timed region runs, read from sysfs (hwmon freq1_input, else the starred level of
+    pp_dpm_sclk) by a host thread every 20 ms - nothing is launched on the GPU.  None where sysfs is not readable.
+    (Round 3 also sampled `gpu_busy_percent`: it read 0.0 in all 51 samples of the driver's run - the counter is a slow average
+    that a 1 s timed region never moves - and was dropped.)"""
 
     def __init__(self, index=0):
         import glob
-        self.path, self.busy_path = None, None
+        self.path = None
         cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
         if index < len(cards):
             self.path = cards[index]
             hw = sorted(glob.glob(os.path.join(os.path.dirname(cards[index]), "hwmon", "hwmon*", "freq1_input")))
             if hw:
                 self.path = hw[0]                # current shader clock in Hz (pp_dpm_sclk's starred level is 94 MHz on some boxes of the pool)
-            bp = os.path.join(os.path.dirname(cards[index]), "gpu_busy_percent")
-            if os.path.exists(bp):
-                self.busy_path = bp
-        self.samples, self.busy, self._stop, self._thr = [], [], False, None
-
-    def read_busy(self):
-        try:
-            return float(open(self.busy_path).read().strip())
-        except Exception:
-            return None
+        self.samples, self._stop, self._thr = [], False, None
 
     def read(self):
         try:
@@ -100,10 +92,6 @@ class ClockSampler:
                     v = self.read()
                     if v is not None:
                         self.samples.append(v)
-                    if self.busy_path:
-                        b = self.read_busy()
-                        if b is not None:
-                            self.busy.append(b)
                     time.sleep(0.02)
             self._thr = threading.Thread(target=loop, daemon=True)
             self._thr.start()
@@ -119,12 +107,6 @@ class ClockSampler:
             return None
         s = sorted(self.samples)
         return {"min": s[0], "median": s[len(s) // 2], "max": s[-1], "samples": len(s), "source": self.path}
-
-    def busy_summary(self):
-        if not self.busy:
-            return None
-        s = sorted(self.busy)
-        return {"min": s[0], "median": s[len(s) // 2], "max": s[-1], "samples": len(s), "source": self.busy_path}
 
 
 def launch_ranks(n, argv):
@@ -368,15 +350,161 @@ def loader_side_bench(steps=16, ncol=21600):
             "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 3)}}
 
 
-def timed_blocks(torch, dist, device, step, steps, first_step, min_seconds, max_blocks=2000, after_block=None):
+class LegFailed(RuntimeError):
+    """A leg failed on SOME rank (agreed on with a MAX all-reduce in timed_blocks): every rank raises it together."""
+
+
+def inject_failure(where, rank):
+    """Test switch: CS_BENCH_INJECT_FAIL="<rank>:<where>" raises on that rank at that point (tests/test_bench_gpu.py)."""
+    spec = os.environ.get("CS_BENCH_INJECT_FAIL", "")
+    if spec and spec.split(":")[0] == str(rank) and spec.split(":")[1] == where:
+        raise RuntimeError(f"injected failure on rank {rank} at '{where}' (CS_BENCH_INJECT_FAIL)")
+
+
+class FailureReporter:
+    """N > 1: a failure of ANY rank before the JSON line must still end in ONE line from rank 0 (with "error") and a non-zero
+    exit - no re-exec, no second attempt in this process tree.  A failing rank r > 0 leaves its message in a run-private
+    directory and exits 1; the launcher (torch.distributed.run) then sends SIGTERM to the other ranks.  Rank 0 may be blocked
+    inside a collective or a stream synchronisation at that moment, where a Python-level signal handler never runs: it keeps a
+    watcher THREAD on the interpreter's signal wake-up pipe (`signal.set_wakeup_fd`: written from the C-level handler), which
+    prints the error line and ends the process.  Rank 0's own exceptions print the line directly.
+    (online_testing/.../train_mlp_h5loader.py:195-207,470-473 relies on torchrun's teardown alone.)"""
+
+    def __init__(self, rank, world):
+        import tempfile
+        self.rank, self.world, self.done = rank, world, False
+        # one directory per launch: the ranks share their parent (the launcher), so its pid names the run and nothing stale is read
+        self.dir = os.path.join(tempfile.gettempdir(), "cs_bench_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid()))
+        os.makedirs(self.dir, exist_ok=True)
+        if rank == 0 and world > 1:
+            import signal
+            import threading
+            r, w = os.pipe()
+            os.set_blocking(w, False)
+            signal.set_wakeup_fd(w, warn_on_full_buffer=False)
+            signal.signal(signal.SIGTERM, lambda *_: None)         # keep the default action (die silently) from running
+            threading.Thread(target=self._watch, args=(r, int(signal.SIGTERM)), daemon=True).start()
+
+    def _watch(self, rfd, sigterm):
+        while True:
+            data = os.read(rfd, 16)
+            if not data:
+                return
+            if sigterm in data and not self.done:
+                time.sleep(0.3)                                    # the failing rank writes its message before it exits
+                self.emit("terminated by the launcher (SIGTERM): another rank failed")
+                os._exit(1)
+
+    def peer_errors(self):
+        out = {}
+        try:
+            for f in sorted(os.listdir(self.dir)):
+                if f.startswith("rank") and f.endswith(".err"):
+                    out[f[4:-4]] = open(os.path.join(self.dir, f)).read()[:600]
+        except OSError:
+            pass
+        return out
+
+    def emit(self, msg):
+        line = json.dumps({"metric": "training columns/sec", "value": None, "unit": "columns/s", "n_gpus": self.world,
+                           "error": msg[:600], "failed_ranks": self.peer_errors()})
+        sys.stdout.write(line + "\n")
+        sys.stdout.flush()
+
+    def fail(self, exc):
+        import traceback
+        msg = f"{type(exc).__name__}: {exc}"
+        if self.rank == 0:
+            self.done = True
+            self.emit(msg)
+        else:
+            try:
+                with open(os.path.join(self.dir, f"rank{self.rank}.err"), "w") as f:
+                    f.write(msg + "\n" + traceback.format_exc()[-400:])
+            except OSError:
+                pass
+        traceback.print_exc()
+        sys.stderr.flush()
+        os._exit(1)                                                # no teardown collectives: the group is broken
+
+
+def sweep_point(torch, device, b, steps, blocks=10, lr=1e-3):
+    """One more batch size of SURVEY 8(d) config (2) (B in {1024, 8192, 65536}) in the driver's line: `blocks` blocks of `steps`
+    steps (median), AFTER the headline's timed region and on a model of its own, plus the per-kernel event pass for the dominant kernel."""
+    import ctypes
+    from climsim_amd import _lib
+    from climsim_amd.mlp import MLPEmulator
+    m = MLPEmulator(units=UNITS, activation="leakyrelu", optimizer="Adam", max_batch=b, seed=None, device=device.index,
+                    cooperative=b <= 2048)                       # one process on this GPU: small batches take the cooperative chain
+    m.set_weights(synthetic_init(0))
+    rows = max(4 * b, 1 << 18)
+    x, y = synth_on_device(torch, rows, 4321, device)
+    g = torch.Generator(device=device)
+    g.manual_seed(99)
+    perm = torch.randperm(rows, device=device, generator=g)
+    loss = torch.zeros(2, dtype=torch.float32, device=device)
+    nb = rows // b
+
+    def step(i):
+        m.train_on_batch(x, y, lr, row_idx=perm[(i % nb) * b:(i % nb + 1) * b], loss=loss)
+    for i in range(max(5, steps // 2)):
+        step(i)
+    secs = []
+    for k in range(blocks):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(k * steps + i)
+        torch.cuda.synchronize()
+        secs.append(time.perf_counter() - t0)
+        m.check()
+    med = sorted(secs)[len(secs) // 2] / steps
+    reps = 20
+    with _lib.profile_session(ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)) as prof:
+        for r in range(reps):
+            step(r)
+    ks = {k: v[0] / reps for k, v in prof.times.items() if v[1] > 0}            # ms per step, raw event durations
+    scale = min(1.0, med * 1e3 / sum(ks.values())) if ks else 1.0
+    dom = max((k for k in FLOPS_PER_COL if k in ks), key=lambda k: ks[k])
+    dom_ms = ks[dom] * scale
+    out = {"per_gpu_batch": b, "value": round(b / med, 1), "unit": "columns/s", "ms_per_step": round(med * 1e3, 4), "blocks": blocks,
+           "steps_per_block": steps, "cooperative_chain": bool(b <= 2048),
+           "whole_step_frac": round(TRAIN_FLOPS_PER_COL * b / med / 1e12 / PEAK_BF16_TFLOPS, 4),
+           "dominant_kernel": KERNEL_NAMES[dom], "dominant_us": round(dom_ms * 1e3, 2),
+           "dominant_frac": round(FLOPS_PER_COL[dom] * b / (dom_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+           "kernels_us": {k: round(v * scale * 1e3, 2) for k, v in ks.items()}, "coop_timeouts": m.coop_timeouts}
+    m.close()
+    del x, y
+    torch.cuda.empty_cache()
+    return out
+
+
+def agree_or_raise(torch, dist, device, err, msg):
+    """Every rank learns whether ANY rank failed (MAX all-reduce of a flag) and all raise LegFailed together."""
+    if dist:
+        t = torch.tensor([1.0 if err else 0.0], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        err = float(t.item()) > 0
+    if err:
+        raise LegFailed(msg or "another rank failed in this leg")
+
+
+def timed_blocks(torch, dist, device, step, steps, first_step, min_seconds, max_blocks=2000, after_block=None, warmup=0):
     """Blocks of EXACTLY `steps` steps, each bracketed by barrier + synchronize on both sides and reduced with MAX over the
     ranks, repeated until the blocks add up to `min_seconds` of step time (a 3 ms region says little about a GPU that has
-    not reached its clocks).  Returns the per-block seconds."""
+    not reached its clocks).  Returns the per-block seconds.  `warmup` untimed steps run first.  A failure of `after_block`
+    (the engine's health check between blocks: every rank is at the same point, outside any collective) on ANY rank travels
+    with the block's time through the MAX all-reduce, so that every rank raises LegFailed together instead of one rank leaving
+    the others inside the next barrier.  (A step that raises on one rank cannot be absorbed - the others are inside the step's
+    collective - and ends the run: FailureReporter.)"""
     secs, it = [], first_step
+    for i in range(warmup):
+        step(i)
     while True:
         if dist:
             dist.barrier()
         torch.cuda.synchronize()
+        err, msg = 0.0, ""
         t0 = time.perf_counter()
         for i in range(steps):
             step(it + i)
@@ -385,11 +513,16 @@ def timed_blocks(torch, dist, device, step, steps, first_step, min_seconds, max_
             dist.barrier()
         el = time.perf_counter() - t0
         if after_block:
-            after_block()                        # outside the timed interval: e.g. the cooperative chain's time-out counter
+            try:
+                after_block()                    # outside the timed interval: e.g. the cooperative chain's time-out counter
+            except Exception as e:               # noqa: BLE001
+                err, msg = 1.0, f"{type(e).__name__}: {e}"
         if dist:
-            t = torch.tensor([el], dtype=torch.float64, device=device)
+            t = torch.tensor([el, err], dtype=torch.float64, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el = float(t.item())
+            el, err = float(t[0].item()), float(t[1].item())
+        if err:
+            raise LegFailed(msg or "another rank failed in this leg")
         secs.append(el)
         it += steps
         # every rank sees the same (MAX-reduced) times, so all take the same decision
@@ -425,21 +558,38 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU-baseline timing (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event pass")
     ap.add_argument("--no-extras", action="store_true", help="skip the side figures")
-    ap.add_argument("--extras", default="pub_mlp,cnn,loader,stream", help="which side figures to take (comma-separated)")
+    ap.add_argument("--extras", default="pub_mlp,cnn,loader,stream,sweep", help="which side figures to take (comma-separated)")
     ap.add_argument("--train-only", action="store_true", help="counter runs: nothing but the training steps (no held-out "
                     "evaluation, no prediction pass), so that per-kernel averages are averages over training launches")
     args = ap.parse_args()
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs between the ranks of this pool's hosts
+    if args.collective == "oneshot" or args.time_oneshot:
+        os.environ.setdefault("CS_DP_IPC_MULTI_DEVICE", "1")     # the flags ARE the caller's consent to a path that has not run over xGMI yet
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and "RANK" not in os.environ:
         raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))   # parent: no GPU call, children do the work
-    import torch
     rank = int(os.environ.get("RANK", "0"))
+    reporter = FailureReporter(rank, world) if world > 1 else None
+    try:
+        run(args, world, rank)
+    except SystemExit:
+        raise
+    except BaseException as e:               # noqa: BLE001 - N > 1: rank 0 must still print ONE line (with "error") and exit non-zero
+        if reporter is None:
+            raise
+        reporter.fail(e)
+    if reporter is not None:
+        reporter.done = True
+
+
+def run(args, world, rank):
+    import torch
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback for the engine)")
+    inject_failure("start", rank)
     # development / tests: every rank on cuda:0 with gloo collectives, so that the N > 1 flow of this file (barriers, MAX over
     # ranks, strong leg, comm figures, rank 0's line) can run on a one-GPU box; RCCL cannot put two ranks on one device
     share_gpu = os.environ.get("CS_BENCH_SHARE_GPU") == "1"
@@ -475,8 +625,8 @@ def main():
     WL = args.weak_large_batch if (multi and args.weak_large_batch != B) else 0       # second weak leg: compute hides the collective's share
     model = MLPEmulator(units=UNITS, activation="leakyrelu", optimizer="Adam", max_batch=max(B, sb, gb if sb else 0, WL), seed=None, device=local_rank,
                         flags=int(os.environ.get("CS_FLAGS", "0")),   # engine flags: tuning experiments only
-                        cooperative=not share_gpu)                     # one process per GPU: batches <= 2048 columns (--batch, the strong
-                                                                       # leg at N >= 4) may take the cooperative chain
+                        cooperative=not multi)                         # one process on the GPU: a --batch <= 2048 headline may take the cooperative
+                                                                       # chain; under N > 1 the strong leg runs WITHOUT it first and with it second
     model.set_weights(synthetic_init(0))
     x, y = synth_on_device(torch, args.rows, 20230614 + rank, device)
     xv, yv = synth_on_device(torch, 65536, 777, device)
@@ -491,29 +641,44 @@ def main():
     dp = DataParallel(model, dist if multi else None, grad_payload=args.grad_payload, collective=args.collective if multi else None)
     dp.broadcast_weights()
 
-    def make_step(b, collective=True, one_call=False):
+    def make_step(b, collective=True, one_call=False, mdl=None, dpx=None):
         # every rank owns its own HBM-resident shard of the split, so its local batch is a slice of
         # its own permutation (equivalent to the round-robin deal of a global permutation)
+        mdl, dpx = mdl or model, dpx or dp
         nb = args.rows // b
         scale = 1.0 / (128.0 * b * (world if collective else 1))
 
         def step(i):
             idx = perm[(i % nb) * b:(i % nb + 1) * b]
             if multi and not one_call:
-                model.loss_grads(x, y, row_idx=idx, loss=loss)
+                mdl.loss_grads(x, y, row_idx=idx, loss=loss)
                 if collective:
-                    dp.all_reduce_grads()                           # ONE RCCL all-reduce per step (cs_dp_allreduce, compute stream)
-                model.apply_gradients(lr, scale)
+                    dpx.all_reduce_grads()                          # ONE RCCL all-reduce per step (cs_dp_allreduce, compute stream)
+                mdl.apply_gradients(lr, scale)
             else:
-                model.train_on_batch(x, y, lr, row_idx=idx, loss=loss)
+                mdl.train_on_batch(x, y, lr, row_idx=idx, loss=loss)
         return step
 
-    def timed(stepfn, cols_per_step):
-        for i in range(args.warmup):
-            stepfn(i)
-        secs_ = timed_blocks(torch, dist, device, stepfn, args.steps, args.warmup, args.min_seconds, after_block=model.check)
+    def timed(stepfn, cols_per_step, mdl=None, tag=None):
+        def health():
+            if tag:
+                inject_failure(tag, rank)        # tests: a rank whose check fails between two blocks
+            (mdl or model).check()               # e.g. a bounded wait of the cooperative chain that ran out on this rank
+        secs_ = timed_blocks(torch, dist, device, stepfn, args.steps, args.warmup, args.min_seconds, after_block=health, warmup=args.warmup)
         st_, med_ = block_stats(secs_, args.steps, cols_per_step)
         return st_, med_
+
+    from climsim_amd._lib import EngineError
+
+    def agreed(fn):
+        """A leg that must not take the line down: its outcome ({"error": ...} or its result) is the SAME on every rank.  Only
+        failures that every rank sees together are absorbed here: LegFailed (health checks between blocks, agreed on in
+        timed_blocks) and the EngineError of the native communicators' set-up (RcclComm / IpcComm raise on every rank or on none).
+        Anything else - one rank alone - would leave the others inside a collective: it ends the run through FailureReporter."""
+        try:
+            return fn()
+        except (LegFailed, EngineError) as e:
+            return {"error": f"{type(e).__name__}: {e}"[:300]}
 
     step = make_step(B)
     for i in range(args.warmup):
@@ -582,34 +747,66 @@ def main():
                 if dp.native is not None else "torch.distributed.all_reduce", "nranks": dist.get_world_size(),
                 "allreduce_us_oneshot_ipc": other_us if dp.collective == "rccl" else us["fp32"], "oneshot_ipc_error": other_err,
                 "rccl_comm_count": rccl_n, "rccl_user_rank": rccl_r,       # ncclCommCount / ncclCommUserRank of the engine's own communicator (rank 0's view)
+                "rccl_comm_matches_nranks": (rccl_n == dist.get_world_size()) if rccl_n is not None else None,
                 "payload": dp.payload, "bytes": n_grad * (2 if dp.payload == "bf16" else 4), "allreduce_us_per_step": us[dp.payload],
                 "allreduce_us_fp32_payload": us["fp32"], "allreduce_us_bf16_payload": us["bf16"],
                 "note": "median over 20 steps of the slowest rank's event pair around the collective; includes the wait for the slowest "
                         "rank's gradients; the timed steps use `payload` (--grad-payload; bf16 adds a pack and an unpack kernel inside the pair)"}
         if sb:
-            st, smed = timed(make_step(sb), gb)
-            # what the leg has to beat, measured by every rank on its own GPU with no collective: (a) the per-GPU share of the
-            # work alone (what is left is the exposed collective), (b) ONE GPU taking the whole global batch (MAX over ranks)
-            _, cmed = timed(make_step(sb, collective=False), sb)
-            _, omed = timed(make_step(gb, collective=False, one_call=True), gb)
-            v_strong, v_one = gb * args.steps / smed, gb * args.steps / omed
-            strong = {"scaling": "strong", "global_batch": gb, "per_gpu_batch": sb, "value": round(v_strong, 1), "unit": "columns/s",
-                      "ms_per_step": round(smed / args.steps * 1e3, 4), "timing": st,
-                      "compute_only_ms_per_step": round(cmed / args.steps * 1e3, 4),
-                      "predicted_ms_per_step": round(cmed / args.steps * 1e3 + us[dp.payload] * 1e-3, 4),
-                      "one_gpu_same_global_batch": {"value": round(v_one, 1), "ms_per_step": round(omed / args.steps * 1e3, 4)},
-                      "speedup_vs_one_gpu": round(v_strong / v_one, 3), "scales": bool(v_strong > v_one),
-                      "verdict": ("%d GPUs beat one GPU at global batch %d" % (world, gb)) if v_strong > v_one else
-                                 ("NOT scaling: one GPU at global batch %d is faster than %d GPUs at %d columns each - the step is "
-                                  "compute + one exposed all-reduce, and at this per-GPU batch the collective outweighs the compute it saves" % (gb, world, sb)),
-                      "config": "BASELINE configs[3]: MLP DDP, RCCL all-reduce over xGMI, global batch 8192"}
+            def strong_leg(mdl, dpx, coop):
+                st, smed = timed(make_step(sb, mdl=mdl, dpx=dpx), gb, mdl, tag="strong_coop_check" if coop else "strong_check")
+                # what the leg has to beat, measured by every rank on its own GPU with no collective: (a) the per-GPU share of the
+                # work alone (what is left is the exposed collective), (b) ONE GPU taking the whole global batch (MAX over ranks)
+                _, cmed = timed(make_step(sb, collective=False, mdl=mdl, dpx=dpx), sb, mdl)
+                _, omed = timed(make_step(gb, collective=False, one_call=True, mdl=mdl, dpx=dpx), gb, mdl)
+                v_strong, v_one = gb * args.steps / smed, gb * args.steps / omed
+                return {"scaling": "strong", "global_batch": gb, "per_gpu_batch": sb, "value": round(v_strong, 1), "unit": "columns/s",
+                        "cooperative_chain": bool(coop and sb <= 2048),
+                        "ms_per_step": round(smed / args.steps * 1e3, 4), "timing": st,
+                        "compute_only_ms_per_step": round(cmed / args.steps * 1e3, 4),
+                        "predicted_ms_per_step": round(cmed / args.steps * 1e3 + us[dp.payload] * 1e-3, 4),
+                        "one_gpu_same_global_batch": {"value": round(v_one, 1), "ms_per_step": round(omed / args.steps * 1e3, 4)},
+                        "speedup_vs_one_gpu": round(v_strong / v_one, 3), "scales": bool(v_strong > v_one),
+                        "verdict": ("%d GPUs beat one GPU at global batch %d" % (world, gb)) if v_strong > v_one else
+                                   ("NOT scaling: one GPU at global batch %d is faster than %d GPUs at %d columns each - the step is "
+                                    "compute + one exposed all-reduce, and at this per-GPU batch the collective outweighs the compute it saves" % (gb, world, sb)),
+                        "config": "BASELINE configs[3]: MLP DDP, RCCL all-reduce over xGMI, global batch 8192"}
+            # first WITHOUT the cooperative chain (plain launches only: nothing in it waits for another workgroup), then - where the
+            # per-GPU batch is small enough for it - WITH it, on a model of its own; each leg's failure stays inside its object
+            strong = agreed(lambda: strong_leg(model, dp, False))
+            if sb <= 2048 and os.environ.get("CS_BENCH_STRONG_COOP", "1") != "0":
+                def coop_leg():
+                    # (two ranks sharing ONE device - the tests' stand-in for N > 1 - must not launch cooperatively: the leg's flow runs, plain)
+                    m2, err = None, ""
+                    try:
+                        m2 = MLPEmulator(units=UNITS, activation="leakyrelu", optimizer="Adam", max_batch=max(sb, gb), seed=None, device=local_rank, cooperative=not share_gpu)
+                        m2.set_weights(synthetic_init(0))
+                        m2.gradient_tensor()
+                    except EngineError as e:
+                        err = str(e)
+                    try:
+                        agree_or_raise(torch, dist, device, bool(err), err)      # every rank has its model, or no rank goes on
+                        dp2 = DataParallel(m2, dist, grad_payload=args.grad_payload, collective=args.collective)
+                        try:
+                            return strong_leg(m2, dp2, True)
+                        finally:
+                            torch.cuda.synchronize()
+                            dp2.close()
+                    finally:
+                        if m2 is not None:
+                            m2.close()
+                strong_coop = agreed(coop_leg)
+                if isinstance(strong, dict):
+                    strong["with_cooperative_chain"] = strong_coop
         if WL:
-            wt, wmed = timed(make_step(WL), WL * world)
-            _, wcmed = timed(make_step(WL, collective=False), WL)
-            weak_large = {"scaling": "weak", "per_gpu_batch": WL, "global_batch": WL * world, "value": round(WL * world * args.steps / wmed, 1),
-                          "unit": "columns/s", "ms_per_step": round(wmed / args.steps * 1e3, 4), "timing": wt,
-                          "compute_only_ms_per_step": round(wcmed / args.steps * 1e3, 4),
-                          "note": "second weak leg: at this per-GPU batch the step's compute is ~10x the collective"}
+            def weak_large_leg():
+                wt, wmed = timed(make_step(WL), WL * world)
+                _, wcmed = timed(make_step(WL, collective=False), WL)
+                return {"scaling": "weak", "per_gpu_batch": WL, "global_batch": WL * world, "value": round(WL * world * args.steps / wmed, 1),
+                        "unit": "columns/s", "ms_per_step": round(wmed / args.steps * 1e3, 4), "timing": wt,
+                        "compute_only_ms_per_step": round(wcmed / args.steps * 1e3, 4),
+                        "note": "second weak leg: at this per-GPU batch the step's compute is ~10x the collective"}
+            weak_large = agreed(weak_large_leg)
 
     # ---- untimed: held-out error of the model that was just trained, per-kernel timing, CPU baseline
     if args.train_only:
@@ -701,6 +898,9 @@ def main():
             extras["loader"] = side_bench(loader_side_bench)
         if "stream" in want:
             extras["stream"] = side_bench(stream_side_bench)
+        if "sweep" in want:
+            # SURVEY 8(d) config (2) names B in {1024, 8192, 65536}: the other two sizes, after (and apart from) the headline's timed region
+            extras["sweep"] = {str(b): side_bench(lambda b=b: sweep_point(torch, device, b, args.steps)) for b in (1024, 65536) if b != B}
 
     if rank == 0:
         out = {"metric": "training columns/sec", "value": round(value, 1), "unit": "columns/s",
@@ -711,7 +911,7 @@ def main():
                           "init": "glorot_uniform kernels, zero biases, ReLU-head bias +%.2f (synthetic recipe only: keeps the 8 ReLU outputs alive, see synthetic_init)" % RELU_HEAD_BIAS,
                           "per_gpu_batch": B, "global_batch": B * world, "rows_resident_per_gpu": args.rows,
                           "parallelism": f"dp{world}", "params": n_params},
-               "timing": {**timing, "value_from": "median block", "gpu_sclk_mhz": clk.summary(), "gpu_busy_percent": clk.busy_summary()},
+               "timing": {**timing, "value_from": "median block", "gpu_sclk_mhz": clk.summary()},
                "coop_timeouts": coop_timeouts,
                "comm": comm, "strong": strong, "weak_large": weak_large,
                "heldout": {"mse": held["mse"], "mae": held["mae"], "rows": 65536, "per_variable": per_var,

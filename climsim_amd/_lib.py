@@ -58,6 +58,7 @@ SIGNATURES = {
     "cs_mlp_num_params": (_I64, [_P]),
     "cs_mlp_device_bytes": (_I64, [_P]),
     "cs_mlp_check": (C.c_int, [_P, _P]),
+    "cs_mlp_set_train_accuracy": (C.c_int, [_P, _P]),
     "cs_mlp_coop_timeouts": (_I64, [_P]),
     "cs_dp_unique_id": (C.c_int, [C.c_char_p, _P]),
     "cs_dp_init": (C.c_int, [C.POINTER(_P), C.c_char_p, _P, C.c_int, C.c_int, C.c_int]),
@@ -71,6 +72,7 @@ SIGNATURES = {
     "cs_dp_ipc_buffer": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_I64)]),
     "cs_dp_ipc_allreduce": (C.c_int, [_P, _I64, _P]),
     "cs_dp_ipc_timeouts": (_I64, [_P]),
+    "cs_dp_ipc_set_timeout_ms": (C.c_int, [_P, C.c_double]),
     "cs_dp_ipc_destroy": (None, [_P]),
     "cs_mlp_set_norm": (C.c_int, [_P, _P, _P]),
     "cs_mlp_set_head_options": (C.c_int, [_P, C.c_int, _P, C.c_int64]),

@@ -163,6 +163,8 @@ struct cs_mlp {
     // training step without gradient atomics (WgradArgs.plain): extra partial-sum buffers, how many of them hold this step's
     // contributions (consumed by the optimiser launch that follows), and whether the backward pass runs inside a step
     float* Gx = nullptr; int gx_parts = 0; bool in_step = false;
+    // training-pass `accuracy` (cs_mlp_set_train_accuracy): the heads also write their predictions here and a small kernel counts argmax matches
+    unsigned long long* acc_count = nullptr; float* yhat_train = nullptr;
     std::vector<void*> allocs;
 };
 
@@ -618,6 +620,12 @@ int run_backward(cs_mlp* h, int64_t n, bool atomics_needed, hipStream_t st) {
     return CS_OK;
 }
 
+// Keras' `accuracy` metric of the TRAINING pass (compile(metrics=['mse','mae','accuracy']), step2_retrain.py:160-162: the CSVLogger
+// column `accuracy`): argmax(y_true) == argmax(y_pred) over the batch the step just predicted, added to the caller's counter.
+void train_accuracy(cs_mlp* h, const float* y_dev, const int64_t* row_idx_dev, int64_t n, hipStream_t st) {
+    hipLaunchKernelGGL(k_argmax_match, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, (const float*)h->yhat_train, y_dev, row_idx_dev, n, h->n_out, h->acc_count);
+}
+
 int check_batch(const cs_mlp* h, int64_t n) {
     if (!h) return fail(CS_ERR_INVALID, "null handle");
     if (n <= 0 || n > h->cfg.max_batch) return fail(CS_ERR_INVALID, "n=%lld outside 1..max_batch=%d", (long long)n, h->cfg.max_batch);
@@ -861,6 +869,19 @@ int cs_mlp_set_dropout(cs_mlp_t* h, double rate, uint64_t seed) {
     return CS_OK;
 }
 
+int cs_mlp_set_train_accuracy(cs_mlp_t* h, unsigned long long* count_dev) {
+    if (!h) return fail(CS_ERR_INVALID, "null handle");
+    if (count_dev && !h->yhat_train) {
+        HIP_TRY(hipSetDevice(h->cfg.device));
+        void* p = nullptr;
+        if (hipMalloc(&p, sizeof(float) * (size_t)h->m_pad_max * h->n_out) != hipSuccess) return fail(CS_ERR_NOMEM, "hipMalloc of the training-pass prediction buffer failed");
+        h->allocs.push_back(p);
+        h->yhat_train = (float*)p;
+    }
+    h->acc_count = count_dev;
+    return CS_OK;
+}
+
 int cs_mlp_set_weights(cs_mlp_t* h, const float* host, int64_t n, void* stream) {
     if (!h || !host) return fail(CS_ERR_INVALID, "null argument");
     if (n != h->n_params_keras) return fail(CS_ERR_INVALID, "expected %lld floats, got %lld", (long long)h->n_params_keras, (long long)n);
@@ -980,8 +1001,9 @@ int cs_mlp_loss_grads(cs_mlp_t* h, const float* x_dev, const float* y_dev, const
         if (h->grads_dirty) HIP_TRY(hipMemsetAsync(h->G, 0, sizeof(float) * h->n_params, st));
     }
     h->grads_dirty = true;
-    rc = run_forward(h, x_dev, row_idx_dev, n, normalise, nullptr, y_dev, loss_dev, true, st);
+    rc = run_forward(h, x_dev, row_idx_dev, n, normalise, h->acc_count ? h->yhat_train : nullptr, y_dev, loss_dev, true, st);
     if (rc) return rc;
+    if (h->acc_count) train_accuracy(h, y_dev, row_idx_dev, n, st);
     return run_backward(h, n, accumulate != 0, st);
 }
 
@@ -1025,9 +1047,10 @@ int cs_mlp_train_step(cs_mlp_t* h, const float* x_dev, const float* y_dev, const
     h->grads_dirty = true;
     float* slot = h->loss_ring + LOSS_STRIPES * LOSS_STRIPE_FLOATS * h->loss_cur;
     h->loss_striped = true;
-    rc = run_forward(h, x_dev, row_idx_dev, n, normalise, nullptr, y_dev, slot, true, st);
+    rc = run_forward(h, x_dev, row_idx_dev, n, normalise, h->acc_count ? h->yhat_train : nullptr, y_dev, slot, true, st);
     h->loss_striped = false;
     if (rc) return rc;
+    if (h->acc_count) train_accuracy(h, y_dev, row_idx_dev, n, st);
     h->in_step = true;
     rc = run_backward(h, n, false, st);
     h->in_step = false;
@@ -1167,7 +1190,7 @@ int cs_categorical_accuracy(const float* pred_dev, const float* target_dev, int6
     if (n <= 0 || width <= 0) return fail(CS_ERR_INVALID, "empty input");
     hipStream_t st = (hipStream_t)stream;
     if (!accumulate) HIP_TRY(hipMemsetAsync(count_dev, 0, sizeof(unsigned long long), st));
-    CS_LAUNCH(k_argmax_match, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, pred_dev, target_dev, n, (int)width, count_dev);
+    CS_LAUNCH(k_argmax_match, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, pred_dev, target_dev, (const int64_t*)nullptr, n, (int)width, count_dev);
     HIP_TRY(hipGetLastError());
     return CS_OK;
 }
@@ -1681,10 +1704,16 @@ int cs_dp_allreduce_bf16(cs_dp_t* c, float* buf, int64_t n, void* stream) {
 //       kernel ends, this rank's buffer holds the complete sum.
 // The buffers are hipMalloc'ed by the library and exported / opened with hipIpc* handles (the handles travel through the
 // launcher's rendezvous); the engine's gradient buffer is REBOUND to the exchange buffer (cs_mlp_set_grad_buffer), so there
-// is no copy.  Peer accesses are system-scope (sc0 sc1: no stale line in a local cache across steps), every wait is bounded
-// (a time-out is counted in `err` and reported by the call that follows, never a hang).  Correctness is tested with two
-// processes on one device (tests/test_dp_ipc_gpu.py); over real xGMI links it has NOT run (one GPU per box in this pool), which
-// is why RCCL stays the default.
+// is no copy.  Peer accesses are system-scope (sc0 sc1), and - round 4, advisor - buffer and flag page are FINE-GRAINED
+// allocations (hipExtMallocWithFlags(hipDeviceMallocFinegrained), what RCCL uses for its own exchange buffers): a peer's writes
+// over xGMI bypass the owner's L2, so with ordinary (coarse-grained) memory the owner's weight-gradient / optimiser kernels, which
+// touch the buffer with plain cached accesses, could read a stale line or write a dirty one back over a pushed sum; fine-grained
+// lines are kept coherent for every accessor.  Every wait is bounded by WALL CLOCK (s_memrealtime, default 30 s: ordinary rank
+// skew - a checkpoint on rank 0, a lazy first-step build - must not trip it; CS_DP_IPC_TIMEOUT_MS) and a time-out is counted in
+// `err` and reported by the call that follows, never a hang; ranks should be barrier-aligned before the first step.
+// Correctness is tested with two processes on one device (tests/test_dp_ipc_gpu.py); over real xGMI links it has NOT run (one
+// GPU per box in this pool): RCCL stays the default, and connecting buffers that live on DIFFERENT devices is refused unless
+// CS_DP_IPC_MULTI_DEVICE=1 says the caller knows (bench.py sets it for its explicit --collective oneshot / --time-oneshot).
 #define CS_DP_IPC_MAX 8
 struct IpcArgs {
     float* buf[CS_DP_IPC_MAX];          // gradient exchange buffer of every rank (peer-mapped; [rank] is the local one)
@@ -1694,7 +1723,7 @@ struct IpcArgs {
     int world, rank;
     unsigned epoch;
     int64_t n;
-    int spin_limit;
+    unsigned long long timeout_ticks;   // 100 MHz ticks (s_memrealtime) a wait may last
 };
 __device__ __forceinline__ void sys_store_u32(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ unsigned sys_load_u32(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
@@ -1714,9 +1743,9 @@ __global__ __launch_bounds__(256) void k_dp_oneshot(const IpcArgs a) {
     // (0) my gradients are complete (the kernels that wrote them ended before this launch: their lines are in memory)
     if (blockIdx.x == 0 && tid < a.world) sys_store_u32(a.flags[tid] + a.rank, a.epoch);
     if (tid < a.world) {
-        int spins = 0;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         while ((int)(sys_load_u32(a.flags[a.rank] + tid) - a.epoch) < 0) {
-            if (++spins > a.spin_limit) { __hip_atomic_fetch_add(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+            if (__builtin_amdgcn_s_memrealtime() - t0 > a.timeout_ticks) { __hip_atomic_fetch_add(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
             __builtin_amdgcn_s_sleep(4);
         }
     }
@@ -1744,9 +1773,9 @@ __global__ __launch_bounds__(256) void k_dp_oneshot(const IpcArgs a) {
     if (tid == 0) __hip_atomic_store(a.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (tid < a.world) {
         sys_store_u32(a.flags[tid] + CS_DP_IPC_MAX + a.rank, a.epoch);
-        int spins = 0;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         while ((int)(sys_load_u32(a.flags[a.rank] + CS_DP_IPC_MAX + tid) - a.epoch) < 0) {
-            if (++spins > a.spin_limit) { __hip_atomic_fetch_add(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+            if (__builtin_amdgcn_s_memrealtime() - t0 > a.timeout_ticks) { __hip_atomic_fetch_add(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
             __builtin_amdgcn_s_sleep(4);
         }
     }
@@ -1762,8 +1791,10 @@ struct cs_dp_ipc {
     bool opened[CS_DP_IPC_MAX] = {};
     bool connected = false;
     unsigned epoch = 0;
-    int spin_limit = 1 << 22;
+    double timeout_ms = 30000.0;        // CS_DP_IPC_TIMEOUT_MS / cs_dp_ipc_set_timeout_ms
+    char dev_id[64] = {};               // PCI bus id of the device the buffers live on (also stored in the flag page for the peers)
 };
+#define CS_DP_IPC_ID_WORD 768           // word offset of the owner's device id inside its flag page (64 bytes)
 
 int cs_dp_ipc_create(cs_dp_ipc_t** out, int world, int rank, int device, int64_t n_floats) {
     if (!out) return fail(CS_ERR_INVALID, "null argument");
@@ -1774,15 +1805,18 @@ int cs_dp_ipc_create(cs_dp_ipc_t** out, int world, int rank, int device, int64_t
     cs_dp_ipc* c = new cs_dp_ipc();
     struct Guard { cs_dp_ipc* p; ~Guard() { if (p) cs_dp_ipc_destroy(p); } } guard{c};
     c->world = world; c->rank = rank; c->device = device; c->n = n_floats;
-    HIP_TRY(hipMalloc((void**)&c->buf, sizeof(float) * n_floats));
+    // fine-grained device memory: coherent for local cached accesses AND for the peers' writes over xGMI (see the block comment)
+    HIP_TRY(hipExtMallocWithFlags((void**)&c->buf, sizeof(float) * n_floats, hipDeviceMallocFinegrained));
     HIP_TRY(hipMemset(c->buf, 0, sizeof(float) * n_floats));
-    HIP_TRY(hipMalloc((void**)&c->flags, 4096));
+    HIP_TRY(hipExtMallocWithFlags((void**)&c->flags, 4096, hipDeviceMallocFinegrained));
     HIP_TRY(hipMemset(c->flags, 0, 4096));
     c->arrive = c->flags + 512;                                     // same allocation, never touched by a peer
+    HIP_TRY(hipDeviceGetPCIBusId(c->dev_id, (int)sizeof c->dev_id, device));
+    HIP_TRY(hipMemcpy(c->flags + CS_DP_IPC_ID_WORD, c->dev_id, sizeof c->dev_id, hipMemcpyHostToDevice));
     HIP_TRY(hipHostMalloc((void**)&c->err_host, 64, hipHostMallocMapped | hipHostMallocCoherent));
     memset(c->err_host, 0, 64);
     HIP_TRY(hipHostGetDevicePointer((void**)&c->err_dev, c->err_host, 0));
-    if (const char* e = getenv("CS_DP_IPC_SPIN_LIMIT")) c->spin_limit = atoi(e);
+    if (const char* e = getenv("CS_DP_IPC_TIMEOUT_MS")) c->timeout_ms = atof(e);
     HIP_TRY(hipDeviceSynchronize());
     c->peer_buf[rank] = c->buf; c->peer_flags[rank] = c->flags;
     guard.p = nullptr;
@@ -1812,8 +1846,22 @@ int cs_dp_ipc_connect(cs_dp_ipc_t* c, const void* all_handles) {
         HIP_TRY(hipIpcOpenMemHandle((void**)&c->peer_buf[r], h[0], hipIpcMemLazyEnablePeerAccess));
         c->opened[r] = true;
         HIP_TRY(hipIpcOpenMemHandle((void**)&c->peer_flags[r], h[1], hipIpcMemLazyEnablePeerAccess));
+        // which device does the peer's buffer live on?  (its owner wrote the PCI bus id into its flag page)
+        char peer_id[64] = {};
+        HIP_TRY(hipMemcpy(peer_id, c->peer_flags[r] + CS_DP_IPC_ID_WORD, sizeof peer_id, hipMemcpyDeviceToHost));
+        peer_id[63] = 0;
+        const char* allow = getenv("CS_DP_IPC_MULTI_DEVICE");
+        if (strcmp(peer_id, c->dev_id) != 0 && !(allow && atoi(allow) == 1))
+            return fail(CS_ERR_STATE, "rank %d's exchange buffer lives on another device (%s, mine %s): the one-shot all-reduce has never run across "
+                                      "xGMI links - set CS_DP_IPC_MULTI_DEVICE=1 to try it, or use the RCCL collective (default)", r, peer_id, c->dev_id);
     }
     c->connected = true;
+    return CS_OK;
+}
+
+int cs_dp_ipc_set_timeout_ms(cs_dp_ipc_t* c, double ms) {
+    if (!c || !(ms > 0.0)) return fail(CS_ERR_INVALID, "bad argument");
+    c->timeout_ms = ms;
     return CS_OK;
 }
 
@@ -1832,7 +1880,8 @@ int cs_dp_ipc_allreduce(cs_dp_ipc_t* c, int64_t n_floats, void* stream) {
                     *reinterpret_cast<const volatile unsigned*>(c->err_host));
     IpcArgs a{};
     for (int r = 0; r < c->world; ++r) { a.buf[r] = c->peer_buf[r]; a.flags[r] = c->peer_flags[r]; }
-    a.arrive = c->arrive; a.err = c->err_dev; a.world = c->world; a.rank = c->rank; a.epoch = ++c->epoch; a.n = n_floats; a.spin_limit = c->spin_limit;
+    a.arrive = c->arrive; a.err = c->err_dev; a.world = c->world; a.rank = c->rank; a.epoch = ++c->epoch; a.n = n_floats;
+    a.timeout_ticks = (unsigned long long)(c->timeout_ms * 1e5);          // s_memrealtime counts at 100 MHz
     const int64_t pieces = (n_floats / 4 + c->world - 1) / c->world;
     const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(64, (pieces + 1023) / 1024));
     hipLaunchKernelGGL(k_dp_oneshot, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);

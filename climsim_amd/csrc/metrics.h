@@ -73,8 +73,10 @@ __global__ __launch_bounds__(256) void k_metrics_finish(double* __restrict__ acc
 
 // Keras' `accuracy` metric on a model with a multi-column output (compile(metrics=['accuracy']) with a (B,128) target
 // resolves to categorical_accuracy: argmax(y_true, -1) == argmax(y_pred, -1); step2_retrain.py:160-162).  One wave per
-// row; ties take the first maximum like tf.argmax.  count_dev += number of matching rows.
+// row; ties take the first maximum like tf.argmax.  count_dev += number of matching rows.  `row_idx` (or null): target row of
+// prediction row m (the training pass scores the batch it gathered by index).
 __global__ __launch_bounds__(256) void k_argmax_match(const float* __restrict__ pred, const float* __restrict__ target,
+                                                      const int64_t* __restrict__ row_idx,
                                                       int64_t n, int width, unsigned long long* __restrict__ count) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int64_t row = (int64_t)blockIdx.x * 4 + wid;
@@ -83,8 +85,9 @@ __global__ __launch_bounds__(256) void k_argmax_match(const float* __restrict__ 
     if (row < n) {
         float bp = -INFINITY, bt = -INFINITY;
         int ip = 0x7fffffff, it = 0x7fffffff;
+        const int64_t trow = row_idx ? row_idx[row] : row;
         for (int c = lane; c < width; c += 64) {
-            const float p = pred[row * width + c], t = target[row * width + c];
+            const float p = pred[row * width + c], t = target[trow * width + c];
             if (p > bp || (p == bp && c < ip)) { bp = p; ip = c; }
             if (t > bt || (t == bt && c < it)) { bt = t; it = c; }
         }

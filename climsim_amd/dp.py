@@ -98,7 +98,10 @@ class IpcComm:
     The ENGINE'S gradient buffer is rebound to the exchange buffer, so the collective works in place.  An option
     (`DataParallel(collective="oneshot")`, CS_DP_COLLECTIVE=oneshot): it has run with two processes on one device only."""
 
-    def __init__(self, dist, device, engine):
+    def __init__(self, dist, device, engine, timeout_ms: float | None = None):
+        """`timeout_ms`: wall-clock bound of every wait inside the collective (default 30 s, CS_DP_IPC_TIMEOUT_MS): ranks may be
+        skewed by a checkpoint, a validation pass or a lazy first-step build on one of them; align them with a barrier before
+        the first step (the constructor ends with one).  A wait that runs out is counted and fails the NEXT call."""
         import ctypes as C
         import torch
         from . import _lib
@@ -116,6 +119,8 @@ class IpcComm:
                     or self._lib.cs_dp_ipc_export(self._c, rec) != 0:
                 ok, err = 0, self._lib.cs_last_error().decode()
         self._agree(dist, device, ok, "exchange buffer setup failed", err)
+        if timeout_ms is not None:
+            self._check(self._lib.cs_dp_ipc_set_timeout_ms(self._c, float(timeout_ms)))
         import numpy as np
         xdev = device if dist.get_backend() == "nccl" else "cpu"          # the handle records travel through the rendezvous' own medium
         mine = torch.from_numpy(np.frombuffer(rec.raw, dtype=np.uint8).copy()).to(xdev)
@@ -155,13 +160,16 @@ class IpcComm:
 
     def close(self):
         if getattr(self, "_c", None) is not None and self._c.value:
-            if getattr(self, "tensor", None) is not None:
-                # the engine must not keep pointing into an allocation that is about to be freed: give it a torch tensor again
-                self._torch.cuda.synchronize()
-                self._engine.bind_gradient_tensor(self._torch.zeros(self._n_grad, dtype=self._torch.float32, device=self.tensor.device))
-                self.tensor = None
-            self._lib.cs_dp_ipc_destroy(self._c)
-            self._c = self._C.c_void_p()
+            try:
+                if getattr(self, "tensor", None) is not None:
+                    # the engine must not keep pointing into an allocation that is about to be freed: give it a torch tensor again
+                    # (an engine that was closed first raises here - the exchange buffer is freed all the same)
+                    self._torch.cuda.synchronize()
+                    dev, self.tensor = self.tensor.device, None
+                    self._engine.bind_gradient_tensor(self._torch.zeros(self._n_grad, dtype=self._torch.float32, device=dev))
+            finally:
+                self._lib.cs_dp_ipc_destroy(self._c)
+                self._c = self._C.c_void_p()
 
     def __del__(self):
         try:
@@ -177,14 +185,16 @@ def shard_of_batch(perm, step: int, global_batch: int, rank: int, world: int):
 
 
 class DataParallel:
-    def __init__(self, engine, dist=None, output_length: int = 128, grad_payload: str | None = None, collective: str | None = None):
+    def __init__(self, engine, dist=None, output_length: int = 128, grad_payload: str | None = None, collective: str | None = None,
+                 oneshot_timeout_ms: float | None = None):
         """`grad_payload`: "fp32" (default; what DDP in the reference sends) or "bf16" - the gradient sums cross the links
         as bf16 (half the bytes: 2.39 MB for the 5x512 MLP, 26.4 MB for the CNN) and are widened back before the optimiser,
         whose moments and master weights stay float32.  Every rank receives the same reduced buffer either way, so the
         replicas stay bit-identical to each other; against fp32 sums the update carries bf16 rounding of the gradient.
         Environment default: CS_DP_PAYLOAD.
         `collective`: "rccl" (default) or "oneshot" - the one-kernel all-reduce over peer-mapped buffers (IpcComm; one node,
-        at most 8 ranks, fp32 payload; an option until a measured scaling curve says otherwise).  Environment: CS_DP_COLLECTIVE."""
+        at most 8 ranks, fp32 payload; an option until a measured scaling curve says otherwise).  Environment: CS_DP_COLLECTIVE.
+        `oneshot_timeout_ms`: wall-clock bound of the one-shot collective's waits (default 30 s; IpcComm)."""
         self.engine, self.dist = engine, dist
         self.payload = grad_payload or os.environ.get("CS_DP_PAYLOAD", "fp32")
         if self.payload not in ("fp32", "bf16"):
@@ -202,7 +212,7 @@ class DataParallel:
         if self.collective == "oneshot" and dist is not None and getattr(self.grad, "is_cuda", False):
             if self.payload != "fp32":
                 raise ValueError("collective='oneshot' sums float32 (grad_payload='fp32')")
-            self.native = IpcComm(dist, self.grad.device, engine)     # raises on EVERY rank or on none
+            self.native = IpcComm(dist, self.grad.device, engine, timeout_ms=oneshot_timeout_ms)     # raises on EVERY rank or on none
             self.grad = engine.gradient_tensor()                      # now the exchange buffer
         elif dist is not None and getattr(self.grad, "is_cuda", False) and os.environ.get("CS_DP_NATIVE", "1") != "0":
             from ._lib import EngineError

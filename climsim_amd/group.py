@@ -111,8 +111,12 @@ class MLPGroup:
 
     def evaluate(self, x, y, batch_size: Optional[int] = None, normalise: bool = False):
         """model.evaluate of every member on the same held-out split, one launch per batch for the whole group:
-        [{'loss', 'mse', 'mae'}] per member (loss = mse; a member trained with 'mae' / 'huber' reports that loss in 'loss')."""
+        [{'loss', 'mse', 'mae'}] per member, `loss` = `mse` as MLPEmulator.evaluate reports it (the first sum of the heads'
+        epilogue: squared errors - SmoothL1 terms for a member built with loss='huber').  numpy / CPU inputs are moved to the
+        group's device once."""
         import torch
+        x = self.models[0]._to_device(x, self.models[0].input_length)
+        y = self.models[0]._to_device(y, self.models[0].output_length)
         bs = min(batch_size or min(m.max_batch for m in self.models), min(m.max_batch for m in self.models))
         tot = torch.zeros((self.k, 2), dtype=torch.float32, device=self.device)
         for i, lo in enumerate(range(0, x.shape[0], bs)):

@@ -402,7 +402,7 @@ class MLPEmulator:
             shuffle: bool = True, seed: int = 0, normalise: bool = False, csv_log: Optional[str] = None,
             checkpoint_best: Optional[str] = None, checkpoint_last: Optional[str] = None,
             early_stopping_patience: Optional[int] = None, steps_per_epoch: Optional[int] = None,
-            distributed: bool = False, verbose: int = 0):
+            distributed: bool = False, verbose: int = 0, train_accuracy: Optional[bool] = None):
         """model.fit on an HBM-resident split.
 
         The reference pipeline (step2_retrain.py:266-277) streams files through a windowed
@@ -420,7 +420,7 @@ class MLPEmulator:
         if validation_data is not None:
             val = (self._to_device(validation_data[0], self.input_length),
                    self._to_device(validation_data[1], self.output_length))
-        sched = learning_rate or ConstantLearningRate(1e-3)
+        sched = ConstantLearningRate(1e-3) if learning_rate is None else learning_rate
         if not callable(sched):
             sched = ConstantLearningRate(float(sched))
         from .dp import DataParallel, shard_of_batch
@@ -446,9 +446,15 @@ class MLPEmulator:
             history.update({k: [] for k in ("val_loss", "val_mse", "val_mae", "val_accuracy")})
         # keras.callbacks.CSVLogger writes `epoch` + the log keys in sorted order (step2_retrain.py:262; the reference's own
         # logs: baseline_models/ED/model/ED_ClimSIM_1_3.csv:1 `epoch,accuracy,loss,lr,mae,mse,val_accuracy,val_loss,val_mae,
-        # val_mse`) and "NA" for a key without a value: the training-pass `accuracy` (argmax match, meaningless for a
-        # regression) is not accumulated by the fused training kernels, `val_accuracy` is computed on the validation pass.
-        csv_keys = sorted(["accuracy", *history.keys()])
+        # val_mse`) and "NA" for a key without a value.  The training-pass `accuracy` (argmax match over the 128 outputs -
+        # meaningless for a regression, but a column of the reference's log) is counted by the engine when asked for
+        # (cs_mlp_set_train_accuracy: on by default when a CSV log is written), `val_accuracy` on the validation pass.
+        want_acc = bool(csv_log) if train_accuracy is None else bool(train_accuracy)
+        acc_count = torch.zeros(1, dtype=torch.int64, device=self.device) if want_acc else None
+        if want_acc:
+            history["accuracy"] = []
+            _lib.check(self.lib.cs_mlp_set_train_accuracy(self._h, _ptr(acc_count)))
+        csv_keys = sorted({"accuracy", *history.keys()})
         best, wait = math.inf, 0
         writer = None
         if csv_log and rank == 0:
@@ -465,6 +471,8 @@ class MLPEmulator:
                 lr = sched(self.iterations)
                 # one [sum sq err, sum abs err] slot per step, written by the engine: nothing is launched to add them up
                 step_loss = torch.zeros((steps, 2), dtype=torch.float32, device=self.device)
+                if want_acc:
+                    acc_count.zero_()
                 for s in range(steps):
                     lr = sched(self.iterations)
                     if distributed:
@@ -479,6 +487,11 @@ class MLPEmulator:
                 if self.cooperative:
                     self.check()         # a cooperative launch that timed out during the epoch fails the epoch, not the next checkpoint
                 row = {"loss": float(tr[0]), "mse": float(tr[0]), "mae": float(tr[1]), "lr": float(lr)}
+                if want_acc:
+                    hits = acc_count.clone()
+                    if distributed:
+                        dist.all_reduce(hits)
+                    row["accuracy"] = float(hits.item()) / (batch_size * steps)
                 if val is not None:
                     ev = self.evaluate(val[0], val[1], normalise=normalise, accuracy=True)
                     row.update({"val_loss": ev["loss"], "val_mse": ev["mse"], "val_mae": ev["mae"], "val_accuracy": ev["accuracy"]})
@@ -506,6 +519,8 @@ class MLPEmulator:
         finally:
             if writer:
                 f.close()
+            if want_acc:
+                self.lib.cs_mlp_set_train_accuracy(self._h, None)
             dp.close()                     # the engine's RCCL communicator never outlives the call, also on an exception
         return history
 

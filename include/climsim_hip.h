@@ -248,6 +248,12 @@ int cs_mlp_group_profile_step(cs_mlp_group_t* g, const float* const* x_dev, cons
                               const int64_t* const* row_idx_dev, const int64_t* n, int normalise, const float* lr,
                               float* loss_dev, void* stream, cs_kernel_times* out);
 
+/* Training-pass `accuracy` (the CSVLogger column `accuracy`, step2_retrain.py:160-162,262): with a non-null count_dev every later
+ * cs_mlp_train_step / cs_mlp_loss_grads also writes the predictions of its batch into an internal buffer and adds the number of rows
+ * with argmax(y_true) == argmax(y_pred) to *count_dev (the caller zeroes it per epoch; accuracy = count / rows seen).  Null switches
+ * it off again (the default: a regression has no use for it, and it costs 512 B of stores per column). */
+int cs_mlp_set_train_accuracy(cs_mlp_t* h, unsigned long long* count_dev);
+
 /* Keras' `accuracy` metric for a (B, width) regression target (compile(metrics=['mse','mae','accuracy']),
  * step2_retrain.py:160-162; for a multi-column target Keras resolves it to categorical_accuracy:
  * argmax(y_true, -1) == argmax(y_pred, -1), first maximum on ties).  *count_dev (+)= number of matching rows of
@@ -357,6 +363,10 @@ int  cs_dp_ipc_connect(cs_dp_ipc_t* c, const void* all_records);
 int  cs_dp_ipc_buffer(cs_dp_ipc_t* c, void** dev_ptr, int64_t* n_floats);
 int  cs_dp_ipc_allreduce(cs_dp_ipc_t* c, int64_t n_floats, void* stream);
 int64_t cs_dp_ipc_timeouts(const cs_dp_ipc_t* c);
+/* Bound of every wait inside cs_dp_ipc_allreduce in wall-clock milliseconds (default 30000, environment CS_DP_IPC_TIMEOUT_MS at
+ * creation): generous on purpose - rank skew from a checkpoint, a validation pass or a first-step build on one rank is not a
+ * fault of the collective; a wait that does run out is counted (cs_dp_ipc_timeouts) and fails the next call, never hangs. */
+int  cs_dp_ipc_set_timeout_ms(cs_dp_ipc_t* c, double ms);
 void cs_dp_ipc_destroy(cs_dp_ipc_t* c);
 
 const char* cs_last_error(void);

@@ -62,3 +62,45 @@ def test_bench_gpus_n_starts_its_own_ranks():
     assert r.returncode != 0
     assert "must be launched with torch.distributed.run" not in (r.stdout + r.stderr)
     assert (r.stdout + r.stderr).count("bench.py needs a GPU") >= 1
+
+
+def test_failure_reporter_prints_one_error_line_when_rank_zero_is_blocked(tmp_path):
+    """bench.py, N > 1 (round 4): a rank r > 0 that fails leaves its message and exits; the launcher then SIGTERMs rank 0, which may
+    be blocked in a C call where Python-level handlers never run - its watcher thread on the signal wake-up pipe prints the ONE
+    line (with "error" and the failed rank's message) and ends the process with a non-zero code.  No GPU involved."""
+    import signal
+    import subprocess
+    import sys
+    import time
+    child = tmp_path / "child.py"
+    child.write_text(
+        "import os, sys, time\n"
+        f"sys.path.insert(0, {REPO!r})\n"
+        "import bench\n"
+        "rank = int(sys.argv[1])\n"
+        "rep = bench.FailureReporter(rank, 2)\n"
+        "if rank == 1:\n"
+        "    try:\n"
+        "        raise RuntimeError('boom on rank 1')\n"
+        "    except RuntimeError as e:\n"
+        "        rep.fail(e)\n"
+        "print('ready', flush=True)\n"
+        "import ctypes\n"
+        "libc = ctypes.CDLL(None)\n"
+        "while True:\n"
+        "    libc.sleep(60)\n"                     # (a signal ends one sleep(); the main thread goes straight back into C)
+    )
+    # both "ranks" share this test process as their parent (as ranks share the launcher), hence one report directory
+    env = dict(os.environ, MASTER_PORT="45678")
+    r1 = subprocess.run([sys.executable, str(child), "1"], capture_output=True, text=True, env=env, timeout=120)
+    assert r1.returncode == 1 and "boom on rank 1" in r1.stderr
+    p0 = subprocess.Popen([sys.executable, str(child), "0"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+    assert p0.stdout.readline().strip() == "ready"
+    time.sleep(0.2)
+    p0.send_signal(signal.SIGTERM)
+    out, _ = p0.communicate(timeout=60)
+    assert p0.returncode == 1
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["value"] is None and d["n_gpus"] == 2 and "SIGTERM" in d["error"] and "boom on rank 1" in d["failed_ranks"]["1"]

@@ -15,12 +15,16 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FAST = ["--steps", "5", "--warmup", "2", "--min-seconds", "0.05", "--rows", "65536", "--cpu-budget", "0", "--no-extras"]
 
 
-def run(args, env_extra=None):
+def run_raw(args, env_extra=None):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
     env.update(env_extra or {})
-    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), *args], capture_output=True, text=True, env=env, timeout=900)
+    return subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), *args], capture_output=True, text=True, env=env, timeout=900)
+
+
+def run(args, env_extra=None):
+    r = run_raw(args, env_extra)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     return json.loads(r.stdout.strip().splitlines()[-1])
 
@@ -38,7 +42,7 @@ def test_one_gpu_line():
     # chain's time-out counter, and no output whose R2 is negative because a ReLU head died (synthetic_init)
     assert sum(k["ms_per_step"] for k in d["kernels"].values()) <= d["ms_per_step"] * 1.001
     assert 0 < d["kernels_note"]["scaled_by"] <= 1.0
-    assert d["coop_timeouts"] == 0 and "gpu_busy_percent" in d["timing"]
+    assert d["coop_timeouts"] == 0 and "gpu_busy_percent" not in d["timing"]      # round 4: the dead sysfs field is gone
     assert "ReLU-head bias" in d["config"]["init"]
 
 
@@ -75,3 +79,54 @@ def test_two_ranks_start_themselves_and_report_weak_strong_and_comm():
     assert c["nranks"] == 2 and c["bytes"] == 4787200 and c["allreduce_us_per_step"] > 0
     # the one-shot all-reduce over peer-mapped buffers is timed beside the collective in use (two processes on one device here)
     assert c["oneshot_ipc_error"] is None and c["allreduce_us_oneshot_ipc"] > 0
+
+
+def test_one_gpu_line_carries_the_batch_sweep():
+    """Round 4: SURVEY 8(d) config (2) names B in {1024, 8192, 65536}; the other two sizes ride in the driver's line (`sweep`),
+    measured after the headline's timed region on models of their own."""
+    d = run(["--steps", "5", "--warmup", "2", "--min-seconds", "0.05", "--rows", "65536", "--cpu-budget", "0", "--no-profile", "--extras", "sweep"])
+    sw = d["sweep"]
+    assert set(sw) == {"1024", "65536"}
+    for b, p in sw.items():
+        assert "error" not in p, p
+        assert p["per_gpu_batch"] == int(b) and p["blocks"] == 10 and p["steps_per_block"] == 5
+        assert p["value"] == pytest.approx(int(b) / (p["ms_per_step"] * 1e-3), rel=1e-3)
+        assert 0 < p["whole_step_frac"] < 1 and 0 < p["dominant_frac"] < 1 and p["dominant_kernel"].startswith("k_")
+        assert p["dominant_us"] <= p["ms_per_step"] * 1e3 * 1.001 and p["coop_timeouts"] == 0
+    assert sw["1024"]["cooperative_chain"] is True and sw["65536"]["cooperative_chain"] is False
+    assert sw["65536"]["value"] > sw["1024"]["value"]
+
+
+N2 = ["--gpus", "2", *FAST, "--no-profile", "--batch", "2048", "--weak-large-batch", "0"]
+
+
+def test_two_ranks_strong_leg_runs_plain_first_then_on_a_cooperative_model():
+    """Round 4 (first contact with N > 1): the strong leg runs WITHOUT the cooperative chain first and on a second model with it
+    after that (here, two ranks on one device, that model stays plain - the flow is what is tested), both reported."""
+    d = run([*N2, "--strong-global-batch", "4096"], {"CS_BENCH_SHARE_GPU": "1"})
+    s = d["strong"]
+    assert s["per_gpu_batch"] == 2048 and s["cooperative_chain"] is False and s["value"] > 0
+    c = s["with_cooperative_chain"]
+    assert "error" not in c, c
+    assert c["per_gpu_batch"] == 2048 and c["value"] > 0 and c["one_gpu_same_global_batch"]["value"] > 0
+    assert "rccl_comm_matches_nranks" in d["comm"]          # None here (gloo on one device); a boolean with the engine's RCCL communicator
+
+
+def test_two_ranks_a_failed_health_check_in_the_strong_leg_stays_inside_the_leg():
+    """A rank whose check fails between two blocks of the cooperative strong leg (what a timed-out cooperative launch looks like):
+    every rank leaves the leg together, the leg reports the error, the line and its weak value survive, exit code 0."""
+    d = run([*N2, "--strong-global-batch", "4096"], {"CS_BENCH_SHARE_GPU": "1", "CS_BENCH_INJECT_FAIL": "1:strong_coop_check"})
+    assert d["value"] > 0 and d["strong"]["value"] > 0
+    assert "injected failure on rank 1" in d["strong"]["with_cooperative_chain"]["error"]
+
+
+def test_two_ranks_a_rank_that_dies_ends_in_one_error_line_from_rank_zero():
+    """A rank that fails before the JSON line (here: rank 1 at start-up, while rank 0 waits in the rendezvous): rank 0 prints ONE
+    line with "error" - from its watcher thread, it is blocked itself - and the command exits non-zero."""
+    r = run_raw(N2, {"CS_BENCH_SHARE_GPU": "1", "CS_BENCH_INJECT_FAIL": "1:start"})
+    assert r.returncode != 0
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads(lines[-1])
+    assert d["value"] is None and d["n_gpus"] == 2 and d["error"]
+    assert "injected failure on rank 1" in d["failed_ranks"]["1"]

@@ -346,3 +346,80 @@ def test_cnn_full_size_training_is_stable(CNN):
     assert h["val_loss"][-1] < before["loss"]
     assert m.iterations == 40
     assert abs(h["lr"][0] - 1e-4) < 2e-6                     # 40 steps into a 1.68 M-step half cycle: still ~1e-4
+
+
+# ------------------------------------------------------------------------------------------------ the grid config 3 launches
+# Round 4 (review item 3): parity on the launch shape BASELINE configs[2] / hpo_train.py:294-336 actually uses - batch 512 =
+# 128 row tiles x 2 channel tiles = 256 workgroups, every XCD carrying in-launch stage hand-offs - not only on <= 20 workgroups.
+@pytest.fixture(scope="module")
+def full512(CNN):
+    depth, width, n = 12, 406, 512
+    ws = CO.glorot_cnn(seed=5, bias_scale=0.02, gain=0.8, depth=depth, channels=width)
+    x3, y3 = make_xy(n, 31)
+    m = CNN.CNNEmulator(depth=depth, channel_width=width, max_batch=n, trainable=True, loss="mae", dropout=0.175, seed=9)
+    m.set_weights(ws)
+    pred = m.predict(x3)                                         # inference mode (dropout off), the whole grid
+    got = m._losses(m.loss_grads(x3, y3).cpu().numpy(), n)       # training mode (dropout on)
+    grads = m.get_gradients(1.0 / (n * 60))
+    m.close()
+    return ws, x3, y3, pred, got, grads
+
+
+def test_cnn_batch512_loss_and_every_gradient_match_oracle(full512):
+    """(i) depth 12, width 406, batch 512, dropout 0.175, mae_adjusted: loss and every gradient tensor against torch autograd on the
+    CPU with the engine's bf16 rounding points and dropout hash (about a minute of host time).  Bars as at 4 columns
+    (test_cnn_full_depth_gradients): cosine >= 0.999 per tensor, norm within 5 %, losses within 1 %."""
+    ws, x3, y3, _, got, grads = full512
+    ref, gref = CO.loss_and_grads(ws, x3, y3, depth=12, loss="mae", rate=0.175, seed=9, bf16=True)
+    assert abs(got["mae_adjusted"] - ref["mae_adjusted"]) <= 1e-2 * ref["mae_adjusted"]
+    assert abs(got["mse_adjusted"] - ref["mse_adjusted"]) <= 1e-2 * ref["mse_adjusted"]
+    assert len(grads) == len(gref) == 12 * 6 + 6
+    worst = (1.0, 0, 1.0)
+    for i, (g, r) in enumerate(zip(grads, gref)):
+        assert g.shape == r.shape and np.all(np.isfinite(g))
+        c, ratio = cos_rel(g, r)
+        if c < worst[0]:
+            worst = (c, i, ratio)
+        assert c >= 0.999 and abs(ratio - 1) <= 0.05, (i, c, ratio)
+    from conftest import record_margin
+    record_margin("cnn_b512_worst_one_minus_cos", 1.0 - worst[0])
+    print("batch 512: worst cosine", worst)
+
+
+def test_cnn_batch512_predictions_of_scattered_columns_match_oracle(full512):
+    """(ii) rows are independent, so the oracle forward on 8 scattered columns of the batch (first / last row tile, tile borders,
+    both halves of the grid) is exact parity for the predictions of the whole 256-workgroup launch at no cost.  Depth-12 bar of
+    test_cnn_forward_matches_oracle: as close to the fp32 oracle as the bf16-emulating oracle is."""
+    ws, x3, _, pred, _, _ = full512
+    cols = np.array([0, 3, 4, 255, 256, 259, 380, 511])          # 240-row tiles = 4 columns: tile borders at multiples of 4
+    got = pred[cols]
+    ref16 = CO.forward(ws, x3[cols], depth=12, bf16=True)
+    ref32 = CO.forward(ws, x3[cols], depth=12, bf16=False)
+    assert rms_rel(got, ref32) <= 1.3 * rms_rel(ref16, ref32) + 1e-4
+    assert rms_rel(got, ref16) <= 3.0 * rms_rel(ref16, ref32) + 1e-4
+    for j in range(len(cols)):                                    # per column too: no single tile may be off
+        assert rms_rel(got[j], ref32[j]) <= 2.0 * rms_rel(ref16, ref32) + 2e-4, (int(cols[j]), rms_rel(got[j], ref32[j]))
+    assert np.all(np.isfinite(pred)) and np.all(pred[:, :, 2:] >= 0)
+
+
+def test_cnn_batch512_chained_launches_match_one_conv_per_launch(CNN, monkeypatch):
+    """(iii) the bit-identity of programs of convs (stage hand-offs through L2 + flags) with one conv per launch, on the full grid:
+    256 workgroups, 128 row-tile pairs handing over on every XCD (the round-3 test ran 37 columns = 10 row tiles)."""
+    depth, width, n = 12, 406, 512
+    ws = CO.glorot_cnn(seed=6, bias_scale=0.05, depth=depth, channels=width)
+    x3, y3 = make_xy(n, 33)
+    res = []
+    for fuse in ("1", "12"):
+        monkeypatch.setenv("CS_CNN_FUSE", fuse)
+        m = CNN.CNNEmulator(depth=depth, channel_width=width, max_batch=n, trainable=True, loss="mae", dropout=0.175, seed=3)
+        m.set_weights(ws)
+        pred = m.predict(x3)
+        sums = m.loss_grads(x3, y3).cpu().numpy()
+        res.append((pred, sums, m.get_gradients(1.0 / (n * 60))))
+        m.close()
+    np.testing.assert_array_equal(res[0][0], res[1][0])
+    np.testing.assert_allclose(res[0][1], res[1][1], rtol=1e-6)
+    for a, b in zip(res[0][2], res[1][2]):
+        # the weight-gradient kernel adds its partial sums with float atomics: only its inputs are bit-identical
+        c, ratio = cos_rel(a, b)
+        assert c >= 0.999999 and abs(ratio - 1) <= 1e-5

@@ -238,13 +238,21 @@ def test_fit_predict_evaluate_api(M, tmp_path):
     # keras.callbacks.CSVLogger layout (baseline_models/ED/model/ED_ClimSIM_1_3.csv:1): epoch + sorted log keys, "NA" where absent
     assert rows[0] == "epoch,accuracy,loss,lr,mae,mse,val_accuracy,val_loss,val_mae,val_mse" and len(rows) == 4
     last = dict(zip(rows[0].split(","), rows[-1].split(",")))
-    assert last["accuracy"] == "NA" and float(last["val_loss"]) == pytest.approx(hist["val_loss"][-1])
+    # round 4: the training-pass `accuracy` column is filled (cs_mlp_set_train_accuracy; "NA" in rounds 1-3)
+    assert 0.0 <= float(last["accuracy"]) <= 1.0 and float(last["accuracy"]) == pytest.approx(hist["accuracy"][-1])
+    assert float(last["val_loss"]) == pytest.approx(hist["val_loss"][-1])
     ev = m.evaluate(xv, yv, accuracy=True)
     pv = m.predict(xv)
     assert ev["accuracy"] == pytest.approx(float(np.mean(pv.argmax(1) == yv.argmax(1))), abs=1e-12)   # Keras categorical_accuracy
     assert float(last["val_accuracy"]) == pytest.approx(ev["accuracy"])
     after = m.evaluate(xv, yv, batch_size=100)                      # ragged batches
     assert after["loss"] == pytest.approx(hist["val_loss"][-1], rel=1e-4)
+    # the training-pass accuracy is Keras' categorical accuracy of the batches the steps predicted: with a zero learning rate
+    # (weights stand still) one epoch over the first 1024 rows must count exactly what predict + argmax count on those rows
+    h0 = m.fit(x[:1024], y[:1024], batch_size=256, epochs=1, learning_rate=0.0, shuffle=True, train_accuracy=True)
+    p0 = m.predict(x[:1024])
+    assert h0["accuracy"][0] == pytest.approx(float(np.mean(p0.argmax(1) == y[:1024].argmax(1))), abs=1e-12)
+    assert "accuracy" not in m.fit(x[:1024], y[:1024], batch_size=256, epochs=1, learning_rate=0.0)      # off without a CSV log
     pred = m.predict(xv, batch_size=300)
     assert np.mean((pred - yv) ** 2) == pytest.approx(after["mse"], rel=1e-3)
 
