@@ -321,6 +321,7 @@ struct WgradLayer {
     int wg_begin;                // first workgroup of this layer in the grouped grid
 };
 #define WGRAD_MAX_LAYERS 18
+#define CS_WGRAD_PARTS 2          // partial-sum buffers beside the gradient buffer (training steps with <= 3 row splits)
 struct WgradArgs {               // ALL layers of the step in one launch: grid.x = sum(tiles * splitk)
     int n_layers;
     WgradLayer L[WGRAD_MAX_LAYERS];
@@ -533,55 +534,72 @@ struct OptArgs {
 //   SGD     : w -= lr*g
 //   torch Adam (torch.optim.Adam, torch 2.x _single_tensor_adam; online_testing/.../train_mlp_h5loader.py:210-211):
 //            m.lerp_(g, 1-b1); v = v*b2 + (1-b2) g g; w -= (lr/(1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
-__device__ __forceinline__ void opt_update4(const OptArgs& a, int64_t i0, float (&wv)[4]) {
+// The update rule on four consecutive parameters at flat offset i0, given their UNSCALED gradient sums g (reads and writes P,
+// M, V; leaves the new weights in wv).  Shared by k_optimizer and by the weight-gradient kernel's fused tail (wgrad2.h).
+// One parameter: w, m, v in registers, g already scaled.  (One function for every caller, so that the vector form of k_optimizer,
+// the fused tail of the weight-gradient kernel and its one-per-lane bias update contract their multiply-adds identically.)
+__device__ __forceinline__ void opt_elem(const OptArgs& a, const float gv, float& w, float& m, float& v) {
+    if (a.kind == 3) {
+        w -= a.lr * gv;
+    } else if (a.kind == 2) {
+        v = a.rho * v + a.omrho * (gv * gv);
+        w -= (a.lr * gv) * (1.f / sqrtf(v + a.eps));
+    } else if (a.kind == 0) {
+        m += (gv - m) * a.omb1;
+        v += (gv * gv - v) * a.omb2;
+        w -= (m * a.alpha) / (sqrtf(v) + a.eps);
+    } else if (a.kind == 4) {   // torch.optim.Adam: alpha = lr / (1 - b1^t), bc2 = sqrt(1 - b2^t)
+        m += a.omb1 * (gv - m);
+        v = v * a.beta2 + (a.omb2 * gv) * gv;
+        w -= (a.alpha * m) / (sqrtf(v) / a.bc2 + a.eps);
+    } else {
+        m = a.beta1 * m + a.omb1 * gv;
+        v = a.beta2 * v + a.omb2 * (gv * gv);
+        const float mhat = m / a.bc1;
+        if (a.radam_rect) w -= a.lr * (a.radam_r * mhat / (sqrtf(v / a.bc2) + a.eps));
+        else w -= a.lr * mhat;
+    }
+}
+
+// The update rule on four consecutive parameters at flat offset i0, given their UNSCALED gradient sums g (reads and writes P,
+// M, V; leaves the new weights in wv).  Shared by k_optimizer and by the weight-gradient kernel's fused tail (wgrad2.h).
+__device__ __forceinline__ void opt_rule4(const OptArgs& a, int64_t i0, const float4 g, float (&wv)[4]) {
     const float4 w = *reinterpret_cast<const float4*>(a.P + i0);
     wv[0] = w.x; wv[1] = w.y; wv[2] = w.z; wv[3] = w.w;
-    if (a.recast_only) return;
+    const float gv[4] = {g.x * a.grad_scale, g.y * a.grad_scale, g.z * a.grad_scale, g.w * a.grad_scale};
+    float mv[4] = {0.f, 0.f, 0.f, 0.f}, vv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (a.kind != 3) { const float4 v4 = *reinterpret_cast<const float4*>(a.V + i0); vv[0] = v4.x; vv[1] = v4.y; vv[2] = v4.z; vv[3] = v4.w; }
+    if (a.kind != 3 && a.kind != 2) { const float4 m4 = *reinterpret_cast<const float4*>(a.M + i0); mv[0] = m4.x; mv[1] = m4.y; mv[2] = m4.z; mv[3] = m4.w; }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) opt_elem(a, gv[e], wv[e], mv[e], vv[e]);
+    if (a.kind != 3 && a.kind != 2) *reinterpret_cast<float4*>(a.M + i0) = make_float4(mv[0], mv[1], mv[2], mv[3]);
+    if (a.kind != 3) *reinterpret_cast<float4*>(a.V + i0) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+    *reinterpret_cast<float4*>(a.P + i0) = make_float4(wv[0], wv[1], wv[2], wv[3]);
+}
+
+__device__ __forceinline__ void opt_update4(const OptArgs& a, int64_t i0, float (&wv)[4]) {
+    if (a.recast_only) {
+        const float4 w = *reinterpret_cast<const float4*>(a.P + i0);
+        wv[0] = w.x; wv[1] = w.y; wv[2] = w.z; wv[3] = w.w;
+        return;
+    }
     float4 g = *reinterpret_cast<const float4*>(a.G + i0);
     for (int q = 0; q < a.gx_n; ++q) {
         const float4 e = *reinterpret_cast<const float4*>(a.Gx + q * a.gx_stride + i0);
         g.x += e.x; g.y += e.y; g.z += e.z; g.w += e.w;
     }
-    const float gv[4] = {g.x * a.grad_scale, g.y * a.grad_scale, g.z * a.grad_scale, g.w * a.grad_scale};
-    if (a.kind == 3) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) wv[e] -= a.lr * gv[e];
-    } else if (a.kind == 2) {
-        float4 v4 = *reinterpret_cast<const float4*>(a.V + i0);
-        float vv[4] = {v4.x, v4.y, v4.z, v4.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            vv[e] = a.rho * vv[e] + a.omrho * (gv[e] * gv[e]);
-            wv[e] -= (a.lr * gv[e]) * (1.f / sqrtf(vv[e] + a.eps));
-        }
-        *reinterpret_cast<float4*>(a.V + i0) = make_float4(vv[0], vv[1], vv[2], vv[3]);
-    } else {
-        float4 m4 = *reinterpret_cast<const float4*>(a.M + i0);
-        float4 v4 = *reinterpret_cast<const float4*>(a.V + i0);
-        float mv[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            if (a.kind == 0) {
-                mv[e] += (gv[e] - mv[e]) * a.omb1;
-                vv[e] += (gv[e] * gv[e] - vv[e]) * a.omb2;
-                wv[e] -= (mv[e] * a.alpha) / (sqrtf(vv[e]) + a.eps);
-            } else if (a.kind == 4) {   // torch.optim.Adam: alpha = lr / (1 - b1^t), bc2 = sqrt(1 - b2^t)
-                mv[e] += a.omb1 * (gv[e] - mv[e]);
-                vv[e] = vv[e] * a.beta2 + (a.omb2 * gv[e]) * gv[e];
-                wv[e] -= (a.alpha * mv[e]) / (sqrtf(vv[e]) / a.bc2 + a.eps);
-            } else {
-                mv[e] = a.beta1 * mv[e] + a.omb1 * gv[e];
-                vv[e] = a.beta2 * vv[e] + a.omb2 * (gv[e] * gv[e]);
-                const float mhat = mv[e] / a.bc1;
-                if (a.radam_rect) wv[e] -= a.lr * (a.radam_r * mhat / (sqrtf(vv[e] / a.bc2) + a.eps));
-                else wv[e] -= a.lr * mhat;
-            }
-        }
-        *reinterpret_cast<float4*>(a.M + i0) = make_float4(mv[0], mv[1], mv[2], mv[3]);
-        *reinterpret_cast<float4*>(a.V + i0) = make_float4(vv[0], vv[1], vv[2], vv[3]);
-    }
-    *reinterpret_cast<float4*>(a.P + i0) = make_float4(wv[0], wv[1], wv[2], wv[3]);
+    opt_rule4(a, i0, g, wv);
     *reinterpret_cast<float4*>(a.G + i0) = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// train_step's loss sums: add the stripes the chain kernels accumulated (loss_flush), hand them to the caller, zero the other slot
+__device__ __forceinline__ void opt_loss_handover(const OptArgs& a) {
+    float s0 = 0.f, s1 = 0.f;
+    for (int i = 0; i < LOSS_STRIPES; ++i) {
+        s0 += a.loss_src[i * LOSS_STRIPE_FLOATS]; s1 += a.loss_src[i * LOSS_STRIPE_FLOATS + 1];
+        a.loss_zero[i * LOSS_STRIPE_FLOATS] = 0.f; a.loss_zero[i * LOSS_STRIPE_FLOATS + 1] = 0.f;
+    }
+    a.loss_dst[0] = s0; a.loss_dst[1] = s1;
 }
 
 // One workgroup = one 32(k) x 32(n) tile of a weight tensor (or 1024 floats of a bias).  The updated tile goes through
@@ -591,14 +609,7 @@ __device__ __forceinline__ void opt_update4(const OptArgs& a, int64_t i0, float 
 // 16.7 us for 1.2 M parameters.)
 __device__ __forceinline__ void optimizer_body(const OptArgs& a, const int bid, u16 (*tile)[40]) {
     const int tid = threadIdx.x;
-    if (bid == 0 && tid == 0 && a.loss_dst) {
-        float s0 = 0.f, s1 = 0.f;
-        for (int i = 0; i < LOSS_STRIPES; ++i) {
-            s0 += a.loss_src[i * LOSS_STRIPE_FLOATS]; s1 += a.loss_src[i * LOSS_STRIPE_FLOATS + 1];
-            a.loss_zero[i * LOSS_STRIPE_FLOATS] = 0.f; a.loss_zero[i * LOSS_STRIPE_FLOATS + 1] = 0.f;
-        }
-        a.loss_dst[0] = s0; a.loss_dst[1] = s1;
-    }
+    if (bid == 0 && tid == 0 && a.loss_dst) opt_loss_handover(a);
     int s = 0;
     while (s + 1 < a.n_seg && bid >= a.seg[s + 1].blk_begin) ++s;
     const Segment sg = a.seg[s];

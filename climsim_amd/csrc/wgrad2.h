@@ -361,12 +361,158 @@ __device__ __forceinline__ bf16x8_t frag_w3(const u16* tile, int mb, int cb, int
     return u.v;
 }
 
+// ---- round 4: the optimiser folded into this kernel (one-call training step, tuned layer chain) ------------------------------
+// Inside cs_mlp_train_step the row splits of a tile used to STORE their partial sums and a k_optimizer launch added them up,
+// applied the update rule and re-cast the bf16 operand copies: 10.8 us + a kernel boundary at 8192 columns, for 43 MB of
+// traffic whose gradient part had just been written.  Now every compute WAVE (a 64 x 64 piece of a 128 x 128 tile) publishes its
+// partial sums write-through (`sc1`), waits for them (`vmcnt(0)`: they are in memory) and takes a ticket from the counter of its
+// piece; the wave that draws the LAST ticket (splitk - 1) fetches the other splits' partials (`sc1` loads: its own CU's L1 never
+// held these lines in this launch, and what the producers wrote went through to memory), adds them IN SPLIT ORDER - its own
+// contribution from LDS - so that the sum has the bits k_optimizer's `G + Gx[0] + Gx[1]` had, applies the rule (opt_rule4: the
+// same code), and writes P / M / V and both fragment-major operand copies of its 64 x 64 piece (8 + 8 blocks of 1 KiB, each
+// lying wholly inside the piece).  No wave ever waits for another: the last arriver exists by construction (a ticket per
+// arrival), so nothing can hang, and the pieces of one tile may be finished by waves of different workgroups.  The counters
+// return to zero inside the launch.  k_optimizer stays for the two-call (data-parallel) form, set_weights and every other path.
+struct WgradFuse {
+    int on;
+    unsigned* tickets;               // [tiles of all layers][4 waves], zero between launches
+    float* part0;                    // row split 0's partial sums (a buffer of its own: the gradient buffer G is not touched and stays zero)
+    OptArgs opt;                     // the step's scalars; P / M / V; loss hand-over (done by work id 0)
+    u16* Wf[WGRAD_MAX_LAYERS];       // fragment-major forward operand copy of every layer
+    u16* Wb[WGRAD_MAX_LAYERS];       // ... backward operand copy (null for layer 0)
+};
+
+__device__ __forceinline__ void st_sc1_f4(float* p, const float4 x) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4 v = {x.x, x.y, x.z, x.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void st_sc1_f1(float* p, const float x) { asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(x) : "memory"); }
+
+// `reg`: this wave's 16 KiB of the idle ring holding its four 32 x 32 result tiles as [(i * 2 + j)][row k][col n] floats.
+__device__ __forceinline__ void wgrad3_fused_tail(const WgradArgs& pa, const WgradFuse& fz, const WgradLayer& p, const int li, const int tile_id,
+                                                  const int split, const int k0, const int n0, const int wk, const int wn, const int wid,
+                                                  const int lane, float* reg, const float bias_sum, const bool do_bias) {
+    const int rr = lane >> 3, c4 = (lane & 7) * 4;
+    const int64_t w_off = p.dW - pa.g_base, b_off = p.db - pa.g_base;          // flat offsets of this layer's kernel / bias
+    auto buf_of = [&](int s) -> float* { return s == 0 ? fz.part0 : pa.part + (int64_t)(s - 1) * pa.part_stride; };
+    // (1) publish this split's partial sums, write-through
+    float* mine = buf_of(split);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int row = pass * 8 + rr;
+            const int k = k0 + wk * 64 + (t >> 1) * 32 + row;
+            const float4 v = *reinterpret_cast<const float4*>(reg + t * 1024 + row * 32 + c4);
+            if (k < p.k_real) st_sc1_f4(mine + w_off + (int64_t)k * p.N + n0 + wn * 64 + (t & 1) * 32 + c4, v);
+        }
+    const int nb = n0 + wn * 64 + wk * 32 + lane;                               // bias column of this lane (tiles with k0 == 0)
+    if (do_bias && lane < 32) st_sc1_f1(mine + b_off + nb, bias_sum);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                             // every store of this wave is in memory
+    // (2) ticket of this wave's piece
+    unsigned* tk = fz.tickets + ((unsigned)tile_id * 4u + (unsigned)wid);
+    unsigned ticket = 0;
+    if (lane == 0) ticket = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ticket = __builtin_amdgcn_readfirstlane(ticket);
+    if ((int)ticket != pa.splitk - 1) return;                                    // somebody else finishes this piece
+    if (lane == 0) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+    // (3) last arriver: sum in split order, update, re-cast
+    const OptArgs& a = fz.opt;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    static_assert(CS_WGRAD_PARTS == 2, "three partial-sum slots per pass are written out below");
+    float* const b0 = buf_of(0); float* const b1 = buf_of(1); float* const b2 = buf_of(2);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        // the other splits' partials of one 32 x 32 tile: all loads in flight together.  Named scalars (tied asm operands cannot be
+        // array elements: hipcc moves such arrays to scratch); slot s of pass p = o<p><s>, this wave's own slot stays zero.
+        f4 o00 = zero4, o01 = zero4, o02 = zero4, o10 = zero4, o11 = zero4, o12 = zero4, o20 = zero4, o21 = zero4, o22 = zero4, o30 = zero4, o31 = zero4, o32 = zero4;
+#define WG3F_LD(P, A0, A1, A2)                                                                                          \
+        {                                                                                                               \
+            const int k_ = min(k0 + wk * 64 + (t >> 1) * 32 + (P) * 8 + rr, p.k_real - 1);                              \
+            const int64_t off_ = w_off + (int64_t)k_ * p.N + n0 + wn * 64 + (t & 1) * 32 + c4;                          \
+            if (split != 0) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "+v"(A0) : "v"(b0 + off_) : "memory"); \
+            if (split != 1) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "+v"(A1) : "v"(b1 + off_) : "memory"); \
+            if (pa.splitk > 2 && split != 2) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "+v"(A2) : "v"(b2 + off_) : "memory"); \
+        }
+        WG3F_LD(0, o00, o01, o02) WG3F_LD(1, o10, o11, o12) WG3F_LD(2, o20, o21, o22) WG3F_LD(3, o30, o31, o32)
+#undef WG3F_LD
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(o00), "+v"(o01), "+v"(o02), "+v"(o10), "+v"(o11), "+v"(o12),
+                                              "+v"(o20), "+v"(o21), "+v"(o22), "+v"(o30), "+v"(o31), "+v"(o32) :: "memory");
+#define WG3F_UP(P, A0, A1, A2)                                                                                          \
+        {                                                                                                               \
+            const int row_ = (P) * 8 + rr;                                                                              \
+            const int k_ = k0 + wk * 64 + (t >> 1) * 32 + row_;                                                         \
+            float* slot_ = reg + t * 1024 + row_ * 32 + c4;                                                             \
+            const float4 own_ = *reinterpret_cast<const float4*>(slot_);                                                \
+            const float4 p0_ = split == 0 ? own_ : make_float4(A0[0], A0[1], A0[2], A0[3]);                             \
+            const float4 p1_ = split == 1 ? own_ : make_float4(A1[0], A1[1], A1[2], A1[3]);                             \
+            float4 g_ = make_float4(p0_.x + p1_.x, p0_.y + p1_.y, p0_.z + p1_.z, p0_.w + p1_.w);      /* ((p0 + p1) + p2): k_optimizer's order */ \
+            if (pa.splitk > 2) {                                                                                        \
+                const float4 p2_ = split == 2 ? own_ : make_float4(A2[0], A2[1], A2[2], A2[3]);                         \
+                g_.x += p2_.x; g_.y += p2_.y; g_.z += p2_.z; g_.w += p2_.w;                                             \
+            }                                                                                                           \
+            float wv_[4] = {0.f, 0.f, 0.f, 0.f};                                                                        \
+            if (k_ < p.k_real) opt_rule4(a, w_off + (int64_t)k_ * p.N + n0 + wn * 64 + (t & 1) * 32 + c4, g_, wv_);    \
+            *reinterpret_cast<float4*>(slot_) = make_float4(wv_[0], wv_[1], wv_[2], wv_[3]);   /* the piece's new weights (rows >= K: zeros) */ \
+        }
+        WG3F_UP(0, o00, o01, o02) WG3F_UP(1, o10, o11, o12) WG3F_UP(2, o20, o21, o22) WG3F_UP(3, o30, o31, o32)
+#undef WG3F_UP
+    }
+    if (do_bias && lane < 32) {
+        float v0 = bias_sum, v1 = bias_sum, v2 = bias_sum;
+        if (split != 0) asm volatile("global_load_dword %0, %1, off sc1" : "+v"(v0) : "v"(b0 + b_off + nb) : "memory");
+        if (split != 1) asm volatile("global_load_dword %0, %1, off sc1" : "+v"(v1) : "v"(b1 + b_off + nb) : "memory");
+        if (pa.splitk > 2 && split != 2) asm volatile("global_load_dword %0, %1, off sc1" : "+v"(v2) : "v"(b2 + b_off + nb) : "memory");
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(v0), "+v"(v1), "+v"(v2) :: "memory");
+        float g = v0 + v1;
+        if (pa.splitk > 2) g += v2;
+        const int64_t i0 = b_off + nb;                                            // one parameter per lane
+        float w = a.P[i0], m = a.kind == 3 || a.kind == 2 ? 0.f : a.M[i0], v = a.kind == 3 ? 0.f : a.V[i0];
+        opt_elem(a, g * a.grad_scale, w, m, v);
+        if (a.kind != 3 && a.kind != 2) a.M[i0] = m;
+        if (a.kind != 3) a.V[i0] = v;
+        a.P[i0] = w;
+    }
+    // (4) operand copies of the 64 x 64 piece (LDS operations of one wave complete in order: no barrier).  Forward blocks (k / 16,
+    // n / 32): lane L holds W[16 kb + 8 (L >> 5) + 0..7][n = L & 31]; backward blocks (n / 16, k / 32): W[k = L & 31][16 nb + 8 (L >> 5) + 0..7].
+    const int tiles_n = p.N >> 5, tiles_kp = p.tiles_k * 4;                      // 32-wide tiles along n / along the padded k
+    u16* Wf = fz.Wf[li]; u16* Wb = fz.Wb[li];
+    const int nl = lane & 31, h8 = 8 * (lane >> 5);
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)                                               // k16 blocks of the piece
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {                                            // n32 blocks
+            const int kl = kb * 16 + h8;                                         // first of 8 consecutive k inside the piece (0..63)
+            const float* src = reg + ((kl >> 5) * 2 + j) * 1024 + (kl & 31) * 32 + nl;
+            unsigned q[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) q[e] = cvt_pk_bf16(src[(2 * e) * 32], src[(2 * e + 1) * 32]);
+            const int64_t blk = (int64_t)((k0 + wk * 64) / 16 + kb) * tiles_n + (n0 + wn * 64) / 32 + j;
+            if (Wf) *reinterpret_cast<uint4*>(Wf + ((blk * 64 + lane) << 3)) = make_uint4(q[0], q[1], q[2], q[3]);
+        }
+    if (Wb) {
+#pragma unroll
+        for (int nbk = 0; nbk < 4; ++nbk)                                        // n16 blocks of the piece
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {                                        // k32 blocks
+                const int ncl = nbk * 16 + h8;                                   // first of 8 consecutive n inside the piece (0..63)
+                const float* src = reg + (i * 2 + (ncl >> 5)) * 1024 + nl * 32 + (ncl & 31);
+                const float4 lo = *reinterpret_cast<const float4*>(src), hi = *reinterpret_cast<const float4*>(src + 4);
+                const int64_t blk = (int64_t)((n0 + wn * 64) / 16 + nbk) * tiles_kp + (k0 + wk * 64) / 32 + i;
+                *reinterpret_cast<uint4*>(Wb + ((blk * 64 + lane) << 3)) =
+                    make_uint4(cvt_pk_bf16(lo.x, lo.y), cvt_pk_bf16(lo.z, lo.w), cvt_pk_bf16(hi.x, hi.y), cvt_pk_bf16(hi.z, hi.w));
+            }
+    }
+}
+
 // SLOTS ring slots of R-row stages (R x 128 columns of both operands).  R = 32: 16 KiB stages, 64 KiB ring, two workgroups per CU
 // (8 such slots, one workgroup per CU with seven stages requested ahead, measured 40.0 against 38.1 us at 8192 columns).
 // R = 64: 32 KiB stages, 128 KiB ring, one workgroup per CU - half the barriers, and the fragment reads of a stage's second
 // half run under the MFMAs of its first (with one compute wave per SIMD nothing else hides the LDS latency).
-template <int SLOTS, int R>
-__device__ __forceinline__ void wgrad3_body(const WgradArgs& pa, const int work, u16* ring) {
+template <int SLOTS, int R, bool FUSE = false>
+__device__ __forceinline__ void wgrad3_body(const WgradArgs& pa, const int work, u16* ring, const WgradFuse& fz) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wk = (wid >> 1) & 1, wn = wid & 1;
@@ -471,6 +617,21 @@ __device__ __forceinline__ void wgrad3_body(const WgradArgs& pa, const int work,
             for (int j = 0; j < 2; ++j) asm volatile("" :: "v"(acc[i][j]));
         return;
     }
+    if constexpr (FUSE) {
+        if (work == 0 && tid == 0 && fz.opt.loss_dst) opt_loss_handover(fz.opt);      // the chain kernel of this step has ended: its loss sums are final
+        float* reg = reinterpret_cast<float*>(ring) + wid * (4 * 32 * 32);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    reg[(i * 2 + j) * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = acc[i][j][r];
+        int tile_id = tile;
+        for (int l2 = 0; l2 < li; ++l2) tile_id += pa.L[l2].tiles_k * pa.L[l2].tiles_n;
+        wgrad3_fused_tail(pa, fz, p, li, tile_id, split, k0, n0, wk, wn, wid, lane, reg, accb[0], do_bias);
+        return;
+    }
     float* dW = p.dW; float* db = p.db;
     if (pa.plain && split > 0) {                                      // this row split's own buffer (WgradArgs.plain)
         float* mine = pa.part + (int64_t)(split - 1) * pa.part_stride;
@@ -523,7 +684,14 @@ __device__ __forceinline__ void wgrad3_body(const WgradArgs& pa, const int work,
 template <int SLOTS, int R>
 __global__ __launch_bounds__(WG3_THREADS) void k_wgrad3(const WgradArgs pa) {
     extern __shared__ __attribute__((aligned(16))) u16 ring[];    // [stage][H|Z][R][128]
-    wgrad3_body<SLOTS, R>(pa, xcd_work_id(blockIdx.x, gridDim.x), ring);
+    wgrad3_body<SLOTS, R>(pa, xcd_work_id(blockIdx.x, gridDim.x), ring, WgradFuse{});
+}
+
+// the same with the optimiser folded in (WgradFuse above): the one-call training step of the tuned layer chain
+template <int SLOTS, int R>
+__global__ __launch_bounds__(WG3_THREADS) void k_wgrad3_opt(const WgradArgs pa, const WgradFuse fz) {
+    extern __shared__ __attribute__((aligned(16))) u16 ring[];    // [stage][H|Z][R][128]
+    wgrad3_body<SLOTS, R, true>(pa, xcd_work_id(blockIdx.x, gridDim.x), ring, fz);
 }
 
 // K members in one launch (csrc/group.h): the grid is the concatenation of the members' grids; consecutive work ids
@@ -532,5 +700,5 @@ __global__ __launch_bounds__(WG3_THREADS) void k_wgrad3_group(const WgradArgs* _
     extern __shared__ __attribute__((aligned(16))) u16 ring[];
     const int work = xcd_work_id(blockIdx.x, gridDim.x);
     const int m = group_member(tab, work);
-    wgrad3_body<4, 32>(members[tab.idx[m]], work - tab.begin[m], ring);
+    wgrad3_body<4, 32>(members[tab.idx[m]], work - tab.begin[m], ring, WgradFuse{});
 }
