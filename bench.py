@@ -518,11 +518,11 @@ def timed_blocks(torch, dist, device, step, steps, first_step, min_seconds, max_
             except Exception as e:               # noqa: BLE001
                 err, msg = 1.0, f"{type(e).__name__}: {e}"
         if dist:
-            t = torch.tensor([el, err], dtype=torch.float64, device=device)
+            t = torch.tensor([el, err * (dist.get_rank() + 1)], dtype=torch.float64, device=device)      # (which rank: the highest that failed)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el, err = float(t[0].item()), float(t[1].item())
         if err:
-            raise LegFailed(msg or "another rank failed in this leg")
+            raise LegFailed(msg or "rank %d failed its health check in this leg" % (int(err) - 1))
         secs.append(el)
         it += steps
         # every rank sees the same (MAX-reduced) times, so all take the same decision

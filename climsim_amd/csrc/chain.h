@@ -70,6 +70,7 @@ struct ChainArgs {
                              // the forward half would sit in front of that half's weight stream: memory operations complete in order)
     int ablate;              // timing experiments only (CS_CHAIN_ABLATE): 4 no global stores, 8 no warm-up
     int store_nt;            // activations / gradients leave with the non-temporal policy (host: batches the L2s cannot hold anyway)
+    int trunk_i0, trunk_n;   // stages trunk_i0 .. trunk_i0 + trunk_n - 1 run as ONE continuous weight stream (chain_trunk; 0 / 0: off)
     unsigned long long* dbg; // optional [grid][64] s_memtime stamps (CS_CHAIN_DBG), null in production
 };
 
@@ -410,6 +411,142 @@ __device__ __forceinline__ void chain_stage(u16* X, const float* bias_lds, const
     chain_stamp(p, bid, tid, slot);
 }
 
+// ---- round 4: a run of 512-wide stages as ONE continuous weight stream ------------------------------------------------------
+// Per stage the chain used to: prime its queue (8 k16-steps, 16 KiB per wave), run the k-loop, barrier, epilogue, barrier - and
+// only then prime the next stage: nothing was in flight on the vector-memory pipe (the pipe that bounds a 32-row tile) while the
+// epilogue and the two barriers ran, and every stage began with the fill latency of its queue (tools/chain_stamps.py: 5.3 us per
+// 512 x 512 stage against 4.8 for the stream alone, plus 1.2 us of epilogue).  The attempt to prime stage s + 1 from inside stage s
+// died on hipcc copying queue registers across the per-stage template dispatch (see chain_stage).  Here the stages of a run have ONE
+// shape (every wave = all rows x 64 columns, contraction 128 or 512), so ONE function instance carries the queue from stage to stage:
+// the last 8 steps of stage s refill their slots with steps 0..7 of stage s + 1, which then fly under the epilogue, the mask
+// store and the barriers.  Everything this wave sends to memory between those loads and their first use is issued from `asm`
+// with a FIXED count (sign-mask store or load: 1; copy-out of the stage output: BM / 8 stores), so the first 8 waits of the next
+// stage are `vmcnt(2 * 7 + BM / 8 + 1)` exactly - a compiler-issued access in that window would make hipcc wait `vmcnt(0)` for
+// it somewhere, draining the queue.  Used by the training passes of ReLU / LeakyReLU models on 32-row tiles (the bench workload);
+// ELU (epilogue loads), prediction (no copies, no masks: other counts) and taller tiles keep chain_stage.
+template <int BMROWS>
+__device__ __forceinline__ void chain_copy_out512_asm(const u16* __restrict__ X, u16* __restrict__ out, int ldo, int64_t m0, int tid, bool nt) {
+#pragma unroll
+    for (int it = 0; it < BMROWS / 8; ++it) {                  // BMROWS x 64 16-byte pieces over 512 threads
+        const int g = tid + it * 512, r = g >> 6, c = g & 63;
+        const uint4 v = *reinterpret_cast<const uint4*>(X + r * CHAIN_PITCH + ((c ^ (r & 15)) << 3));
+        const u32x4_t vv = {v.x, v.y, v.z, v.w};
+        u16* dst = out + (m0 + r) * ldo + c * 8;
+        // (s_nop 1: nothing pads an asm store, and the next instruction may rewrite its data registers - cdna_hip_programming.md 5.7)
+        if (nt) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(dst), "v"(vv) : "memory");
+        else asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(vv) : "memory");
+    }
+}
+
+template <int BM, int EPI, bool ELU>
+__device__ __forceinline__ void chain_trunk(u16* X, const float* bias_lds, const ChainArgs& p, int bid, const int i0, const int cnt,
+                                            const int64_t m0, const int wid, const int tid, int& slot, ChainPending& pend) {
+    static_assert(BM == 32 && !ELU, "the counted window below is written for 32-row tiles without ELU");
+    constexpr int MT = BM / 32, NT = 2, D = 8;
+    constexpr int EXTRA = BM / 8 + 1;                          // asm memory operations between a stage's tail loads and the next stage's first wait
+    constexpr unsigned STEPB = 16 * 64 * 16;                   // bytes per k16-step of a 512-wide stage (16 column tiles of 1 KiB)
+    const int jt0 = wid * 2;
+    ChainQ Q;
+    f32x16_t acc[MT][NT];
+    bf16x8_t afA[MT], afB[MT];
+    // ONE block body serves every position in the run (hipcc keeps the queue in place only along a single path: with a body per
+    // variant - head of a continuing stage, main, tail with / without a next stage - it split the queue's live ranges and put
+    // v_mov copies of registers whose loads were still in flight on the edges between them).  What varies is scalar:
+    //   wmode  0: vmcnt(14) - slot d has landed when at most the 14 younger weight loads are outstanding
+    //          1: vmcnt(14 + EXTRA) - first block of a continuing stage: EXTRA younger asm operations sit behind the primed loads
+    //          2: vmcnt(14 - 2 d) - last block of the run: nothing is refilled, count down as chain_mma does
+    //   rbase  uniform byte address the slot of step d is refilled from, + d * STEPB: this stage's step s0 + 8 + d, or the NEXT
+    //          stage's step d (last block of a stage); 0 = no refill.  The per-lane part is one 32-bit offset (SADDR form).
+#define TR_AF(dst, dd, sbase)                                                                                  \
+    _Pragma("unroll") for (int a = 0; a < MT; ++a)                                                             \
+        dst[a] = *reinterpret_cast<const bf16x8_t*>(X + a * 32 * CHAIN_PITCH + aoff[(dd) & 7] + 16 * ((sbase) + ((dd) >> 3) * 8));
+#define TR_STEP(d, Q0, Q1, AC, AN)                                                                             \
+    {                                                                                                          \
+        TR_AF(AN, (d) + 1, s0)                                                                                 \
+        asm volatile("s_cmp_eq_u32 %2, 0\n\ts_cbranch_scc0 1f\n\ts_waitcnt vmcnt(%3)\n\ts_branch 3f\n"         \
+                     "1:\n\ts_cmp_eq_u32 %2, 1\n\ts_cbranch_scc0 2f\n\ts_waitcnt vmcnt(%4)\n\ts_branch 3f\n"   \
+                     "2:\n\ts_waitcnt vmcnt(%5)\n3:"                                                           \
+                     : "+v"(Q0), "+v"(Q1) : "s"(wmode), "i"(NT * (D - 1)), "i"(NT * (D - 1) + EXTRA), "i"(NT * (D - 1 - (d))) : "memory", "scc"); \
+        _Pragma("unroll") for (int a = 0; a < MT; ++a) {                                                       \
+            acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, Q0), AC[a], acc[a][0], 0, 0, 0); \
+            acc[a][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, Q1), AC[a], acc[a][1], 0, 0, 0); \
+        }                                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        {                                                                                                      \
+            const unsigned long long rb_ = rbase + (unsigned long long)((d) * STEPB);                          \
+            asm volatile("s_cmp_eq_u64 %3, 0\n\ts_cbranch_scc1 1f\n\ts_nop 2\n\t"                              \
+                         "global_load_dwordx4 %0, %2, %3" CHAIN_LOAD_MOD "\n\tglobal_load_dwordx4 %1, %2, %3 offset:1024" CHAIN_LOAD_MOD "\n1:" \
+                         : "+v"(Q0), "+v"(Q1) : "v"(voff), "s"(rb_) : "memory", "scc");                        \
+        }                                                                                                      \
+    }
+    for (int st = 0; st < cnt; ++st) {
+        const ChainStage& S = p.st[i0 + st];
+        const bool cont = st > 0, has_next = st + 1 < cnt, last = (i0 + st + 1 == p.n_stages);
+        const int ks = S.Kc >> 4;
+        // (everything derived from the lane id is recomputed per stage from an OPAQUE copy: hipcc otherwise hoists it out of the
+        //  stage loop and keeps it live across the whole kernel)
+        int lane = tid & 63;
+        asm volatile("" : "+v"(lane));
+        const int arow = lane & 31, ahalf = lane >> 5;
+        // A fragment of step s0 + d (s0 a multiple of 8): element offset arow * PITCH + (((2 (s0 + d) + ahalf) ^ (arow & 15)) << 3) =
+        // aoff[d] + 16 s0 - the XOR only touches the low four bits of the chunk index.  The look-ahead read behind a stage's last step
+        // is not clamped: it lands in the next row or in the bias block behind X, and its value is never used.
+        int aoff[8];
+#pragma unroll
+        for (int d = 0; d < 8; ++d) aoff[d] = arow * CHAIN_PITCH + (((2 * d + ahalf) ^ (arow & 15)) << 3);
+        const unsigned voff = (unsigned)(jt0 * 64 + lane) * 16u;                               // this lane's 16 bytes inside a k16-step
+        const unsigned long long own = (unsigned long long)(uintptr_t)S.wfrag;
+        const unsigned long long nxt = has_next ? (unsigned long long)(uintptr_t)p.st[i0 + st + 1].wfrag : 0ull;
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+            for (int b = 0; b < NT; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+        unsigned* mword = reinterpret_cast<unsigned*>(S.mask) + (int64_t)bid * 512 + tid;      // 32-row tiles: one sign word per thread and stage
+        unsigned mskw = 0u;
+        if (EPI == EPI_DGRAD) asm volatile("global_load_dword %0, %1, off" : "=v"(mskw) : "v"(mword) : "memory");   // (1 operation)
+        if (!cont) {
+            chain_prime_t<NT, D>(Q, S.wfrag, ks, 16, jt0, lane);
+            if (pend.out) {                                    // the stage in front of the run left its output to us: behind the priming loads, as chain_mma
+                chain_copy_out<BM>(X, pend.out, pend.ldo, pend.width, m0, tid, pend.nt != 0);
+                pend.out = nullptr;
+            }
+        } else {
+            // output of the previous stage of the run -> global memory (BM / 8 operations); its first weights have been in flight since that stage's tail
+            const ChainStage& Sp = p.st[i0 + st - 1];
+            chain_copy_out512_asm<BM>(X, Sp.out, Sp.ldo, m0, tid, p.store_nt != 0);
+        }
+        TR_AF(afA, 0, 0)
+        for (int s0 = 0; s0 < ks; s0 += D) {
+            const bool tail = s0 + D >= ks;
+            const int wmode = (cont && s0 == 0) ? 1 : ((tail && !has_next) ? 2 : 0);
+            const unsigned long long rbase = !tail ? own + (unsigned long long)(s0 + D) * STEPB : nxt;
+            TR_STEP(0, Q.q00, Q.q01, afA, afB) TR_STEP(1, Q.q10, Q.q11, afB, afA)
+            TR_STEP(2, Q.q20, Q.q21, afA, afB) TR_STEP(3, Q.q30, Q.q31, afB, afA)
+            TR_STEP(4, Q.q40, Q.q41, afA, afB) TR_STEP(5, Q.q50, Q.q51, afB, afA)
+            TR_STEP(6, Q.q60, Q.q61, afA, afB) TR_STEP(7, Q.q70, Q.q71, afB, afA)
+        }
+        if (EPI == EPI_DGRAD) asm volatile("" : "+v"(mskw));   // landed long ago (older than every weight load waited for above)
+        __syncthreads();                                       // every wave has finished reading X for this stage
+        chain_stamp(p, bid, tid, slot);
+        u32x4_t msk = u32x4_t{mskw, 0u, 0u, 0u};
+        chain_epilogue<MT, NT, EPI, ELU>(X, bias_lds, p, S, last, m0, jt0, 0, lane, acc, msk);
+        if (EPI == EPI_HIDDEN) {                               // (1 operation)
+            const unsigned mw = msk[0];
+            asm volatile("global_store_dword %0, %1, off\n\ts_nop 1" ::"v"(mword), "v"(mw) : "memory");
+        }
+        __syncthreads();                                       // X now holds this stage's output
+        if (!has_next) {
+            if (last) chain_copy_out<BM>(X, S.out, S.ldo, S.Nc, m0, tid, p.store_nt != 0);      // nobody comes after: copy now
+            else pend = ChainPending{S.out, S.ldo, S.Nc, p.store_nt};                          // the stage behind the run copies it
+        }
+        chain_stamp(p, bid, tid, slot);
+    }
+#undef TR_AF
+#undef TR_STEP
+}
+
 // dynamic LDS: [BM][CHAIN_PITCH] bf16 activations | CHAIN_MAX_BIAS floats | BM int64 row indices
 template <int BM>
 constexpr int chain_lds_bytes() { return BM * CHAIN_PITCH * 2 + CHAIN_MAX_BIAS * 4 + BM * 8; }
@@ -521,6 +658,13 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const ChainDyn& d
     float sq = 0.f, ab = 0.f;
     ChainPending pend{nullptr, 0, 0, 0};
     for (int i = 0; i < p.n_stages; ++i) {
+        if constexpr (BM == 32 && !ELU) {
+            if (p.trunk_n > 1 && i == p.trunk_i0) {            // a run of 512-wide stages as one continuous weight stream (chain_trunk)
+                chain_trunk<BM, BWD ? EPI_DGRAD : EPI_HIDDEN, ELU>(X, bias_lds, p, bid, i, p.trunk_n, m0, wid, tid, slot, pend);
+                i += p.trunk_n - 1;
+                continue;
+            }
+        }
         const ChainStage& S = p.st[i];
         const bool last = (i + 1 == p.n_stages);
         constexpr int E = BWD ? EPI_DGRAD : EPI_HIDDEN;

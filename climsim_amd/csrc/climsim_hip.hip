@@ -329,6 +329,29 @@ int chain_bm_of(int flags, int n_cu, int64_t n) {
 
 int chain_bm(const cs_mlp* h, int64_t n) { return chain_bm_of(h->cfg.flags, h->n_cu, n); }
 
+// Longest run of stages that chain_trunk (chain.h) can carry as one continuous weight stream: 512-wide hidden / dgrad stages that
+// store their output and a sign mask (training passes), contraction a multiple of 128, and 256 or more for every stage behind the
+// first (its first 8 k16-steps are requested by the stage in front, the next 8 by its own head block).
+void chain_find_trunk(const cs_mlp* h, ChainArgs& c) {
+    c.trunk_i0 = 0; c.trunk_n = 0;
+    static const bool off = getenv("CS_CHAIN_TRUNK") && atoi(getenv("CS_CHAIN_TRUNK")) == 0;
+    if (off || h->cfg.act == CS_ACT_ELU || c.ablate || c.mask_bm64) return;
+    int best0 = 0, bestn = 0;
+    for (int i = 0; i < c.n_stages;) {
+        int n = 0;
+        while (i + n < c.n_stages) {
+            const ChainStage& S = c.st[i + n];
+            const bool ok = S.Nc == 512 && (S.epi == EPI_HIDDEN || S.epi == EPI_DGRAD) && S.out && S.mask && S.ldo == 512 && (S.Kc % 128) == 0 && S.Kc <= 512 &&
+                            (n == 0 || S.Kc >= 256);
+            if (!ok) break;
+            ++n;
+        }
+        if (n > bestn) { best0 = i; bestn = n; }
+        i += n > 0 ? n : 1;
+    }
+    if (bestn > 1) { c.trunk_i0 = best0; c.trunk_n = bestn; }
+}
+
 // The same for the wide chain (k_chainw: act' from the global activation copies, any output width).
 void chainw_bwd_args(const cs_mlp* h, int64_t n, ChainArgs& c) {
     c.n_stages = h->L - 1;
@@ -358,6 +381,7 @@ void chain_bwd_args(const cs_mlp* h, int64_t n, ChainArgs& c) {
     c.store_nt = n >= h->chain_nt_min ? 1 : 0;
     c.dz_in = h->layers[h->L - 1].dZ; c.ld_dz_in = 128; c.w_in = 128;
     c.n_rows = n; c.act = h->cfg.act; c.slope = (h->cfg.act == CS_ACT_RELU) ? 0.f : h->cfg.alpha;
+    chain_find_trunk(h, c);
 }
 
 // Forward layer chain (tuned or wide): stage i <-> layer i.
@@ -374,7 +398,7 @@ void chain_fwd_args(const cs_mlp* h, bool wide, const float* x, const int64_t* r
         if (l + 1 < h->L) { S.out = want_dz ? h->layers[l + 1].H : nullptr; S.ldo = h->layers[l + 1].Kp; S.epi = EPI_HIDDEN; S.mask = want_dz ? ly.mask : nullptr; }      // (null for ELU models on the wide chain: never allocated)
         else { S.out = nullptr; S.ldo = 0; S.epi = EPI_OUT; S.mask = nullptr; }
     }
-    if (!wide) { c.ablate = h->chain_ablate; c.dbg = h->dbg; c.store_nt = n >= h->chain_nt_min ? 1 : 0; }
+    if (!wide) { c.ablate = h->chain_ablate; c.dbg = h->dbg; c.store_nt = n >= h->chain_nt_min ? 1 : 0; chain_find_trunk(h, c); }
     c.x = x; c.row_idx = row_idx; c.n_in = h->cfg.n_in; c.kp0 = l0.Kp; c.sub = h->sub; c.div = h->div;
     c.normalise = normalise; c.h0 = want_dz ? l0.H : nullptr; c.ldh0 = l0.Kp; c.n_rows = n;
     c.act = h->cfg.act; c.slope = (h->cfg.act == CS_ACT_RELU) ? 0.f : h->cfg.alpha;
@@ -530,7 +554,7 @@ int run_backward(cs_mlp* h, int64_t n, bool atomics_needed, hipStream_t st) {
         const bool forced = h->cfg.flags & (CS_FLAG_CHAIN_BM32 | CS_FLAG_CHAIN_BM64 | CS_FLAG_CHAIN_BM128);
         static const int64_t hybrid_max = getenv("CS_CHAIN_HYBRID_MAX") ? atoll(getenv("CS_CHAIN_HYBRID_MAX")) : 0;
         if ((bm == 64 && !forced && n <= hybrid_max && h->cfg.act != CS_ACT_ELU) || (h->cfg.flags & CS_FLAG_CHAIN_BWD32_ON_FWD64)) {
-            bm = 32; c.mask_bm64 = 1;
+            bm = 32; c.mask_bm64 = 1; c.trunk_n = 0;
         }
         ProfScope ps(CS_K_CHAIN_BWD, st);
         launch_chain<true>(h, bm, m_pad, c, st);

@@ -577,6 +577,14 @@ __device__ __forceinline__ void opt_rule4(const OptArgs& a, int64_t i0, const fl
     *reinterpret_cast<float4*>(a.P + i0) = make_float4(wv[0], wv[1], wv[2], wv[3]);
 }
 
+// The rule on values already in registers (the fused tail of the weight-gradient kernel loads P / M / V of many parameters up front).
+__device__ __forceinline__ void opt_rule4v(const OptArgs& a, const float4 g, float4& w, float4& m, float4& v) {
+    opt_elem(a, g.x * a.grad_scale, w.x, m.x, v.x);
+    opt_elem(a, g.y * a.grad_scale, w.y, m.y, v.y);
+    opt_elem(a, g.z * a.grad_scale, w.z, m.z, v.z);
+    opt_elem(a, g.w * a.grad_scale, w.w, m.w, v.w);
+}
+
 __device__ __forceinline__ void opt_update4(const OptArgs& a, int64_t i0, float (&wv)[4]) {
     if (a.recast_only) {
         const float4 w = *reinterpret_cast<const float4*>(a.P + i0);

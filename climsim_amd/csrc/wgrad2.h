@@ -385,9 +385,11 @@ struct WgradFuse {
 __device__ __forceinline__ void st_sc1_f4(float* p, const float4 x) {
     typedef float f4 __attribute__((ext_vector_type(4)));
     const f4 v = {x.x, x.y, x.z, x.w};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    // (the trailing s_nop: hipcc pads nothing behind an asm store, and its next instruction may rewrite the data registers before the
+    //  store has read them - cdna_hip_programming.md section 5.7)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
-__device__ __forceinline__ void st_sc1_f1(float* p, const float x) { asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(x) : "memory"); }
+__device__ __forceinline__ void st_sc1_f1(float* p, const float x) { asm volatile("global_store_dword %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(x) : "memory"); }
 
 // `reg`: this wave's 16 KiB of the idle ring holding its four 32 x 32 result tiles as [(i * 2 + j)][row k][col n] floats.
 __device__ __forceinline__ void wgrad3_fused_tail(const WgradArgs& pa, const WgradFuse& fz, const WgradLayer& p, const int li, const int tile_id,
@@ -417,47 +419,73 @@ __device__ __forceinline__ void wgrad3_fused_tail(const WgradArgs& pa, const Wgr
     ticket = __builtin_amdgcn_readfirstlane(ticket);
     if ((int)ticket != pa.splitk - 1) return;                                    // somebody else finishes this piece
     if (lane == 0) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
-    // (3) last arriver: sum in split order, update, re-cast
+    // (3) last arriver: sum in split order, update, re-cast.  ONE wave works here, so what it keeps in flight is the tail's speed
+    // (the first form - 8 loads, wait, then 3 dependent loads per float4 - took 40 us where k_optimizer's 1200 workgroups take 10):
+    // per half of the piece (two 32 x 32 tiles = 8 float4 per lane) all 16 partial-sum loads and all 24 P / M / V loads go out before
+    // anything is waited for (160 VGPRs; the accumulators are dead by now).
     const OptArgs& a = fz.opt;
     typedef float f4 __attribute__((ext_vector_type(4)));
     const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    static_assert(CS_WGRAD_PARTS == 2, "three partial-sum slots per pass are written out below");
+    static_assert(CS_WGRAD_PARTS == 2, "three partial-sum slots per item are written out below");
     float* const b0 = buf_of(0); float* const b1 = buf_of(1); float* const b2 = buf_of(2);
+    const bool three = pa.splitk > 2;
+    // the two OTHER splits' buffers (with two splits: the other one, twice - the second value is not used)
+    float* const oa = split == 0 ? b1 : b0;
+    float* const ob = split == 2 ? b1 : (three ? b2 : oa);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        // the other splits' partials of one 32 x 32 tile: all loads in flight together.  Named scalars (tied asm operands cannot be
-        // array elements: hipcc moves such arrays to scratch); slot s of pass p = o<p><s>, this wave's own slot stays zero.
-        f4 o00 = zero4, o01 = zero4, o02 = zero4, o10 = zero4, o11 = zero4, o12 = zero4, o20 = zero4, o21 = zero4, o22 = zero4, o30 = zero4, o31 = zero4, o32 = zero4;
-#define WG3F_LD(P, A0, A1, A2)                                                                                          \
-        {                                                                                                               \
-            const int k_ = min(k0 + wk * 64 + (t >> 1) * 32 + (P) * 8 + rr, p.k_real - 1);                              \
-            const int64_t off_ = w_off + (int64_t)k_ * p.N + n0 + wn * 64 + (t & 1) * 32 + c4;                          \
-            if (split != 0) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "+v"(A0) : "v"(b0 + off_) : "memory"); \
-            if (split != 1) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "+v"(A1) : "v"(b1 + off_) : "memory"); \
-            if (pa.splitk > 2 && split != 2) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "+v"(A2) : "v"(b2 + off_) : "memory"); \
+    for (int half = 0; half < 2; ++half) {
+        // named scalars: tied asm operands cannot be array elements (hipcc moves such arrays to scratch).  x<i> / y<i>: item i = (tile
+        // 2 * half + (i >> 2), pass i & 3) of the other splits' buffers oa / ob.
+        f4 x0 = zero4, x1 = zero4, x2 = zero4, x3 = zero4, x4 = zero4, x5 = zero4, x6 = zero4, x7 = zero4;
+        f4 y0 = zero4, y1 = zero4, y2 = zero4, y3 = zero4, y4 = zero4, y5 = zero4, y6 = zero4, y7 = zero4;
+        int64_t off[8]; bool live[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int t = 2 * half + (i >> 2), row = (i & 3) * 8 + rr;
+            const int k = k0 + wk * 64 + (t >> 1) * 32 + row;
+            live[i] = k < p.k_real;
+            off[i] = w_off + (int64_t)min(k, p.k_real - 1) * p.N + n0 + wn * 64 + (t & 1) * 32 + c4;
         }
-        WG3F_LD(0, o00, o01, o02) WG3F_LD(1, o10, o11, o12) WG3F_LD(2, o20, o21, o22) WG3F_LD(3, o30, o31, o32)
+#define WG3F_LD(I, XA, YA)                                                                                   \
+        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "+v"(XA) : "v"(oa + off[I]) : "memory");        \
+        if (three) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "+v"(YA) : "v"(ob + off[I]) : "memory");
+        WG3F_LD(0, x0, y0) WG3F_LD(1, x1, y1) WG3F_LD(2, x2, y2) WG3F_LD(3, x3, y3)
+        WG3F_LD(4, x4, y4) WG3F_LD(5, x5, y5) WG3F_LD(6, x6, y6) WG3F_LD(7, x7, y7)
 #undef WG3F_LD
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(o00), "+v"(o01), "+v"(o02), "+v"(o10), "+v"(o11), "+v"(o12),
-                                              "+v"(o20), "+v"(o21), "+v"(o22), "+v"(o30), "+v"(o31), "+v"(o32) :: "memory");
-#define WG3F_UP(P, A0, A1, A2)                                                                                          \
-        {                                                                                                               \
-            const int row_ = (P) * 8 + rr;                                                                              \
-            const int k_ = k0 + wk * 64 + (t >> 1) * 32 + row_;                                                         \
-            float* slot_ = reg + t * 1024 + row_ * 32 + c4;                                                             \
-            const float4 own_ = *reinterpret_cast<const float4*>(slot_);                                                \
-            const float4 p0_ = split == 0 ? own_ : make_float4(A0[0], A0[1], A0[2], A0[3]);                             \
-            const float4 p1_ = split == 1 ? own_ : make_float4(A1[0], A1[1], A1[2], A1[3]);                             \
-            float4 g_ = make_float4(p0_.x + p1_.x, p0_.y + p1_.y, p0_.z + p1_.z, p0_.w + p1_.w);      /* ((p0 + p1) + p2): k_optimizer's order */ \
-            if (pa.splitk > 2) {                                                                                        \
-                const float4 p2_ = split == 2 ? own_ : make_float4(A2[0], A2[1], A2[2], A2[3]);                         \
-                g_.x += p2_.x; g_.y += p2_.y; g_.z += p2_.z; g_.w += p2_.w;                                             \
-            }                                                                                                           \
-            float wv_[4] = {0.f, 0.f, 0.f, 0.f};                                                                        \
-            if (k_ < p.k_real) opt_rule4(a, w_off + (int64_t)k_ * p.N + n0 + wn * 64 + (t & 1) * 32 + c4, g_, wv_);    \
-            *reinterpret_cast<float4*>(slot_) = make_float4(wv_[0], wv_[1], wv_[2], wv_[3]);   /* the piece's new weights (rows >= K: zeros) */ \
+        float4 pw[8], pm[8], pv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            pw[i] = *reinterpret_cast<const float4*>(a.P + off[i]);
+            pm[i] = (a.kind == 3 || a.kind == 2) ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(a.M + off[i]);
+            pv[i] = a.kind == 3 ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(a.V + off[i]);
         }
-        WG3F_UP(0, o00, o01, o02) WG3F_UP(1, o10, o11, o12) WG3F_UP(2, o20, o21, o22) WG3F_UP(3, o30, o31, o32)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7),
+                                              "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3), "+v"(y4), "+v"(y5), "+v"(y6), "+v"(y7) :: "memory");
+#define WG3F_UP(I, XA, YA)                                                                                   \
+        {                                                                                                     \
+            const int t_ = 2 * half + ((I) >> 2), row_ = ((I) & 3) * 8 + rr;                                  \
+            float* slot_ = reg + t_ * 1024 + row_ * 32 + c4;                                                  \
+            const float4 own_ = *reinterpret_cast<const float4*>(slot_);                                      \
+            const float4 xa_ = make_float4(XA[0], XA[1], XA[2], XA[3]), yb_ = make_float4(YA[0], YA[1], YA[2], YA[3]); \
+            /* ((p0 + p1) + p2): k_optimizer's order.  oa / ob hold the other splits in ascending order */    \
+            const float4 p0_ = split == 0 ? own_ : xa_;                                                       \
+            const float4 p1_ = split == 1 ? own_ : (split == 0 ? xa_ : yb_);                                  \
+            float4 g_ = make_float4(p0_.x + p1_.x, p0_.y + p1_.y, p0_.z + p1_.z, p0_.w + p1_.w);              \
+            if (three) {                                                                                      \
+                const float4 p2_ = split == 2 ? own_ : yb_;                                                   \
+                g_.x += p2_.x; g_.y += p2_.y; g_.z += p2_.z; g_.w += p2_.w;                                   \
+            }                                                                                                 \
+            float4 w_ = pw[I], m_ = pm[I], v_ = pv[I];                                                        \
+            opt_rule4v(a, g_, w_, m_, v_);                                                                    \
+            if (live[I]) {                                                                                    \
+                if (a.kind != 3 && a.kind != 2) *reinterpret_cast<float4*>(a.M + off[I]) = m_;                \
+                if (a.kind != 3) *reinterpret_cast<float4*>(a.V + off[I]) = v_;                               \
+                *reinterpret_cast<float4*>(a.P + off[I]) = w_;                                                \
+            } else w_ = make_float4(0.f, 0.f, 0.f, 0.f);                  /* rows >= K: zeros in the operand copies */ \
+            *reinterpret_cast<float4*>(slot_) = w_;                       /* the piece's new weights */       \
+        }
+        WG3F_UP(0, x0, y0) WG3F_UP(1, x1, y1) WG3F_UP(2, x2, y2) WG3F_UP(3, x3, y3)
+        WG3F_UP(4, x4, y4) WG3F_UP(5, x5, y5) WG3F_UP(6, x6, y6) WG3F_UP(7, x7, y7)
 #undef WG3F_UP
     }
     if (do_bias && lane < 32) {

@@ -114,8 +114,9 @@ def test_optimiser_folded_into_the_weight_gradient_launch_is_bit_identical(M, n,
     """Round 4: inside cs_mlp_train_step the last-arriving wave of every 64 x 64 piece of a weight-gradient tile adds the row
     splits' partial sums in split order, applies the update rule and re-casts both fragment-major operand copies (WgradFuse,
     csrc/wgrad2.h) - no k_optimizer launch.  CS_WGRAD_FUSE_OPT=0 keeps the launch.  Same sums in the same order through the
-    same rule (opt_rule4 / opt_elem), so after six steps the two models must agree BIT FOR BIT: loss sums, weights, both
-    optimiser slots, and - through the bf16 operand copies - predictions; the gradient buffer is handed back zeroed by both.
+    same rule (opt_elem), so after six steps the two models must agree BIT FOR BIT: weights, both optimiser slots, and - through
+    the bf16 operand copies - predictions (the loss sums come from float atomics over 256 workgroups: equal to rounding); the
+    gradient buffer is handed back zeroed by both.
     Sizes: 3 row splits (8192, 4096), 2 (1024), a ragged batch (3000)."""
     cfg = O.MLPConfig(hidden=CFG)
     ws = O.glorot_init(cfg, 5)
@@ -133,7 +134,7 @@ def test_optimiser_folded_into_the_weight_gradient_launch_is_bit_identical(M, n,
         perm = torch.randperm(n, device="cuda", generator=torch.Generator(device="cuda").manual_seed(it))
         la = a.train_on_batch(xd, yd, 1e-3, row_idx=perm).cpu().numpy()
         lb = b.train_on_batch(xd, yd, 1e-3, row_idx=perm).cpu().numpy()
-        np.testing.assert_array_equal(la, lb)
+        np.testing.assert_allclose(la, lb, rtol=1e-6)
     assert float(a.gradient_tensor().abs().max()) == 0.0 and float(b.gradient_tensor().abs().max()) == 0.0
     for wa, wb, w0 in zip(a.get_weights(), b.get_weights(), ws):
         np.testing.assert_array_equal(wa, wb)
