@@ -456,7 +456,8 @@ __device__ __forceinline__ void chain_trunk(u16* X, const float* bias_lds, const
     //          1: vmcnt(14 + EXTRA) - first block of a continuing stage: EXTRA younger asm operations sit behind the primed loads
     //          2: vmcnt(14 - 2 d) - last block of the run: nothing is refilled, count down as chain_mma does
     //   rbase  uniform byte address the slot of step d is refilled from, + d * STEPB: this stage's step s0 + 8 + d, or the NEXT
-    //          stage's step d (last block of a stage); 0 = no refill.  The per-lane part is one 32-bit offset (SADDR form).
+    //          stage's step d (last block of a stage); `refill` = 0: none (last block of the run).  The per-lane part is one
+    //          32-bit offset (SADDR form).
 #define TR_AF(dst, dd, sbase)                                                                                  \
     _Pragma("unroll") for (int a = 0; a < MT; ++a)                                                             \
         dst[a] = *reinterpret_cast<const bf16x8_t*>(X + a * 32 * CHAIN_PITCH + aoff[(dd) & 7] + 16 * ((sbase) + ((dd) >> 3) * 8));
@@ -473,7 +474,7 @@ __device__ __forceinline__ void chain_trunk(u16* X, const float* bias_lds, const
         }                                                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
         {                                                                                                      \
-            const unsigned long long rb_ = rbase + (unsigned long long)((d) * STEPB);                          \
+            const unsigned long long rb_ = refill ? rbase + (unsigned long long)((d) * STEPB) : 0ull;          \
             asm volatile("s_cmp_eq_u64 %3, 0\n\ts_cbranch_scc1 1f\n\ts_nop 2\n\t"                              \
                          "global_load_dwordx4 %0, %2, %3" CHAIN_LOAD_MOD "\n\tglobal_load_dwordx4 %1, %2, %3 offset:1024" CHAIN_LOAD_MOD "\n1:" \
                          : "+v"(Q0), "+v"(Q1) : "v"(voff), "s"(rb_) : "memory", "scc");                        \
@@ -521,7 +522,8 @@ __device__ __forceinline__ void chain_trunk(u16* X, const float* bias_lds, const
         for (int s0 = 0; s0 < ks; s0 += D) {
             const bool tail = s0 + D >= ks;
             const int wmode = (cont && s0 == 0) ? 1 : ((tail && !has_next) ? 2 : 0);
-            const unsigned long long rbase = !tail ? own + (unsigned long long)(s0 + D) * STEPB : nxt;
+            const unsigned long long rbase = !tail ? own + (unsigned long long)(s0 + D) * STEPB : (has_next ? nxt : own);
+            const bool refill = !(tail && !has_next);
             TR_STEP(0, Q.q00, Q.q01, afA, afB) TR_STEP(1, Q.q10, Q.q11, afB, afA)
             TR_STEP(2, Q.q20, Q.q21, afA, afB) TR_STEP(3, Q.q30, Q.q31, afB, afA)
             TR_STEP(4, Q.q40, Q.q41, afA, afB) TR_STEP(5, Q.q50, Q.q51, afB, afA)

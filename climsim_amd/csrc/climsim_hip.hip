@@ -167,7 +167,8 @@ struct cs_mlp {
     // optimiser folded into the weight-gradient launch of a one-call step (WgradFuse, wgrad2.h): ticket counters; the step's learning
     // rate and scale, handed to run_backward; whether that launch did the update
     unsigned* wg_tickets = nullptr; float step_lr = 0.f, step_scale = 0.f; bool fuse_ok = false, fused_done = false;
-    bool fuse_opt_on = true;       // CS_WGRAD_FUSE_OPT=0 at creation: keep the k_optimizer launch (A/B runs, the bit-identity test)
+    bool fuse_opt_on = false;      // CS_WGRAD_FUSE_OPT=1 at creation: fold the optimiser into the weight-gradient launch.  OFF by default: measured SLOWER
+                                   // (8192 columns: 63 us against 34 + 10 us for k_wgrad3 + k_optimizer - see WgradFuse, wgrad2.h)
     std::vector<void*> allocs;
 };
 

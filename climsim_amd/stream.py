@@ -24,11 +24,13 @@ import numpy as np
 
 class StreamedTrainer:
     def __init__(self, model, loader, batch_size: int, slots: int = 2, dist=None, loader_on: str | None = None):
-        """`loader_on`: "main" (default; CS_STREAM_LOADER overrides) runs the loader KERNEL on the training stream - host chunks are
-        still staged and copied on the side stream, the kernel waits for the copy - "side" runs it on the side stream too.  On one
-        GPU the two measure the same (round 3, bench_stream.py: 56.0 / 56.2 M columns/s; the loader is 1.3-1.6 G columns/s, 2 % of a
-        pass, and what separates the pass from loader + steps back to back, 59.6 M, is the short last batch of every chunk);
-        with the kernel on the training stream nothing ever runs beside a step, so a cooperative model is accepted."""
+        """`loader_on`: "main" (default; CS_STREAM_LOADER overrides) runs the loader KERNEL on the training stream, right in front of
+        the chunk's first step; host chunks are staged and copied on the side stream while the PREVIOUS chunk trains (the training
+        stream waits for the copy only when it reaches the chunk - round 4: it used to wait at produce time, in front of the
+        previous chunk's steps, and idled through the whole copy).  "side" runs the kernel on the side stream too.  On one GPU the
+        two measure the same for device-resident chunks (round 3, bench_stream.py: 56.0 / 56.2 M columns/s; the loader is
+        1.3-1.6 G columns/s); with the kernel on the training stream nothing ever runs beside a step, so a cooperative model is
+        accepted."""
         import os
         import torch
         self.loader_on = loader_on or os.environ.get("CS_STREAM_LOADER", "main")
@@ -72,23 +74,22 @@ class StreamedTrainer:
                 return a.to(self.device, non_blocking=True)
             return a
         if self.loader_on == "main":
-            # copies on the side stream (they overlap the steps already queued), the kernel on the training stream behind them
-            host = any(isinstance(a, np.ndarray) for a in (mli, mlo))
-            if host:
+            # Host chunks: staged and copied on the side stream NOW (gated on the chunk that used this slot: at most `slots` raw
+            # chunks are ever staged, however far the host runs ahead), so the copy overlaps the steps of the chunk in front.  The
+            # loader kernel and the wait for the copy are issued by _consume, behind those steps (`ready` = None marks the
+            # entry as raw).
+            copied = None
+            if any(isinstance(a, np.ndarray) for a in (mli, mlo)):
                 with torch.cuda.stream(self.side):
                     if free_event is not None:
                         self.side.wait_event(free_event)
                     mli, mlo = dev(mli), dev(mlo)
                     copied = torch.cuda.Event()
                     copied.record(self.side)
-                main.wait_event(copied)
                 for a in (mli, mlo):
                     if a is not None:
                         a.record_stream(main)
-            x, y = self.loader.stack_raw(mli, mlo)           # main-stream order: the slot's previous chunk has been consumed
-            ready = torch.cuda.Event()
-            ready.record(main)
-            return x, y, ready
+            return (mli, mlo), copied, None
         with torch.cuda.stream(self.side):
             if free_event is not None:
                 self.side.wait_event(free_event)             # the slot's previous chunk has been consumed
@@ -103,7 +104,12 @@ class StreamedTrainer:
     def _consume(self, x, y, ready, lr_of_step: Callable[[int], float], gen, passes: int, step0: int):
         torch = self.torch
         main = torch.cuda.current_stream(self.device)
-        main.wait_event(ready)
+        if ready is None:                            # loader_on == "main": x = the raw chunk (on the device), y = its copy event or None
+            if y is not None:
+                main.wait_event(y)
+            x, y = self.loader.stack_raw(*x)
+        else:
+            main.wait_event(ready)
         n = x.shape[0]
         if self.dist is not None:
             # Every rank streams its own timesteps, so chunks may differ in T*ncol.  The ranks must issue the SAME number of

@@ -123,9 +123,10 @@ def test_optimiser_folded_into_the_weight_gradient_launch_is_bit_identical(M, n,
     rng = np.random.default_rng(9)
     for i in range(1, len(ws), 2):
         ws[i] = rng.normal(0, 0.05, ws[i].shape).astype(np.float32)
-    a = M.MLPEmulator(units=CFG, optimizer=opt, max_batch=n, seed=None)                      # fused (default)
+    monkeypatch.setenv("CS_WGRAD_FUSE_OPT", "1")
+    a = M.MLPEmulator(units=CFG, optimizer=opt, max_batch=n, seed=None)                      # fused (opt-in: measured slower, see wgrad2.h)
     monkeypatch.setenv("CS_WGRAD_FUSE_OPT", "0")
-    b = M.MLPEmulator(units=CFG, optimizer=opt, max_batch=n, seed=None)                      # k_optimizer launch
+    b = M.MLPEmulator(units=CFG, optimizer=opt, max_batch=n, seed=None)                      # k_optimizer launch (default)
     monkeypatch.delenv("CS_WGRAD_FUSE_OPT")
     a.set_weights(ws); b.set_weights(ws)
     x, y = O.synth_columns(n, seed=11)

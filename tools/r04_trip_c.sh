@@ -21,3 +21,5 @@ d=json.loads(sys.stdin.read()); print('batch=$b trunk=$t', d['ms_per_step'], {k:
 done; done 2>&1 | tee gpurun_out/r04_c_sizes.log
 echo "== bench tests"
 timeout 900 python -m pytest tests/test_bench_gpu.py -x -q 2>&1 | tail -6 | tee gpurun_out/r04_c_tests1.log
+echo "== stream stamps"
+timeout 600 python tools/stream_stamps.py 4 8 8192 2>&1 | tail -30 | tee gpurun_out/r04_c_stream_stamps.log
