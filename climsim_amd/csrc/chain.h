@@ -68,7 +68,7 @@ struct ChainArgs {
     int fused;               // forward half: dz of the heads also goes to LDS, loss scratch moves to the bias block;
                              // backward half: no prologue load (dz is in X) and no L2 warm-up (a prefetch of Wb issued during
                              // the forward half would sit in front of that half's weight stream: memory operations complete in order)
-    int ablate;              // timing experiments only (CS_CHAIN_ABLATE): 4 no global stores, 8 no warm-up
+    int ablate;              // timing experiments only (CS_CHAIN_ABLATE): 4 no global stores, 8 no warm-up, 128 no contraction split in 128-wide stages
     int store_nt;            // activations / gradients leave with the non-temporal policy (host: batches the L2s cannot hold anyway)
     int trunk_i0, trunk_n;   // stages trunk_i0 .. trunk_i0 + trunk_n - 1 run as ONE continuous weight stream (chain_trunk; 0 / 0: off)
     unsigned long long* dbg; // optional [grid][64] s_memtime stamps (CS_CHAIN_DBG), null in production
@@ -153,9 +153,11 @@ __device__ __forceinline__ void chain_prime_t(ChainQ& Q, const u16* __restrict__
 // (SELF_PRIME is always true: see the note in chain_stage.)
 __device__ __forceinline__ void chainw_copy_out(const u16* __restrict__ X, u16* __restrict__ out, int ldo, int width, int64_t m0, int tid);   // chainw.h
 
+// `kofs`: first k16-step of this wave's share of the contraction (0 = all of it; chain_stage splits the contraction of a 128-wide
+// stage between the two halves of a 32-row tile's waves), `ks_total` the number of steps it takes from there.
 template <int BMROWS, int MT, int NT, int D, bool SELF_PRIME, int PITCH = CHAIN_PITCH, bool WIDE_PEND = false>
 __device__ __forceinline__ void chain_mma(const u16* __restrict__ X, const u16* __restrict__ wfrag, int ks_total, int ntiles,
-                                          int jt0, int mrow0, int tid, f32x16_t (&acc)[MT][NT], ChainPending& pend, int64_t m0) {
+                                          int jt0, int mrow0, int tid, f32x16_t (&acc)[MT][NT], ChainPending& pend, int64_t m0, const int kofs = 0) {
     const int lane = tid & 63;
     ChainQ Q;
     static_assert(D == 4 || D == 8, "queue slots are written out for depth 4 and 8");
@@ -165,8 +167,8 @@ __device__ __forceinline__ void chain_mma(const u16* __restrict__ X, const u16* 
         for (int b = 0; b < NT; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-    const uint4* wp0 = reinterpret_cast<const uint4*>(wfrag) + jt0 * 64 + lane;
     const int sstride = ntiles * 64;             // uint4 per k16 step
+    const uint4* wp0 = reinterpret_cast<const uint4*>(wfrag) + jt0 * 64 + lane + kofs * sstride;
     // The weight stream is issued with inline-asm loads and waited for with COUNTED vmcnt: hipcc's own
     // bookkeeping falls back to vmcnt(0) at the loop header (and rotates the queue through v_mov's that
     // need the data).  Protocol: slot d is refilled right after its last use; before its next use
@@ -175,7 +177,7 @@ __device__ __forceinline__ void chain_mma(const u16* __restrict__ X, const u16* 
     // the first version did, cost 25 % more bytes on the path that bounds the kernel: the per-CU vector-memory pipe).
 #define CHAIN_AF(dst, step)                                                                                    \
     _Pragma("unroll") for (int a = 0; a < MT; ++a)                                                             \
-        dst[a] = *reinterpret_cast<const bf16x8_t*>(X + chain_lds_off_p<PITCH>(arow + a * 32, (2 * min((step), ks_total - 1) + ahalf) * 8));
+        dst[a] = *reinterpret_cast<const bf16x8_t*>(X + chain_lds_off_p<PITCH>(arow + a * 32, (2 * (kofs + min((step), ks_total - 1)) + ahalf) * 8));
 // A fragments of step s+1 are read from LDS while the MFMAs of step s run (AC = current, AN = next).
 #define CHAIN_STEP(d, Q0, Q1, AC, AN, TAIL)                                                                    \
     {                                                                                                          \
@@ -221,7 +223,7 @@ __device__ __forceinline__ void chain_mma(const u16* __restrict__ X, const u16* 
     }
     // Older compiler-issued memory ops need no explicit drain: completion is in order, so the first counted
     // wait below also covers them.
-    if (SELF_PRIME) chain_prime_t<NT, D>(Q, wfrag, ks_total, ntiles, jt0, lane);
+    if (SELF_PRIME) chain_prime_t<NT, D>(Q, wfrag + (int64_t)kofs * sstride * 8, ks_total, ntiles, jt0, lane);
     // The previous stage's output (= this stage's input, intact in X until the barrier behind this k-loop) still has to go to
     // global memory.  32-row tiles: NOW, behind the queue-priming loads (in front of them a vmcnt(0) for the stores cost ~1 us
     // per stage).  Taller tiles: behind the LAST weight load of the stage (below).
@@ -348,15 +350,22 @@ __device__ __forceinline__ void chain_stamp(const ChainArgs& p, int bid, int tid
     ++slot;
 }
 
+// `dup`: a 128-wide stage on a 32-row tile - four column tiles for eight waves, waves 4-7 own the same tiles as waves 0-3.  They used
+// to repeat the whole stage ("identical values to identical places"): twice the weight requests on the pipe that bounds the tile, and
+// an epilogue that shared every SIMD's VALU with its own copy (round-4 stamps: 7.7k clocks for the 32 k16-steps of 512 -> 128, 4.8k for
+// the heads' epilogue).  Now the two halves SPLIT the contraction when it has 16 steps or more (partial sums of waves 4-7 meet in the
+// part of X the 128-wide output leaves free), and only waves 0-3 run the epilogue.
 template <int BMROWS, int MT, int NT, int EPI, bool ELU>
 __device__ __forceinline__ void chain_stage(u16* X, const float* bias_lds, const int64_t* rows_lds, const ChainArgs& p,
                                             const ChainDyn& d_, int bid, const ChainStage& S, bool last, int64_t m0, int jt0, int mrow0, int tid,
-                                            float& sq, float& ab, int& slot, ChainPending& pend) {
+                                            float& sq, float& ab, int& slot, ChainPending& pend, const bool dup = false) {
     const int lane = tid & 63;
+    const bool upper = dup && tid >= 256;                      // waves 4-7 of a `dup` stage
+    const bool ksplit = dup && (S.Kc >> 4) >= 16 && !(p.ablate & 128);
     f32x16_t acc[MT][NT];
     float4 tgt[MT][4];                                         // heads: target rows, in flight during the k-loop
     if constexpr (EPI == EPI_OUT) {
-        if (d_.y) {
+        if (d_.y && !upper) {
 #pragma unroll
             for (int a = 0; a < MT; ++a) {
                 const int64_t r = rows_lds[mrow0 + a * 32 + (lane & 31)];
@@ -369,7 +378,7 @@ __device__ __forceinline__ void chain_stage(u16* X, const float* bias_lds, const
     u32x4_t msk = u32x4_t{0u, 0u, 0u, 0u};
     u32x4_t* mptr = S.mask ? S.mask + (int64_t)bid * 512 + tid : nullptr;
     const bool remap = BMROWS == 32 && p.mask_bm64;            // 32-row tiles over the sign masks of a 64-row forward pass
-    if (EPI == EPI_DGRAD && !ELU) {
+    if (EPI == EPI_DGRAD && !ELU && !upper) {
         // The forward pass ran 64-row tiles, this pass 32-row tiles: workgroup 2i+a0 covers row tile a0 of forward
         // workgroup i.  Forward layout: tile t = a*NT+b in dword t>>1, half t&1; 128-wide stages put rows 32..63 on
         // waves 4..7 (threads 256..511).  (The dword is picked AFTER the k-loop: a use here would make hipcc wait for
@@ -382,21 +391,48 @@ __device__ __forceinline__ void chain_stage(u16* X, const float* bias_lds, const
     // (Priming the NEXT stage's queue here, so that its first loads fly during this epilogue, was tried: the queue
     //  registers then live across the stage dispatch, hipcc copies / spills them - 140-300 B of scratch per lane - and a
     //  copy of a register whose asm load has not landed yet is garbage.  The queue stays local to chain_mma.)
-    if (MT <= 2 && (S.Kc & 127) == 0) chain_mma<BMROWS, MT, NT, 8, true>(X, S.wfrag, S.Kc >> 4, S.Nc >> 5, jt0, mrow0, tid, acc, pend, m0);
-    else chain_mma<BMROWS, MT, NT, 4, true>(X, S.wfrag, S.Kc >> 4, S.Nc >> 5, jt0, mrow0, tid, acc, pend, m0);
+    const int ks_all = S.Kc >> 4, ks_mine = ksplit ? ks_all >> 1 : ks_all, kofs = (ksplit && upper) ? ks_all >> 1 : 0;
+    if (MT <= 2 && (S.Kc & 127) == 0 && (!ksplit || (ks_mine & 7) == 0)) chain_mma<BMROWS, MT, NT, 8, true>(X, S.wfrag, ks_mine, S.Nc >> 5, jt0, mrow0, tid, acc, pend, m0, kofs);
+    else chain_mma<BMROWS, MT, NT, 4, true>(X, S.wfrag, ks_mine, S.Nc >> 5, jt0, mrow0, tid, acc, pend, m0, kofs);
     if (EPI == EPI_DGRAD && !ELU && remap) {
         const int a0 = bid & 1;
         msk[0] = S.Nc == 512 ? (a0 ? msk[1] : msk[0]) : (S.Nc == 256 ? msk[0] >> (16 * a0) : msk[0]);
     }
     __syncthreads();                         // every wave has finished reading X for this stage
+    if constexpr (BMROWS == 32 && MT == 1 && NT == 1) {
+        if (ksplit) {
+            // partial sums of waves 4-7 -> the 768 bytes behind the 128-wide output in every 1-KiB row of X (24 KiB free, 16 KiB used;
+            // float index f = (wave * 16 + r) * 64 + lane, 192 floats per row: consecutive lanes, consecutive banks) -> waves 0-3
+            float* Xf = reinterpret_cast<float*>(X);
+            const int q = (tid >> 6) & 3;
+            if (upper) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int f = (q * 16 + r) * 64 + lane;
+                    Xf[(f / 192) * 256 + 64 + f % 192] = acc[0][0][r];
+                }
+            }
+            __syncthreads();
+            if (!upper) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int f = (q * 16 + r) * 64 + lane;
+                    acc[0][0][r] += Xf[(f / 192) * 256 + 64 + f % 192];
+                }
+            }
+        }
+    }
     chain_stamp(p, bid, tid, slot);
-    if (p.ablate & 16) {                     // timing experiment: no epilogue at all
+    if (upper) {                             // the tile's other half of waves owns these columns' epilogue
+        asm volatile("" :: "v"(acc[0][0][0]));
+    } else if (p.ablate & 16) {              // timing experiment: no epilogue at all
         asm volatile("" :: "v"(acc[0][0][0]));
     } else if constexpr (EPI == EPI_OUT) {
         chain_heads<MT>(bias_lds, tgt, p, d_, S, m0, jt0, mrow0, lane, acc, sq, ab, p.fused ? X : nullptr);
     } else {
         chain_epilogue<MT, NT, EPI, ELU>(X, bias_lds, p, S, last, m0, jt0, mrow0, lane, acc, msk);
         if (EPI == EPI_HIDDEN && mptr) {
+            // (the stage's sign words belong to the threads that ran the epilogue: waves 0-3 of a `dup` stage, forward and backward)
             // a 32-row tile has 32 elements per thread: only word 0 carries bits, and only that word is stored
             // (12.6 -> 3.1 MB of mask traffic per pass at 8192 columns); 64 / 128-row tiles store all four
             if (BMROWS == 32) reinterpret_cast<unsigned*>(S.mask)[(int64_t)bid * 512 + tid] = msk[0];
@@ -678,11 +714,10 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const ChainDyn& d
             // (32-row tiles: four column waves cover the tile; waves 4-7 repeat their work - identical values to
             //  identical places - and are dropped from the loss sums)
             chain_stage<BM, (BM >= 64 ? BM / 64 : 1), 1, EPI_OUT, ELU>(X, bias_lds, rows_lds, p, d_, bid, S, last, m0, wid & 3,
-                                                                      BM >= 64 ? (wid >> 2) * (BM / 2) : 0, tid, sq, ab, slot, pend);
-            if (BM < 64 && wid >= 4) { sq = 0.f; ab = 0.f; }
+                                                                      BM >= 64 ? (wid >> 2) * (BM / 2) : 0, tid, sq, ab, slot, pend, BM < 64);
         } else {                    // 128: wave = half the rows x 32 columns
             chain_stage<BM, (BM >= 64 ? BM / 64 : 1), 1, E, ELU>(X, bias_lds, rows_lds, p, d_, bid, S, last, m0, wid & 3,
-                                                                BM >= 64 ? (wid >> 2) * (BM / 2) : 0, tid, sq, ab, slot, pend);
+                                                                BM >= 64 ? (wid >> 2) * (BM / 2) : 0, tid, sq, ab, slot, pend, BM < 64);
         }
     }
     // (scratch: X is free, the heads stage ended with a barrier - except under k_chain_fb, where X now holds dz of the

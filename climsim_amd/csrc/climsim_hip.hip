@@ -164,11 +164,6 @@ struct cs_mlp {
     float* Gx = nullptr; int gx_parts = 0; bool in_step = false;
     // training-pass `accuracy` (cs_mlp_set_train_accuracy): the heads also write their predictions here and a small kernel counts argmax matches
     unsigned long long* acc_count = nullptr; float* yhat_train = nullptr;
-    // optimiser folded into the weight-gradient launch of a one-call step (WgradFuse, wgrad2.h): ticket counters; the step's learning
-    // rate and scale, handed to run_backward; whether that launch did the update
-    unsigned* wg_tickets = nullptr; float step_lr = 0.f, step_scale = 0.f; bool fuse_ok = false, fused_done = false;
-    bool fuse_opt_on = false;      // CS_WGRAD_FUSE_OPT=1 at creation: fold the optimiser into the weight-gradient launch.  OFF by default: measured SLOWER
-                                   // (8192 columns: 63 us against 34 + 10 us for k_wgrad3 + k_optimizer - see WgradFuse, wgrad2.h)
     std::vector<void*> allocs;
 };
 
@@ -336,7 +331,7 @@ int chain_bm(const cs_mlp* h, int64_t n) { return chain_bm_of(h->cfg.flags, h->n
 void chain_find_trunk(const cs_mlp* h, ChainArgs& c) {
     c.trunk_i0 = 0; c.trunk_n = 0;
     static const bool off = getenv("CS_CHAIN_TRUNK") && atoi(getenv("CS_CHAIN_TRUNK")) == 0;
-    if (off || h->cfg.act == CS_ACT_ELU || c.ablate || c.mask_bm64) return;
+    if (off || h->cfg.act == CS_ACT_ELU || (c.ablate & ~128) || c.mask_bm64) return;
     int best0 = 0, bestn = 0;
     for (int i = 0; i < c.n_stages;) {
         int n = 0;
@@ -638,18 +633,7 @@ int run_backward(cs_mlp* h, int64_t n, bool atomics_needed, hipStream_t st) {
             // one round of workgroups: 64-row stages (the whole LDS as ring); more: 32-row stages, two workgroups per CU
             static const int rows_env = getenv("CS_WGRAD3_ROWS") ? atoi(getenv("CS_WGRAD3_ROWS")) : 0;
             const bool r64 = (rows_env ? rows_env == 64 : wg <= ncu) && (m_pad / 64) >= splitk;
-            // one-call step of the tuned chain without gradient atomics: the last-arriving wave of every tile piece also applies the
-            // optimiser and re-casts the operand copies (WgradFuse, wgrad2.h) - no k_optimizer launch behind this one
-            if (w.plain && h->fuse_opt_on && h->fuse_ok && h->use_chain && tiles <= 1024 && !w.ablate) {
-                WgradFuse fz{};
-                fz.on = 1; fz.tickets = h->wg_tickets; fz.part0 = h->Gx + (int64_t)CS_WGRAD_PARTS * h->n_params;
-                fz.opt = fill_opt_args(h, h->step_lr, h->step_scale, false);       // (consumes the loss hand-over and gx_parts)
-                for (int l = 0; l < h->L; ++l) { fz.Wf[l] = h->layers[l].Wf; fz.Wb[l] = h->layers[l].Wb; }
-                if (r64) CS_LAUNCH((k_wgrad3_opt<4, 64>), dim3((unsigned)wg), dim3(WG3_THREADS), WG3_LDS_BYTES_64, st, w, fz);
-                else CS_LAUNCH((k_wgrad3_opt<4, 32>), dim3((unsigned)wg), dim3(WG3_THREADS), WG3_LDS_BYTES, st, w, fz);
-                h->fused_done = true;
-            }
-            else if (r64) CS_LAUNCH((k_wgrad3<4, 64>), dim3((unsigned)wg), dim3(WG3_THREADS), WG3_LDS_BYTES_64, st, w);
+            if (r64) CS_LAUNCH((k_wgrad3<4, 64>), dim3((unsigned)wg), dim3(WG3_THREADS), WG3_LDS_BYTES_64, st, w);
             else CS_LAUNCH((k_wgrad3<4, 32>), dim3((unsigned)wg), dim3(WG3_THREADS), WG3_LDS_BYTES, st, w);
         }
         else if (tr) CS_LAUNCH(k_wgrad<true>, dim3((unsigned)wg), dim3(256), 0, st, w);
@@ -757,10 +741,7 @@ int cs_mlp_create(cs_mlp_t** out, const cs_mlp_cfg* cfg) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad2l), hipFuncAttributeMaxDynamicSharedMemorySize, WG2L_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad3<4, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, WG3_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad3<4, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, WG3_LDS_BYTES_64));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad3_opt<4, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, WG3_LDS_BYTES));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad3_opt<4, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, WG3_LDS_BYTES_64));
     if (const char* e = getenv("CS_WGRAD3")) h->wgrad3 = atoi(e) != 0;
-    if (const char* e = getenv("CS_WGRAD_FUSE_OPT")) h->fuse_opt_on = atoi(e) != 0;
     if (cfg->flags & CS_FLAG_COOP) h->coop_mode = -1;
     if (const char* e = getenv("CS_COOP")) { const int v = atoi(e); h->coop_mode = v == 1 ? -1 : v; }
     if (h->use_chain) {
@@ -787,7 +768,7 @@ int cs_mlp_create(cs_mlp_t** out, const cs_mlp_cfg* cfg) {
     A((void**)&h->M, sizeof(float) * off);
     A((void**)&h->V, sizeof(float) * off);
     A((void**)&h->G, sizeof(float) * off);
-    A((void**)&h->Gx, sizeof(float) * off * (CS_WGRAD_PARTS + 1));      // + row split 0's buffer of the fused weight-gradient / optimiser launch
+    A((void**)&h->Gx, sizeof(float) * off * CS_WGRAD_PARTS);
     A((void**)&h->loss_ring, sizeof(float) * 2 * LOSS_STRIPES * LOSS_STRIPE_FLOATS);
     A((void**)&h->keep_store, sizeof(float) * h->n_outp);
     A((void**)&h->sub, sizeof(float) * cfg->n_in);
@@ -804,7 +785,6 @@ int cs_mlp_create(cs_mlp_t** out, const cs_mlp_cfg* cfg) {
         }
     }
     A((void**)&h->seg_dev, sizeof(Segment) * 2 * h->L);
-    A((void**)&h->wg_tickets, sizeof(unsigned) * 4 * 1024);            // [128 x 128 tiles of all layers][4 compute waves]
     if (h->use_chain) {
         A((void**)&h->coop_arrive, sizeof(unsigned) * 256 * (1 + 2 * CHAIN_MAX_STAGES * 8));
         A((void**)&h->coop_xcc, sizeof(unsigned) * 256);
@@ -1094,21 +1074,13 @@ int cs_mlp_train_step(cs_mlp_t* h, const float* x_dev, const float* y_dev, const
     h->loss_striped = false;
     if (rc) return rc;
     if (h->acc_count) train_accuracy(h, y_dev, row_idx_dev, n, st);
-    // the optimiser's inputs are known before the weight gradients are launched: that launch may apply the update itself (WgradFuse)
+    h->in_step = true;
+    rc = run_backward(h, n, false, st);
+    h->in_step = false;
+    if (rc) { h->gx_parts = 0; return rc; }
     h->opt_loss_src = slot; h->opt_loss_dst = loss_dev; h->opt_loss_zero = h->loss_ring + LOSS_STRIPES * LOSS_STRIPE_FLOATS * (h->loss_cur ^ 1);
     h->loss_cur ^= 1;
-    h->step_lr = lr; h->step_scale = 1.0f / ((float)h->n_out * (float)n);
-    h->in_step = true; h->fuse_ok = true; h->fused_done = false;
-    rc = run_backward(h, n, false, st);
-    h->in_step = false; h->fuse_ok = false;
-    if (rc) { h->gx_parts = 0; h->opt_loss_dst = nullptr; return rc; }
-    if (h->fused_done) {                 // (the fused launch never touched G: it is still the zeroed buffer the step started from)
-        h->fused_done = false;
-        h->iterations += 1;
-        h->grads_dirty = false;
-        return CS_OK;
-    }
-    return cs_mlp_apply(h, lr, h->step_scale, stream);
+    return cs_mlp_apply(h, lr, 1.0f / ((float)h->n_out * (float)n), stream);
 }
 
 int cs_mlp_profile_step(cs_mlp_t* h, const float* x_dev, const float* y_dev, const int64_t* row_idx_dev, int64_t n,

@@ -535,9 +535,8 @@ struct OptArgs {
 //   torch Adam (torch.optim.Adam, torch 2.x _single_tensor_adam; online_testing/.../train_mlp_h5loader.py:210-211):
 //            m.lerp_(g, 1-b1); v = v*b2 + (1-b2) g g; w -= (lr/(1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
 // The update rule on four consecutive parameters at flat offset i0, given their UNSCALED gradient sums g (reads and writes P,
-// M, V; leaves the new weights in wv).  Shared by k_optimizer and by the weight-gradient kernel's fused tail (wgrad2.h).
-// One parameter: w, m, v in registers, g already scaled.  (One function for every caller, so that the vector form of k_optimizer,
-// the fused tail of the weight-gradient kernel and its one-per-lane bias update contract their multiply-adds identically.)
+// M, V; leaves the new weights in wv).
+// One parameter: w, m, v in registers, g already scaled.
 __device__ __forceinline__ void opt_elem(const OptArgs& a, const float gv, float& w, float& m, float& v) {
     if (a.kind == 3) {
         w -= a.lr * gv;
@@ -562,7 +561,7 @@ __device__ __forceinline__ void opt_elem(const OptArgs& a, const float gv, float
 }
 
 // The update rule on four consecutive parameters at flat offset i0, given their UNSCALED gradient sums g (reads and writes P,
-// M, V; leaves the new weights in wv).  Shared by k_optimizer and by the weight-gradient kernel's fused tail (wgrad2.h).
+// M, V; leaves the new weights in wv).
 __device__ __forceinline__ void opt_rule4(const OptArgs& a, int64_t i0, const float4 g, float (&wv)[4]) {
     const float4 w = *reinterpret_cast<const float4*>(a.P + i0);
     wv[0] = w.x; wv[1] = w.y; wv[2] = w.z; wv[3] = w.w;
@@ -575,14 +574,6 @@ __device__ __forceinline__ void opt_rule4(const OptArgs& a, int64_t i0, const fl
     if (a.kind != 3 && a.kind != 2) *reinterpret_cast<float4*>(a.M + i0) = make_float4(mv[0], mv[1], mv[2], mv[3]);
     if (a.kind != 3) *reinterpret_cast<float4*>(a.V + i0) = make_float4(vv[0], vv[1], vv[2], vv[3]);
     *reinterpret_cast<float4*>(a.P + i0) = make_float4(wv[0], wv[1], wv[2], wv[3]);
-}
-
-// The rule on values already in registers (the fused tail of the weight-gradient kernel loads P / M / V of many parameters up front).
-__device__ __forceinline__ void opt_rule4v(const OptArgs& a, const float4 g, float4& w, float4& m, float4& v) {
-    opt_elem(a, g.x * a.grad_scale, w.x, m.x, v.x);
-    opt_elem(a, g.y * a.grad_scale, w.y, m.y, v.y);
-    opt_elem(a, g.z * a.grad_scale, w.z, m.z, v.z);
-    opt_elem(a, g.w * a.grad_scale, w.w, m.w, v.w);
 }
 
 __device__ __forceinline__ void opt_update4(const OptArgs& a, int64_t i0, float (&wv)[4]) {

@@ -361,186 +361,12 @@ __device__ __forceinline__ bf16x8_t frag_w3(const u16* tile, int mb, int cb, int
     return u.v;
 }
 
-// ---- round 4: the optimiser folded into this kernel (one-call training step, tuned layer chain) ------------------------------
-// Inside cs_mlp_train_step the row splits of a tile used to STORE their partial sums and a k_optimizer launch added them up,
-// applied the update rule and re-cast the bf16 operand copies: 10.8 us + a kernel boundary at 8192 columns, for 43 MB of
-// traffic whose gradient part had just been written.  Now every compute WAVE (a 64 x 64 piece of a 128 x 128 tile) publishes its
-// partial sums write-through (`sc1`), waits for them (`vmcnt(0)`: they are in memory) and takes a ticket from the counter of its
-// piece; the wave that draws the LAST ticket (splitk - 1) fetches the other splits' partials (`sc1` loads: its own CU's L1 never
-// held these lines in this launch, and what the producers wrote went through to memory), adds them IN SPLIT ORDER - its own
-// contribution from LDS - so that the sum has the bits k_optimizer's `G + Gx[0] + Gx[1]` had, applies the rule (opt_rule4: the
-// same code), and writes P / M / V and both fragment-major operand copies of its 64 x 64 piece (8 + 8 blocks of 1 KiB, each
-// lying wholly inside the piece).  No wave ever waits for another: the last arriver exists by construction (a ticket per
-// arrival), so nothing can hang, and the pieces of one tile may be finished by waves of different workgroups.  The counters
-// return to zero inside the launch.  k_optimizer stays for the two-call (data-parallel) form, set_weights and every other path.
-struct WgradFuse {
-    int on;
-    unsigned* tickets;               // [tiles of all layers][4 waves], zero between launches
-    float* part0;                    // row split 0's partial sums (a buffer of its own: the gradient buffer G is not touched and stays zero)
-    OptArgs opt;                     // the step's scalars; P / M / V; loss hand-over (done by work id 0)
-    u16* Wf[WGRAD_MAX_LAYERS];       // fragment-major forward operand copy of every layer
-    u16* Wb[WGRAD_MAX_LAYERS];       // ... backward operand copy (null for layer 0)
-};
-
-__device__ __forceinline__ void st_sc1_f4(float* p, const float4 x) {
-    typedef float f4 __attribute__((ext_vector_type(4)));
-    const f4 v = {x.x, x.y, x.z, x.w};
-    // (the trailing s_nop: hipcc pads nothing behind an asm store, and its next instruction may rewrite the data registers before the
-    //  store has read them - cdna_hip_programming.md section 5.7)
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
-}
-__device__ __forceinline__ void st_sc1_f1(float* p, const float x) { asm volatile("global_store_dword %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(x) : "memory"); }
-
-// `reg`: this wave's 16 KiB of the idle ring holding its four 32 x 32 result tiles as [(i * 2 + j)][row k][col n] floats.
-__device__ __forceinline__ void wgrad3_fused_tail(const WgradArgs& pa, const WgradFuse& fz, const WgradLayer& p, const int li, const int tile_id,
-                                                  const int split, const int k0, const int n0, const int wk, const int wn, const int wid,
-                                                  const int lane, float* reg, const float bias_sum, const bool do_bias) {
-    const int rr = lane >> 3, c4 = (lane & 7) * 4;
-    const int64_t w_off = p.dW - pa.g_base, b_off = p.db - pa.g_base;          // flat offsets of this layer's kernel / bias
-    auto buf_of = [&](int s) -> float* { return s == 0 ? fz.part0 : pa.part + (int64_t)(s - 1) * pa.part_stride; };
-    // (1) publish this split's partial sums, write-through
-    float* mine = buf_of(split);
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {
-            const int row = pass * 8 + rr;
-            const int k = k0 + wk * 64 + (t >> 1) * 32 + row;
-            const float4 v = *reinterpret_cast<const float4*>(reg + t * 1024 + row * 32 + c4);
-            if (k < p.k_real) st_sc1_f4(mine + w_off + (int64_t)k * p.N + n0 + wn * 64 + (t & 1) * 32 + c4, v);
-        }
-    const int nb = n0 + wn * 64 + wk * 32 + lane;                               // bias column of this lane (tiles with k0 == 0)
-    if (do_bias && lane < 32) st_sc1_f1(mine + b_off + nb, bias_sum);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                             // every store of this wave is in memory
-    // (2) ticket of this wave's piece
-    unsigned* tk = fz.tickets + ((unsigned)tile_id * 4u + (unsigned)wid);
-    unsigned ticket = 0;
-    if (lane == 0) ticket = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    ticket = __builtin_amdgcn_readfirstlane(ticket);
-    if ((int)ticket != pa.splitk - 1) return;                                    // somebody else finishes this piece
-    if (lane == 0) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
-    // (3) last arriver: sum in split order, update, re-cast.  ONE wave works here, so what it keeps in flight is the tail's speed
-    // (the first form - 8 loads, wait, then 3 dependent loads per float4 - took 40 us where k_optimizer's 1200 workgroups take 10):
-    // per half of the piece (two 32 x 32 tiles = 8 float4 per lane) all 16 partial-sum loads and all 24 P / M / V loads go out before
-    // anything is waited for (160 VGPRs; the accumulators are dead by now).
-    const OptArgs& a = fz.opt;
-    typedef float f4 __attribute__((ext_vector_type(4)));
-    const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    static_assert(CS_WGRAD_PARTS == 2, "three partial-sum slots per item are written out below");
-    float* const b0 = buf_of(0); float* const b1 = buf_of(1); float* const b2 = buf_of(2);
-    const bool three = pa.splitk > 2;
-    // the two OTHER splits' buffers (with two splits: the other one, twice - the second value is not used)
-    float* const oa = split == 0 ? b1 : b0;
-    float* const ob = split == 2 ? b1 : (three ? b2 : oa);
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        // named scalars: tied asm operands cannot be array elements (hipcc moves such arrays to scratch).  x<i> / y<i>: item i = (tile
-        // 2 * half + (i >> 2), pass i & 3) of the other splits' buffers oa / ob.
-        f4 x0 = zero4, x1 = zero4, x2 = zero4, x3 = zero4, x4 = zero4, x5 = zero4, x6 = zero4, x7 = zero4;
-        f4 y0 = zero4, y1 = zero4, y2 = zero4, y3 = zero4, y4 = zero4, y5 = zero4, y6 = zero4, y7 = zero4;
-        int64_t off[8]; bool live[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int t = 2 * half + (i >> 2), row = (i & 3) * 8 + rr;
-            const int k = k0 + wk * 64 + (t >> 1) * 32 + row;
-            live[i] = k < p.k_real;
-            off[i] = w_off + (int64_t)min(k, p.k_real - 1) * p.N + n0 + wn * 64 + (t & 1) * 32 + c4;
-        }
-#define WG3F_LD(I, XA, YA)                                                                                   \
-        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "+v"(XA) : "v"(oa + off[I]) : "memory");        \
-        if (three) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "+v"(YA) : "v"(ob + off[I]) : "memory");
-        WG3F_LD(0, x0, y0) WG3F_LD(1, x1, y1) WG3F_LD(2, x2, y2) WG3F_LD(3, x3, y3)
-        WG3F_LD(4, x4, y4) WG3F_LD(5, x5, y5) WG3F_LD(6, x6, y6) WG3F_LD(7, x7, y7)
-#undef WG3F_LD
-        float4 pw[8], pm[8], pv[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            pw[i] = *reinterpret_cast<const float4*>(a.P + off[i]);
-            pm[i] = (a.kind == 3 || a.kind == 2) ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(a.M + off[i]);
-            pv[i] = a.kind == 3 ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(a.V + off[i]);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7),
-                                              "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3), "+v"(y4), "+v"(y5), "+v"(y6), "+v"(y7) :: "memory");
-#define WG3F_UP(I, XA, YA)                                                                                   \
-        {                                                                                                     \
-            const int t_ = 2 * half + ((I) >> 2), row_ = ((I) & 3) * 8 + rr;                                  \
-            float* slot_ = reg + t_ * 1024 + row_ * 32 + c4;                                                  \
-            const float4 own_ = *reinterpret_cast<const float4*>(slot_);                                      \
-            const float4 xa_ = make_float4(XA[0], XA[1], XA[2], XA[3]), yb_ = make_float4(YA[0], YA[1], YA[2], YA[3]); \
-            /* ((p0 + p1) + p2): k_optimizer's order.  oa / ob hold the other splits in ascending order */    \
-            const float4 p0_ = split == 0 ? own_ : xa_;                                                       \
-            const float4 p1_ = split == 1 ? own_ : (split == 0 ? xa_ : yb_);                                  \
-            float4 g_ = make_float4(p0_.x + p1_.x, p0_.y + p1_.y, p0_.z + p1_.z, p0_.w + p1_.w);              \
-            if (three) {                                                                                      \
-                const float4 p2_ = split == 2 ? own_ : yb_;                                                   \
-                g_.x += p2_.x; g_.y += p2_.y; g_.z += p2_.z; g_.w += p2_.w;                                   \
-            }                                                                                                 \
-            float4 w_ = pw[I], m_ = pm[I], v_ = pv[I];                                                        \
-            opt_rule4v(a, g_, w_, m_, v_);                                                                    \
-            if (live[I]) {                                                                                    \
-                if (a.kind != 3 && a.kind != 2) *reinterpret_cast<float4*>(a.M + off[I]) = m_;                \
-                if (a.kind != 3) *reinterpret_cast<float4*>(a.V + off[I]) = v_;                               \
-                *reinterpret_cast<float4*>(a.P + off[I]) = w_;                                                \
-            } else w_ = make_float4(0.f, 0.f, 0.f, 0.f);                  /* rows >= K: zeros in the operand copies */ \
-            *reinterpret_cast<float4*>(slot_) = w_;                       /* the piece's new weights */       \
-        }
-        WG3F_UP(0, x0, y0) WG3F_UP(1, x1, y1) WG3F_UP(2, x2, y2) WG3F_UP(3, x3, y3)
-        WG3F_UP(4, x4, y4) WG3F_UP(5, x5, y5) WG3F_UP(6, x6, y6) WG3F_UP(7, x7, y7)
-#undef WG3F_UP
-    }
-    if (do_bias && lane < 32) {
-        float v0 = bias_sum, v1 = bias_sum, v2 = bias_sum;
-        if (split != 0) asm volatile("global_load_dword %0, %1, off sc1" : "+v"(v0) : "v"(b0 + b_off + nb) : "memory");
-        if (split != 1) asm volatile("global_load_dword %0, %1, off sc1" : "+v"(v1) : "v"(b1 + b_off + nb) : "memory");
-        if (pa.splitk > 2 && split != 2) asm volatile("global_load_dword %0, %1, off sc1" : "+v"(v2) : "v"(b2 + b_off + nb) : "memory");
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(v0), "+v"(v1), "+v"(v2) :: "memory");
-        float g = v0 + v1;
-        if (pa.splitk > 2) g += v2;
-        const int64_t i0 = b_off + nb;                                            // one parameter per lane
-        float w = a.P[i0], m = a.kind == 3 || a.kind == 2 ? 0.f : a.M[i0], v = a.kind == 3 ? 0.f : a.V[i0];
-        opt_elem(a, g * a.grad_scale, w, m, v);
-        if (a.kind != 3 && a.kind != 2) a.M[i0] = m;
-        if (a.kind != 3) a.V[i0] = v;
-        a.P[i0] = w;
-    }
-    // (4) operand copies of the 64 x 64 piece (LDS operations of one wave complete in order: no barrier).  Forward blocks (k / 16,
-    // n / 32): lane L holds W[16 kb + 8 (L >> 5) + 0..7][n = L & 31]; backward blocks (n / 16, k / 32): W[k = L & 31][16 nb + 8 (L >> 5) + 0..7].
-    const int tiles_n = p.N >> 5, tiles_kp = p.tiles_k * 4;                      // 32-wide tiles along n / along the padded k
-    u16* Wf = fz.Wf[li]; u16* Wb = fz.Wb[li];
-    const int nl = lane & 31, h8 = 8 * (lane >> 5);
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb)                                               // k16 blocks of the piece
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {                                            // n32 blocks
-            const int kl = kb * 16 + h8;                                         // first of 8 consecutive k inside the piece (0..63)
-            const float* src = reg + ((kl >> 5) * 2 + j) * 1024 + (kl & 31) * 32 + nl;
-            unsigned q[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) q[e] = cvt_pk_bf16(src[(2 * e) * 32], src[(2 * e + 1) * 32]);
-            const int64_t blk = (int64_t)((k0 + wk * 64) / 16 + kb) * tiles_n + (n0 + wn * 64) / 32 + j;
-            if (Wf) *reinterpret_cast<uint4*>(Wf + ((blk * 64 + lane) << 3)) = make_uint4(q[0], q[1], q[2], q[3]);
-        }
-    if (Wb) {
-#pragma unroll
-        for (int nbk = 0; nbk < 4; ++nbk)                                        // n16 blocks of the piece
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {                                        // k32 blocks
-                const int ncl = nbk * 16 + h8;                                   // first of 8 consecutive n inside the piece (0..63)
-                const float* src = reg + (i * 2 + (ncl >> 5)) * 1024 + nl * 32 + (ncl & 31);
-                const float4 lo = *reinterpret_cast<const float4*>(src), hi = *reinterpret_cast<const float4*>(src + 4);
-                const int64_t blk = (int64_t)((n0 + wn * 64) / 16 + nbk) * tiles_kp + (k0 + wk * 64) / 32 + i;
-                *reinterpret_cast<uint4*>(Wb + ((blk * 64 + lane) << 3)) =
-                    make_uint4(cvt_pk_bf16(lo.x, lo.y), cvt_pk_bf16(lo.z, lo.w), cvt_pk_bf16(hi.x, hi.y), cvt_pk_bf16(hi.z, hi.w));
-            }
-    }
-}
-
 // SLOTS ring slots of R-row stages (R x 128 columns of both operands).  R = 32: 16 KiB stages, 64 KiB ring, two workgroups per CU
 // (8 such slots, one workgroup per CU with seven stages requested ahead, measured 40.0 against 38.1 us at 8192 columns).
 // R = 64: 32 KiB stages, 128 KiB ring, one workgroup per CU - half the barriers, and the fragment reads of a stage's second
 // half run under the MFMAs of its first (with one compute wave per SIMD nothing else hides the LDS latency).
-template <int SLOTS, int R, bool FUSE = false>
-__device__ __forceinline__ void wgrad3_body(const WgradArgs& pa, const int work, u16* ring, const WgradFuse& fz) {
+template <int SLOTS, int R>
+__device__ __forceinline__ void wgrad3_body(const WgradArgs& pa, const int work, u16* ring) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wk = (wid >> 1) & 1, wn = wid & 1;
@@ -645,21 +471,6 @@ __device__ __forceinline__ void wgrad3_body(const WgradArgs& pa, const int work,
             for (int j = 0; j < 2; ++j) asm volatile("" :: "v"(acc[i][j]));
         return;
     }
-    if constexpr (FUSE) {
-        if (work == 0 && tid == 0 && fz.opt.loss_dst) opt_loss_handover(fz.opt);      // the chain kernel of this step has ended: its loss sums are final
-        float* reg = reinterpret_cast<float*>(ring) + wid * (4 * 32 * 32);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    reg[(i * 2 + j) * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = acc[i][j][r];
-        int tile_id = tile;
-        for (int l2 = 0; l2 < li; ++l2) tile_id += pa.L[l2].tiles_k * pa.L[l2].tiles_n;
-        wgrad3_fused_tail(pa, fz, p, li, tile_id, split, k0, n0, wk, wn, wid, lane, reg, accb[0], do_bias);
-        return;
-    }
     float* dW = p.dW; float* db = p.db;
     if (pa.plain && split > 0) {                                      // this row split's own buffer (WgradArgs.plain)
         float* mine = pa.part + (int64_t)(split - 1) * pa.part_stride;
@@ -712,14 +523,7 @@ __device__ __forceinline__ void wgrad3_body(const WgradArgs& pa, const int work,
 template <int SLOTS, int R>
 __global__ __launch_bounds__(WG3_THREADS) void k_wgrad3(const WgradArgs pa) {
     extern __shared__ __attribute__((aligned(16))) u16 ring[];    // [stage][H|Z][R][128]
-    wgrad3_body<SLOTS, R>(pa, xcd_work_id(blockIdx.x, gridDim.x), ring, WgradFuse{});
-}
-
-// the same with the optimiser folded in (WgradFuse above): the one-call training step of the tuned layer chain
-template <int SLOTS, int R>
-__global__ __launch_bounds__(WG3_THREADS) void k_wgrad3_opt(const WgradArgs pa, const WgradFuse fz) {
-    extern __shared__ __attribute__((aligned(16))) u16 ring[];    // [stage][H|Z][R][128]
-    wgrad3_body<SLOTS, R, true>(pa, xcd_work_id(blockIdx.x, gridDim.x), ring, fz);
+    wgrad3_body<SLOTS, R>(pa, xcd_work_id(blockIdx.x, gridDim.x), ring);
 }
 
 // K members in one launch (csrc/group.h): the grid is the concatenation of the members' grids; consecutive work ids
@@ -728,5 +532,5 @@ __global__ __launch_bounds__(WG3_THREADS) void k_wgrad3_group(const WgradArgs* _
     extern __shared__ __attribute__((aligned(16))) u16 ring[];
     const int work = xcd_work_id(blockIdx.x, gridDim.x);
     const int m = group_member(tab, work);
-    wgrad3_body<4, 32>(members[tab.idx[m]], work - tab.begin[m], ring, WgradFuse{});
+    wgrad3_body<4, 32>(members[tab.idx[m]], work - tab.begin[m], ring);
 }

@@ -65,9 +65,10 @@ class GpuColumnLoader:
             rows.append(np.asarray(mlo[src], np.float64).reshape(du.var_lens[v], -1))
         return a, np.concatenate(rows)
 
-    def stack_raw(self, mli_raw, mlo_raw=None, want_x=True, want_y=True):
+    def stack_raw(self, mli_raw, mlo_raw=None, want_x=True, want_y=True, extra_rows: int = 0):
         """mli_raw (T, n_in, ncol), mlo_raw (T, n_out, ncol): numpy or device tensors, float64 or float32.
-        Returns (x (T*ncol, n_in), y (T*ncol, n_out)) float32 device tensors."""
+        Returns (x (T*ncol, n_in), y (T*ncol, n_out)) float32 device tensors.  `extra_rows`: the tensors are allocated that many rows
+        longer (uninitialised tail: the streamed trainer appends the rows the previous chunk's last batch left over)."""
         import torch
         def dev(a):
             if a is None:
@@ -82,8 +83,8 @@ class GpuColumnLoader:
         if fin != self.n_in or (b is not None and tuple(b.shape) != (T, self.n_out, ncol)):
             raise ValueError(f"expected (T,{self.n_in},ncol) and (T,{self.n_out},ncol)")
         want_y = want_y and b is not None
-        x = torch.empty((T * ncol, self.n_in), dtype=torch.float32, device=self.device) if want_x else None
-        y = torch.empty((T * ncol, self.n_out), dtype=torch.float32, device=self.device) if want_y else None
+        x = torch.empty((T * ncol + extra_rows, self.n_in), dtype=torch.float32, device=self.device) if want_x else None
+        y = torch.empty((T * ncol + extra_rows, self.n_out), dtype=torch.float32, device=self.device) if want_y else None
         st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         for lo in range(0, T, 32768):                         # grid.y limit
             hi = min(T, lo + 32768)

@@ -23,14 +23,19 @@ import numpy as np
 
 
 class StreamedTrainer:
-    def __init__(self, model, loader, batch_size: int, slots: int = 2, dist=None, loader_on: str | None = None):
+    def __init__(self, model, loader, batch_size: int, slots: int = 2, dist=None, loader_on: str | None = None, carry_remainder: bool = True):
         """`loader_on`: "main" (default; CS_STREAM_LOADER overrides) runs the loader KERNEL on the training stream, right in front of
         the chunk's first step; host chunks are staged and copied on the side stream while the PREVIOUS chunk trains (the training
         stream waits for the copy only when it reaches the chunk - round 4: it used to wait at produce time, in front of the
         previous chunk's steps, and idled through the whole copy).  "side" runs the kernel on the side stream too.  On one GPU the
         two measure the same for device-resident chunks (round 3, bench_stream.py: 56.0 / 56.2 M columns/s; the loader is
         1.3-1.6 G columns/s); with the kernel on the training stream nothing ever runs beside a step, so a cooperative model is
-        accepted."""
+        accepted.
+        `carry_remainder` (round 4): the rows a chunk's last batch would leave short are carried into the next chunk's permutation
+        instead of forming a partial batch per chunk - the reference batches AFTER its shuffle buffer, across file boundaries
+        (`.unbatch().shuffle(...).batch(bs)`, step2_retrain.py:266-277), so only the last batch of a pass is short there too.  At
+        the high-res width a chunk of 8 timesteps is 21 batches of 8192 + 768 rows: the partial step costs two thirds of a full
+        one.  With one pass per chunk only (`passes_per_chunk` > 1 keeps per-chunk batching); False restores rounds 1-3."""
         import os
         import torch
         self.loader_on = loader_on or os.environ.get("CS_STREAM_LOADER", "main")
@@ -47,6 +52,8 @@ class StreamedTrainer:
         self.torch, self.model, self.loader, self.batch, self.slots = torch, model, loader, int(batch_size), int(slots)
         self.device = model.device
         self.side = torch.cuda.Stream(device=self.device)
+        self.aux = torch.cuda.Stream(device=self.device)          # the chunks' permutations (a handful of small sort kernels each)
+        self._carrying = False
         self.dist = dist
         self.world = dist.get_world_size() if dist is not None else 1
         self._dp = None
@@ -55,6 +62,9 @@ class StreamedTrainer:
             self._dp = DataParallel(model, dist, model.output_length)
         self.rows_seen = 0
         self.rows_dropped = 0
+        self.carry = bool(carry_remainder)
+        self._carry_x = self._carry_y = None
+        self._carry_n = 0
 
     # ---- producer (side stream)
     def _produce(self, raw, free_event):
@@ -93,7 +103,7 @@ class StreamedTrainer:
         with torch.cuda.stream(self.side):
             if free_event is not None:
                 self.side.wait_event(free_event)             # the slot's previous chunk has been consumed
-            x, y = self.loader.stack_raw(dev(mli), dev(mlo))
+            x, y = self.loader.stack_raw(dev(mli), dev(mlo), extra_rows=self.batch if self._carrying else 0)
             ready = torch.cuda.Event()
             ready.record(self.side)
         x.record_stream(main)
@@ -107,10 +117,18 @@ class StreamedTrainer:
         if ready is None:                            # loader_on == "main": x = the raw chunk (on the device), y = its copy event or None
             if y is not None:
                 main.wait_event(y)
-            x, y = self.loader.stack_raw(*x)
+            x, y = self.loader.stack_raw(*x, extra_rows=self.batch if self._carrying else 0)
         else:
             main.wait_event(ready)
-        n = x.shape[0]
+        carrying = self._carrying
+        n_new = x.shape[0] - (self.batch if carrying else 0)      # rows the loader wrote; the tail is headroom for carried rows
+        r = self._carry_n if carrying else 0
+        if r:                                        # the previous chunk's leftover rows join this chunk's permutation
+            x[n_new:n_new + r].copy_(self._carry_x[:r])
+            y[n_new:n_new + r].copy_(self._carry_y[:r])
+            self._carry_n = 0
+        n = n_new + r
+        n_have = n
         if self.dist is not None:
             # Every rank streams its own timesteps, so chunks may differ in T*ncol.  The ranks must issue the SAME number of
             # all-reduces and normalise by the SAME global row count: agree on the smallest chunk and drop the surplus
@@ -118,7 +136,7 @@ class StreamedTrainer:
             t = torch.tensor([n, -n], dtype=torch.int64, device=self.device)
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
             n_max, n = int(t[0].item()), int(-t[1].item())
-            self.rows_dropped += x.shape[0] - n
+            self.rows_dropped += n_have - n
             if n <= 0:
                 raise ValueError("a rank produced an empty chunk")
         step = step0
@@ -126,11 +144,27 @@ class StreamedTrainer:
         sums = torch.zeros((passes * ((n + self.batch - 1) // self.batch), 2), dtype=torch.float32, device=self.device)
         self._sums.append(sums)
         k = 0
+        n_train = (n // self.batch) * self.batch if carrying else n      # carrying: whole batches only, the rest travels on
         for _ in range(passes):
-            perm = torch.randperm(x.shape[0], device=self.device, generator=gen)
-            if n < x.shape[0]:
+            # the permutation is drawn on a stream of its own: the host runs chunks ahead of the GPU, so these small kernels run
+            # beside the steps of an EARLIER chunk instead of between two steps of this one (0.09 ms per chunk at the high-res width)
+            with torch.cuda.stream(self.aux):
+                perm = torch.randperm(n_have, device=self.device, generator=gen)
+                drawn = torch.cuda.Event()
+                drawn.record(self.aux)
+            perm.record_stream(main)
+            main.wait_event(drawn)
+            if n < n_have:
                 perm = perm[:n]                      # a random subset of this rank's rows, as many as the smallest rank has
-            for lo in range(0, n, self.batch):
+            if carrying and n_train < n:
+                left = perm[n_train:n]
+                if self._carry_x is None:
+                    self._carry_x = torch.empty((self.batch, x.shape[1]), dtype=torch.float32, device=self.device)
+                    self._carry_y = torch.empty((self.batch, y.shape[1]), dtype=torch.float32, device=self.device)
+                torch.index_select(x, 0, left, out=self._carry_x[:left.numel()])
+                torch.index_select(y, 0, left, out=self._carry_y[:left.numel()])
+                self._carry_n = int(left.numel())
+            for lo in range(0, n_train, self.batch):
                 idx = perm[lo:lo + self.batch]
                 lr = lr_of_step(step)
                 if self.dist is None:
@@ -143,8 +177,26 @@ class StreamedTrainer:
                 k += 1
         done = torch.cuda.Event()
         done.record(main)
-        self.rows_seen += n * passes
+        self.rows_seen += n_train * passes
         return done, step
+
+    def _flush_carry(self, lr_of_step, step):
+        """The rows still carried when the pass ends: its one short batch (the reference's last batch of an epoch)."""
+        r, self._carry_n = self._carry_n, 0
+        if not r:
+            return step
+        torch = self.torch
+        sums = torch.zeros((1, 2), dtype=torch.float32, device=self.device)
+        self._sums.append(sums)
+        lr = lr_of_step(step)
+        if self.dist is None:
+            self.model.train_on_batch(self._carry_x[:r], self._carry_y[:r], lr, loss=sums[0])
+        else:                                        # every rank carries the same count (the chunks' row counts are agreed on)
+            self.model.loss_grads(self._carry_x[:r], self._carry_y[:r], loss=sums[0])
+            self._dp.all_reduce_grads()
+            self.model.apply_gradients(lr, 1.0 / (self.model.output_length * r * self.world))
+        self.rows_seen += r
+        return step + 1
 
     def fit_chunks(self, chunks: Iterable, learning_rate=1e-3, passes_per_chunk: int = 1, seed: int = 0):
         """Train on a stream of raw chunks `(mli_raw (T, n_in, ncol), mlo_raw (T, n_out, ncol))`.
@@ -157,6 +209,8 @@ class StreamedTrainer:
         self._sums = []
         self.rows_seen = 0
         self.rows_dropped = 0
+        self._carrying = self.carry and passes_per_chunk == 1
+        self._carry_n = 0
         it = iter(chunks)
         ring = []                                  # [(x, y, ready)] produced, not yet consumed
         free = []                                  # `done` events of consumed chunks, oldest first
@@ -189,7 +243,10 @@ class StreamedTrainer:
             done, step = self._consume(x, y, ready, lr_of_step, gen, passes_per_chunk, step)   # ... while this one trains
             free.append(done)
             del x, y
-        s = np.sum([t.cpu().numpy().astype(np.float64).sum(axis=0) for t in self._sums], axis=0) if self._sums else np.zeros(2)
+        if self._carrying:
+            step = self._flush_carry(lr_of_step, step)
+        # one device-side concatenation and ONE copy (a copy per chunk was a host synchronisation per chunk at the end of the pass)
+        s = torch.cat(self._sums).double().sum(dim=0).cpu().numpy() if self._sums else np.zeros(2)
         self._sums = []
         denom = max(self.rows_seen, 1) * self.model.output_length
         return {"loss": float(s[0]) / denom, "mae": float(s[1]) / denom, "rows": self.rows_seen, "steps": step - step_start}

@@ -107,46 +107,3 @@ def test_training_step_without_gradient_atomics_equals_the_two_call_form(M, n, o
     b.loss_grads(xd, yd)
     for u, v in zip(ga, b.get_gradients(1.0)):
         assert rel(u, v) <= 1e-4
-
-
-@pytest.mark.parametrize("n,opt", [(8192, "Adam"), (8192, "RAdam"), (4096, "RMSprop"), (1024, "SGD"), (3000, "Adam")])
-def test_optimiser_folded_into_the_weight_gradient_launch_is_bit_identical(M, n, opt, monkeypatch):
-    """Round 4: inside cs_mlp_train_step the last-arriving wave of every 64 x 64 piece of a weight-gradient tile adds the row
-    splits' partial sums in split order, applies the update rule and re-casts both fragment-major operand copies (WgradFuse,
-    csrc/wgrad2.h) - no k_optimizer launch.  CS_WGRAD_FUSE_OPT=0 keeps the launch.  Same sums in the same order through the
-    same rule (opt_elem), so after six steps the two models must agree BIT FOR BIT: weights, both optimiser slots, and - through
-    the bf16 operand copies - predictions (the loss sums come from float atomics over 256 workgroups: equal to rounding); the
-    gradient buffer is handed back zeroed by both.
-    Sizes: 3 row splits (8192, 4096), 2 (1024), a ragged batch (3000)."""
-    cfg = O.MLPConfig(hidden=CFG)
-    ws = O.glorot_init(cfg, 5)
-    rng = np.random.default_rng(9)
-    for i in range(1, len(ws), 2):
-        ws[i] = rng.normal(0, 0.05, ws[i].shape).astype(np.float32)
-    monkeypatch.setenv("CS_WGRAD_FUSE_OPT", "1")
-    a = M.MLPEmulator(units=CFG, optimizer=opt, max_batch=n, seed=None)                      # fused (opt-in: measured slower, see wgrad2.h)
-    monkeypatch.setenv("CS_WGRAD_FUSE_OPT", "0")
-    b = M.MLPEmulator(units=CFG, optimizer=opt, max_batch=n, seed=None)                      # k_optimizer launch (default)
-    monkeypatch.delenv("CS_WGRAD_FUSE_OPT")
-    a.set_weights(ws); b.set_weights(ws)
-    x, y = O.synth_columns(n, seed=11)
-    xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
-    for it in range(6):
-        perm = torch.randperm(n, device="cuda", generator=torch.Generator(device="cuda").manual_seed(it))
-        la = a.train_on_batch(xd, yd, 1e-3, row_idx=perm).cpu().numpy()
-        lb = b.train_on_batch(xd, yd, 1e-3, row_idx=perm).cpu().numpy()
-        np.testing.assert_allclose(la, lb, rtol=1e-6)
-    assert float(a.gradient_tensor().abs().max()) == 0.0 and float(b.gradient_tensor().abs().max()) == 0.0
-    for wa, wb, w0 in zip(a.get_weights(), b.get_weights(), ws):
-        np.testing.assert_array_equal(wa, wb)
-        assert np.any(wa != w0)
-    (ma, va, ia), (mb, vb, ib) = a.get_optimizer_state(), b.get_optimizer_state()
-    assert ia == ib == 6
-    for u, v in zip(ma + va, mb + vb):
-        np.testing.assert_array_equal(u, v)
-    np.testing.assert_array_equal(a.predict(xd, as_numpy=False).cpu().numpy(), b.predict(xd, as_numpy=False).cpu().numpy())
-    # the two-call form (data parallel) after fused steps: one clean gradient buffer, same gradients as the unfused model's
-    a.loss_grads(xd, yd); b.loss_grads(xd, yd)
-    for u, v in zip(a.get_gradients(1.0), b.get_gradients(1.0)):
-        assert rel(u, v) <= 1e-4
-    a.close(); b.close()

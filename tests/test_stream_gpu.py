@@ -57,10 +57,13 @@ def test_streamed_training_equals_materialised_training(raw_tree, lowres_assets,
         StreamedTrainer(a, ld, batch_size=4 * B)
 
 
-def test_streamed_training_at_highres_width(raw_tree, lowres_assets):
+@pytest.mark.parametrize("carry", [False, True])
+def test_streamed_training_at_highres_width(raw_tree, lowres_assets, carry):
     """BASELINE config 5 shape: chunks of 21,600-column timesteps (and one ragged 21,601-column chunk) resident in HBM as
-    float64 raw fields, cfg-MLP-sized batches of 8192.  Streaming (loader on the side stream, double-buffered) must equal
-    materialising every chunk first; the last batch of a chunk is partial (43,200 = 5 x 8192 + 2,240)."""
+    float64 raw fields, cfg-MLP-sized batches of 8192.  Streaming (double-buffered) must equal materialising every chunk first.
+    carry=False: every chunk ends in a partial batch (43,200 = 5 x 8192 + 2,240).  carry=True (the default since round 4): the
+    leftover rows join the next chunk's permutation, as the reference's `.unbatch().shuffle().batch()` batches across files
+    (step2_retrain.py:266-277) - whole batches only, ONE short batch at the end of the pass, every row trained on exactly once."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from climsim_amd.loader import GpuColumnLoader
@@ -84,19 +87,32 @@ def test_streamed_training_at_highres_width(raw_tree, lowres_assets):
         chunks.append((a, b))
     B, LR = 8192, 1e-3
     m1 = MLPEmulator(units=(128, 128), max_batch=B, seed=3)
-    out = StreamedTrainer(m1, ld, batch_size=B, slots=2).fit_chunks(iter(chunks), learning_rate=LR, seed=4)
+    out = StreamedTrainer(m1, ld, batch_size=B, slots=2, carry_remainder=carry).fit_chunks(iter(chunks), learning_rate=LR, seed=4)
     rows = sum(c[0].shape[0] * c[0].shape[2] for c in chunks)
-    assert out["rows"] == rows and out["steps"] == sum(-(-c[0].shape[0] * c[0].shape[2] // B) for c in chunks)
+    assert out["rows"] == rows
+    assert out["steps"] == (-(-rows // B) if carry else sum(-(-c[0].shape[0] * c[0].shape[2] // B) for c in chunks)) == m1.iterations
     m2 = MLPEmulator(units=(128, 128), max_batch=B, seed=3)
     gen = torch.Generator(device="cuda")
     gen.manual_seed(4)
     tot = np.zeros(2)
+    cx = cy = None                                   # carried rows (carry=True): materialised here with plain torch ops
+    seen = 0
     for mli, mlo in chunks:
         x, y = ld.stack_raw(mli, mlo)
         assert bool(torch.isfinite(x).all()) and bool(torch.isfinite(y).all())
+        if carry and cx is not None:
+            x, y = torch.cat([x, cx]), torch.cat([y, cy])
         perm = torch.randperm(x.shape[0], device="cuda", generator=gen)
-        for lo in range(0, x.shape[0], B):
+        n_train = (x.shape[0] // B) * B if carry else x.shape[0]
+        for lo in range(0, n_train, B):
             tot += m2.train_on_batch(x, y, LR, row_idx=perm[lo:lo + B]).cpu().numpy()
+        seen += n_train
+        if carry:
+            cx, cy = x[perm[n_train:]].contiguous(), y[perm[n_train:]].contiguous()
+    if carry and cx is not None and cx.shape[0]:
+        tot += m2.train_on_batch(cx, cy, LR).cpu().numpy()
+        seen += cx.shape[0]
+    assert seen == rows
     for wa, wb in zip(m1.get_weights(), m2.get_weights()):
         np.testing.assert_allclose(wa, wb, rtol=0, atol=1e-3 * max(1.0, float(np.abs(wb).max())))
     assert abs(out["loss"] - tot[0] / (rows * 128)) <= 1e-3 * tot[0] / (rows * 128)
