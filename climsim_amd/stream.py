@@ -52,7 +52,6 @@ class StreamedTrainer:
         self.torch, self.model, self.loader, self.batch, self.slots = torch, model, loader, int(batch_size), int(slots)
         self.device = model.device
         self.side = torch.cuda.Stream(device=self.device)
-        self.aux = torch.cuda.Stream(device=self.device)          # the chunks' permutations (a handful of small sort kernels each)
         self._carrying = False
         self.dist = dist
         self.world = dist.get_world_size() if dist is not None else 1
@@ -146,14 +145,10 @@ class StreamedTrainer:
         k = 0
         n_train = (n // self.batch) * self.batch if carrying else n      # carrying: whole batches only, the rest travels on
         for _ in range(passes):
-            # the permutation is drawn on a stream of its own: the host runs chunks ahead of the GPU, so these small kernels run
-            # beside the steps of an EARLIER chunk instead of between two steps of this one (0.09 ms per chunk at the high-res width)
-            with torch.cuda.stream(self.aux):
-                perm = torch.randperm(n_have, device=self.device, generator=gen)
-                drawn = torch.cuda.Event()
-                drawn.record(self.aux)
-            perm.record_stream(main)
-            main.wait_event(drawn)
+            # (on the training stream.  Round 4 drew it on a stream of its own so that its small sort kernels would run beside an
+            #  earlier chunk's steps: the pass got SLOWER, 11.7 -> 13.3 ms for 4 chunks - a layer-chain launch needs every compute
+            #  unit whole, and a sort workgroup sitting on one of them costs that launch a second round of workgroups)
+            perm = torch.randperm(n_have, device=self.device, generator=gen)
             if n < n_have:
                 perm = perm[:n]                      # a random subset of this rank's rows, as many as the smallest rank has
             if carrying and n_train < n:
