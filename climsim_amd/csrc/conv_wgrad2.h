@@ -238,7 +238,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv_wgrad2(const CwArgs pa) {
 
 // The same kernel with the operand requests moved to FOUR LOADER WAVES (waves 8..11): a 1-KiB LDS-DMA piece costs the wave that
 // issues it 100-185 clocks when it sits between ds_reads and MFMAs and ~20 in a wave that does nothing else (k_wgrad3,
-// contraction 39.9 -> 32.3 us from this change alone).  The eight compute waves (64 x 112 each) keep
+// LAB_NOTES.md (rounds 1-3, section 4): contraction 39.9 -> 32.3 us from this change alone).  The eight compute waves (64 x 112 each) keep
 // the software pipeline of k_conv_wgrad2<8> minus its four pieces per slab and their running source state; loader lw owns
 // pieces 4 lw .. 4 lw + 3 of both operands.  A barrier still promises "slab s + 1 has landed, slab s is out of use".
 // Measured (depth 12, width 406, batch 512, step): 4.11 ms with k_conv_wgrad2<8>, 4.39 with two loader waves (32 pieces per

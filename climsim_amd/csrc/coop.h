@@ -4,7 +4,7 @@
 // weight-gradient kernel needs anyway - before the next layer starts.
 //
 // Why: one CU cannot pull the 4.65 MB of both weight sets through its vector-memory path in less than ~40 us (measured 80 us for
-// the whole fused chain, flat from 1024 to 8192 columns: DESIGN.md section 4 "Round 2").  With C members per tile a CU
+// the whole fused chain, flat from 1024 to 8192 columns: LAB_NOTES.md, "Round 2").  With C members per tile a CU
 // streams 1/C of that; what it costs is one all-gather among the C members per layer.  Measured for exactly this pattern
 // (tools/handoff_probe.hip, profiles/r02_handoff_probe.txt): 1.7-1.9 us per layer boundary.  13 boundaries per step.
 //

@@ -1,6 +1,6 @@
 // Development probe (hipcc --offload-arch=gfx950 -O3 sstore_probe.hip -o probe && ./probe): do scalar stores work on the MI355X?
 // Per-wave 64-bit lane masks from v_cmp, written with s_store_dwordx2 + s_dcache_wb, read back by a second kernel.  Result on the
-// pool: "0 mismatches of 1048576".  (what comes next, item 3.)
+// pool: "0 mismatches of 1048576".  (LAB_NOTES.md, rounds 1-3.)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>

@@ -1,7 +1,7 @@
 // Development probe (hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/wring_probe.hip -o tools/wring_probe.bin && tools/wring_probe.bin):
 // does a LOADER-WAVE weight ring let the layer chain overlap its weight stream with its MFMAs?
 //
-// DESIGN.md ("What comes next" 1): k_chain_fb's time is the SUM of its weight stream and its MFMAs at every tile height - the same
+// LAB_NOTES.md (rounds 1-3, "What comes next" 1): k_chain_fb's time is the SUM of its weight stream and its MFMAs at every tile height - the same
 // waves issue both.  This probe runs the chain's weight traffic only (13 "layers" of 512 x 512 bf16 weights in fragment order, 32
 // k16-steps x 16 column tiles x 1 KiB per layer, every workgroup the same 6.8 MB from L2, 2 column tiles per compute wave) with
 // M MFMAs per 1-KiB fragment (M = 1: 32-row tiles, 2: 64 rows, 4: 128 rows) in two forms:
