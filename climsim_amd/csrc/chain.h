@@ -68,7 +68,7 @@ struct ChainArgs {
     int fused;               // forward half: dz of the heads also goes to LDS, loss scratch moves to the bias block;
                              // backward half: no prologue load (dz is in X) and no L2 warm-up (a prefetch of Wb issued during
                              // the forward half would sit in front of that half's weight stream: memory operations complete in order)
-    int ablate;              // timing experiments only (CS_CHAIN_ABLATE): 4 no global stores, 8 no warm-up, 128 no contraction split in 128-wide stages, 256 / 512 no early priming of the run's queue (backward / forward)
+    int ablate;              // timing experiments only (CS_CHAIN_ABLATE): 4 no global stores, 8 no warm-up, 128 no contraction split in 128-wide stages
     int store_nt;            // activations / gradients leave with the non-temporal policy (host: batches the L2s cannot hold anyway)
     int trunk_i0, trunk_n;   // stages trunk_i0 .. trunk_i0 + trunk_n - 1 run as ONE continuous weight stream (chain_trunk; 0 / 0: off)
     unsigned long long* dbg; // optional [grid][64] s_memtime stamps (CS_CHAIN_DBG), null in production
@@ -155,26 +155,9 @@ __device__ __forceinline__ void chainw_copy_out(const u16* __restrict__ X, u16* 
 
 // `kofs`: first k16-step of this wave's share of the contraction (0 = all of it; chain_stage splits the contraction of a 128-wide
 // stage between the two halves of a 32-row tile's waves), `ks_total` the number of steps it takes from there.
-template <int BMROWS, int MT, int NT, int D, bool SELF_PRIME, int PITCH, bool WIDE_PEND, int XNEXT>
-__device__ __forceinline__ void chain_mma(const u16* __restrict__ X, const u16* __restrict__ wfrag, int ks_total, int ntiles,
-                                          int jt0, int mrow0, int tid, f32x16_t (&acc)[MT][NT], ChainPending& pend, int64_t m0, const int kofs,
-                                          ChainQ& XQ, const u16* xw, int xks, int xjt0);
-// (the common form: no following run to prime)
 template <int BMROWS, int MT, int NT, int D, bool SELF_PRIME, int PITCH = CHAIN_PITCH, bool WIDE_PEND = false>
 __device__ __forceinline__ void chain_mma(const u16* __restrict__ X, const u16* __restrict__ wfrag, int ks_total, int ntiles,
                                           int jt0, int mrow0, int tid, f32x16_t (&acc)[MT][NT], ChainPending& pend, int64_t m0, const int kofs = 0) {
-    ChainQ none;
-    chain_mma<BMROWS, MT, NT, D, SELF_PRIME, PITCH, WIDE_PEND, 0>(X, wfrag, ks_total, ntiles, jt0, mrow0, tid, acc, pend, m0, kofs, none, nullptr, 0, 0);
-}
-
-// `XQ` (with XNEXT = 16): the queue of the run of 512-wide stages that FOLLOWS this stage (chain_trunk) is primed here, right behind this
-// stage's own priming loads, so that its first 8 steps land under this stage's k-loop and epilogue instead of starting a memory
-// latency of their own (the stage in front of the backward run is 8 steps long: 5.6-7k clocks of pure latency, twice).  Only for
-// stages of exactly D steps: every wait then counts the 16 younger loads on top.
-template <int BMROWS, int MT, int NT, int D, bool SELF_PRIME, int PITCH, bool WIDE_PEND, int XNEXT>
-__device__ __forceinline__ void chain_mma(const u16* __restrict__ X, const u16* __restrict__ wfrag, int ks_total, int ntiles,
-                                          int jt0, int mrow0, int tid, f32x16_t (&acc)[MT][NT], ChainPending& pend, int64_t m0, const int kofs,
-                                          ChainQ& XQ, const u16* xw, int xks, int xjt0) {
     const int lane = tid & 63;
     ChainQ Q;
     static_assert(D == 4 || D == 8, "queue slots are written out for depth 4 and 8");
@@ -200,8 +183,8 @@ __device__ __forceinline__ void chain_mma(const u16* __restrict__ X, const u16* 
     {                                                                                                          \
         const int s = s0 + (d);                                                                                \
         if (MT <= 2) { CHAIN_AF(AN, s + 1) } else { CHAIN_AF(AC, s) }                                          \
-        if (NT == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(Q0), "+v"(Q1) : "i"(XNEXT + ((TAIL) ? NT * (D - 1 - (d)) : NT * (D - 1))) : "memory"); \
-        else asm volatile("s_waitcnt vmcnt(%1)" : "+v"(Q0) : "i"(XNEXT + ((TAIL) ? NT * (D - 1 - (d)) : NT * (D - 1))) : "memory"); \
+        if (NT == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(Q0), "+v"(Q1) : "i"((TAIL) ? NT * (D - 1 - (d)) : NT * (D - 1)) : "memory"); \
+        else asm volatile("s_waitcnt vmcnt(%1)" : "+v"(Q0) : "i"((TAIL) ? NT * (D - 1 - (d)) : NT * (D - 1)) : "memory"); \
         _Pragma("unroll") for (int a = 0; a < MT; ++a) {                                                       \
             acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, Q0), AC[a], acc[a][0], 0, 0, 0); \
             if (NT == 2)                                                                                       \
@@ -241,10 +224,6 @@ __device__ __forceinline__ void chain_mma(const u16* __restrict__ X, const u16* 
     // Older compiler-issued memory ops need no explicit drain: completion is in order, so the first counted
     // wait below also covers them.
     if (SELF_PRIME) chain_prime_t<NT, D>(Q, wfrag + (int64_t)kofs * sstride * 8, ks_total, ntiles, jt0, lane);
-    if constexpr (XNEXT > 0) {
-        static_assert(XNEXT == 16, "the following run's queue: 8 steps x 2 column tiles");
-        chain_prime_t<2, 8>(XQ, xw, xks, 16, xjt0, lane);       // (ks_total == D here: no refill follows, the counts above hold for every step)
-    }
     // The previous stage's output (= this stage's input, intact in X until the barrier behind this k-loop) still has to go to
     // global memory.  32-row tiles: NOW, behind the queue-priming loads (in front of them a vmcnt(0) for the stores cost ~1 us
     // per stage).  Taller tiles: behind the LAST weight load of the stage (below).
@@ -376,11 +355,10 @@ __device__ __forceinline__ void chain_stamp(const ChainArgs& p, int bid, int tid
 // an epilogue that shared every SIMD's VALU with its own copy (round-4 stamps: 7.7k clocks for the 32 k16-steps of 512 -> 128, 4.8k for
 // the heads' epilogue).  Now the two halves SPLIT the contraction when it has 16 steps or more (partial sums of waves 4-7 meet in the
 // part of X the 128-wide output leaves free), and only waves 0-3 run the epilogue.
-template <int BMROWS, int MT, int NT, int EPI, bool ELU, int XN>
-__device__ __forceinline__ void chain_stage_x(u16* X, const float* bias_lds, const int64_t* rows_lds, const ChainArgs& p,
-                                              const ChainDyn& d_, int bid, const ChainStage& S, bool last, int64_t m0, int jt0, int mrow0, int tid,
-                                              float& sq, float& ab, int& slot, ChainPending& pend, const bool dup,
-                                              ChainQ& XQ, const ChainStage& XS) {
+template <int BMROWS, int MT, int NT, int EPI, bool ELU>
+__device__ __forceinline__ void chain_stage(u16* X, const float* bias_lds, const int64_t* rows_lds, const ChainArgs& p,
+                                            const ChainDyn& d_, int bid, const ChainStage& S, bool last, int64_t m0, int jt0, int mrow0, int tid,
+                                            float& sq, float& ab, int& slot, ChainPending& pend, const bool dup = false) {
     const int lane = tid & 63;
     const bool upper = dup && tid >= 256;                      // waves 4-7 of a `dup` stage
     const bool ksplit = dup && (S.Kc >> 4) >= 16 && !(p.ablate & 128);
@@ -414,10 +392,7 @@ __device__ __forceinline__ void chain_stage_x(u16* X, const float* bias_lds, con
     //  registers then live across the stage dispatch, hipcc copies / spills them - 140-300 B of scratch per lane - and a
     //  copy of a register whose asm load has not landed yet is garbage.  The queue stays local to chain_mma.)
     const int ks_all = S.Kc >> 4, ks_mine = ksplit ? ks_all >> 1 : ks_all, kofs = (ksplit && upper) ? ks_all >> 1 : 0;
-    if constexpr (XN > 0)                // 8-step stage in front of a run of 512-wide stages: prime that run's queue too (the host checked the shapes)
-        chain_mma<BMROWS, MT, NT, 8, true, CHAIN_PITCH, false, XN>(X, S.wfrag, ks_mine, S.Nc >> 5, jt0, mrow0, tid, acc, pend, m0, kofs,
-                                                                 XQ, XS.wfrag, XS.Kc >> 4, (tid >> 6) * 2);
-    else if (MT <= 2 && (S.Kc & 127) == 0 && (!ksplit || (ks_mine & 7) == 0)) chain_mma<BMROWS, MT, NT, 8, true>(X, S.wfrag, ks_mine, S.Nc >> 5, jt0, mrow0, tid, acc, pend, m0, kofs);
+    if (MT <= 2 && (S.Kc & 127) == 0 && (!ksplit || (ks_mine & 7) == 0)) chain_mma<BMROWS, MT, NT, 8, true>(X, S.wfrag, ks_mine, S.Nc >> 5, jt0, mrow0, tid, acc, pend, m0, kofs);
     else chain_mma<BMROWS, MT, NT, 4, true>(X, S.wfrag, ks_mine, S.Nc >> 5, jt0, mrow0, tid, acc, pend, m0, kofs);
     if (EPI == EPI_DGRAD && !ELU && remap) {
         const int a0 = bid & 1;
@@ -472,15 +447,6 @@ __device__ __forceinline__ void chain_stage_x(u16* X, const float* bias_lds, con
     chain_stamp(p, bid, tid, slot);
 }
 
-// (the common form: no following run to prime)
-template <int BMROWS, int MT, int NT, int EPI, bool ELU>
-__device__ __forceinline__ void chain_stage(u16* X, const float* bias_lds, const int64_t* rows_lds, const ChainArgs& p,
-                                            const ChainDyn& d_, int bid, const ChainStage& S, bool last, int64_t m0, int jt0, int mrow0, int tid,
-                                            float& sq, float& ab, int& slot, ChainPending& pend, const bool dup = false) {
-    ChainQ none;
-    chain_stage_x<BMROWS, MT, NT, EPI, ELU, 0>(X, bias_lds, rows_lds, p, d_, bid, S, last, m0, jt0, mrow0, tid, sq, ab, slot, pend, dup, none, S);
-}
-
 // ---- round 4: a run of 512-wide stages as ONE continuous weight stream ------------------------------------------------------
 // Per stage the chain used to: prime its queue (8 k16-steps, 16 KiB per wave), run the k-loop, barrier, epilogue, barrier - and
 // only then prime the next stage: nothing was in flight on the vector-memory pipe (the pipe that bounds a 32-row tile) while the
@@ -510,15 +476,15 @@ __device__ __forceinline__ void chain_copy_out512_asm(const u16* __restrict__ X,
 
 template <int BM, int EPI, bool ELU>
 __device__ __forceinline__ void chain_trunk(u16* X, const float* bias_lds, const ChainArgs& p, int bid, const int i0, const int cnt,
-                                            const int64_t m0, const int wid, const int tid, int& slot, ChainPending& pend, ChainQ& Q, const bool primed) {
+                                            const int64_t m0, const int wid, const int tid, int& slot, ChainPending& pend) {
     static_assert(BM == 32 && !ELU, "the counted window below is written for 32-row tiles without ELU");
     constexpr int MT = BM / 32, NT = 2, D = 8;
     constexpr int EXTRA = BM / 8 + 1;                          // asm memory operations between a stage's tail loads and the next stage's first wait
     constexpr unsigned STEPB = 16 * 64 * 16;                   // bytes per k16-step of a 512-wide stage (16 column tiles of 1 KiB)
     const int jt0 = wid * 2;
+    ChainQ Q;
     f32x16_t acc[MT][NT];
     bf16x8_t afA[MT], afB[MT];
-    // (`Q` belongs to chain_body: the stage in front of the run - or the kernel's prologue - may have primed it already, `primed`)
     // ONE block body serves every position in the run (hipcc keeps the queue in place only along a single path: with a body per
     // variant - head of a continuing stage, main, tail with / without a next stage - it split the queue's live ranges and put
     // v_mov copies of registers whose loads were still in flight on the edges between them).  What varies is scalar:
@@ -578,7 +544,7 @@ __device__ __forceinline__ void chain_trunk(u16* X, const float* bias_lds, const
         unsigned mskw = 0u;
         if (EPI == EPI_DGRAD) asm volatile("global_load_dword %0, %1, off" : "=v"(mskw) : "v"(mword) : "memory");   // (1 operation)
         if (!cont) {
-            if (!primed) chain_prime_t<NT, D>(Q, S.wfrag, ks, 16, jt0, lane);
+            chain_prime_t<NT, D>(Q, S.wfrag, ks, 16, jt0, lane);
             if (pend.out) {                                    // the stage in front of the run left its output to us: behind the priming loads, as chain_mma
                 chain_copy_out<BM>(X, pend.out, pend.ldo, pend.width, m0, tid, pend.nt != 0);
                 pend.out = nullptr;
@@ -629,17 +595,6 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const ChainDyn& d
     const int64_t m0 = (int64_t)bid * BM;
     int slot = 0;
     chain_stamp(p, bid, tid, slot);
-    // Queue of the run of 512-wide stages (chain_trunk).  When the run opens the pass (forward), its first 8 steps are requested HERE,
-    // in front of the prologue's own loads: they land while the row indices and the gathered rows make their two dependent round
-    // trips, and the run's first stage no longer starts with a memory latency of its own (7.9k clocks for 8 k16-steps, round-4 stamps).
-    ChainQ TQ;
-    bool tq_primed = false;
-    if constexpr (!BWD && BM == 32 && !ELU) {
-        if (p.trunk_n > 1 && p.trunk_i0 == 0 && !(p.ablate & 512)) {
-            chain_prime_t<2, 8>(TQ, p.st[0].wfrag, p.st[0].Kc >> 4, 16, wid * 2, tid & 63);
-            tq_primed = true;
-        }
-    }
     if (p.dbg && tid == 0) {                 // development: 100 MHz wall clock + placement (HW_ID, XCC_ID) of this workgroup
         p.dbg[(int64_t)bid * 64 + 61] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) |
                                                (unsigned)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
@@ -740,28 +695,14 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const ChainDyn& d
 
     float sq = 0.f, ab = 0.f;
     ChainPending pend{nullptr, 0, 0, 0};
-    int i = 0;
-    // The run of 512-wide stages (chain_trunk), when the host found one (chain_find_trunk: it starts at stage 0, or at stage 1 behind
-    // ONE 8-step 128-wide stage - the forward and the backward pass of the 5 x 512 model).  Straight-line code from the queue's first
-    // load to the end of the run: the queue then lives in registers only there (held across the generic stage loop below - whose
-    // stages bring their own queues - hipcc parked it in scratch, asm loads in flight and all).
-    if constexpr (BM == 32 && !ELU) {
-        if (p.trunk_n > 1) {
-            if (p.trunk_i0 == 1) {
-                const ChainStage& S0 = p.st[0];
-                if (!(p.ablate & 256)) {                       // stage 0 also primes the run's queue (chain_mma, XNEXT)
-                    chain_stage_x<BM, 1, 1, BWD ? EPI_DGRAD : EPI_HIDDEN, ELU, 16>(X, bias_lds, rows_lds, p, d_, bid, S0, false, m0, wid & 3, 0, tid, sq, ab, slot, pend, true,
-                                                                                  TQ, p.st[1]);
-                    tq_primed = true;
-                } else {
-                    chain_stage<BM, 1, 1, BWD ? EPI_DGRAD : EPI_HIDDEN, ELU>(X, bias_lds, rows_lds, p, d_, bid, S0, false, m0, wid & 3, 0, tid, sq, ab, slot, pend, true);
-                }
+    for (int i = 0; i < p.n_stages; ++i) {
+        if constexpr (BM == 32 && !ELU) {
+            if (p.trunk_n > 1 && i == p.trunk_i0) {            // a run of 512-wide stages as one continuous weight stream (chain_trunk)
+                chain_trunk<BM, BWD ? EPI_DGRAD : EPI_HIDDEN, ELU>(X, bias_lds, p, bid, i, p.trunk_n, m0, wid, tid, slot, pend);
+                i += p.trunk_n - 1;
+                continue;
             }
-            chain_trunk<BM, BWD ? EPI_DGRAD : EPI_HIDDEN, ELU>(X, bias_lds, p, bid, p.trunk_i0, p.trunk_n, m0, wid, tid, slot, pend, TQ, tq_primed);
-            i = p.trunk_i0 + p.trunk_n;
         }
-    }
-    for (; i < p.n_stages; ++i) {
         const ChainStage& S = p.st[i];
         const bool last = (i + 1 == p.n_stages);
         constexpr int E = BWD ? EPI_DGRAD : EPI_HIDDEN;
@@ -769,7 +710,9 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const ChainDyn& d
             chain_stage<BM, BM / 32, 2, E, ELU>(X, bias_lds, rows_lds, p, d_, bid, S, last, m0, wid * 2, 0, tid, sq, ab, slot, pend);
         } else if (S.Nc == 256) {   // wave = all BM rows x 32 columns
             chain_stage<BM, BM / 32, 1, E, ELU>(X, bias_lds, rows_lds, p, d_, bid, S, last, m0, wid, 0, tid, sq, ab, slot, pend);
-        } else if (!BWD && S.epi == EPI_OUT) {   // heads: 128 wide, wave = half the rows x 32 columns (32-row tiles: `dup`, see chain_stage)
+        } else if (!BWD && S.epi == EPI_OUT) {   // heads: 128 wide, wave = half the rows x 32 columns
+            // (32-row tiles: four column waves cover the tile; waves 4-7 repeat their work - identical values to
+            //  identical places - and are dropped from the loss sums)
             chain_stage<BM, (BM >= 64 ? BM / 64 : 1), 1, EPI_OUT, ELU>(X, bias_lds, rows_lds, p, d_, bid, S, last, m0, wid & 3,
                                                                       BM >= 64 ? (wid >> 2) * (BM / 2) : 0, tid, sq, ab, slot, pend, BM < 64);
         } else {                    // 128: wave = half the rows x 32 columns

@@ -331,7 +331,7 @@ int chain_bm(const cs_mlp* h, int64_t n) { return chain_bm_of(h->cfg.flags, h->n
 void chain_find_trunk(const cs_mlp* h, ChainArgs& c) {
     c.trunk_i0 = 0; c.trunk_n = 0;
     static const bool off = getenv("CS_CHAIN_TRUNK") && atoi(getenv("CS_CHAIN_TRUNK")) == 0;
-    if (off || h->cfg.act == CS_ACT_ELU || (c.ablate & ~(128 | 256 | 512)) || c.mask_bm64) return;
+    if (off || h->cfg.act == CS_ACT_ELU || (c.ablate & ~128) || c.mask_bm64) return;
     int best0 = 0, bestn = 0;
     for (int i = 0; i < c.n_stages;) {
         int n = 0;
@@ -345,10 +345,7 @@ void chain_find_trunk(const cs_mlp* h, ChainArgs& c) {
         if (n > bestn) { best0 = i; bestn = n; }
         i += n > 0 ? n : 1;
     }
-    // chain_body runs the run as straight-line code from the pass's first stage: it must start at stage 0, or at stage 1 behind one
-    // 8-step 128-wide stage (which then also primes the run's queue); anything else keeps one launch-of-stages per chain_stage
-    const bool at0 = best0 == 0, at1 = best0 == 1 && c.st[0].Nc == 128 && c.st[0].Kc == 128 && c.st[0].epi != EPI_OUT;
-    if (bestn > 1 && (at0 || at1)) { c.trunk_i0 = best0; c.trunk_n = bestn; }
+    if (bestn > 1) { c.trunk_i0 = best0; c.trunk_n = bestn; }
 }
 
 // The same for the wide chain (k_chainw: act' from the global activation copies, any output width).
