@@ -61,6 +61,7 @@ class StreamedTrainer:
             self._dp = DataParallel(model, dist, model.output_length)
         self.rows_seen = 0
         self.rows_dropped = 0
+        self.trace = None                    # development: set to a list to collect (label, event) marks on the training stream (tools/stream_stamps.py)
         self.carry = bool(carry_remainder)
         self._carry_x = self._carry_y = None
         self._carry_n = 0
@@ -109,16 +110,24 @@ class StreamedTrainer:
         y.record_stream(main)
         return x, y, ready
 
+    def _mark(self, label):
+        if self.trace is not None:
+            e = self.torch.cuda.Event(enable_timing=True)
+            e.record()
+            self.trace.append((label, e))
+
     # ---- consumer (main stream)
     def _consume(self, x, y, ready, lr_of_step: Callable[[int], float], gen, passes: int, step0: int):
         torch = self.torch
         main = torch.cuda.current_stream(self.device)
+        self._mark("chunk")
         if ready is None:                            # loader_on == "main": x = the raw chunk (on the device), y = its copy event or None
             if y is not None:
                 main.wait_event(y)
             x, y = self.loader.stack_raw(*x, extra_rows=self.batch if self._carrying else 0)
         else:
             main.wait_event(ready)
+        self._mark("loaded")
         carrying = self._carrying
         n_new = x.shape[0] - (self.batch if carrying else 0)      # rows the loader wrote; the tail is headroom for carried rows
         r = self._carry_n if carrying else 0
@@ -128,6 +137,7 @@ class StreamedTrainer:
             self._carry_n = 0
         n = n_new + r
         n_have = n
+        self._mark("carried_in")
         if self.dist is not None:
             # Every rank streams its own timesteps, so chunks may differ in T*ncol.  The ranks must issue the SAME number of
             # all-reduces and normalise by the SAME global row count: agree on the smallest chunk and drop the surplus
@@ -151,6 +161,7 @@ class StreamedTrainer:
             perm = torch.randperm(n_have, device=self.device, generator=gen)
             if n < n_have:
                 perm = perm[:n]                      # a random subset of this rank's rows, as many as the smallest rank has
+            self._mark("perm")
             if carrying and n_train < n:
                 left = perm[n_train:n]
                 if self._carry_x is None:
@@ -159,6 +170,7 @@ class StreamedTrainer:
                 torch.index_select(x, 0, left, out=self._carry_x[:left.numel()])
                 torch.index_select(y, 0, left, out=self._carry_y[:left.numel()])
                 self._carry_n = int(left.numel())
+            self._mark("carried_out")
             for lo in range(0, n_train, self.batch):
                 idx = perm[lo:lo + self.batch]
                 lr = lr_of_step(step)
@@ -170,6 +182,7 @@ class StreamedTrainer:
                     self.model.apply_gradients(lr, 1.0 / (self.model.output_length * idx.numel() * self.world))
                 step += 1
                 k += 1
+        self._mark("steps")
         done = torch.cuda.Event()
         done.record(main)
         self.rows_seen += n_train * passes

@@ -71,9 +71,17 @@ one_pass("loader + steps in stream order")
 from climsim_amd.stream import StreamedTrainer  # noqa: E402
 st = StreamedTrainer(model, ld, batch_size=B, slots=2)
 st.fit_chunks(iter(chunks[:2]), learning_rate=1e-3)
-torch.cuda.synchronize(); t0 = time.perf_counter()
-st.fit_chunks(iter(chunks), learning_rate=1e-3, seed=1)
-torch.cuda.synchronize(); print("StreamedTrainer.fit_chunks wall ms", round((time.perf_counter() - t0) * 1e3, 2))
+for carry in (True, False):
+    st = StreamedTrainer(model, ld, batch_size=B, slots=2, carry_remainder=carry)
+    st.fit_chunks(iter(chunks[:2]), learning_rate=1e-3)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    r = st.fit_chunks(iter(chunks), learning_rate=1e-3, seed=1)
+    torch.cuda.synchronize(); print("StreamedTrainer.fit_chunks carry=%s wall ms" % carry, round((time.perf_counter() - t0) * 1e3, 2), "steps", r["steps"])
+    st.trace = []
+    st.fit_chunks(iter(chunks), learning_rate=1e-3, seed=1)
+    torch.cuda.synchronize()
+    tr = st.trace
+    print("   phases (ms since the previous mark):", " | ".join("%s %.3f" % (tr[i][0], tr[i - 1][1].elapsed_time(tr[i][1])) for i in range(1, len(tr))))
 xs = [ld.stack_raw(a, b) for a, b in chunks]
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for x, y in xs:
