@@ -252,7 +252,9 @@ class StreamedTrainer:
             free.append(done)
             del x, y
         if self._carrying:
+            self._mark("flush_begin")
             step = self._flush_carry(lr_of_step, step)
+            self._mark("flush_end")
         # one device-side concatenation and ONE copy (a copy per chunk was a host synchronisation per chunk at the end of the pass)
         s = torch.cat(self._sums).double().sum(dim=0).cpu().numpy() if self._sums else np.zeros(2)
         self._sums = []

@@ -82,6 +82,12 @@ for carry in (True, False):
     torch.cuda.synchronize()
     tr = st.trace
     print("   phases (ms since the previous mark):", " | ".join("%s %.3f" % (tr[i][0], tr[i - 1][1].elapsed_time(tr[i][1])) for i in range(1, len(tr))))
+for nb in (768, 3072, 8192, 3072, 768):
+    xx, yy = xs_probe = ld.stack_raw(*chunks[0])
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(10):
+        model.train_on_batch(xx[:nb], yy[:nb], 1e-3)
+    torch.cuda.synchronize(); print("10 steps of %d rows: %.1f us each" % (nb, (time.perf_counter() - t0) * 1e5))
 xs = [ld.stack_raw(a, b) for a, b in chunks]
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for x, y in xs:
