@@ -67,9 +67,13 @@ def run(nch=8, T=8, B=8192, reps=5):
         xs.clear()
         xs.extend(ld.stack_raw(a, b) for a, b in chunks)
 
+    from climsim_amd.shuffle import chunk_seed, device_permutation
+    drawn = [0]
+
     def train_only():
         for x, y in xs:
-            perm = torch.randperm(x.shape[0], device=dev, generator=gen)
+            perm = device_permutation(x.shape[0], chunk_seed(1, drawn[0]), dev)       # the permutation kernel the streamed trainer uses
+            drawn[0] += 1
             for lo in range(0, x.shape[0], B):
                 model.train_on_batch(x, y, 1e-3, row_idx=perm[lo:lo + B])
 

@@ -1161,6 +1161,18 @@ int cs_normalise_rows(const float* x_dev, const int64_t* row_idx_dev, int64_t n,
     return CS_OK;
 }
 
+int cs_permutation(int64_t n, uint64_t seed, int64_t* out_dev, void* stream) {
+    if (!out_dev) return fail(CS_ERR_INVALID, "null output");
+    if (n <= 0 || n > ((int64_t)1 << 31)) return fail(CS_ERR_INVALID, "n=%lld outside 1..2^31", (long long)n);
+    int bits = 2;                                        // at least one bit per half
+    while (((int64_t)1 << bits) < n) ++bits;
+    const unsigned s0 = (unsigned)seed, s1 = (unsigned)(seed >> 32);
+    const unsigned k0 = mix32(s0 ^ 0x9e3779b9u), k1 = mix32(s1 + 0x85ebca6bu), k2 = mix32(k0 ^ s1 ^ 0xc2b2ae35u), k3 = mix32(k1 + s0 + 0x27d4eb2fu);
+    hipLaunchKernelGGL(k_permutation, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, bits, k0, k1, k2, k3, out_dev);
+    HIP_TRY(hipGetLastError());
+    return CS_OK;
+}
+
 int cs_loader_stack(const void* mli_dev, const void* mlo_dev, int32_t src_f64, int64_t n_steps, int32_t ncol, int32_t n_in,
                     const double* in_sub_dev, const double* in_div_dev, int32_t n_out, const int32_t* tend_src_dev,
                     const double* out_scale_dev, float* x_out_dev, float* y_out_dev, void* stream) {

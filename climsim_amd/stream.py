@@ -23,7 +23,8 @@ import numpy as np
 
 
 class StreamedTrainer:
-    def __init__(self, model, loader, batch_size: int, slots: int = 2, dist=None, loader_on: str | None = None, carry_remainder: bool = True):
+    def __init__(self, model, loader, batch_size: int, slots: int = 2, dist=None, loader_on: str | None = None, carry_remainder: bool = True,
+                 shuffle: str = "feistel"):
         """`loader_on`: "main" (default; CS_STREAM_LOADER overrides) runs the loader KERNEL on the training stream, right in front of
         the chunk's first step; host chunks are staged and copied on the side stream while the PREVIOUS chunk trains (the training
         stream waits for the copy only when it reaches the chunk - round 4: it used to wait at produce time, in front of the
@@ -35,7 +36,10 @@ class StreamedTrainer:
         instead of forming a partial batch per chunk - the reference batches AFTER its shuffle buffer, across file boundaries
         (`.unbatch().shuffle(...).batch(bs)`, step2_retrain.py:266-277), so only the last batch of a pass is short there too.  At
         the high-res width a chunk of 8 timesteps is 21 batches of 8192 + 768 rows: the partial step costs two thirds of a full
-        one.  With one pass per chunk only (`passes_per_chunk` > 1 keeps per-chunk batching); False restores rounds 1-3."""
+        one.  With one pass per chunk only (`passes_per_chunk` > 1 keeps per-chunk batching); False restores rounds 1-3.
+        `shuffle`: "feistel" (default, round 4) draws a chunk's permutation with `cs_permutation` (climsim_amd/shuffle.py: one small
+        kernel, seeds `chunk_seed(seed, k)` for the k-th permutation of a pass); "torch" draws `torch.randperm` from a generator
+        seeded once per pass (rounds 1-3: 0.09 ms of sort kernels per high-res chunk)."""
         import os
         import torch
         self.loader_on = loader_on or os.environ.get("CS_STREAM_LOADER", "main")
@@ -62,6 +66,10 @@ class StreamedTrainer:
         self.rows_seen = 0
         self.rows_dropped = 0
         self.trace = None                    # development: set to a list to collect (label, event) marks on the training stream (tools/stream_stamps.py)
+        if shuffle not in ("feistel", "torch"):
+            raise ValueError("shuffle must be 'feistel' or 'torch'")
+        self.shuffle = shuffle
+        self._perm_count = 0
         self.carry = bool(carry_remainder)
         self._carry_x = self._carry_y = None
         self._carry_n = 0
@@ -158,7 +166,12 @@ class StreamedTrainer:
             # (on the training stream.  Round 4 drew it on a stream of its own so that its small sort kernels would run beside an
             #  earlier chunk's steps: the pass got SLOWER, 11.7 -> 13.3 ms for 4 chunks - a layer-chain launch needs every compute
             #  unit whole, and a sort workgroup sitting on one of them costs that launch a second round of workgroups)
-            perm = torch.randperm(n_have, device=self.device, generator=gen)
+            if self.shuffle == "torch":
+                perm = torch.randperm(n_have, device=self.device, generator=gen)
+            else:
+                from .shuffle import chunk_seed, device_permutation
+                perm = device_permutation(n_have, chunk_seed(self._seed, self._perm_count), self.device)
+                self._perm_count += 1
             if n < n_have:
                 perm = perm[:n]                      # a random subset of this rank's rows, as many as the smallest rank has
             self._mark("perm")
@@ -214,6 +227,7 @@ class StreamedTrainer:
         lr_of_step = learning_rate if callable(learning_rate) else (lambda s, v=float(learning_rate): v)
         gen = torch.Generator(device=self.device)
         gen.manual_seed(seed)
+        self._seed, self._perm_count = int(seed), 0
         self._sums = []
         self.rows_seen = 0
         self.rows_dropped = 0

@@ -181,6 +181,12 @@ int cs_mlp_profile_step(cs_mlp_t* h, const float* x_dev, const float* y_dev, con
  * [fwd|bwd][workgroup][64 slots] shader-clock ticks.  Not for production use. */
 int cs_mlp_debug_stamps(cs_mlp_t* h, unsigned long long* host, int64_t n_words);
 
+/* The shuffle of the input pipeline (`.unbatch().shuffle(buffer, reshuffle_each_iteration).batch(bs)`, step2_retrain.py:266-277) for
+ * rows that live in HBM: out_dev[0..n) = a permutation of 0..n-1 keyed by `seed` (4-round Feistel network over the index bits,
+ * cycle-walked into range: a bijection by construction, one pass, no sort).  The row indices cs_mlp_train_step / cs_mlp_loss_grads
+ * gather by.  n <= 2^31. */
+int cs_permutation(int64_t n, uint64_t seed, int64_t* out_dev, void* stream);
+
 /* Stand-alone loader-path kernel (data_utils.py:807-809 + :894-897 on device): out = (x-sub)/div,
  * inf/nan -> 0, float32 -> float32; rows gathered through row_idx when given. */
 int cs_normalise_rows(const float* x_dev, const int64_t* row_idx_dev, int64_t n, int32_t width,

@@ -47,6 +47,12 @@ def test_mlp_entries_refuse_null_handles_and_buffers(lib):
     bad(lib, lib.cs_mlp_profile_step(None, f4, f4, None, 4, 0, 1e-3, f4, None, None))
     bad(lib, lib.cs_mlp_debug_stamps(None, None, 0))
     bad(lib, lib.cs_profile_end(None))
+    bad(lib, lib.cs_mlp_set_train_accuracy(None, None), b"null handle")
+    i8 = (C.c_int64 * 8)()
+    bad(lib, lib.cs_permutation(8, 1, None, None), b"null")
+    bad(lib, lib.cs_permutation(0, 1, i8, None), b"outside")
+    bad(lib, lib.cs_permutation((1 << 31) + 1, 1, i8, None), b"outside")
+    bad(lib, lib.cs_dp_ipc_set_timeout_ms(None, 1.0))
 
 
 def test_config_ranges(lib):

@@ -32,7 +32,7 @@ def test_streamed_training_equals_materialised_training(raw_tree, lowres_assets,
     B, LR = 128, 1e-3
 
     a = MLPEmulator(units=(128, 128), max_batch=B, seed=3)
-    st = StreamedTrainer(a, ld, batch_size=B, slots=2, loader_on=loader_on)      # loader kernel on the training stream (default) / on the side stream
+    st = StreamedTrainer(a, ld, batch_size=B, slots=2, loader_on=loader_on, shuffle="torch")      # loader kernel on the training stream (default) / on the side stream
     out = st.fit_chunks(iter(chunks), learning_rate=LR, passes_per_chunk=2, seed=11)
     rows = sum(c[0].shape[0] * c[0].shape[2] for c in chunks)
     assert out["rows"] == 2 * rows and out["steps"] == 2 * sum(-(-c[0].shape[0] * 384 // B) for c in chunks) == a.iterations
@@ -57,13 +57,14 @@ def test_streamed_training_equals_materialised_training(raw_tree, lowres_assets,
         StreamedTrainer(a, ld, batch_size=4 * B)
 
 
-@pytest.mark.parametrize("carry", [False, True])
-def test_streamed_training_at_highres_width(raw_tree, lowres_assets, carry):
+@pytest.mark.parametrize("carry,shuffle", [(False, "torch"), (True, "feistel")])
+def test_streamed_training_at_highres_width(raw_tree, lowres_assets, carry, shuffle):
     """BASELINE config 5 shape: chunks of 21,600-column timesteps (and one ragged 21,601-column chunk) resident in HBM as
     float64 raw fields, cfg-MLP-sized batches of 8192.  Streaming (double-buffered) must equal materialising every chunk first.
     carry=False: every chunk ends in a partial batch (43,200 = 5 x 8192 + 2,240).  carry=True (the default since round 4): the
     leftover rows join the next chunk's permutation, as the reference's `.unbatch().shuffle().batch()` batches across files
-    (step2_retrain.py:266-277) - whole batches only, ONE short batch at the end of the pass, every row trained on exactly once."""
+    (step2_retrain.py:266-277) - whole batches only, ONE short batch at the end of the pass, every row trained on exactly once.
+    shuffle: `torch.randperm` from one generator per pass (rounds 1-3) / the one-kernel keyed permutation (climsim_amd/shuffle.py)."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from climsim_amd.loader import GpuColumnLoader
@@ -87,7 +88,8 @@ def test_streamed_training_at_highres_width(raw_tree, lowres_assets, carry):
         chunks.append((a, b))
     B, LR = 8192, 1e-3
     m1 = MLPEmulator(units=(128, 128), max_batch=B, seed=3)
-    out = StreamedTrainer(m1, ld, batch_size=B, slots=2, carry_remainder=carry).fit_chunks(iter(chunks), learning_rate=LR, seed=4)
+    from climsim_amd.shuffle import chunk_seed, device_permutation
+    out = StreamedTrainer(m1, ld, batch_size=B, slots=2, carry_remainder=carry, shuffle=shuffle).fit_chunks(iter(chunks), learning_rate=LR, seed=4)
     rows = sum(c[0].shape[0] * c[0].shape[2] for c in chunks)
     assert out["rows"] == rows
     assert out["steps"] == (-(-rows // B) if carry else sum(-(-c[0].shape[0] * c[0].shape[2] // B) for c in chunks)) == m1.iterations
@@ -96,13 +98,14 @@ def test_streamed_training_at_highres_width(raw_tree, lowres_assets, carry):
     gen.manual_seed(4)
     tot = np.zeros(2)
     cx = cy = None                                   # carried rows (carry=True): materialised here with plain torch ops
-    seen = 0
+    seen = nperm = 0
     for mli, mlo in chunks:
         x, y = ld.stack_raw(mli, mlo)
         assert bool(torch.isfinite(x).all()) and bool(torch.isfinite(y).all())
         if carry and cx is not None:
             x, y = torch.cat([x, cx]), torch.cat([y, cy])
-        perm = torch.randperm(x.shape[0], device="cuda", generator=gen)
+        perm = torch.randperm(x.shape[0], device="cuda", generator=gen) if shuffle == "torch" else device_permutation(x.shape[0], chunk_seed(4, nperm))
+        nperm += 1
         n_train = (x.shape[0] // B) * B if carry else x.shape[0]
         for lo in range(0, n_train, B):
             tot += m2.train_on_batch(x, y, LR, row_idx=perm[lo:lo + B]).cpu().numpy()
