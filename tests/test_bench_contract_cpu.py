@@ -43,6 +43,26 @@ def test_round3_bench_line_carries_the_repaired_fields():
     assert c["kind"] == "port" and c["value"] > 0 and c["unit"] == d["unit"]
 
 
+def test_round4_bench_line_carries_the_sweep():
+    """The line committed at the end of round 4 (profiles/r04_bench_b8192.json): SURVEY 8(d) config (2) names B in {1024, 8192, 65536} -
+    the other two sizes ride inside the driver's line (`sweep`), the dead `gpu_busy_percent` field is gone, the traffic figure is this round's."""
+    d = json.loads(open(os.path.join(REPO, "profiles", "r04_bench_b8192.json")).read().strip().splitlines()[-1])
+    assert d["metric"] == "training columns/sec" and d["n_gpus"] == 1 and d["vs_baseline"] is None and d["dtype"] == "bf16"
+    assert d["config"]["per_gpu_batch"] == 8192 and "workload" in d["config"]
+    sw = d["sweep"]
+    assert set(sw) == {"1024", "65536"}
+    for b, p in sw.items():
+        assert p["per_gpu_batch"] == int(b) and p["blocks"] == 10 and p["unit"] == "columns/s"
+        assert abs(p["value"] - int(b) / (p["ms_per_step"] * 1e-3)) <= 0.01 * p["value"]
+        assert 0 < p["whole_step_frac"] < 1 and 0 < p["dominant_frac"] < 1 and p["dominant_kernel"].startswith("k_") and p["coop_timeouts"] == 0
+    assert sw["65536"]["value"] > d["value"] > sw["1024"]["value"]
+    assert "gpu_busy_percent" not in d["timing"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["traffic"] > 0 and r["traffic_source"].startswith("profiles/r04_")
+    assert sum(k["ms_per_step"] for k in d["kernels"].values()) <= d["ms_per_step"] * 1.001
+    assert d["stream"]["value"] > 0 and d["cnn"]["ms_per_step"] > 0 and d["cpu_baseline"]["kind"] == "port"
+
+
 def test_bench_defaults_and_flags():
     src = open(os.path.join(REPO, "bench.py")).read()
     for flag in ("--gpus", "--steps", "--warmup"):
