@@ -33,9 +33,11 @@ timeout 300 python bench_hpo.py 2>&1 | tail -1 > gpurun_out/r04_hpo_bench.json; 
 echo "== CNN"; bash tools/r04_cnn_trip.sh 2>&1 | tail -30
 echo "== chain stamps + A/B of this round's chain changes (same box)"
 timeout 300 python tools/chain_stamps.py 8192 2>&1 | grep -v amdgpu.ids | tail -12 > gpurun_out/r04_chain_stamps.txt; cat gpurun_out/r04_chain_stamps.txt
-{ echo "k_chain_fb<32> at 8192 columns, same box, us per launch (bench.py --steps 100, per-kernel events): CS_CHAIN_TRUNK=0 = one queue per stage (round 3);"
-  echo "CS_CHAIN_ABLATE bits: 128 no contraction split in 128-wide stages, 256 / 512 no early priming of the run's queue (backward / forward)"
-  for rep in 1 2; do for cfg in "0 0" "1 896" "1 768" "1 512" "1 256" "1 128" "1 0"; do set -- $cfg
+{ echo "k_chain_fb<32> at 8192 columns, same box, back to back, us per launch (bench.py --steps 100, per-kernel events scaled to the step):"
+  echo "  trunk=0           : one weight queue per stage (round 3: CS_CHAIN_TRUNK=0)"
+  echo "  trunk=1 ablate=128: the run of 512-wide stages as one continuous weight stream (chain_trunk), 128-wide stages repeated by both wave halves"
+  echo "  trunk=1 ablate=0  : + the two wave halves split the contraction of the 128-wide stages, one epilogue (what ships)"
+  for rep in 1 2; do for cfg in "0 0" "1 128" "1 0"; do set -- $cfg
   CS_CHAIN_TRUNK=$1 CS_CHAIN_ABLATE=$2 timeout 300 python bench.py --steps 100 --warmup 10 --cpu-budget 0 --no-extras 2>/dev/null | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); print('trunk=$1 ablate=$2 step ms', d['ms_per_step'], {k:round(v['ms_per_step']*1e3,1) for k,v in d['kernels'].items()})"
