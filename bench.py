@@ -66,9 +66,21 @@ class ClockSampler:
         import glob
         self.path = None
         cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
-        if index < len(cards):
-            self.path = cards[index]
-            hw = sorted(glob.glob(os.path.join(os.path.dirname(cards[index]), "hwmon", "hwmon*", "freq1_input")))
+        # The box's sysfs lists every GPU of the host, the process sees only its own: pick the card by PCI address (card<index>
+        # read a neighbour's clock on round 4's boxes - 96-158 MHz beside a busy GPU), fall back to the index.
+        want = None
+        try:
+            pr = torch.cuda.get_device_properties(index)
+            want = "%04x:%02x:%02x." % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        except Exception:
+            pass
+        pick = [c for c in cards if want and os.path.basename(os.path.realpath(os.path.dirname(c))).startswith(want)]
+        self.matched_by = "pci address" if pick else "card index"
+        if not pick and index < len(cards):
+            pick = [cards[index]]
+        if pick:
+            self.path = pick[0]
+            hw = sorted(glob.glob(os.path.join(os.path.dirname(pick[0]), "hwmon", "hwmon*", "freq1_input")))
             if hw:
                 self.path = hw[0]                # current shader clock in Hz (pp_dpm_sclk's starred level is 94 MHz on some boxes of the pool)
         self.samples, self._stop, self._thr = [], False, None
@@ -106,7 +118,7 @@ class ClockSampler:
         if not self.samples:
             return None
         s = sorted(self.samples)
-        return {"min": s[0], "median": s[len(s) // 2], "max": s[-1], "samples": len(s), "source": self.path}
+        return {"min": s[0], "median": s[len(s) // 2], "max": s[-1], "samples": len(s), "source": self.path, "card_matched_by": self.matched_by}
 
 
 def launch_ranks(n, argv):
