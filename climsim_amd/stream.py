@@ -24,7 +24,7 @@ import numpy as np
 
 class StreamedTrainer:
     def __init__(self, model, loader, batch_size: int, slots: int = 2, dist=None, loader_on: str | None = None, carry_remainder: bool = True,
-                 shuffle: str = "feistel"):
+                 shuffle: str = "feistel", side_priority: int | None = None):
         """`loader_on`: "main" (default; CS_STREAM_LOADER overrides) runs the loader KERNEL on the training stream, right in front of
         the chunk's first step; host chunks are staged and copied on the side stream while the PREVIOUS chunk trains (the training
         stream waits for the copy only when it reaches the chunk - round 4: it used to wait at produce time, in front of the
@@ -55,7 +55,8 @@ class StreamedTrainer:
             raise ValueError("StreamedTrainer drives a side stream: build the model with cooperative=False")
         self.torch, self.model, self.loader, self.batch, self.slots = torch, model, loader, int(batch_size), int(slots)
         self.device = model.device
-        self.side = torch.cuda.Stream(device=self.device)
+        # `side_priority`: HIP stream priority of the side stream (torch numbering: larger = lower; None = default)
+        self.side = torch.cuda.Stream(device=self.device) if side_priority is None else torch.cuda.Stream(device=self.device, priority=int(side_priority))
         self._carrying = False
         self.dist = dist
         self.world = dist.get_world_size() if dist is not None else 1
