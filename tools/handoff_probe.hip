@@ -33,10 +33,16 @@ __device__ __forceinline__ void ld4_sc1(const void* p0, const void* p1, const vo
                  : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(p0), "v"(p1), "v"(p2), "v"(p3) : "memory");
 }
 
+// ---- round 4: "LL" form (the low-latency protocol of collective libraries): the payload travels in 8-byte units {4 B data, 4 B tag},
+// tag = a number unique to (launch repetition, stage); an aligned 8-byte store is atomic, so a consumer that reads a unit whose tag is
+// the stage's has its data - no drain, no flag, no second round trip: consumers poll the DATA.  Twice the bytes (small here).
+__device__ __forceinline__ void st_plain(void* p, u32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
 // act: [cluster][stage & 1][member][slice_bytes]   cnt: [rep][cluster][stage]
 __global__ __launch_bounds__(512) void k_probe(const uint4* __restrict__ weights, size_t weight_vec, int stream_vec_per_thread, char* act,
                                                unsigned* cnt, int c, int slice_bytes, int reps, int do_handoff,
-                                               unsigned long long* t_out, unsigned* sink_out) {
+                                               unsigned long long* t_out, unsigned* sink_out, unsigned tag0) {
     extern __shared__ u32x4 lds[];
     const int tid = threadIdx.x, b = blockIdx.x;
     const int xcd = b & 7, slot = b >> 3;
@@ -57,6 +63,35 @@ __global__ __launch_bounds__(512) void k_probe(const uint4* __restrict__ weights
                 for (int u = 0; u < 8; ++u) sink ^= q[u].x ^ q[u].w;
             }
             if (!do_handoff) continue;
+            if (do_handoff >= 2) {
+                // LL: a 16-B store = two units {d0, tag, d1, tag}; slice payload slice_bytes -> 2 * slice_bytes on the wire
+                const unsigned tag = (unsigned)(rep * STAGES + s + 1) + tag0;
+                char* mine = act + (((size_t)cluster * 2 + (s & 1)) * c + member) * (size_t)(2 * slice_bytes);
+                for (int o = tid * 16; o < 2 * slice_bytes; o += 512 * 16) {
+                    const u32x4 v = {sink | 1u, tag, (unsigned)tid, tag};
+                    if (do_handoff == 2) st_sc1(mine + o, v); else st_plain(mine + o, v);
+                }
+                // gather: the whole tile (own slice too: uniform count), 2 * tile_bytes / 512 threads / 16 B = NLL loads per thread
+                const char* base = act + ((size_t)cluster * 2 + (s & 1)) * c * (size_t)(2 * slice_bytes);
+                const int total = 2 * c * slice_bytes;
+                int spins = 0;
+                for (int g = 0; g < total; g += 4 * 512 * 16) {
+                    u32x4 a, b2, c2, d;
+                    const int o0 = g + tid * 16;
+                    for (;;) {
+                        ld4_sc1(base + o0, base + o0 + 8192, base + o0 + 16384, base + o0 + 24576, a, b2, c2, d);
+                        const bool ok = a.y == tag && a.w == tag && b2.y == tag && b2.w == tag && c2.y == tag && c2.w == tag && d.y == tag && d.w == tag;
+                        if (__builtin_amdgcn_ballot_w64(!ok) == 0ull || ++spins > (1 << 20)) break;
+                    }
+                    const int l = (g >> 15) * 2048 + tid;              // payload: 8 B per 16-B load, 16 KB per trip
+                    reinterpret_cast<uint2*>(lds)[l] = make_uint2(a.x, a.z); reinterpret_cast<uint2*>(lds)[l + 512] = make_uint2(b2.x, b2.z);
+                    reinterpret_cast<uint2*>(lds)[l + 1024] = make_uint2(c2.x, c2.z); reinterpret_cast<uint2*>(lds)[l + 1536] = make_uint2(d.x, d.z);
+                    sink ^= a.x ^ d.z;
+                }
+                if (spins > (1 << 20) && (tid & 63) == 0) atomicAdd(cnt, 1u);     // a wait that ran out: reported by the host
+                __syncthreads();
+                continue;
+            }
             // (2) publish
             char* mine = act + (((size_t)cluster * 2 + (s & 1)) * c + member) * slice_bytes;
             for (int o = tid * 16; o < slice_bytes; o += 512 * 16) st_sc1(mine + o, u32x4{sink, (unsigned)s, (unsigned)rep, (unsigned)tid});
@@ -89,14 +124,18 @@ __global__ __launch_bounds__(512) void k_probe(const uint4* __restrict__ weights
     if (tid == 0) { t_out[b] = t1 - t0; sink_out[b] = sink + lds[tid + 7].x; }
 }
 
+static unsigned g_tag0 = 0;
 static double run(int c, int stream_kb, int do_handoff, const uint4* wdev, size_t wvec, char* act, unsigned* cnt, unsigned long long* tdev,
-                  unsigned* sdev, int reps) {
-    const int slice = ROWS * 512 * 2 / c;                       // bf16 slice of a 32 x 512 layer output
+                  unsigned* sdev, int reps, int rows = ROWS) {
+    const int slice = rows * 512 * 2 / c;                       // bf16 slice of a rows x 512 layer output
+    g_tag0 += 100000u;                                          // tags of one launch never match those of an earlier one
     const int grid = 256;
     hipMemset(cnt, 0, sizeof(unsigned) * (size_t)reps * 256 * STAGES);
     const int per_thread = stream_kb * 1024 / 16 / 512;         // uint4 per thread per stage
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_probe), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
-    hipLaunchKernelGGL(k_probe, dim3(grid), dim3(512), 100 * 1024, 0, wdev, wvec, per_thread, act, cnt, c, slice, reps, do_handoff, tdev, sdev);
+    hipLaunchKernelGGL(k_probe, dim3(grid), dim3(512), 100 * 1024, 0, wdev, wvec, per_thread, act, cnt, c, slice, reps, do_handoff, tdev, sdev, g_tag0);
+    hipDeviceSynchronize();
+    if (do_handoff >= 2) { unsigned to = 0; hipMemcpy(&to, cnt, 4, hipMemcpyDeviceToHost); if (to) printf("  !! %u waits ran out (c = %d, mode %d)\n", to, c, do_handoff); }
     hipDeviceSynchronize();
     std::vector<unsigned long long> t(grid);
     hipMemcpy(t.data(), tdev, grid * 8, hipMemcpyDeviceToHost);
@@ -110,7 +149,7 @@ int main() {
     uint4* wdev; char* act; unsigned* cnt; unsigned long long* tdev; unsigned* sdev;
     const int reps = 20;
     hipMalloc(&wdev, wbytes); hipMemset(wdev, 1, wbytes);
-    hipMalloc(&act, (size_t)256 * 2 * ROWS * 512 * 2); hipMemset(act, 0, (size_t)256 * 2 * ROWS * 512 * 2);
+    hipMalloc(&act, (size_t)256 * 2 * 64 * 512 * 4); hipMemset(act, 0, (size_t)256 * 2 * 64 * 512 * 4);
     hipMalloc(&cnt, sizeof(unsigned) * (size_t)reps * 256 * STAGES);
     hipMalloc(&tdev, 256 * 8); hipMalloc(&sdev, 256 * 4);
     printf("per-stage cost of a c-way split of a 32-row tile (256 workgroups, one per CU, 13 stages x %d repetitions; max over workgroups)\n", reps);
@@ -122,6 +161,19 @@ int main() {
         const double both = run(c, skb, 1, wdev, wbytes / 16, act, cnt, tdev, sdev, reps);
         printf("c = %d: weight stream alone (%3d KB) %.2f us | hand-off alone (publish %5d B, gather %5d B) %.2f us | both %.2f us  (x13 = %.1f us per pass)\n",
                c, skb, a, ROWS * 1024 / c, ROWS * 1024 - ROWS * 1024 / c, h, both, both * 13);
+    }
+    printf("LL form (8-byte units {data, tag}, consumers poll the data; no drain, no flag): hand-off alone | with the weight stream\n");
+    for (int c : {2, 4, 8}) {
+        const int skb = 512 / c;
+        run(c, skb, 2, wdev, wbytes / 16, act, cnt, tdev, sdev, reps);
+        const double h2 = run(c, 0, 2, wdev, wbytes / 16, act, cnt, tdev, sdev, reps), b2 = run(c, skb, 2, wdev, wbytes / 16, act, cnt, tdev, sdev, reps);
+        const double h3 = run(c, 0, 3, wdev, wbytes / 16, act, cnt, tdev, sdev, reps), b3 = run(c, skb, 3, wdev, wbytes / 16, act, cnt, tdev, sdev, reps);
+        printf("c = %d: sc1 stores %.2f us | %.2f us ; plain stores (one XCD: its L2 is the meeting point) %.2f us | %.2f us\n", c, h2, b2, h3, b3);
+    }
+    {   // the 8192-column question: 64-row tiles shared by two CUs, each streams half a layer
+        const double f1 = run(2, 0, 1, wdev, wbytes / 16, act, cnt, tdev, sdev, reps, 64), l2 = run(2, 0, 2, wdev, wbytes / 16, act, cnt, tdev, sdev, reps, 64);
+        const double l3 = run(2, 0, 3, wdev, wbytes / 16, act, cnt, tdev, sdev, reps, 64), b3 = run(2, 256, 3, wdev, wbytes / 16, act, cnt, tdev, sdev, reps, 64);
+        printf("64-row tile on two CUs (publish 32 KB, gather 64 KB): flag form %.2f us | LL sc1 %.2f us | LL plain %.2f us | LL plain + 256 KB stream %.2f us\n", f1, l2, l3, b3);
     }
     const double full = run(8, 512, 0, wdev, wbytes / 16, act, cnt, tdev, sdev, reps);
     printf("one CU streaming a whole 512 x 512 layer (today's chain): %.2f us per stage (x13 = %.1f us per pass)\n", full, full * 13);
