@@ -70,6 +70,7 @@ class ClockSampler:
         # read a neighbour's clock on round 4's boxes - 96-158 MHz beside a busy GPU), fall back to the index.
         want = None
         try:
+            import torch
             pr = torch.cuda.get_device_properties(index)
             want = "%04x:%02x:%02x." % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
         except Exception:
