@@ -157,6 +157,8 @@ struct cs_mlp {
     int coop_spin_limit = COOP_SPIN_LIMIT;
     unsigned* coop_xcc = nullptr;      // [tiles] XCC ids seen per tile (roll call of the members)
     unsigned coop_epoch = 0;
+    char* coop_ll = nullptr;           // tagged exchange blocks of the cooperative chain (coop.h, "LL exchange"); CS_COOP_LL=0: flag protocol
+    size_t coop_ll_bytes = 0;
     int coop_c_last = 0; int64_t coop_tiles_last = 0;
     bool coop_used = false;
     // training step without gradient atomics (WgradArgs.plain): extra partial-sum buffers, how many of them hold this step's
@@ -442,14 +444,19 @@ int run_forward(cs_mlp* h, const float* x, const int64_t* row_idx, int64_t n, in
             if (h->coop_c_last != coop_c || h->coop_tiles_last != m_pad / 32) {     // another launch shape: the counters start over
                 HIP_TRY(hipMemsetAsync(h->coop_arrive, 0, sizeof(unsigned) * 256 * (1 + 2 * CHAIN_MAX_STAGES * 8), st));
                 HIP_TRY(hipMemsetAsync(h->coop_xcc, 0, sizeof(unsigned) * 256, st));
+                if (h->coop_ll) HIP_TRY(hipMemsetAsync(h->coop_ll, 0, h->coop_ll_bytes, st));      // old tags must not meet the epochs that start over
                 h->coop_epoch = 0; h->coop_c_last = coop_c; h->coop_tiles_last = m_pad / 32;
             }
             if (h->coop_epoch >= 0x0fffffffu) {                                      // far from wrapping epoch * 8
                 HIP_TRY(hipMemsetAsync(h->coop_arrive, 0, sizeof(unsigned) * 256 * (1 + 2 * CHAIN_MAX_STAGES * 8), st));
+                if (h->coop_ll) HIP_TRY(hipMemsetAsync(h->coop_ll, 0, h->coop_ll_bytes, st));
                 h->coop_epoch = 0;
             }
             static const int warm = getenv("CS_COOP_WARM") ? atoi(getenv("CS_COOP_WARM")) : 0;
-            CoopArgs co{coop_c, ++h->coop_epoch, h->coop_arrive, h->coop_arrive + 256, h->coop_xcc, h->coop_error, h->coop_spin_limit, warm, h->dbg};
+            const int n_seq = c.n_stages + cb.n_stages;
+            const bool ll_fits = h->coop_ll && m_pad / 32 <= 64 && n_seq <= 2 * h->L;
+            CoopArgs co{coop_c, ++h->coop_epoch, h->coop_arrive, h->coop_arrive + 256, h->coop_xcc, h->coop_error, h->coop_spin_limit, warm, h->dbg,
+                        ll_fits ? h->coop_ll : nullptr, n_seq};
             h->coop_used = true;
             ProfScope ps(CS_K_CHAIN_FB, st);
             const dim3 cg((unsigned)((m_pad / 32) * coop_c));
@@ -788,6 +795,11 @@ int cs_mlp_create(cs_mlp_t** out, const cs_mlp_cfg* cfg) {
     if (h->use_chain) {
         A((void**)&h->coop_arrive, sizeof(unsigned) * 256 * (1 + 2 * CHAIN_MAX_STAGES * 8));
         A((void**)&h->coop_xcc, sizeof(unsigned) * 256);
+        static const bool ll_on = !(getenv("CS_COOP_LL") && atoi(getenv("CS_COOP_LL")) == 0);
+        if (h->coop_mode != 0 && ll_on) {                     // up to 64 row tiles (256 workgroups / 4 members) x 2 L exchanges x 64 KiB
+            h->coop_ll_bytes = (size_t)64 * (2 * h->L) * COOP_LL_BLOCK;
+            A((void**)&h->coop_ll, h->coop_ll_bytes);
+        }
     }
     // stamps: the chain kernels write [fwd|bwd][workgroup][64], the cooperative chain [workgroup][128] for up to 256 workgroups
     if (getenv("CS_CHAIN_DBG")) A((void**)&h->dbg, (size_t)std::max<int64_t>(2 * (h->m_pad_max / 32) * 64, 256 * 128) * 8);

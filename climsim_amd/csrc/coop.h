@@ -45,6 +45,8 @@ struct CoopArgs {
     int spin_limit;              // polls before a wait gives up
     int warm;                    // development (CS_COOP_WARM): 4 = take the write-through (sc1) path even when the members share an XCD
     unsigned long long* dbg;     // development (CS_CHAIN_DBG): [workgroup][128] s_memtime stamps, null in production
+    char* ll;                    // round 4: [tile][n_seq][32 rows][COOP_LL_PITCH] tagged exchange lines (see "LL exchange"); null = flag protocol
+    int n_seq;                   // exchanges per step (stages of the forward chain + of the backward chain)
 };
 __device__ __forceinline__ void coop_stamp(const CoopArgs& co, int& slot, int tid) {
     if (co.dbg && tid == 0 && slot < 128) co.dbg[(size_t)blockIdx.x * 128 + slot] = __builtin_amdgcn_s_memtime();
@@ -77,6 +79,81 @@ __device__ __forceinline__ void coop_load4_sc1(const void* p0, const void* p1, c
                  : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(p0), "v"(p1), "v"(p2), "v"(p3) : "memory");
     o[0] = make_uint4(a[0], a[1], a[2], a[3]); o[1] = make_uint4(b[0], b[1], b[2], b[3]);
     o[2] = make_uint4(c[0], c[1], c[2], c[3]); o[3] = make_uint4(d[0], d[1], d[2], d[3]);
+}
+
+// ---- LL exchange (round 4).  The flag protocol above costs four dependent trips to L2 per stage: the stores' drain, the flag store,
+// the poll that sees it, the gather (stamps at 1024 columns: 1.0 us epilogue + drain, 1.9 us publish / wait / gather, of 4 us per
+// stage).  Here the payload itself says when it is there - the form collective libraries call "LL": every 8-byte unit on the wire is
+// {4 bytes of data, 4-byte tag}, tag = the step's epoch; an aligned 8-byte unit is written and read whole, so a consumer that finds
+// the stage's tag in a unit has the data beside it.  Producers store their slice once more in this form (16-B stores = two units; no
+// drain, no barrier, no flag) and consumers poll the DATA: two trips.  tools/handoff_probe.hip, same XCD, 8 members: 1.07 us per
+// stage against 1.71 (profiles/r04_handoff_probe.txt).  Every (tile, exchange) has its own 64 KiB block, written once per step: a
+// tag never has to tell two stages apart, and no member can still be reading a block that is being rewritten (the launch boundary
+// lies between).  Twice the bytes (64 KiB per tile and stage) - nothing at these sizes.  The tensors the weight-gradient kernel
+// reads are still written in their own layout, by plain stores nobody waits for.
+#define COOP_LL_PITCH 2048                                  // bytes per row: 512 columns x (2 B data + 2 B of tag)
+#define COOP_LL_BLOCK (32 * COOP_LL_PITCH)
+__device__ __forceinline__ void coop_ll_store(char* p, uint4 pk, unsigned tag, bool same_xcd) {      // 8 columns -> 32 bytes
+    coop_store(p, make_uint4(pk.x, tag, pk.y, tag), same_xcd);
+    coop_store(p + 16, make_uint4(pk.z, tag, pk.w, tag), same_xcd);
+}
+__device__ __forceinline__ void coop_ll_load4(const void* p0, const void* p1, const void* p2, const void* p3, uint4 (&lo)[4], uint4 (&hi)[4]) {
+    u32x4n a, b, c, d, e, f, g, h;
+    asm volatile("global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %8, off offset:16 sc1\n\t"
+                 "global_load_dwordx4 %2, %9, off sc1\n\tglobal_load_dwordx4 %3, %9, off offset:16 sc1\n\t"
+                 "global_load_dwordx4 %4, %10, off sc1\n\tglobal_load_dwordx4 %5, %10, off offset:16 sc1\n\t"
+                 "global_load_dwordx4 %6, %11, off sc1\n\tglobal_load_dwordx4 %7, %11, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d), "=&v"(e), "=&v"(f), "=&v"(g), "=&v"(h) : "v"(p0), "v"(p1), "v"(p2), "v"(p3) : "memory");
+    lo[0] = make_uint4(a[0], a[1], a[2], a[3]); hi[0] = make_uint4(b[0], b[1], b[2], b[3]);
+    lo[1] = make_uint4(c[0], c[1], c[2], c[3]); hi[1] = make_uint4(d[0], d[1], d[2], d[3]);
+    lo[2] = make_uint4(e[0], e[1], e[2], e[3]); hi[2] = make_uint4(f[0], f[1], f[2], f[3]);
+    lo[3] = make_uint4(g[0], g[1], g[2], g[3]); hi[3] = make_uint4(h[0], h[1], h[2], h[3]);
+}
+// The other members' slices of rows [0, 32) x [0, width) go from the tile's LL block into X.  No barrier in front: the caller's
+// barrier behind the k-loop has retired every read of X, and the slices written here are not the caller's own.
+__device__ __forceinline__ void coop_exchange_ll(const CoopArgs& co, const char* blk, int need, int width, u16* X, int tid, bool published, int& slot, int member) {
+    coop_stamp(co, slot, tid);                                       // [2] epilogue done (nothing drained)
+    {
+        const int wid = tid >> 6, lane = tid & 63;
+        const int nsh = __builtin_ctz(need);
+        const int parts = 8 >> nsh, psh = 3 - nsh;
+        const int mslot = wid >> psh, part = wid & (parts - 1);
+        const int ws = width >> nsh;
+        if (mslot != member || !published) {
+            const int cps = ws >> 3, csh = __builtin_ctz(cps);
+            const int rows = 32 >> psh, total = rows << csh;
+            const void* ptr[4];
+            int dst[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int it = lane + 64 * j;
+                const bool ok = it < total;
+                const int itc = ok ? it : 0;
+                const int r = part * rows + (itc >> csh), c = (mslot << csh) + (itc & (cps - 1));
+                ptr[j] = blk + r * COOP_LL_PITCH + c * 32;
+                dst[j] = ok ? chain_lds_off(r, c * 8) : -1;
+            }
+            uint4 lo[4], hi[4];
+            int spins = 0;
+            for (;;) {
+                coop_ll_load4(ptr[0], ptr[1], ptr[2], ptr[3], lo, hi);
+                bool ok = true;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    ok = ok && (dst[j] < 0 || (lo[j].y == co.epoch && lo[j].w == co.epoch && hi[j].y == co.epoch && hi[j].w == co.epoch));
+                if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
+                if (++spins > co.spin_limit) {                       // bounded: counted, reported by the host on its next call
+                    if (lane == 0) __hip_atomic_fetch_add(co.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    break;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (dst[j] >= 0) *reinterpret_cast<uint4*>(X + dst[j]) = make_uint4(lo[j].x, lo[j].z, hi[j].x, hi[j].z);
+        }
+    }
+    __syncthreads();
+    coop_stamp(co, slot, tid);                                       // [3] gathered
 }
 
 // All members of the tile have published stage `seq` (`need` arrivals per step), then: the columns of rows [m0, m0+32) x
@@ -175,10 +252,11 @@ __device__ __forceinline__ void coop_request_weights(const ChainStage& S, int C,
 
 // One stage for one member.  EPI_HIDDEN / EPI_DGRAD / EPI_OUT as in chain.h.  Returns through `own_lo / own_hi` the
 // columns this member produced (for the exchange that follows).  `q`: this wave's weights (coop_request_weights).
-template <int EPI, int QN>
+template <int EPI, int QN, class REQ>
 __device__ __forceinline__ void coop_stage(const ChainArgs& p, const ChainStage& S, int C, int member, u16* X, float* red,
                                            const float* bias_lds, const int64_t* rows_lds, int64_t m0, int tid, float& sq, float& ab,
-                                           int& own_lo, int& own_hi, const CoopArgs& co, int& slot, bool same_xcd, const uint4 (&q)[QN]) {
+                                           int& own_lo, int& own_hi, const CoopArgs& co, int& slot, bool same_xcd, const uint4 (&q)[QN],
+                                           char* ll, REQ request_next) {
     const int lane = tid & 63, wid = tid >> 6;
     const CoopPart pt = coop_part(S, C, member, wid);
     const int ntiles = pt.ntiles, tiles_c = pt.tiles_c, ksplit = pt.ksplit;
@@ -224,6 +302,9 @@ __device__ __forceinline__ void coop_stage(const ChainArgs& p, const ChainStage&
         for (int j = 0; j < 4; ++j)
             *reinterpret_cast<float4*>(dst + 8 * j) = make_float4(acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]);
     }
+    // LL exchange: nothing drains behind the epilogue, so the next stage's weights are requested HERE (the k-loop has consumed q) and
+    // land under the reduction, the epilogue and the exchange
+    if (ll) request_next();
     coop_stamp(co, slot, tid);                                       // [0] wave 0's k-loop done
     __syncthreads();                                                 // partial sums complete; nobody reads X (the stage input) any more
     coop_stamp(co, slot, tid);                                       // [1] everyone's
@@ -245,14 +326,16 @@ __device__ __forceinline__ void coop_stage(const ChainArgs& p, const ChainStage&
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = act_fwd(v[e] + bb[e], p.act, p.slope);
                 pk = make_uint4(cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3]), cvt_pk_bf16(v[4], v[5]), cvt_pk_bf16(v[6], v[7]));
-                if (S.out) coop_store(S.out + row * S.ldo + n, pk, same_xcd);
+                if (ll) coop_ll_store(ll + m * COOP_LL_PITCH + n * 4, pk, co.epoch, same_xcd);
+                if (S.out) coop_store(S.out + row * S.ldo + n, pk, same_xcd || ll != nullptr);
             } else if (EPI == EPI_DGRAD) {
                 const uint4 h = it == it_a ? pre_h : *reinterpret_cast<const uint4*>(S.hprev + row * S.ldh + n);   // own slice of the forward pass
                 const unsigned hw[4] = {h.x, h.y, h.z, h.w};
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] *= act_bwd_from_h(bf2f((u16)(hw[e >> 1] >> (16 * (e & 1)))), p.act, p.slope);
                 pk = make_uint4(cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3]), cvt_pk_bf16(v[4], v[5]), cvt_pk_bf16(v[6], v[7]));
-                if (S.out) coop_store(S.out + row * S.ldo + n, pk, same_xcd);
+                if (ll) coop_ll_store(ll + m * COOP_LL_PITCH + n * 4, pk, co.epoch, same_xcd);
+                if (S.out) coop_store(S.out + row * S.ldo + n, pk, same_xcd || ll != nullptr);
             } else {                                                 // heads: bias, per-column activation, loss sums, dz
                 const float* bb = bias_lds + S.bias_off + n;
                 const bool valid = row < p.n_rows;
@@ -271,7 +354,8 @@ __device__ __forceinline__ void coop_stage(const ChainArgs& p, const ChainStage&
                     for (int e = 0; e < 4; ++e) d[4 * hlf + e] = dd[e];
                 }
                 pk = make_uint4(cvt_pk_bf16(d[0], d[1]), cvt_pk_bf16(d[2], d[3]), cvt_pk_bf16(d[4], d[5]), cvt_pk_bf16(d[6], d[7]));
-                if (p.dz_out) coop_store(p.dz_out + row * p.ld_dz_out + n, pk, same_xcd);
+                if (ll) coop_ll_store(ll + m * COOP_LL_PITCH + n * 4, pk, co.epoch, same_xcd);
+                if (p.dz_out) coop_store(p.dz_out + row * p.ld_dz_out + n, pk, same_xcd || ll != nullptr);
             }
             *reinterpret_cast<uint4*>(X + chain_lds_off(m, n)) = pk;
         }
@@ -346,19 +430,23 @@ __global__ __launch_bounds__(512) void k_chain_coop_fb(const ChainArgs pf, const
     coop_stamp(co, slot, tid);                                       // prologue done
     // ---- forward.  Right after a stage's MFMAs the NEXT stage's weights are requested: they arrive while this stage is
     // reduced, published and exchanged.
+    char* const ll_tile = co.ll ? co.ll + (size_t)tile * co.n_seq * COOP_LL_BLOCK : nullptr;
     for (int i = 0; i < pf.n_stages; ++i, ++seq) {
         const ChainStage& S = pf.st[i];
         int lo, hi;
         const int need = min(C, S.Nc >> 5);
+        char* const blk = ll_tile ? ll_tile + (size_t)seq * COOP_LL_BLOCK : nullptr;
         if (S.epi == EPI_OUT) {
-            coop_stage<EPI_OUT, QN>(pf, S, C, member, X, red, bias_lds, rows_lds, m0, tid, sq, ab, lo, hi, co, slot, same_xcd, wq);
             // dz of the heads: the input of the backward pass, every member needs all of it
-            coop_exchange(co, tile, seq, need, pf.dz_out, pf.ld_dz_out, m0, S.Nc, lo, hi, X, tid, lo >= 0, slot, same_xcd, member,
-                          [&]() { coop_request_weights<QN>(pb.st[0], C, member, tid, wq); });                    // first backward stage
+            auto req = [&]() { coop_request_weights<QN>(pb.st[0], C, member, tid, wq); };                       // first backward stage
+            coop_stage<EPI_OUT, QN>(pf, S, C, member, X, red, bias_lds, rows_lds, m0, tid, sq, ab, lo, hi, co, slot, same_xcd, wq, blk, req);
+            if (blk) coop_exchange_ll(co, blk, need, S.Nc, X, tid, lo >= 0, slot, member);
+            else coop_exchange(co, tile, seq, need, pf.dz_out, pf.ld_dz_out, m0, S.Nc, lo, hi, X, tid, lo >= 0, slot, same_xcd, member, req);
         } else {
-            coop_stage<EPI_HIDDEN, QN>(pf, S, C, member, X, red, bias_lds, rows_lds, m0, tid, sq, ab, lo, hi, co, slot, same_xcd, wq);
-            coop_exchange(co, tile, seq, need, S.out, S.ldo, m0, S.Nc, lo, hi, X, tid, lo >= 0, slot, same_xcd, member,
-                          [&]() { coop_request_weights<QN>(pf.st[i + 1], C, member, tid, wq); });               // (a hidden stage is never the last forward one)
+            auto req = [&]() { coop_request_weights<QN>(pf.st[i + 1], C, member, tid, wq); };                   // (a hidden stage is never the last forward one)
+            coop_stage<EPI_HIDDEN, QN>(pf, S, C, member, X, red, bias_lds, rows_lds, m0, tid, sq, ab, lo, hi, co, slot, same_xcd, wq, blk, req);
+            if (blk) coop_exchange_ll(co, blk, need, S.Nc, X, tid, lo >= 0, slot, member);
+            else coop_exchange(co, tile, seq, need, S.out, S.ldo, m0, S.Nc, lo, hi, X, tid, lo >= 0, slot, same_xcd, member, req);
         }
     }
     if (pf.y) loss_flush(pf.loss, pf.loss_stripes, (unsigned)w, sq, ab, red, tid, 8);
@@ -366,9 +454,13 @@ __global__ __launch_bounds__(512) void k_chain_coop_fb(const ChainArgs pf, const
     for (int i = 0; i < pb.n_stages; ++i, ++seq) {
         const ChainStage& S = pb.st[i];
         int lo, hi;
-        coop_stage<EPI_DGRAD, QN>(pb, S, C, member, X, red, bias_lds, rows_lds, m0, tid, sq, ab, lo, hi, co, slot, same_xcd, wq);
-        if (i + 1 < pb.n_stages)
-            coop_exchange(co, tile, seq, min(C, S.Nc >> 5), S.out, S.ldo, m0, S.Nc, lo, hi, X, tid, lo >= 0, slot, same_xcd, member,
-                          [&]() { coop_request_weights<QN>(pb.st[i + 1], C, member, tid, wq); });
+        const bool more = i + 1 < pb.n_stages;
+        char* const blk = (ll_tile && more) ? ll_tile + (size_t)seq * COOP_LL_BLOCK : nullptr;
+        auto req = [&]() { if (more) coop_request_weights<QN>(pb.st[more ? i + 1 : i], C, member, tid, wq); };
+        coop_stage<EPI_DGRAD, QN>(pb, S, C, member, X, red, bias_lds, rows_lds, m0, tid, sq, ab, lo, hi, co, slot, same_xcd, wq, blk, req);
+        if (more) {
+            if (blk) coop_exchange_ll(co, blk, min(C, S.Nc >> 5), S.Nc, X, tid, lo >= 0, slot, member);
+            else coop_exchange(co, tile, seq, min(C, S.Nc >> 5), S.out, S.ldo, m0, S.Nc, lo, hi, X, tid, lo >= 0, slot, same_xcd, member, req);
+        }
     }
 }
