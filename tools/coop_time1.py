@@ -23,5 +23,5 @@ for B in [int(v) for v in sys.argv[1:]] or [1024]:
             m.train_on_batch(x, y, 1e-3)
     m.get_weights()
     print(B, "LL=%s WARM=%s" % (os.environ.get("CS_COOP_LL", "1"), os.environ.get("CS_COOP_WARM", "0")), "step us", round(best * 1e6, 1),
-          {k: round(v[0] / 60 * 1e3, 1) for k, v in prof.times.items() if v[1]}, "timeouts", m.coop_timeouts() if hasattr(m, "coop_timeouts") else "", flush=True)
+          {k: round(v[0] / 60 * 1e3, 1) for k, v in prof.times.items() if v[1]}, "timeouts", m.coop_timeouts, flush=True)
     m.close()
