@@ -111,10 +111,8 @@ __device__ __forceinline__ void coop_ll_load4(const void* p0, const void* p1, co
 }
 // The other members' slices of rows [0, 32) x [0, width) go from the tile's LL block into X.  No barrier in front: the caller's
 // barrier behind the k-loop has retired every read of X, and the slices written here are not the caller's own.
-template <class REQ>
-__device__ __forceinline__ void coop_exchange_ll(const CoopArgs& co, const char* blk, int need, int width, u16* X, int tid, bool published, int& slot, int member, REQ request_next) {
+__device__ __forceinline__ void coop_exchange_ll(const CoopArgs& co, const char* blk, int need, int width, u16* X, int tid, bool published, int& slot, int member) {
     coop_stamp(co, slot, tid);                                       // [2] epilogue done (nothing drained)
-    if (co.warm & 8) request_next();                                 // experiment: the flag protocol's place
     {
         const int wid = tid >> 6, lane = tid & 63;
         const int nsh = __builtin_ctz(need);
@@ -137,13 +135,6 @@ __device__ __forceinline__ void coop_exchange_ll(const CoopArgs& co, const char*
             }
             uint4 lo[4], hi[4];
             int spins = 0;
-            if (co.warm & 32) {                                      // experiment: wait on ONE unit per lane, then fetch the lot
-                for (;;) {
-                    const uint4 t = coop_load_sc1(ptr[0]);
-                    if (__builtin_amdgcn_ballot_w64(dst[0] >= 0 && t.y != co.epoch) == 0ull || ++spins > co.spin_limit) break;
-                    if (co.warm & 16) __builtin_amdgcn_s_sleep(2);
-                }
-            }
             for (;;) {
                 coop_ll_load4(ptr[0], ptr[1], ptr[2], ptr[3], lo, hi);
                 bool ok = true;
@@ -155,7 +146,6 @@ __device__ __forceinline__ void coop_exchange_ll(const CoopArgs& co, const char*
                     if (lane == 0) __hip_atomic_fetch_add(co.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     break;
                 }
-                if (co.warm & 16) __builtin_amdgcn_s_sleep(2);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -314,7 +304,7 @@ __device__ __forceinline__ void coop_stage(const ChainArgs& p, const ChainStage&
     }
     // LL exchange: nothing drains behind the epilogue, so the next stage's weights are requested HERE (the k-loop has consumed q) and
     // land under the reduction, the epilogue and the exchange
-    if (ll && !(co.warm & 8)) request_next();
+    if (ll) request_next();
     coop_stamp(co, slot, tid);                                       // [0] wave 0's k-loop done
     __syncthreads();                                                 // partial sums complete; nobody reads X (the stage input) any more
     coop_stamp(co, slot, tid);                                       // [1] everyone's
@@ -450,12 +440,12 @@ __global__ __launch_bounds__(512) void k_chain_coop_fb(const ChainArgs pf, const
             // dz of the heads: the input of the backward pass, every member needs all of it
             auto req = [&]() { coop_request_weights<QN>(pb.st[0], C, member, tid, wq); };                       // first backward stage
             coop_stage<EPI_OUT, QN>(pf, S, C, member, X, red, bias_lds, rows_lds, m0, tid, sq, ab, lo, hi, co, slot, same_xcd, wq, blk, req);
-            if (blk) coop_exchange_ll(co, blk, need, S.Nc, X, tid, lo >= 0, slot, member, req);
+            if (blk) coop_exchange_ll(co, blk, need, S.Nc, X, tid, lo >= 0, slot, member);
             else coop_exchange(co, tile, seq, need, pf.dz_out, pf.ld_dz_out, m0, S.Nc, lo, hi, X, tid, lo >= 0, slot, same_xcd, member, req);
         } else {
             auto req = [&]() { coop_request_weights<QN>(pf.st[i + 1], C, member, tid, wq); };                   // (a hidden stage is never the last forward one)
             coop_stage<EPI_HIDDEN, QN>(pf, S, C, member, X, red, bias_lds, rows_lds, m0, tid, sq, ab, lo, hi, co, slot, same_xcd, wq, blk, req);
-            if (blk) coop_exchange_ll(co, blk, need, S.Nc, X, tid, lo >= 0, slot, member, req);
+            if (blk) coop_exchange_ll(co, blk, need, S.Nc, X, tid, lo >= 0, slot, member);
             else coop_exchange(co, tile, seq, need, S.out, S.ldo, m0, S.Nc, lo, hi, X, tid, lo >= 0, slot, same_xcd, member, req);
         }
     }
@@ -469,7 +459,7 @@ __global__ __launch_bounds__(512) void k_chain_coop_fb(const ChainArgs pf, const
         auto req = [&]() { if (more) coop_request_weights<QN>(pb.st[more ? i + 1 : i], C, member, tid, wq); };
         coop_stage<EPI_DGRAD, QN>(pb, S, C, member, X, red, bias_lds, rows_lds, m0, tid, sq, ab, lo, hi, co, slot, same_xcd, wq, blk, req);
         if (more) {
-            if (blk) coop_exchange_ll(co, blk, min(C, S.Nc >> 5), S.Nc, X, tid, lo >= 0, slot, member, req);
+            if (blk) coop_exchange_ll(co, blk, min(C, S.Nc >> 5), S.Nc, X, tid, lo >= 0, slot, member);
             else coop_exchange(co, tile, seq, min(C, S.Nc >> 5), S.out, S.ldo, m0, S.Nc, lo, hi, X, tid, lo >= 0, slot, same_xcd, member, req);
         }
     }
