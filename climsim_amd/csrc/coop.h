@@ -250,6 +250,22 @@ __device__ __forceinline__ void coop_request_weights(const ChainStage& S, int C,
         if (d < pt.ksteps) q[d] = w[d * sstride];
 }
 
+template <int KS>
+__device__ __forceinline__ void coop_sum_parts(const float* src, float (&v)[8]) {
+    float4 a[KS], b[KS];
+#pragma unroll
+    for (int kq = 0; kq < KS; ++kq) {
+        a[kq] = *reinterpret_cast<const float4*>(src + kq * (32 * COOP_RED_PITCH));
+        b[kq] = *reinterpret_cast<const float4*>(src + kq * (32 * COOP_RED_PITCH) + 4);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+#pragma unroll
+    for (int kq = 0; kq < KS; ++kq) {
+        v[0] += a[kq].x; v[1] += a[kq].y; v[2] += a[kq].z; v[3] += a[kq].w; v[4] += b[kq].x; v[5] += b[kq].y; v[6] += b[kq].z; v[7] += b[kq].w;
+    }
+}
+
 // One stage for one member.  EPI_HIDDEN / EPI_DGRAD / EPI_OUT as in chain.h.  Returns through `own_lo / own_hi` the
 // columns this member produced (for the exchange that follows).  `q`: this wave's weights (coop_request_weights).
 template <int EPI, int QN, class REQ>
@@ -312,17 +328,21 @@ __device__ __forceinline__ void coop_stage(const ChainArgs& p, const ChainStage&
         for (int it = tid; it < 32 * groups; it += 512) {
             const int m = it >> gsh, g = it & (groups - 1);
             const int ct = g >> 2, c8 = (g & 3) * 8;
-            float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            for (int kq = 0; kq < ksplit; ++kq) {
-                const float* src = red + (ct * ksplit + kq) * (32 * COOP_RED_PITCH) + m * COOP_RED_PITCH + c8;
-                const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
-                v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+            float v[8];
+            {   // the partial sums of the waves that split the contraction: all reads issued, ONE wait (a read -> wait -> add chain per
+                // part was 4 LDS latencies per stage at 8 members), same order of additions
+                const float* src = red + (ct * ksplit) * (32 * COOP_RED_PITCH) + m * COOP_RED_PITCH + c8;
+                if (ksplit == 4) coop_sum_parts<4>(src, v);
+                else if (ksplit == 8) coop_sum_parts<8>(src, v);
+                else if (ksplit == 2) coop_sum_parts<2>(src, v);
+                else coop_sum_parts<1>(src, v);
             }
             const int n = own_lo + ct * 32 + c8;                     // column of the stage output
             const int64_t row = m0 + m;
             uint4 pk;
             if (EPI == EPI_HIDDEN) {
-                const float* bb = bias_lds + S.bias_off + n;
+                const float4 b0 = *reinterpret_cast<const float4*>(bias_lds + S.bias_off + n), b1 = *reinterpret_cast<const float4*>(bias_lds + S.bias_off + n + 4);
+                const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = act_fwd(v[e] + bb[e], p.act, p.slope);
                 pk = make_uint4(cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3]), cvt_pk_bf16(v[4], v[5]), cvt_pk_bf16(v[6], v[7]));
