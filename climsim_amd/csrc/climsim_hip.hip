@@ -795,7 +795,7 @@ int cs_mlp_create(cs_mlp_t** out, const cs_mlp_cfg* cfg) {
     if (h->use_chain) {
         A((void**)&h->coop_arrive, sizeof(unsigned) * 256 * (1 + 2 * CHAIN_MAX_STAGES * 8));
         A((void**)&h->coop_xcc, sizeof(unsigned) * 256);
-        static const bool ll_on = !(getenv("CS_COOP_LL") && atoi(getenv("CS_COOP_LL")) == 0);
+        const bool ll_on = !(getenv("CS_COOP_LL") && atoi(getenv("CS_COOP_LL")) == 0);        // read per handle: tests build both
         if (h->coop_mode != 0 && ll_on) {                     // up to 64 row tiles (256 workgroups / 4 members) x 2 L exchanges x 64 KiB
             h->coop_ll_bytes = (size_t)64 * (2 * h->L) * COOP_LL_BLOCK;
             A((void**)&h->coop_ll, h->coop_ll_bytes);

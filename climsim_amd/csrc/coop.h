@@ -8,7 +8,10 @@
 // streams 1/C of that; what it costs is one all-gather among the C members per layer.  Measured for exactly this pattern
 // (tools/handoff_probe.hip, profiles/r02_handoff_probe.txt): 1.7-1.9 us per layer boundary.  13 boundaries per step.
 //
-// Protocol per stage (MI355X_MICROARCH.md "inter-workgroup visibility", form R1; placement-independent):
+// Exchange per stage, round 4 (default; "LL exchange" below): producers store their slice a second time as 8-byte units {data, tag =
+// the step's epoch}, consumers poll the data itself - no drain, no barrier, no flag: 54.5 against 57.8 us per launch at 1024 columns,
+// 62.9 against 70.5 at 2048, 51.3 against 58.3 at 256 (same box, profiles/r04_coop_ll_ab.txt).
+// Flag protocol (rounds 2-3; CS_COOP_LL=0; MI355X_MICROARCH.md "inter-workgroup visibility", form R1; placement-independent):
 //   producer: the slice is stored WRITE-THROUGH (global_store ... sc1), every storing wave drains (s_waitcnt vmcnt(0)),
 //             workgroup barrier, ONE lane stores the step's epoch into the member's flag word of the stage (agent scope);
 //   consumer: lane m of wave 0 polls member m's flag (relaxed agent loads, s_sleep, BOUNDED: on a time-out the error word is

@@ -1,5 +1,6 @@
 """Cooperative layer chain (csrc/coop.h, CS_FLAG_COOP): a 32-row tile split over C = 8 / 4 / 2 workgroups that exchange
-every layer's output inside the launch (write-through stores + agent-scope arrival counters + sc1 loads).  Held to the
+every layer's output inside the launch (round 4: tagged 8-byte units that consumers poll; CS_COOP_LL=0: write-through stores +
+agent-scope arrival flags + sc1 loads).  Held to the
 bf16-emulating oracle with the tolerances of tests/test_mlp_gpu.py, for every member count, activation and stage shape
 (512 / 256 / 128-wide layers: 128-wide stages have fewer computing members than the tile has), over several steps so that
 the monotonic arrival counters go through several epochs, and to the one-workgroup-per-tile chain on the same inputs."""
@@ -55,6 +56,31 @@ def test_coop_loss_and_gradients_match_oracle(M, act, n, units):
     for i, (g, r) in enumerate(zip(m.get_gradients(1.0 / (128 * n)), ref_g)):
         assert g.shape == r.shape and rel(g, r) <= 5e-3, (i, rel(g, r))
     m.close()
+
+
+@pytest.mark.parametrize("n,units", [(1024, (512, 512, 512, 512, 512)), (2000, (512, 256, 128)), (77, (128, 128, 128))])
+def test_tagged_exchange_and_flag_protocol_give_the_same_bits(M, monkeypatch, n, units):
+    """Round 4: the exchange of a stage's output between the members of a tile goes through tagged 8-byte units that the consumers
+    poll (coop.h, "LL exchange"); CS_COOP_LL=0 keeps rounds 2-3's drain + flag + gather.  Same arithmetic, same order: gradients,
+    weights after five steps and predictions must be IDENTICAL, bit for bit."""
+    x, y = O.synth_columns(n, seed=11)
+    xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    out = {}
+    for ll in ("1", "0"):
+        monkeypatch.setenv("CS_COOP_LL", ll)
+        m, cfg, ws = make(M, units, "leakyrelu")
+        m.loss_grads(xd, yd)
+        g = [a.copy() for a in m.get_gradients(1.0)]
+        for _ in range(5):
+            m.train_on_batch(xd, yd, 1e-3)
+        m.check()
+        out[ll] = (g, [w.copy() for w in m.get_weights()], np.asarray(m.predict(xd[:256])))
+        m.close()
+    for a, b in zip(out["1"][0], out["0"][0]):
+        assert np.array_equal(a, b)
+    for a, b in zip(out["1"][1], out["0"][1]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(out["1"][2], out["0"][2])
 
 
 def test_coop_training_tracks_oracle_and_the_plain_chain(M):
