@@ -422,6 +422,7 @@ int run_forward(cs_mlp* h, const float* x, const int64_t* row_idx, int64_t n, in
     if (h->use_chain) {
         ChainArgs c{};
         chain_fwd_args(h, false, x, row_idx, n, normalise, yhat, y, loss, h->loss_striped, want_dz, c);
+        if (n > h->cfg.max_batch) c.dbg = nullptr;             // (prediction beyond max_batch: the stamps buffer is sized by max_batch)
         const int bm = chain_bm(h, n);
         h->bwd_chain_done = false;
         // training: the backward chain rides in the same launch (k_chain_fb) - unless the backward pass is asked to use
@@ -663,6 +664,22 @@ int check_batch(const cs_mlp* h, int64_t n) {
         return fail(CS_ERR_STATE, "the cooperative layer chain timed out waiting for a member workgroup in an earlier call: the state of this handle "
                                   "(weights, optimiser slots) is invalid; CS_FLAG_COOP needs the device to itself");
     return CS_OK;
+}
+
+// Rows one cs_mlp_forward call may take.  Prediction and evaluation keep nothing for a backward pass (no activation copies, no
+// sign masks): on the layer-chain paths the only per-row state is the caller's own buffers, so a call is not bound by max_batch
+// (which sizes the TRAINING buffers).  128-row tiles need chunks of >= 32768 rows to fill the chip: 390 M columns/s against 200 M
+// at 8192 (profiles/r04_predict_time.txt).  Models on the per-layer path stage activations in the arena: max_batch.
+#define CS_FORWARD_MAX_ROWS ((int64_t)1 << 22)
+int64_t forward_limit(const cs_mlp* h) {
+    if (h->use_chain || (h->use_chainw && h->chainw_max_n >= CS_FORWARD_MAX_ROWS)) return std::max<int64_t>(h->cfg.max_batch, CS_FORWARD_MAX_ROWS);
+    return h->cfg.max_batch;
+}
+
+int check_batch_forward(const cs_mlp* h, int64_t n) {
+    if (!h) return fail(CS_ERR_INVALID, "null handle");
+    if (n > h->cfg.max_batch && n <= forward_limit(h)) return check_batch(h, h->cfg.max_batch);     // (the other checks of check_batch)
+    return check_batch(h, n);
 }
 
 }  // namespace
@@ -1011,7 +1028,7 @@ int cs_mlp_set_opt_state(cs_mlp_t* h, const float* host_m, const float* host_v, 
 
 int cs_mlp_forward(cs_mlp_t* h, const float* x_dev, const int64_t* row_idx_dev, int64_t n, int normalise,
                    float* yhat_dev, const float* y_dev, float* loss_dev, int accumulate, void* stream) {
-    int rc = check_batch(h, n);
+    int rc = check_batch_forward(h, n);
     if (rc) return rc;
     if (!x_dev) return fail(CS_ERR_INVALID, "x_dev is null");
     if (y_dev && !loss_dev) return fail(CS_ERR_INVALID, "targets given without loss_dev");
@@ -1041,6 +1058,8 @@ int cs_mlp_loss_grads(cs_mlp_t* h, const float* x_dev, const float* y_dev, const
     if (h->acc_count) train_accuracy(h, y_dev, row_idx_dev, n, st);
     return run_backward(h, n, accumulate != 0, st);
 }
+
+int64_t cs_mlp_forward_limit(const cs_mlp_t* h) { return h ? forward_limit(h) : 0; }
 
 int cs_mlp_grad_buffer(cs_mlp_t* h, void** dev_ptr, int64_t* n_floats) {
     if (!h || !dev_ptr || !n_floats) return fail(CS_ERR_INVALID, "null argument");

@@ -363,11 +363,17 @@ class MLPEmulator:
         return self._split(flat * np.float32(grad_scale))
 
     # ---- Keras-like API
+    def _forward_chunk(self, batch_size: Optional[int]) -> int:
+        """Rows per cs_mlp_forward call of predict / evaluate: the caller's `batch_size`, else 65536 where the engine takes calls
+        beyond max_batch (layer-chain paths: nothing is kept per row; tall tiles fill the chip from 32768 rows), else max_batch."""
+        limit = int(self.lib.cs_mlp_forward_limit(self._h))
+        return max(1, min(int(batch_size) if batch_size else max(self.max_batch, min(65536, limit)), limit))
+
     def predict(self, x, batch_size: Optional[int] = None, normalise: bool = False, as_numpy: bool = True):
         """model.predict: (N,124) -> (N,128) float32 in scaled output space."""
         torch = _torch()
         x = self._to_device(x, self.input_length)
-        bs = min(batch_size or self.max_batch, self.max_batch)
+        bs = self._forward_chunk(batch_size)
         out = torch.empty((x.shape[0], self.output_length), dtype=torch.float32, device=self.device)
         for lo in range(0, x.shape[0], bs):
             hi = min(lo + bs, x.shape[0])
@@ -380,7 +386,7 @@ class MLPEmulator:
         categorical accuracy: the share of rows with argmax(y_true) == argmax(y_pred) (cs_categorical_accuracy)."""
         torch = _torch()
         x, y = self._to_device(x, self.input_length), self._to_device(y, self.output_length)
-        bs = min(batch_size or self.max_batch, self.max_batch)
+        bs = self._forward_chunk(batch_size)
         tot = torch.zeros(2, dtype=torch.float32, device=self.device)
         hits = torch.zeros(1, dtype=torch.int64, device=self.device) if accuracy else None
         yhat = torch.empty((bs, self.output_length), dtype=torch.float32, device=self.device) if accuracy else None

@@ -123,6 +123,10 @@ int cs_mlp_set_opt_state(cs_mlp_t* h, const float* host_m, const float* host_v, 
  *   y_dev      targets (indexed like x_dev) or NULL; when given, loss_dev[0] += sum (yhat-y)^2,
  *              loss_dev[1] += sum |yhat-y| over n*128 elements (loss_dev is zeroed first unless
  *              accumulate != 0).  mse = loss_dev[0]/(128 n), mae = loss_dev[1]/(128 n). */
+/* Rows ONE cs_mlp_forward call may take: max_batch sizes the training buffers; prediction / evaluation on the layer-chain paths keep
+ * no per-row state of their own, so they take up to 2^22 rows per call (128-row tiles fill the chip from 32768 rows: 390 M columns/s
+ * against 200 M in calls of 8192).  max_batch for models on the per-layer path. */
+int64_t cs_mlp_forward_limit(const cs_mlp_t* h);
 int cs_mlp_forward(cs_mlp_t* h, const float* x_dev, const int64_t* row_idx_dev, int64_t n, int normalise,
                    float* yhat_dev, const float* y_dev, float* loss_dev, int accumulate, void* stream);
 

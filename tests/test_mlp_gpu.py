@@ -216,11 +216,37 @@ def test_error_behaviour(M):
     from climsim_amd import _lib
     x = torch.zeros((512, 124), device="cuda")
     with pytest.raises(_lib.EngineError):
-        m.forward_batch(x, yhat=torch.empty((512, 128), device="cuda"))        # n > max_batch
+        m.train_on_batch(x, torch.zeros((512, 128), device="cuda"), 1e-3)      # n > max_batch: max_batch sizes the training buffers
+    m2, *_ = make_model(M, (128, 128), max_batch=256, flags=2)                 # per-layer path: forward stages activations, same bound
+    with pytest.raises(_lib.EngineError):
+        m2.forward_batch(x, yhat=torch.empty((512, 128), device="cuda"))
+    assert m2.lib.cs_mlp_forward_limit(m2._h) == 256 and m.lib.cs_mlp_forward_limit(m._h) >= 1 << 20
+    m2.close()
     with pytest.raises(_lib.EngineError):
         m.forward_batch(x[:8], yhat=torch.empty((8, 128), device="cuda"), normalise=True)   # no norm set
     with pytest.raises(ValueError):
         m.predict(np.zeros((4, 100), np.float32))
+
+
+@pytest.mark.parametrize("units,act,n", [((512,) * 5, "leakyrelu", 70001), ((768, 640, 512, 640, 640), "leakyrelu", 20000), ((256, 128), "elu", 33000)])
+def test_prediction_and_evaluation_take_calls_beyond_max_batch(M, units, act, n):
+    """Round 4: max_batch sizes the TRAINING buffers; prediction / evaluation on the layer-chain paths keep nothing per row, so one
+    cs_mlp_forward call takes far more rows (cs_mlp_forward_limit) and `predict` / `evaluate` default to calls of 65536 (tall tiles fill
+    the chip: 390 M columns/s against 200 M in calls of 8192).  Same bits as calls of max_batch rows - rows are independent, whatever
+    the tile height - and the same sums."""
+    m, cfg, ws = make_model(M, units, act, max_batch=2048)
+    x, y = O.synth_columns(n, seed=5)
+    xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    big, small = m.predict(xd, as_numpy=False), m.predict(xd, batch_size=2048, as_numpy=False)
+    assert torch.equal(big, small)
+    one = torch.empty_like(big)
+    m.forward_batch(xd, yhat=one)                                               # ONE call of n rows
+    assert torch.equal(one, big)
+    ref = O.forward(ws, x[:512], cfg, bf16=True)
+    assert np.abs(big[:512].cpu().numpy() - ref).max() <= 2e-3 * np.abs(ref).max()
+    eb, es = m.evaluate(xd, yd), m.evaluate(xd, yd, batch_size=2048)
+    assert eb["loss"] == pytest.approx(es["loss"], rel=1e-5) and eb["mae"] == pytest.approx(es["mae"], rel=1e-5)
+    m.close()
 
 
 def test_fit_predict_evaluate_api(M, tmp_path):
