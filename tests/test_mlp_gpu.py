@@ -232,16 +232,21 @@ def test_error_behaviour(M):
 def test_prediction_and_evaluation_take_calls_beyond_max_batch(M, units, act, n):
     """Round 4: max_batch sizes the TRAINING buffers; prediction / evaluation on the layer-chain paths keep nothing per row, so one
     cs_mlp_forward call takes far more rows (cs_mlp_forward_limit) and `predict` / `evaluate` default to calls of 65536 (tall tiles fill
-    the chip: 390 M columns/s against 200 M in calls of 8192).  Same bits as calls of max_batch rows - rows are independent, whatever
-    the tile height - and the same sums."""
+    the chip: 390 M columns/s against 200 M in calls of 8192).  Same predictions as calls of max_batch rows (to accumulation order) and
+    the same sums; held to the oracle."""
     m, cfg, ws = make_model(M, units, act, max_batch=2048)
     x, y = O.synth_columns(n, seed=5)
     xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
     big, small = m.predict(xd, as_numpy=False), m.predict(xd, batch_size=2048, as_numpy=False)
-    assert torch.equal(big, small)
+    # taller tiles sum a 128-wide stage's contraction in another order than 32-row tiles (which split it over the wave halves):
+    # accumulation-order tolerance, the one the oracle comparison uses
+    assert float((big - small).abs().max()) <= 2e-3 * float(small.abs().max())
     one = torch.empty_like(big)
     m.forward_batch(xd, yhat=one)                                               # ONE call of n rows
-    assert torch.equal(one, big)
+    assert float((one - small).abs().max()) <= 2e-3 * float(small.abs().max())
+    again = torch.empty_like(big)
+    m.forward_batch(xd, yhat=again)
+    assert torch.equal(one, again)                                              # and deterministic
     ref = O.forward(ws, x[:512], cfg, bf16=True)
     assert np.abs(big[:512].cpu().numpy() - ref).max() <= 2e-3 * np.abs(ref).max()
     eb, es = m.evaluate(xd, yd), m.evaluate(xd, yd, batch_size=2048)
