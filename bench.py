@@ -843,6 +843,7 @@ def run(args, world, rank):
         torch.cuda.synchronize()
         tps.append(time.perf_counter() - tp)
     predict_cps = n_pred / sorted(tps)[1]
+    predict_rows_per_call = model._forward_chunk(None)
     roofline, kernels, kernels_note = None, None, None
     if not args.no_profile and rank == 0:
         # per-kernel durations over 40 BACK-TO-BACK steps (no synchronisation between them: the regime of the timed region),
@@ -934,7 +935,7 @@ def run(args, world, rank):
                "comm": comm, "strong": strong, "weak_large": weak_large,
                "heldout": {"mse": held["mse"], "mae": held["mae"], "rows": 65536, "per_variable": per_var,
                            "against_cpu_restatement": acceptance},
-               "predict": {"columns_per_s": round(predict_cps, 1), "rows": n_pred, "rows_per_call": model._forward_chunk(None), "passes": "median of 3"},
+               "predict": {"columns_per_s": round(predict_cps, 1), "rows": n_pred, "rows_per_call": predict_rows_per_call, "passes": "median of 3"},
                "roofline": roofline, "kernels": kernels, "kernels_note": kernels_note, "cpu_baseline": cpu, **extras}
         line = json.dumps(out, allow_nan=False)
 
