@@ -61,6 +61,9 @@ def test_round4_bench_line_carries_the_sweep():
     assert r["bound"] == "mfma" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["traffic"] > 0 and r["traffic_source"].startswith("profiles/r04_")
     assert sum(k["ms_per_step"] for k in d["kernels"].values()) <= d["ms_per_step"] * 1.001
     assert d["stream"]["value"] > 0 and d["cnn"]["ms_per_step"] > 0 and d["cpu_baseline"]["kind"] == "port"
+    # prediction in calls of 65536 rows (not bound by max_batch), the shader clock read from the card the process runs on
+    assert d["predict"]["rows_per_call"] == 65536 and d["predict"]["columns_per_s"] > 2.5e8
+    assert d["timing"]["gpu_sclk_mhz"]["card_matched_by"] == "pci address" and d["timing"]["gpu_sclk_mhz"]["median"] > 1000
 
 
 def test_bench_defaults_and_flags():

@@ -37,7 +37,7 @@ def test_one_gpu_line():
     r = d["roofline"]
     assert r["bound"] == "mfma" and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert r["traffic"] is None or r["traffic_source"].startswith("profiles/")
-    assert d["heldout"]["mse"] > 0 and d["predict"]["columns_per_s"] > 0
+    assert d["heldout"]["mse"] > 0 and d["predict"]["columns_per_s"] > 0 and d["predict"]["rows_per_call"] == 65536
     # round 3: the per-kernel figures add up to the step (never above it), sysfs load beside the clocks, the cooperative
     # chain's time-out counter, and no output whose R2 is negative because a ReLU head died (synthetic_init)
     assert sum(k["ms_per_step"] for k in d["kernels"].values()) <= d["ms_per_step"] * 1.001
