@@ -55,7 +55,8 @@ class StreamedTrainer:
             raise ValueError("StreamedTrainer drives a side stream: build the model with cooperative=False")
         self.torch, self.model, self.loader, self.batch, self.slots = torch, model, loader, int(batch_size), int(slots)
         self.device = model.device
-        # `side_priority`: HIP stream priority of the side stream (torch numbering: larger = lower; None = default)
+        # `side_priority`: HIP stream priority of the side stream (torch numbering: larger = lower; None = default).  Measured: no
+        # effect on a pass (profiles/r04_stream_prio_probe.txt) - kept for the probe, not a tuning knob
         self.side = torch.cuda.Stream(device=self.device) if side_priority is None else torch.cuda.Stream(device=self.device, priority=int(side_priority))
         self._carrying = False
         self.dist = dist
