@@ -1243,8 +1243,11 @@ int cs_metrics_columns(const float* pred_dev, const float* target_dev, int64_t n
     HIP_TRY(hipMemsetAsync(stats_dev, 0, sizeof(double) * 6 * items, st));
     int tsplit = (int)((4096 + (int64_t)ncol * ((n_out + 127) / 128) - 1) / ((int64_t)ncol * ((n_out + 127) / 128)));   // ~4096 workgroups
     tsplit = std::max(1, std::min<int>(tsplit, (int)(n_steps / 64)));     // >= 64 time steps per slice: 6 float64 atomics per (column, output, slice)
-    CS_LAUNCH(k_metrics_partial, dim3((unsigned)ncol, (unsigned)((n_out + 127) / 128), (unsigned)tsplit), dim3(256), 0, st,
-                       pred_dev, target_dev, (int)n_steps, ncol, n_out, ps_dev, wa_dev, wb_dev, area_dev, stats_dev);
+    static const bool v4_off = getenv("CS_METRICS_V4") && atoi(getenv("CS_METRICS_V4")) == 0;
+    const bool v4 = !v4_off && n_out % 4 == 0 && (uintptr_t)pred_dev % 16 == 0 && (uintptr_t)target_dev % 16 == 0;
+    const dim3 mgrid((unsigned)ncol, (unsigned)((n_out + 127) / 128), (unsigned)tsplit);
+    if (v4) CS_LAUNCH(k_metrics_partial4, mgrid, dim3(256), 0, st, pred_dev, target_dev, (int)n_steps, ncol, n_out, ps_dev, wa_dev, wb_dev, area_dev, stats_dev);
+    else CS_LAUNCH(k_metrics_partial, mgrid, dim3(256), 0, st, pred_dev, target_dev, (int)n_steps, ncol, n_out, ps_dev, wa_dev, wb_dev, area_dev, stats_dev);
     CS_LAUNCH(k_metrics_finish, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, stats_dev, items, (int)n_steps);
     HIP_TRY(hipGetLastError());
     return CS_OK;

@@ -60,6 +60,83 @@ __global__ __launch_bounds__(256) void k_metrics_partial(const float* __restrict
     }
 }
 
+// Round 4: the same sums with 16-byte loads - a thread owns FOUR consecutive outputs of one time step (32 lanes cover a 512-B row, a
+// wave two time steps, a workgroup eight), MT4_U steps in flight: 4 KB per wave in flight instead of 2, a quarter of the load
+// instructions.  The two half-waves meet by a lane exchange, the four waves in LDS.  Needs n_out % 4 == 0 and 16-byte aligned rows
+// (k_metrics_partial otherwise).  Same float64 arithmetic per element; the order of the additions differs (1e-9 of the host pipeline
+// either way: tests/test_metrics_gpu.py).
+#ifndef MT4_U
+#define MT4_U 2
+#endif
+__global__ __launch_bounds__(256) void k_metrics_partial4(const float* __restrict__ pred, const float* __restrict__ target, int T, int ncol,
+                                                          int n_out, const double* __restrict__ ps, const double* __restrict__ wa,
+                                                          const double* __restrict__ wb, const double* __restrict__ area,
+                                                          double* __restrict__ acc /*[ncol][n_out][6], zeroed*/) {
+    __shared__ double red[3][128][6];
+    const int c = blockIdx.x;
+    const int q = threadIdx.x & 31, tr = threadIdx.x >> 5, wid = threadIdx.x >> 6;      // 4 outputs, time-step lane 0..7
+    const int f0 = blockIdx.y * 128 + 4 * q;
+    const bool live = f0 < n_out;                                                       // n_out % 4 == 0: all four or none
+    const int t0 = (int)((int64_t)T * blockIdx.z / gridDim.z), t1 = (int)((int64_t)T * (blockIdx.z + 1) / gridDim.z);
+    const double ar = area[c];
+    double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0}, shift[4] = {0, 0, 0, 0};
+    double s[4][6];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) s[e][k] = 0.0;
+    if (live) {
+        const float4 tf = *reinterpret_cast<const float4*>(target + (int64_t)c * n_out + f0);      // sample t = 0 of this (c, f)
+        const float tfv[4] = {tf.x, tf.y, tf.z, tf.w};
+        const double ps0 = ps[c];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a[e] = wa[f0 + e]; b[e] = wb[f0 + e]; shift[e] = (double)tfv[e] * ((a[e] + b[e] * ps0) * ar); }
+        for (int tb = t0 + tr; tb < t1; tb += 8 * MT4_U) {
+            float4 pv[MT4_U], tv[MT4_U]; double psv[MT4_U];
+#pragma unroll
+            for (int u = 0; u < MT4_U; ++u) {
+                const int t = tb + 8 * u;
+                const int64_t n = (int64_t)(t < t1 ? t : t0) * ncol + c;
+                psv[u] = ps[n];
+                pv[u] = *reinterpret_cast<const float4*>(pred + n * n_out + f0);
+                tv[u] = *reinterpret_cast<const float4*>(target + n * n_out + f0);
+            }
+#pragma unroll
+            for (int u = 0; u < MT4_U; ++u) {
+                if (tb + 8 * u >= t1) continue;
+                const float pe[4] = {pv[u].x, pv[u].y, pv[u].z, pv[u].w}, te[4] = {tv[u].x, tv[u].y, tv[u].z, tv[u].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const double w = (a[e] + b[e] * psv[u]) * ar;
+                    const double pw = (double)pe[e] * w, tw = (double)te[e] * w;
+                    const double d = pw - tw, ts = tw - shift[e];
+                    s[e][0] += fabs(d); s[e][1] += d * d; s[e][2] += pw; s[e][3] += tw; s[e][4] += ts; s[e][5] += ts * ts;
+                }
+            }
+        }
+    }
+    // the two time-step lanes of a wave (lanes l, l + 32), then the four waves
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) s[e][k] += __shfl_xor(s[e][k], 32, 64);
+    if (wid > 0 && (threadIdx.x & 63) < 32) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) red[wid - 1][4 * q + e][k] = s[e][k];
+    }
+    __syncthreads();
+    if (wid == 0 && (threadIdx.x & 63) < 32 && live) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            double* o = acc + ((int64_t)c * n_out + f0 + e) * 6;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) atomicAdd(o + k, s[e][k] + red[0][4 * q + e][k] + red[1][4 * q + e][k] + red[2][4 * q + e][k]);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_metrics_finish(double* __restrict__ acc, int64_t n_items, int T) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_items) return;
