@@ -65,9 +65,7 @@ __global__ __launch_bounds__(256) void k_metrics_partial(const float* __restrict
 // instructions.  The two half-waves meet by a lane exchange, the four waves in LDS.  Needs n_out % 4 == 0 and 16-byte aligned rows
 // (k_metrics_partial otherwise).  Same float64 arithmetic per element; the order of the additions differs (1e-9 of the host pipeline
 // either way: tests/test_metrics_gpu.py).
-#ifndef MT4_U
-#define MT4_U 2
-#endif
+template <int MT4_U>
 __global__ __launch_bounds__(256) void k_metrics_partial4(const float* __restrict__ pred, const float* __restrict__ target, int T, int ncol,
                                                           int n_out, const double* __restrict__ ps, const double* __restrict__ wa,
                                                           const double* __restrict__ wb, const double* __restrict__ area,
