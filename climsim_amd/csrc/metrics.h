@@ -69,7 +69,7 @@ template <int MT4_U>
 __global__ __launch_bounds__(256) void k_metrics_partial4(const float* __restrict__ pred, const float* __restrict__ target, int T, int ncol,
                                                           int n_out, const double* __restrict__ ps, const double* __restrict__ wa,
                                                           const double* __restrict__ wb, const double* __restrict__ area,
-                                                          double* __restrict__ acc /*[ncol][n_out][6], zeroed*/, int ablate) {
+                                                          double* __restrict__ acc /*[ncol][n_out][6], zeroed*/) {
     __shared__ double red[3][128][6];
     const int c = blockIdx.x;
     const int q = threadIdx.x & 31, tr = threadIdx.x >> 5, wid = threadIdx.x >> 6;      // 4 outputs, time-step lane 0..7
@@ -130,10 +130,7 @@ __global__ __launch_bounds__(256) void k_metrics_partial4(const float* __restric
         for (int e = 0; e < 4; ++e) {
             double* o = acc + ((int64_t)c * n_out + f0 + e) * 6;
 #pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                const double v = s[e][k] + red[0][4 * q + e][k] + red[1][4 * q + e][k] + red[2][4 * q + e][k];
-                if (ablate & 1) { if (blockIdx.z == 0) o[k] = v; } else atomicAdd(o + k, v);        // (timing experiment: no atomics)
-            }
+            for (int k = 0; k < 6; ++k) atomicAdd(o + k, s[e][k] + red[0][4 * q + e][k] + red[1][4 * q + e][k] + red[2][4 * q + e][k]);
         }
     }
 }
