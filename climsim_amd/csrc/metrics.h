@@ -64,7 +64,9 @@ __global__ __launch_bounds__(256) void k_metrics_partial(const float* __restrict
 // wave two time steps, a workgroup eight), MT4_U steps in flight: 4 KB per wave in flight instead of 2, a quarter of the load
 // instructions.  The two half-waves meet by a lane exchange, the four waves in LDS.  Needs n_out % 4 == 0 and 16-byte aligned rows
 // (k_metrics_partial otherwise).  Same float64 arithmetic per element; the order of the additions differs (1e-9 of the host pipeline
-// either way: tests/test_metrics_gpu.py).
+// either way: tests/test_metrics_gpu.py).  0.425 against 0.444 ms on the 1.68 M-row scoring split; MT4_U = 1 / 2 / 4 / 8 steps in
+// flight measure the same (0.421-0.436), and 0.055 ms of the call are the 6 float64 atomics per (column, output, time slice)
+// (0.381 ms without them: profiles/r04_metrics_v4.txt).
 template <int MT4_U>
 __global__ __launch_bounds__(256) void k_metrics_partial4(const float* __restrict__ pred, const float* __restrict__ target, int T, int ncol,
                                                           int n_out, const double* __restrict__ ps, const double* __restrict__ wa,
