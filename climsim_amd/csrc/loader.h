@@ -16,35 +16,37 @@
 #define LD_ABL 0             // development (timing only): 1 = no global stores, 2 = no global loads
 #endif
 
-// Round 4: the float64 quotient in four instructions instead of the compiler's eleven (two v_div_scale, v_rcp, five FMAs, v_div_fmas,
-// v_div_fixup).  The PMC passes over this kernel (profiles/r04_loader_pmc.txt) say it is bound by the NUMBER of vector instructions
-// per element (22, every one 4 clocks per wave whatever its type; waves wait for memory 81 % of their time, but with loads AND stores
-// removed the kernel still takes 0.53 of its 0.91 ms).  y = RN(1/d) comes from the host (a constant for the 1200 s of the tendencies);
-// q0 = RN(v*y), r = v - q0*d (exact in one FMA), q = RN(q0 + r*y): with a correctly rounded reciprocal this IS the correctly rounded
-// v/d wherever nothing over- or underflows on the way (Markstein; held against `v / d` on 3e8 adversarial pairs on the CPU, LAB_NOTES).
-// `v_div_fixup_f64` - the last instruction of the compiler's own sequence - then does what it does there: NaN / inf / zero operands,
-// quotients beyond the exponent range, and the SIGN (a zero quotient keeps the sign of -0 / d, which the FMA form loses).  Quotients
-// below 2^-1000 may differ from the division by an ulp of float64: float32 rounds both to the same signed zero.  The caller checks
-// 2^-400 <= |d| <= 2^400 and passes no reciprocals otherwise (the kernel divides).
-__device__ __forceinline__ double loader_div(double v, double d, double y) {
-    const double q0 = v * y, r = __builtin_fma(-q0, d, v);
-    return __builtin_amdgcn_div_fixup(__builtin_fma(r, y, q0), d, v);
+// Round 4: the float64 quotient without the division sequence.  y = RN(1/d) (formed once per feature on the host, a constant for the
+// 1200 s of the tendencies), q0 = RN(v*y), r = v - q0*d (exact in one FMA), q = RN(q0 + r*y): with a correctly rounded reciprocal and
+// no overflow / underflow on the way this IS the correctly rounded v/d (Markstein's theorem; held against `v / d` on 3e8 adversarial
+// pairs - divisors with all-ones / sparse mantissas, quotients on float32 rounding midpoints - by the check kept in LAB_NOTES, and
+// bit for bit against the host path by tests/test_loader_gpu.py).  r == 0: q0 is the quotient, sign of zero included.  Quotients
+// beyond 2^500 (or non-finite) take the division.  3 float64 operations instead of ~12.
+// Branch-free (a branch per element kept the loads of the next element behind it): `bad` collects the elements whose quotient is
+// beyond 2^500 or not finite - the caller recomputes the whole batch by division when any lane has one (raw inf / nan only).
+// Quotients that are zero or subnormal are returned as they are (sign included), quotients below 2^-500 may be an ulp off: float32
+// rounds both to the same signed zero.
+__device__ __forceinline__ double loader_div(double v, double d, double y, unsigned& bad) {
+    const double q0 = v * y, r = __builtin_fma(-q0, d, v), q = __builtin_fma(r, y, q0);
+    const unsigned e = ((unsigned)(__builtin_bit_cast(unsigned long long, q0) >> 32)) & 0x7ff00000u;
+    bad |= e > ((1023u + 500u) << 20) ? 1u : 0u;
+    return e == 0u ? q0 : q;
 }
 
 template <typename T, bool TARGET, bool FAST = false>
 __device__ __forceinline__ float loader_value(const T* __restrict__ src, const T* __restrict__ mli, int64_t off, int f, int ncol,
                                               const double* __restrict__ p0, const double* __restrict__ p1, const int* __restrict__ tend_src,
-                                              const double* __restrict__ p1r = nullptr) {
+                                              const double* __restrict__ p1r = nullptr, unsigned* bad = nullptr) {
     double v = (LD_ABL & 2) ? (double)(off & 1023) : (double)src[off];
     if (TARGET) {
         const int ts = tend_src[f];
         if (ts >= 0) {
             v -= (double)mli[(int64_t)ts * ncol + (off - (int64_t)f * ncol)];
-            v = FAST ? loader_div(v, 1200.0, 1.0 / 1200.0) : v / 1200.0;
+            v = FAST ? loader_div(v, 1200.0, 1.0 / 1200.0, *bad) : v / 1200.0;
         }
         return (float)(v * p0[f]);
     }
-    v = FAST ? loader_div(v - p0[f], p1[f], p1r[f]) : (v - p0[f]) / p1[f];
+    v = FAST ? loader_div(v - p0[f], p1[f], p1r[f], *bad) : (v - p0[f]) / p1[f];
     return (fabs(v) <= 1.79769313486231570e308) ? (float)v : 0.f;      // inf / nan -> 0, decided on the float64 value
 }
 
@@ -134,15 +136,28 @@ __device__ __forceinline__ void loader_pass3(float* tile, const T* __restrict__ 
         const int nfc = min(128, nf - fc), cpc = nfc >> 2;            // float4 chunks per column in this pass
         for (int q0 = w; q0 < cpc; q0 += 4 * LD3_U) {                  // LD3_U float4s per lane and trip: 4 LD3_U loads in flight
             float4 r[LD3_U];
+            unsigned bad = 0u;
 #pragma unroll
             for (int u = 0; u < LD3_U; ++u) {
                 const int q = q0 + 4 * u, f = fc + 4 * q;
                 float v[4] = {0.f, 0.f, 0.f, 0.f};
                 if (q < cpc && c < ncol) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = loader_value<T, TARGET, FAST>(src, mli, (int64_t)(f + e) * ncol + c, f + e, ncol, p0, p1, tend_src, p1r);
+                    for (int e = 0; e < 4; ++e) v[e] = loader_value<T, TARGET, FAST>(src, mli, (int64_t)(f + e) * ncol + c, f + e, ncol, p0, p1, tend_src, p1r, &bad);
                 }
                 r[u] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+            if (FAST && __builtin_amdgcn_ballot_w64(bad != 0u) != 0ull) {       // some quotient of the wave is out of the fast form's range: divide
+#pragma unroll
+                for (int u = 0; u < LD3_U; ++u) {
+                    const int q = q0 + 4 * u, f = fc + 4 * q;
+                    float v[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (q < cpc && c < ncol) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = loader_value<T, TARGET, false>(src, mli, (int64_t)(f + e) * ncol + c, f + e, ncol, p0, p1, tend_src);
+                    }
+                    r[u] = make_float4(v[0], v[1], v[2], v[3]);
+                }
             }
 #pragma unroll
             for (int u = 0; u < LD3_U; ++u) {

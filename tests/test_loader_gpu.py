@@ -116,11 +116,11 @@ def test_device_loader_rounding_boundaries(L, raw_tree, lowres_assets):
 
 
 def test_reciprocal_entry_gives_the_bits_of_the_dividing_entry(L, lowres_assets):
-    """Round 4: `cs_loader_stack_r` forms the float64 quotients from the caller's correctly rounded reciprocals (a multiply, two FMAs
-    and v_div_fixup; loader.h `loader_div`) and must return EXACTLY what `cs_loader_stack` (a float64 division per element) returns -
-    sign of zero included.  Adversarial divisors (all-ones and sparse mantissas, powers of two, negative, 1e-100 .. 1e100) and values whose
-    quotients sit on float32 rounding midpoints, in the float32 subnormal range, at +-0, around 1e-200 and 1e200, at +-inf and nan;
-    float64 and float32 sources."""
+    """Round 4: `cs_loader_stack_r` forms the float64 quotients from the caller's correctly rounded reciprocals (two FMAs behind a
+    multiply; loader.h `loader_div`) and must return EXACTLY what `cs_loader_stack` (a float64 division per element) returns - sign of
+    zero included.  Adversarial divisors (all-ones and sparse mantissas, powers of two, negative, 1e-100 .. 1e100) and values whose
+    quotients sit on float32 rounding midpoints, in the float32 subnormal range, at +-0, beyond 2^+-500 (those take the division inside
+    the fast kernel), at +-inf and nan; float64 and float32 sources."""
     import ctypes as C
     from climsim_amd import _lib
     lib = _lib.load()
@@ -173,7 +173,7 @@ def test_reciprocal_entry_gives_the_bits_of_the_dividing_entry(L, lowres_assets)
         np.testing.assert_array_equal(outs[0][0], outs[1][0])
         np.testing.assert_array_equal(outs[0][1], outs[1][1])
         xs = outs[1][0].view(np.float32)
-        assert np.isfinite(xs).sum() > 0.9 * xs.size and 0.05 * xs.size < (xs == 0).sum() < 0.5 * xs.size     # the cases are what they claim to be
+        assert np.isfinite(xs).sum() > 0.9 * xs.size and (xs == 0).sum() < 0.2 * xs.size          # the cases are what they claim to be
         if f64:
             assert (outs[1][0] == 0x80000000).any() and (outs[1][0] == 0).any()                   # both zeros occur
 
