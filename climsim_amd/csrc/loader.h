@@ -21,32 +21,29 @@
 // no overflow / underflow on the way this IS the correctly rounded v/d (Markstein's theorem; held against `v / d` on 3e8 adversarial
 // pairs - divisors with all-ones / sparse mantissas, quotients on float32 rounding midpoints - by the check kept in LAB_NOTES, and
 // bit for bit against the host path by tests/test_loader_gpu.py).  r == 0: q0 is the quotient, sign of zero included.  Quotients
-// beyond 2^500 (or non-finite) take the division.  3 float64 operations instead of ~12.
-// Branch-free (a branch per element kept the loads of the next element behind it): `bad` collects the elements whose quotient is
-// beyond 2^500 or not finite - the caller recomputes the whole batch by division when any lane has one (raw inf / nan only).
-// Quotients that are zero or subnormal are returned as they are (sign included), quotients below 2^-500 may be an ulp off: float32
-// rounds both to the same signed zero.
-__device__ __forceinline__ double loader_div(double v, double d, double y, unsigned& bad) {
-    const double q0 = v * y, r = __builtin_fma(-q0, d, v), q = __builtin_fma(r, y, q0);
-    const unsigned e = ((unsigned)(__builtin_bit_cast(unsigned long long, q0) >> 32)) & 0x7ff00000u;
-    bad |= e > ((1023u + 500u) << 20) ? 1u : 0u;
-    return e == 0u ? q0 : q;
+// outside [2^-500, 2^500] (or non-finite) take the division: `ok` is false for them.  4 float64 operations instead of ~15.
+__device__ __forceinline__ double loader_div(double v, double d, double y) {
+    const double q0 = v * y, r = __builtin_fma(-q0, d, v);
+    const double a = __builtin_fabs(q0);
+    const bool ok = a <= 0x1p500 && (a >= 0x1p-500 || r == 0.0);
+    if (!ok) return v / d;
+    return r == 0.0 ? q0 : __builtin_fma(r, y, q0);
 }
 
 template <typename T, bool TARGET, bool FAST = false>
 __device__ __forceinline__ float loader_value(const T* __restrict__ src, const T* __restrict__ mli, int64_t off, int f, int ncol,
                                               const double* __restrict__ p0, const double* __restrict__ p1, const int* __restrict__ tend_src,
-                                              const double* __restrict__ p1r = nullptr, unsigned* bad = nullptr) {
+                                              const double* __restrict__ p1r = nullptr) {
     double v = (LD_ABL & 2) ? (double)(off & 1023) : (double)src[off];
     if (TARGET) {
         const int ts = tend_src[f];
         if (ts >= 0) {
             v -= (double)mli[(int64_t)ts * ncol + (off - (int64_t)f * ncol)];
-            v = FAST ? loader_div(v, 1200.0, 1.0 / 1200.0, *bad) : v / 1200.0;
+            v = FAST ? loader_div(v, 1200.0, 1.0 / 1200.0) : v / 1200.0;
         }
         return (float)(v * p0[f]);
     }
-    v = FAST ? loader_div(v - p0[f], p1[f], p1r[f], *bad) : (v - p0[f]) / p1[f];
+    v = FAST ? loader_div(v - p0[f], p1[f], p1r[f]) : (v - p0[f]) / p1[f];
     return (fabs(v) <= 1.79769313486231570e308) ? (float)v : 0.f;      // inf / nan -> 0, decided on the float64 value
 }
 
@@ -136,28 +133,15 @@ __device__ __forceinline__ void loader_pass3(float* tile, const T* __restrict__ 
         const int nfc = min(128, nf - fc), cpc = nfc >> 2;            // float4 chunks per column in this pass
         for (int q0 = w; q0 < cpc; q0 += 4 * LD3_U) {                  // LD3_U float4s per lane and trip: 4 LD3_U loads in flight
             float4 r[LD3_U];
-            unsigned bad = 0u;
 #pragma unroll
             for (int u = 0; u < LD3_U; ++u) {
                 const int q = q0 + 4 * u, f = fc + 4 * q;
                 float v[4] = {0.f, 0.f, 0.f, 0.f};
                 if (q < cpc && c < ncol) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = loader_value<T, TARGET, FAST>(src, mli, (int64_t)(f + e) * ncol + c, f + e, ncol, p0, p1, tend_src, p1r, &bad);
+                    for (int e = 0; e < 4; ++e) v[e] = loader_value<T, TARGET, FAST>(src, mli, (int64_t)(f + e) * ncol + c, f + e, ncol, p0, p1, tend_src, p1r);
                 }
                 r[u] = make_float4(v[0], v[1], v[2], v[3]);
-            }
-            if (FAST && __builtin_amdgcn_ballot_w64(bad != 0u) != 0ull) {       // some quotient of the wave is out of the fast form's range: divide
-#pragma unroll
-                for (int u = 0; u < LD3_U; ++u) {
-                    const int q = q0 + 4 * u, f = fc + 4 * q;
-                    float v[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (q < cpc && c < ncol) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = loader_value<T, TARGET, false>(src, mli, (int64_t)(f + e) * ncol + c, f + e, ncol, p0, p1, tend_src);
-                    }
-                    r[u] = make_float4(v[0], v[1], v[2], v[3]);
-                }
             }
 #pragma unroll
             for (int u = 0; u < LD3_U; ++u) {

@@ -153,7 +153,7 @@ def test_reciprocal_entry_gives_the_bits_of_the_dividing_entry(L, lowres_assets)
     b = gm / scale[None, :, None] * 1200
     with np.errstate(over="ignore", invalid="ignore"):
         b[:, :120] += np.where(np.isfinite(a[:, :120]), a[:, :120], 0.0)
-    b[:, :120, 40:50] = np.where(np.isfinite(a[:, :120, 40:50]), a[:, :120, 40:50], 0.0)      # tendency exactly 0
+    b[:, :, 40:50] = np.where(np.isfinite(a[:, :n_out, 40:50]), a[:, :n_out, 40:50], 0.0)     # tendency exactly 0
     dev = lambda v, dt: torch.from_numpy(np.ascontiguousarray(v, dt)).cuda()  # noqa: E731
     P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
     with np.errstate(over="ignore", divide="ignore"):
