@@ -106,7 +106,6 @@ SIGNATURES = {
                                             C.POINTER(CsKernelTimes)]),
     "cs_categorical_accuracy": (C.c_int, [_P, _P, _I64, _I32, _P, C.c_int, _P]),
     "cs_loader_stack": (C.c_int, [_P, _P, _I32, _I64, _I32, _I32, _P, _P, _I32, _P, _P, _P, _P, _P]),
-    "cs_loader_stack_r": (C.c_int, [_P, _P, _I32, _I64, _I32, _I32, _P, _P, _P, _I32, _P, _P, _P, _P, _P]),
     "cs_cnn_create": (C.c_int, [C.POINTER(_P), C.POINTER(CsCnnCfg)]),
     "cs_cnn_destroy": (None, [_P]),
     "cs_cnn_num_params": (_I64, [_P]),

@@ -1204,9 +1204,9 @@ int cs_permutation(int64_t n, uint64_t seed, int64_t* out_dev, void* stream) {
     return CS_OK;
 }
 
-int cs_loader_stack_r(const void* mli_dev, const void* mlo_dev, int32_t src_f64, int64_t n_steps, int32_t ncol, int32_t n_in,
-                      const double* in_sub_dev, const double* in_div_dev, const double* in_div_rcp_dev, int32_t n_out, const int32_t* tend_src_dev,
-                      const double* out_scale_dev, float* x_out_dev, float* y_out_dev, void* stream) {
+int cs_loader_stack(const void* mli_dev, const void* mlo_dev, int32_t src_f64, int64_t n_steps, int32_t ncol, int32_t n_in,
+                    const double* in_sub_dev, const double* in_div_dev, int32_t n_out, const int32_t* tend_src_dev,
+                    const double* out_scale_dev, float* x_out_dev, float* y_out_dev, void* stream) {
     if (!mli_dev) return fail(CS_ERR_INVALID, "null mli buffer");
     if (!x_out_dev && !y_out_dev) return fail(CS_ERR_INVALID, "no output buffer");
     if (x_out_dev && (!in_sub_dev || !in_div_dev)) return fail(CS_ERR_INVALID, "inputs need sub/div vectors");
@@ -1216,21 +1216,13 @@ int cs_loader_stack_r(const void* mli_dev, const void* mlo_dev, int32_t src_f64,
     hipStream_t st = (hipStream_t)stream;
     // whole rows staged in LDS, 16-byte contiguous stores (loader.h, round 3): widths that are multiples of 4 and 16-byte aligned outputs
     static const bool v3_off = getenv("CS_LOADER_V3") && atoi(getenv("CS_LOADER_V3")) == 0;
-    static const bool fast_off = getenv("CS_LOADER_FASTDIV") && atoi(getenv("CS_LOADER_FASTDIV")) == 0;
     const bool v3 = !v3_off && n_in % 4 == 0 && (n_out % 4 == 0 || !y_out_dev) && ((uintptr_t)x_out_dev % 16 == 0) && ((uintptr_t)y_out_dev % 16 == 0);
-    const bool fast = in_div_rcp_dev && !fast_off;             // the caller vouches for the reciprocals (see the header)
-    if (v3 && src_f64 && fast)
-        CS_LAUNCH((k_loader_stack3<double, true>), grid, dim3(256), 0, st, (const double*)mli_dev,
-                           (const double*)mlo_dev, ncol, n_in, in_sub_dev, in_div_dev, n_out, tend_src_dev, out_scale_dev, x_out_dev, y_out_dev, in_div_rcp_dev);
-    else if (v3 && src_f64)
-        CS_LAUNCH((k_loader_stack3<double, false>), grid, dim3(256), 0, st, (const double*)mli_dev,
-                           (const double*)mlo_dev, ncol, n_in, in_sub_dev, in_div_dev, n_out, tend_src_dev, out_scale_dev, x_out_dev, y_out_dev, nullptr);
-    else if (v3 && fast)
-        CS_LAUNCH((k_loader_stack3<float, true>), grid, dim3(256), 0, st, (const float*)mli_dev,
-                           (const float*)mlo_dev, ncol, n_in, in_sub_dev, in_div_dev, n_out, tend_src_dev, out_scale_dev, x_out_dev, y_out_dev, in_div_rcp_dev);
+    if (v3 && src_f64)
+        CS_LAUNCH((k_loader_stack3<double>), grid, dim3(256), 0, st, (const double*)mli_dev,
+                           (const double*)mlo_dev, ncol, n_in, in_sub_dev, in_div_dev, n_out, tend_src_dev, out_scale_dev, x_out_dev, y_out_dev);
     else if (v3)
-        CS_LAUNCH((k_loader_stack3<float, false>), grid, dim3(256), 0, st, (const float*)mli_dev,
-                           (const float*)mlo_dev, ncol, n_in, in_sub_dev, in_div_dev, n_out, tend_src_dev, out_scale_dev, x_out_dev, y_out_dev, nullptr);
+        CS_LAUNCH((k_loader_stack3<float>), grid, dim3(256), 0, st, (const float*)mli_dev,
+                           (const float*)mlo_dev, ncol, n_in, in_sub_dev, in_div_dev, n_out, tend_src_dev, out_scale_dev, x_out_dev, y_out_dev);
     else if (src_f64)
         CS_LAUNCH((k_loader_stack2<double, LD_CPL, LD_FCH, LD_U>), grid, dim3(256), 0, st, (const double*)mli_dev,
                            (const double*)mlo_dev, ncol, n_in, in_sub_dev, in_div_dev, n_out, tend_src_dev, out_scale_dev, x_out_dev, y_out_dev);
@@ -1239,13 +1231,6 @@ int cs_loader_stack_r(const void* mli_dev, const void* mlo_dev, int32_t src_f64,
                            (const float*)mlo_dev, ncol, n_in, in_sub_dev, in_div_dev, n_out, tend_src_dev, out_scale_dev, x_out_dev, y_out_dev);
     HIP_TRY(hipGetLastError());
     return CS_OK;
-}
-
-int cs_loader_stack(const void* mli_dev, const void* mlo_dev, int32_t src_f64, int64_t n_steps, int32_t ncol, int32_t n_in,
-                    const double* in_sub_dev, const double* in_div_dev, int32_t n_out, const int32_t* tend_src_dev,
-                    const double* out_scale_dev, float* x_out_dev, float* y_out_dev, void* stream) {
-    return cs_loader_stack_r(mli_dev, mlo_dev, src_f64, n_steps, ncol, n_in, in_sub_dev, in_div_dev, nullptr, n_out, tend_src_dev, out_scale_dev,
-                             x_out_dev, y_out_dev, stream);
 }
 
 int cs_metrics_columns(const float* pred_dev, const float* target_dev, int64_t n_steps, int32_t ncol, int32_t n_out,

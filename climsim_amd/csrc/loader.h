@@ -16,34 +16,16 @@
 #define LD_ABL 0             // development (timing only): 1 = no global stores, 2 = no global loads
 #endif
 
-// Round 4: the float64 quotient without the division sequence.  y = RN(1/d) (formed once per feature on the host, a constant for the
-// 1200 s of the tendencies), q0 = RN(v*y), r = v - q0*d (exact in one FMA), q = RN(q0 + r*y): with a correctly rounded reciprocal and
-// no overflow / underflow on the way this IS the correctly rounded v/d (Markstein's theorem; held against `v / d` on 3e8 adversarial
-// pairs - divisors with all-ones / sparse mantissas, quotients on float32 rounding midpoints - by the check kept in LAB_NOTES, and
-// bit for bit against the host path by tests/test_loader_gpu.py).  r == 0: q0 is the quotient, sign of zero included.  Quotients
-// outside [2^-500, 2^500] (or non-finite) take the division: `ok` is false for them.  4 float64 operations instead of ~15.
-__device__ __forceinline__ double loader_div(double v, double d, double y) {
-    const double q0 = v * y, r = __builtin_fma(-q0, d, v);
-    const double a = __builtin_fabs(q0);
-    const bool ok = a <= 0x1p500 && (a >= 0x1p-500 || r == 0.0);
-    if (!ok) return v / d;
-    return r == 0.0 ? q0 : __builtin_fma(r, y, q0);
-}
-
-template <typename T, bool TARGET, bool FAST = false>
+template <typename T, bool TARGET>
 __device__ __forceinline__ float loader_value(const T* __restrict__ src, const T* __restrict__ mli, int64_t off, int f, int ncol,
-                                              const double* __restrict__ p0, const double* __restrict__ p1, const int* __restrict__ tend_src,
-                                              const double* __restrict__ p1r = nullptr) {
+                                              const double* __restrict__ p0, const double* __restrict__ p1, const int* __restrict__ tend_src) {
     double v = (LD_ABL & 2) ? (double)(off & 1023) : (double)src[off];
     if (TARGET) {
         const int ts = tend_src[f];
-        if (ts >= 0) {
-            v -= (double)mli[(int64_t)ts * ncol + (off - (int64_t)f * ncol)];
-            v = FAST ? loader_div(v, 1200.0, 1.0 / 1200.0) : v / 1200.0;
-        }
+        if (ts >= 0) v = (v - (double)mli[(int64_t)ts * ncol + (off - (int64_t)f * ncol)]) / 1200.0;
         return (float)(v * p0[f]);
     }
-    v = FAST ? loader_div(v - p0[f], p1[f], p1r[f]) : (v - p0[f]) / p1[f];
+    v = (v - p0[f]) / p1[f];
     return (fabs(v) <= 1.79769313486231570e308) ? (float)v : 0.f;      // inf / nan -> 0, decided on the float64 value
 }
 
@@ -122,10 +104,10 @@ __global__ __launch_bounds__(256) void k_loader_stack2(const T* __restrict__ mli
 #ifndef LD3_U
 #define LD3_U 2
 #endif
-template <typename T, bool TARGET, bool FAST>
+template <typename T, bool TARGET>
 __device__ __forceinline__ void loader_pass3(float* tile, const T* __restrict__ src, const T* __restrict__ mli, int nf, int ncol, int c0,
                                              const double* __restrict__ p0, const double* __restrict__ p1,
-                                             const int* __restrict__ tend_src, float* __restrict__ out_rows, const double* __restrict__ p1r) {
+                                             const int* __restrict__ tend_src, float* __restrict__ out_rows) {
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: sub / div / tend_src become scalar loads
     const int c = c0 + lane;
     const int ncols = min(64, ncol - c0);
@@ -139,7 +121,7 @@ __device__ __forceinline__ void loader_pass3(float* tile, const T* __restrict__ 
                 float v[4] = {0.f, 0.f, 0.f, 0.f};
                 if (q < cpc && c < ncol) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = loader_value<T, TARGET, FAST>(src, mli, (int64_t)(f + e) * ncol + c, f + e, ncol, p0, p1, tend_src, p1r);
+                    for (int e = 0; e < 4; ++e) v[e] = loader_value<T, TARGET>(src, mli, (int64_t)(f + e) * ncol + c, f + e, ncol, p0, p1, tend_src);
                 }
                 r[u] = make_float4(v[0], v[1], v[2], v[3]);
             }
@@ -169,16 +151,16 @@ __device__ __forceinline__ void loader_pass3(float* tile, const T* __restrict__ 
     }
 }
 
-template <typename T, bool FAST>
+template <typename T>
 __global__ __launch_bounds__(256) void k_loader_stack3(const T* __restrict__ mli, const T* __restrict__ mlo, int ncol, int n_in,
                                                        const double* __restrict__ sub, const double* __restrict__ div, int n_out,
                                                        const int* __restrict__ tend_src, const double* __restrict__ scale,
-                                                       float* __restrict__ x_out, float* __restrict__ y_out, const double* __restrict__ div_rcp) {
+                                                       float* __restrict__ x_out, float* __restrict__ y_out) {
     __shared__ __attribute__((aligned(16))) float tile[64 * 128];
     const int c0 = blockIdx.x * 64;
     const int64_t t = blockIdx.y;
     const T* a = mli + t * (int64_t)n_in * ncol;
-    if (x_out) loader_pass3<T, false, FAST>(tile, a, a, n_in, ncol, c0, sub, div, nullptr, x_out + (t * ncol + c0) * (int64_t)n_in, div_rcp);
-    if (y_out) loader_pass3<T, true, FAST>(tile, mlo + t * (int64_t)n_out * ncol, a, n_out, ncol, c0, scale, nullptr, tend_src,
-                                           y_out + (t * ncol + c0) * (int64_t)n_out, nullptr);
+    if (x_out) loader_pass3<T, false>(tile, a, a, n_in, ncol, c0, sub, div, nullptr, x_out + (t * ncol + c0) * (int64_t)n_in);
+    if (y_out) loader_pass3<T, true>(tile, mlo + t * (int64_t)n_out * ncol, a, n_out, ncol, c0, scale, nullptr, tend_src,
+                                     y_out + (t * ncol + c0) * (int64_t)n_out);
 }

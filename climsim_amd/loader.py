@@ -48,11 +48,6 @@ class GpuColumnLoader:
             sub, div, scale = np.zeros(self.n_in), np.ones(self.n_in), np.ones(self.n_out)
         f64 = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float64)).to(self.device)  # noqa: E731
         self._sub, self._div, self._scale = f64(sub), f64(div), f64(scale)
-        # reciprocals for cs_loader_stack_r (round 4): the correctly rounded 1/div - only when every divisor is finite and far from the
-        # ends of the float64 range; otherwise the kernel divides
-        d = np.ascontiguousarray(div, np.float64)
-        safe = bool(np.all(np.isfinite(d)) and np.all(np.abs(d) >= 2.0 ** -400) and np.all(np.abs(d) <= 2.0 ** 400))
-        self._div_rcp = f64(1.0 / d) if safe else None
         self._tend = torch.from_numpy(np.asarray(tend, np.int32)).to(self.device)
 
     # ---- host side: one file pair -> feature-major raw blocks
@@ -93,11 +88,10 @@ class GpuColumnLoader:
         st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         for lo in range(0, T, 32768):                         # grid.y limit
             hi = min(T, lo + 32768)
-            _lib.check(self.lib.cs_loader_stack_r(_ptr(a[lo:hi]), _ptr(b[lo:hi]) if b is not None else None, int(a.dtype == torch.float64),
-                                                  hi - lo, ncol, self.n_in, _ptr(self._sub), _ptr(self._div),
-                                                  _ptr(self._div_rcp) if self._div_rcp is not None else None, self.n_out,
-                                                  _ptr(self._tend), _ptr(self._scale),
-                                                  _ptr(x[lo * ncol:]) if want_x else None, _ptr(y[lo * ncol:]) if want_y else None, st))
+            _lib.check(self.lib.cs_loader_stack(_ptr(a[lo:hi]), _ptr(b[lo:hi]) if b is not None else None, int(a.dtype == torch.float64),
+                                                hi - lo, ncol, self.n_in, _ptr(self._sub), _ptr(self._div), self.n_out,
+                                                _ptr(self._tend), _ptr(self._scale),
+                                                _ptr(x[lo * ncol:]) if want_x else None, _ptr(y[lo * ncol:]) if want_y else None, st))
         return x, y
 
     def load_files(self, files: Sequence[str]):

@@ -213,14 +213,6 @@ typedef enum { CS_CNN_LOSS_MAE_ADJUSTED = 0, CS_CNN_LOSS_MSE_ADJUSTED = 1 } cs_c
 int cs_loader_stack(const void* mli_dev, const void* mlo_dev, int32_t src_f64, int64_t n_steps, int32_t ncol, int32_t n_in,
                     const double* in_sub_dev, const double* in_div_dev, int32_t n_out, const int32_t* tend_src_dev,
                     const double* out_scale_dev, float* x_out_dev, float* y_out_dev, void* stream);
-/* The same, with the caller's reciprocals of the divisors: in_div_rcp_dev[f] = the correctly rounded float64 1 / in_div_dev[f] (what
- * `1.0 / div` gives in numpy or C).  The kernel then forms every quotient as q0 = v*rcp, r = fma(-q0, div, v), q = fma(r, rcp, q0) - the
- * correctly rounded v / div for finite divisors with 2^-400 <= |div| <= 2^400 (the caller checks that and passes NULL otherwise) and
- * quotients in [2^-500, 2^500]; anything else, element by element, takes the division.  Same bits as cs_loader_stack, ~1.3x its
- * speed on float64 sources (the division sequence was a third of the kernel).  NULL reciprocals = cs_loader_stack. */
-int cs_loader_stack_r(const void* mli_dev, const void* mlo_dev, int32_t src_f64, int64_t n_steps, int32_t ncol, int32_t n_in,
-                      const double* in_sub_dev, const double* in_div_dev, const double* in_div_rcp_dev, int32_t n_out,
-                      const int32_t* tend_src_dev, const double* out_scale_dev, float* x_out_dev, float* y_out_dev, void* stream);
 
 /* Evaluation metrics on the device: data_utils.output_weighting + calc_MAE / calc_RMSE / calc_R2 / calc_bias with
  * avg_grid=False (data_utils.py:1112-1362, 1432-1497).  pred/target (n_steps*ncol, n_out) float32 rows, row = t*ncol + c;

@@ -89,8 +89,6 @@ def test_group_loader_metrics_dp_and_cnn_entries(lib):
     bad(lib, lib.cs_loader_stack(None, None, 1, 1, 1, 1, f8, f8, 0, None, None, None, None, None), b"mli")
     bad(lib, lib.cs_loader_stack(f8, None, 1, 1, 1, 1, f8, f8, 0, None, None, None, None, None), b"no output")
     bad(lib, lib.cs_loader_stack(f8, None, 1, 70000, 1, 1, f8, f8, 0, None, None, f8, None, None), b"bad sizes")
-    bad(lib, lib.cs_loader_stack_r(None, None, 1, 1, 1, 1, f8, f8, f8, 0, None, None, None, None, None), b"mli")
-    bad(lib, lib.cs_loader_stack_r(f8, None, 1, 1, 1, 1, None, f8, f8, 0, None, None, f8, None, None), b"sub/div")
     bad(lib, lib.cs_metrics_columns(None, None, 1, 1, 1, None, None, None, None, None, None))
     bad(lib, lib.cs_normalise_rows(None, None, 1, 1, None, None, None, None))
     bad(lib, lib.cs_categorical_accuracy(None, None, 1, 1, None, 0, None))
