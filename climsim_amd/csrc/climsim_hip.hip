@@ -1217,16 +1217,25 @@ int cs_loader_stack(const void* mli_dev, const void* mlo_dev, int32_t src_f64, i
     // whole rows staged in LDS, 16-byte contiguous stores (loader.h, round 3): widths that are multiples of 4 and 16-byte aligned outputs
     static const bool v3_off = getenv("CS_LOADER_V3") && atoi(getenv("CS_LOADER_V3")) == 0;
     const bool v3 = !v3_off && n_in % 4 == 0 && (n_out % 4 == 0 || !y_out_dev) && ((uintptr_t)x_out_dev % 16 == 0) && ((uintptr_t)y_out_dev % 16 == 0);
-    static const bool v4_off = getenv("CS_LOADER_V4") && atoi(getenv("CS_LOADER_V4")) == 0;
-    const size_t pair = src_f64 ? 16 : 8;                     // two columns per lane: aligned pairs
-    const bool v4 = v3 && !v4_off && ncol % 2 == 0 && (uintptr_t)mli_dev % pair == 0 && (uintptr_t)mlo_dev % pair == 0;
-    const dim3 grid4((unsigned)((ncol + 127) / 128), (unsigned)n_steps);
-    if (v4 && src_f64)
-        CS_LAUNCH((k_loader_stack4<double>), grid4, dim3(512), 0, st, (const double*)mli_dev,
-                           (const double*)mlo_dev, ncol, n_in, in_sub_dev, in_div_dev, n_out, tend_src_dev, out_scale_dev, x_out_dev, y_out_dev);
-    else if (v4)
-        CS_LAUNCH((k_loader_stack4<float>), grid4, dim3(512), 0, st, (const float*)mli_dev,
-                           (const float*)mlo_dev, ncol, n_in, in_sub_dev, in_div_dev, n_out, tend_src_dev, out_scale_dev, x_out_dev, y_out_dev);
+    static const int v4_cpl = getenv("CS_LOADER_V4") ? atoi(getenv("CS_LOADER_V4")) : 2;      // columns per lane: 0 = the 64-column kernel, 2, 4
+    const int cpl = (v3 && (v4_cpl == 2 || v4_cpl == 4) && ncol % v4_cpl == 0 && (uintptr_t)mli_dev % ((src_f64 ? 8 : 4) * v4_cpl) == 0 &&
+                     (uintptr_t)mlo_dev % ((src_f64 ? 8 : 4) * v4_cpl) == 0) ? v4_cpl : 0;
+    if (cpl) {
+        const dim3 grid4((unsigned)((ncol + 64 * cpl - 1) / (64 * cpl)), (unsigned)n_steps);
+        const size_t lds = (size_t)64 * cpl * 128 * sizeof(float);
+        static bool attr_done = false;
+        if (!attr_done) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_loader_stack4<double, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_loader_stack4<float, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_loader_stack4<double, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_loader_stack4<float, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+            attr_done = true;
+        }
+#define CS_LD4(TT, CC) CS_LAUNCH((k_loader_stack4<TT, CC>), grid4, dim3(256 * CC), lds, st, (const TT*)mli_dev, (const TT*)mlo_dev, ncol, n_in, in_sub_dev, in_div_dev, \
+                                 n_out, tend_src_dev, out_scale_dev, x_out_dev, y_out_dev)
+        if (src_f64 && cpl == 4) CS_LD4(double, 4); else if (src_f64) CS_LD4(double, 2); else if (cpl == 4) CS_LD4(float, 4); else CS_LD4(float, 2);
+#undef CS_LD4
+    }
     else if (v3 && src_f64)
         CS_LAUNCH((k_loader_stack3<double>), grid, dim3(256), 0, st, (const double*)mli_dev,
                            (const double*)mlo_dev, ncol, n_in, in_sub_dev, in_div_dev, n_out, tend_src_dev, out_scale_dev, x_out_dev, y_out_dev);

@@ -185,50 +185,58 @@ __device__ __forceinline__ float loader_conv(double v, double st, bool tend, dou
 #ifndef LD4_U
 #define LD4_U 2
 #endif
-template <typename T, bool TARGET>
+// CPL = columns per lane (2 or 4): 64 CPL columns per workgroup of 4 CPL waves, tile [64 CPL][128] floats (64 / 128 KiB, dynamic LDS).
+template <typename T, bool TARGET, int CPL>
 __device__ __forceinline__ void loader_pass4(float* tile, const T* __restrict__ src, const T* __restrict__ mli, int nf, int ncol, int c0,
                                              const double* __restrict__ p0, const double* __restrict__ p1,
                                              const int* __restrict__ tend_src, float* __restrict__ out_rows) {
-    typedef T T2 __attribute__((ext_vector_type(2)));
-    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);      // 8 waves; features are wave-uniform
-    const int c = c0 + 2 * lane;                                       // this lane's column pair (ncol even: both or neither exist)
-    const int ncols = min(128, ncol - c0);
-    const int key = lane & 7;                                          // bank swizzle of rows 2 lane, 2 lane + 1: (row >> 1) & 7
+    typedef T TV __attribute__((ext_vector_type(CPL)));
+    constexpr int COLS = 64 * CPL, WAVES = 4 * CPL, THREADS = 256 * CPL;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);      // features are wave-uniform
+    const int c = c0 + CPL * lane;                                     // this lane's columns (ncol % CPL == 0: all or none exist)
+    const int ncols = min(COLS, ncol - c0);
+    const int key = lane & 7;                                          // bank swizzle of rows CPL lane + j: (row / CPL) & 7
     for (int fc = 0; fc < nf; fc += 128) {
         const int nfc = min(128, nf - fc), cpc = nfc >> 2;
-        for (int q0 = w; q0 < cpc; q0 += 8 * LD4_U) {
-            float4 r[LD4_U][2];
+        for (int q0 = w; q0 < cpc; q0 += WAVES * LD4_U) {
+            float4 r[LD4_U][CPL];
 #pragma unroll
             for (int u = 0; u < LD4_U; ++u) {
-                const int q = q0 + 8 * u, f = fc + 4 * q;
-                float v0[4] = {0.f, 0.f, 0.f, 0.f}, v1[4] = {0.f, 0.f, 0.f, 0.f};
+                const int q = q0 + WAVES * u, f = fc + 4 * q;
+                float v[CPL][4];
+#pragma unroll
+                for (int j = 0; j < CPL; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[j][e] = 0.f;
                 if (q < cpc && c < ncol) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const T2 raw = *reinterpret_cast<const T2*>(src + (int64_t)(f + e) * ncol + c);
-                        T2 st = {(T)0, (T)0};
+                        const TV raw = *reinterpret_cast<const TV*>(src + (int64_t)(f + e) * ncol + c);
+                        TV st;
+#pragma unroll
+                        for (int j = 0; j < CPL; ++j) st[j] = (T)0;
                         bool tend = false;
                         double k0 = p0[f + e], k1 = 1.0;
                         if (TARGET) {
                             const int ts = tend_src[f + e];
                             tend = ts >= 0;
-                            if (tend) st = *reinterpret_cast<const T2*>(mli + (int64_t)ts * ncol + c);
+                            if (tend) st = *reinterpret_cast<const TV*>(mli + (int64_t)ts * ncol + c);
                         } else {
                             k1 = p1[f + e];
                         }
-                        v0[e] = loader_conv<TARGET>((double)raw[0], (double)st[0], tend, k0, k1);
-                        v1[e] = loader_conv<TARGET>((double)raw[1], (double)st[1], tend, k0, k1);
+#pragma unroll
+                        for (int j = 0; j < CPL; ++j) v[j][e] = loader_conv<TARGET>((double)raw[j], (double)st[j], tend, k0, k1);
                     }
                 }
-                r[u][0] = make_float4(v0[0], v0[1], v0[2], v0[3]);
-                r[u][1] = make_float4(v1[0], v1[1], v1[2], v1[3]);
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) r[u][j] = make_float4(v[j][0], v[j][1], v[j][2], v[j][3]);
             }
 #pragma unroll
             for (int u = 0; u < LD4_U; ++u) {
-                const int q = q0 + 8 * u;
+                const int q = q0 + WAVES * u;
                 if (q < cpc) {
-                    *reinterpret_cast<float4*>(tile + (2 * lane) * 128 + ((q ^ key) << 2)) = r[u][0];
-                    *reinterpret_cast<float4*>(tile + (2 * lane + 1) * 128 + ((q ^ key) << 2)) = r[u][1];
+#pragma unroll
+                    for (int j = 0; j < CPL; ++j) *reinterpret_cast<float4*>(tile + (CPL * lane + j) * 128 + ((q ^ key) << 2)) = r[u][j];
                 }
             }
         }
@@ -236,30 +244,30 @@ __device__ __forceinline__ void loader_pass4(float* tile, const T* __restrict__ 
         const int total = ncols * cpc;
         if (nfc == nf) {
             float4* dst = reinterpret_cast<float4*>(out_rows);        // the tile's rows are one block
-            for (int i = tid; i < total; i += 512) {
+            for (int i = tid; i < total; i += THREADS) {
                 const int cc = i / cpc, q = i - cc * cpc;
-                dst[i] = *reinterpret_cast<const float4*>(tile + cc * 128 + ((q ^ ((cc >> 1) & 7)) << 2));
+                dst[i] = *reinterpret_cast<const float4*>(tile + cc * 128 + ((q ^ ((cc / CPL) & 7)) << 2));
             }
         } else {
-            for (int i = tid; i < total; i += 512) {
+            for (int i = tid; i < total; i += THREADS) {
                 const int cc = i / cpc, q = i - cc * cpc;
-                *reinterpret_cast<float4*>(out_rows + (int64_t)cc * nf + fc + 4 * q) = *reinterpret_cast<const float4*>(tile + cc * 128 + ((q ^ ((cc >> 1) & 7)) << 2));
+                *reinterpret_cast<float4*>(out_rows + (int64_t)cc * nf + fc + 4 * q) = *reinterpret_cast<const float4*>(tile + cc * 128 + ((q ^ ((cc / CPL) & 7)) << 2));
             }
         }
         __syncthreads();
     }
 }
 
-template <typename T>
-__global__ __launch_bounds__(512) void k_loader_stack4(const T* __restrict__ mli, const T* __restrict__ mlo, int ncol, int n_in,
+template <typename T, int CPL>
+__global__ __launch_bounds__(256 * CPL) void k_loader_stack4(const T* __restrict__ mli, const T* __restrict__ mlo, int ncol, int n_in,
                                                        const double* __restrict__ sub, const double* __restrict__ div, int n_out,
                                                        const int* __restrict__ tend_src, const double* __restrict__ scale,
                                                        float* __restrict__ x_out, float* __restrict__ y_out) {
-    __shared__ __attribute__((aligned(16))) float tile[128 * 128];
-    const int c0 = blockIdx.x * 128;
+    extern __shared__ __attribute__((aligned(16))) float ld4_tile[];
+    const int c0 = blockIdx.x * 64 * CPL;
     const int64_t t = blockIdx.y;
     const T* a = mli + t * (int64_t)n_in * ncol;
-    if (x_out) loader_pass4<T, false>(tile, a, a, n_in, ncol, c0, sub, div, nullptr, x_out + (t * ncol + c0) * (int64_t)n_in);
-    if (y_out) loader_pass4<T, true>(tile, mlo + t * (int64_t)n_out * ncol, a, n_out, ncol, c0, scale, nullptr, tend_src,
-                                     y_out + (t * ncol + c0) * (int64_t)n_out);
+    if (x_out) loader_pass4<T, false, CPL>(ld4_tile, a, a, n_in, ncol, c0, sub, div, nullptr, x_out + (t * ncol + c0) * (int64_t)n_in);
+    if (y_out) loader_pass4<T, true, CPL>(ld4_tile, mlo + t * (int64_t)n_out * ncol, a, n_out, ncol, c0, scale, nullptr, tend_src,
+                                          y_out + (t * ncol + c0) * (int64_t)n_out);
 }

@@ -2,16 +2,12 @@
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out; export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_loader_gpu.py tests/test_stream_gpu.py -x -q 2>&1 | grep -E "passed|failed|error|Error|assert|Mismatch" | tail -8 | tee gpurun_out/r04_t_tests.log
-for v in 1 0 1 0; do
+for v in 2 4; do echo "== tests with $v columns per lane"; CS_LOADER_V4=$v timeout 900 python -m pytest tests/test_loader_gpu.py tests/test_stream_gpu.py -x -q 2>&1 | grep -E "passed|failed|error|Error|assert|Mismatch" | tail -4; done | tee gpurun_out/r04_t_tests.log
+for rep in 1 2; do for v in 0 2 4; do
   CS_LOADER_V4=$v timeout 300 python bench_loader.py 64 21600 2>/dev/null | tail -1 | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); print('v4=$v', d['value'], d['ms_per_call'], d['roofline']['frac'])"
-done | tee gpurun_out/r04_t_loader_ab.txt
-for v in 1 0; do
+import json,sys; d=json.loads(sys.stdin.read()); print('64 timesteps, columns per lane $v (0 = 64-column kernel):', d['value'], d['ms_per_call'], d['roofline']['frac'])"
+done; done | tee gpurun_out/r04_t_loader_ab.txt
+for v in 0 2 4; do
   CS_LOADER_V4=$v timeout 300 python bench_loader.py 8 21600 2>/dev/null | tail -1 | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); print('8 timesteps v4=$v', d['value'], d['ms_per_call'], d['roofline']['frac'])"
+import json,sys; d=json.loads(sys.stdin.read()); print('8 timesteps, columns per lane $v:', d['value'], d['ms_per_call'], d['roofline']['frac'])"
 done | tee -a gpurun_out/r04_t_loader_ab.txt
-for v in 1 0; do
-  CS_LOADER_V4=$v timeout 600 python bench_stream.py 2>/dev/null | tail -1 | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); print('v4=$v', d['value'], d['train_only_columns_per_s'], d['loader_only_columns_per_s'], round(d['value']/d['train_only_columns_per_s'],4))"
-done | tee gpurun_out/r04_t_stream_ab.txt
