@@ -1265,11 +1265,7 @@ int cs_metrics_columns(const float* pred_dev, const float* target_dev, int64_t n
     static const bool v4_off = getenv("CS_METRICS_V4") && atoi(getenv("CS_METRICS_V4")) == 0;
     const bool v4 = !v4_off && n_out % 4 == 0 && (uintptr_t)pred_dev % 16 == 0 && (uintptr_t)target_dev % 16 == 0;
     const dim3 mgrid((unsigned)ncol, (unsigned)((n_out + 127) / 128), (unsigned)tsplit);
-    static const int m_cw = getenv("CS_METRICS_CW") ? atoi(getenv("CS_METRICS_CW")) : 2;      // grid columns per workgroup (1 or 2)
-    if (v4 && m_cw == 2 && ncol >= 2)
-        CS_LAUNCH((k_metrics_partial4<2, 2>), dim3((unsigned)((ncol + 1) / 2), mgrid.y, mgrid.z), dim3(256), 0, st, pred_dev, target_dev, (int)n_steps, ncol, n_out,
-                  ps_dev, wa_dev, wb_dev, area_dev, stats_dev);
-    else if (v4) CS_LAUNCH((k_metrics_partial4<2, 1>), mgrid, dim3(256), 0, st, pred_dev, target_dev, (int)n_steps, ncol, n_out, ps_dev, wa_dev, wb_dev, area_dev, stats_dev);
+    if (v4) CS_LAUNCH(k_metrics_partial4<2>, mgrid, dim3(256), 0, st, pred_dev, target_dev, (int)n_steps, ncol, n_out, ps_dev, wa_dev, wb_dev, area_dev, stats_dev);
     else CS_LAUNCH(k_metrics_partial, mgrid, dim3(256), 0, st, pred_dev, target_dev, (int)n_steps, ncol, n_out, ps_dev, wa_dev, wb_dev, area_dev, stats_dev);
     CS_LAUNCH(k_metrics_finish, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, stats_dev, items, (int)n_steps);
     HIP_TRY(hipGetLastError());

@@ -67,21 +67,18 @@ __global__ __launch_bounds__(256) void k_metrics_partial(const float* __restrict
 // either way: tests/test_metrics_gpu.py).  0.425 against 0.444 ms on the 1.68 M-row scoring split; MT4_U = 1 / 2 / 4 / 8 steps in
 // flight measure the same (0.421-0.436), and 0.055 ms of the call are the 6 float64 atomics per (column, output, time slice)
 // (0.381 ms without them: profiles/r04_metrics_v4.txt).
-// CW = grid columns per workgroup (1 or 2).  CW = 2: the two halves of a wave take two ADJACENT grid columns of one time step - rows
-// n and n + 1, one contiguous KiB per wave load instead of two 512-byte pieces a time step apart (the same change that took the loader
-// from 0.58 to 0.64 of the HBM peak: profiles/r04_loader_v4.txt) - and the four waves four time steps.
-template <int MT4_U, int CW>
+template <int MT4_U>
 __global__ __launch_bounds__(256) void k_metrics_partial4(const float* __restrict__ pred, const float* __restrict__ target, int T, int ncol,
                                                           int n_out, const double* __restrict__ ps, const double* __restrict__ wa,
                                                           const double* __restrict__ wb, const double* __restrict__ area,
                                                           double* __restrict__ acc /*[ncol][n_out][6], zeroed*/) {
-    __shared__ double red[3][64][4][6];
-    constexpr int TL = 8 / CW;                                                          // time-step lanes of the workgroup
-    const int q = threadIdx.x & 31, sub = threadIdx.x >> 5, wid = threadIdx.x >> 6, l64 = threadIdx.x & 63;
-    const int c = blockIdx.x * CW + (sub % CW), tr = sub / CW;
+    __shared__ double red[3][128][6];
+    const int c = blockIdx.x;
+    const int q = threadIdx.x & 31, tr = threadIdx.x >> 5, wid = threadIdx.x >> 6;      // 4 outputs, time-step lane 0..7
     const int f0 = blockIdx.y * 128 + 4 * q;
-    const bool live = f0 < n_out && c < ncol;                                           // n_out % 4 == 0: all four outputs or none
+    const bool live = f0 < n_out;                                                       // n_out % 4 == 0: all four or none
     const int t0 = (int)((int64_t)T * blockIdx.z / gridDim.z), t1 = (int)((int64_t)T * (blockIdx.z + 1) / gridDim.z);
+    const double ar = area[c];
     double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0}, shift[4] = {0, 0, 0, 0};
     double s[4][6];
 #pragma unroll
@@ -89,17 +86,16 @@ __global__ __launch_bounds__(256) void k_metrics_partial4(const float* __restric
 #pragma unroll
         for (int k = 0; k < 6; ++k) s[e][k] = 0.0;
     if (live) {
-        const double ar = area[c];
         const float4 tf = *reinterpret_cast<const float4*>(target + (int64_t)c * n_out + f0);      // sample t = 0 of this (c, f)
         const float tfv[4] = {tf.x, tf.y, tf.z, tf.w};
         const double ps0 = ps[c];
 #pragma unroll
         for (int e = 0; e < 4; ++e) { a[e] = wa[f0 + e]; b[e] = wb[f0 + e]; shift[e] = (double)tfv[e] * ((a[e] + b[e] * ps0) * ar); }
-        for (int tb = t0 + tr; tb < t1; tb += TL * MT4_U) {
+        for (int tb = t0 + tr; tb < t1; tb += 8 * MT4_U) {
             float4 pv[MT4_U], tv[MT4_U]; double psv[MT4_U];
 #pragma unroll
             for (int u = 0; u < MT4_U; ++u) {
-                const int t = tb + TL * u;
+                const int t = tb + 8 * u;
                 const int64_t n = (int64_t)(t < t1 ? t : t0) * ncol + c;
                 psv[u] = ps[n];
                 pv[u] = *reinterpret_cast<const float4*>(pred + n * n_out + f0);
@@ -107,7 +103,7 @@ __global__ __launch_bounds__(256) void k_metrics_partial4(const float* __restric
             }
 #pragma unroll
             for (int u = 0; u < MT4_U; ++u) {
-                if (tb + TL * u >= t1) continue;
+                if (tb + 8 * u >= t1) continue;
                 const float pe[4] = {pv[u].x, pv[u].y, pv[u].z, pv[u].w}, te[4] = {tv[u].x, tv[u].y, tv[u].z, tv[u].w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -119,26 +115,24 @@ __global__ __launch_bounds__(256) void k_metrics_partial4(const float* __restric
             }
         }
     }
-    if (CW == 1) {                                      // the two half-waves hold two time steps of one column
+    // the two time-step lanes of a wave (lanes l, l + 32), then the four waves
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) s[e][k] += __shfl_xor(s[e][k], 32, 64);
+    if (wid > 0 && (threadIdx.x & 63) < 32) {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int k = 0; k < 6; ++k) s[e][k] += __shfl_xor(s[e][k], 32, 64);
-    }
-    const bool holder = CW == 2 || l64 < 32;            // lanes whose sums are complete within the wave
-    if (wid > 0 && holder) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int k = 0; k < 6; ++k) red[wid - 1][l64][e][k] = s[e][k];
+            for (int k = 0; k < 6; ++k) red[wid - 1][4 * q + e][k] = s[e][k];
     }
     __syncthreads();
-    if (wid == 0 && holder && live) {
+    if (wid == 0 && (threadIdx.x & 63) < 32 && live) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             double* o = acc + ((int64_t)c * n_out + f0 + e) * 6;
 #pragma unroll
-            for (int k = 0; k < 6; ++k) atomicAdd(o + k, s[e][k] + red[0][l64][e][k] + red[1][l64][e][k] + red[2][l64][e][k]);
+            for (int k = 0; k < 6; ++k) atomicAdd(o + k, s[e][k] + red[0][4 * q + e][k] + red[1][4 * q + e][k] + red[2][4 * q + e][k]);
         }
     }
 }
