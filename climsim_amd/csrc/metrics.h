@@ -66,7 +66,8 @@ __global__ __launch_bounds__(256) void k_metrics_partial(const float* __restrict
 // (k_metrics_partial otherwise).  Same float64 arithmetic per element; the order of the additions differs (1e-9 of the host pipeline
 // either way: tests/test_metrics_gpu.py).  0.425 against 0.444 ms on the 1.68 M-row scoring split; MT4_U = 1 / 2 / 4 / 8 steps in
 // flight measure the same (0.421-0.436), and 0.055 ms of the call are the 6 float64 atomics per (column, output, time slice)
-// (0.381 ms without them: profiles/r04_metrics_v4.txt).
+// (0.381 ms without them: profiles/r04_metrics_v4.txt).  Two adjacent grid columns per workgroup (1 KiB per wave load, what paid in
+// the loader) measured slower here: 0.461-0.466 against 0.433 ms (half the workgroups).
 template <int MT4_U>
 __global__ __launch_bounds__(256) void k_metrics_partial4(const float* __restrict__ pred, const float* __restrict__ target, int T, int ncol,
                                                           int n_out, const double* __restrict__ ps, const double* __restrict__ wa,
