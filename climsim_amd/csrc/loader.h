@@ -165,13 +165,12 @@ __global__ __launch_bounds__(256) void k_loader_stack3(const T* __restrict__ mli
                                      y_out + (t * ncol + c0) * (int64_t)n_out);
 }
 
-// ---- round 4: 128 columns per workgroup, two per lane.  Both HBM-bound kernels that read rows in 512-byte pieces at a large stride
-// (this loader: 64 float64 columns of one feature row; the metrics kernel: one 128-float row) stop near half of the HBM peak whatever
-// their arithmetic, their loads in flight or their instruction count (profiles/r04_loader_pmc.txt, r04_metrics_v4.txt) - the piece
-// per DRAM row activation is what they have in common.  Here a lane reads TWO adjacent columns of a feature row in one 16-byte load
-// (1 KiB per wave instruction and feature row), eight waves share a [128 columns][128 floats] tile (64 KiB: two workgroups per CU,
-// sixteen waves as before), the copy-out is the same contiguous stream.  Needs an even ncol (16-byte aligned pairs); the 64-column
-// kernel otherwise.
+// ---- round 4: 128 columns per workgroup, two per lane.  k_loader_stack3 reads a feature row in 512-byte pieces (64 float64 columns)
+// and stops at 0.58 of the HBM peak whatever its arithmetic, its loads in flight or its instruction count (profiles/r04_loader_pmc.txt).
+// Here a lane reads TWO adjacent columns of a feature row in one 16-byte load (1 KiB per wave instruction and feature row), eight
+// waves share a [128 columns][128 floats] tile (64 KiB: two workgroups per CU, sixteen waves), the copy-out is the same contiguous
+// stream: 0.81 against 0.89 ms per 64 x 21,600 columns = 0.64 of the peak (profiles/r04_loader_v4.txt); four columns per lane (one
+// 1024-thread workgroup per CU) 0.86.  Same arithmetic, same bits.  Needs ncol % CPL == 0 (aligned pairs); k_loader_stack3 otherwise.
 template <bool TARGET>
 __device__ __forceinline__ float loader_conv(double v, double st, bool tend, double k0, double k1) {
     if (TARGET) {
