@@ -7,6 +7,7 @@
 // adjacent (they share slabs in one XCD's L2 when reuse = 4).  A writer kernel fills the tensors first (other XCDs' L2s).
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 typedef unsigned short u16;
@@ -56,16 +57,17 @@ __global__ __launch_bounds__(256) void k_stream(const char* base, size_t tensor_
     if (acc == 0x12345678u) sink[0] = acc;
 }
 
-int main() {
-    const int m = 8192, L = 5;
+int main(int argc, char** argv) {
+    const int m = argc > 1 ? atoi(argv[1]) : 8192, L = 5;      // round 4: ./fill_probe 65536 = tensors that no cache holds
     const size_t tensor = (size_t)m * 1024;
     char* buf; unsigned* sink;
     hipMalloc(&buf, tensor * 2 * L); hipMalloc(&sink, 4);
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_stream), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    printf("5 layers x {H, Z} [8192][512] bf16 = %.1f MB unique; every slab is read by 4 tiles (reuse through one XCD's L2)\n", tensor * 2 * L / 1e6);
+    printf("m = %d: 5 layers x {H, Z} [m][512] bf16 = %.1f MB unique; every slab is read by 4 tiles (reuse through one XCD's L2)\n", m, tensor * 2 * L / 1e6);
     for (int panel = 0; panel < 2; ++panel)
-        for (int splits : {3, 5, 7}) {
+        for (int splits : {3, 5, 7, 16}) {
+            if (m / splits / 32 < 4) continue;
             float best = 1e9, sum = 0;
             const int grid = L * 16 * splits;
             for (int rep = 0; rep < 6; ++rep) {
