@@ -270,3 +270,116 @@ __global__ __launch_bounds__(256 * CPL) void k_loader_stack4(const T* __restrict
     if (y_out) loader_pass4<T, true, CPL>(ld4_tile, mlo + t * (int64_t)n_out * ncol, a, n_out, ncol, c0, scale, nullptr, tend_src,
                                           y_out + (t * ncol + c0) * (int64_t)n_out);
 }
+
+// ---- round 4, second step: ONE pass.  The PMC passes over k_loader_stack4 (profiles/r04_loader_traffic.txt) read 4.11 GB per 64 x 21,600
+// columns, not the 2.79 GB of the raw fields: the tendency targets need the input state rows again, the second pass fetches them a
+// second time (120 of 124 rows for the v1 variables), and at 5.5 GB in 0.83 ms the kernel is at 0.83 of the HBM peak - of its own
+// traffic.  Here the pass runs over the OUTPUT groups: a group of four tendency targets loads its four mlo rows and its four state
+// rows, and when those state rows are four consecutive inputs starting at a multiple of four (the v1 layout: targets 0-119 <- inputs
+// 0-119) the same registers also give that group's four normalised inputs.  Input groups no target group covers (the v1 scalars
+// 120-123) take a short second loop.  x and y tiles sit side by side in LDS ([64 CPL][128] floats each) and leave as two contiguous
+// blocks.  Same arithmetic per element, same bits.  Needs both outputs, n_in, n_out <= 128 and multiples of 4; k_loader_stack4 otherwise.
+template <typename T, int CPL, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_loader_stack5(const T* __restrict__ mli, const T* __restrict__ mlo, int ncol, int n_in,
+                                                              const double* __restrict__ sub, const double* __restrict__ div, int n_out,
+                                                              const int* __restrict__ tend_src, const double* __restrict__ scale,
+                                                              float* __restrict__ x_out, float* __restrict__ y_out) {
+    typedef T TV __attribute__((ext_vector_type(CPL)));
+    constexpr int COLS = 64 * CPL, THREADS = 64 * WAVES;
+    extern __shared__ __attribute__((aligned(16))) float ld5[];
+    float* tile_x = ld5;
+    float* tile_y = ld5 + COLS * 128;
+    int* covered = reinterpret_cast<int*>(ld5 + 2 * COLS * 128);       // [32] input groups that a target group writes
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c0 = blockIdx.x * COLS, c = c0 + CPL * lane;
+    const int64_t t = blockIdx.y;
+    const T* a = mli + t * (int64_t)n_in * ncol;
+    const T* b = mlo + t * (int64_t)n_out * ncol;
+    const int ncols = min(COLS, ncol - c0), key = lane & 7;
+    const int gi = n_in >> 2, go = n_out >> 2;
+    if (tid < 32) covered[tid] = 0;
+    __syncthreads();
+    if (tid < go) {
+        const int s0 = tend_src[4 * tid], s1 = tend_src[4 * tid + 1], s2 = tend_src[4 * tid + 2], s3 = tend_src[4 * tid + 3];
+        if (s0 >= 0 && (s0 & 3) == 0 && s1 == s0 + 1 && s2 == s0 + 2 && s3 == s0 + 3 && s0 + 3 < n_in) covered[s0 >> 2] = 1;
+    }
+    __syncthreads();
+    const bool in_range = c < ncol;
+    // ---- target groups (and the input groups they cover)
+    for (int q = w; q < go; q += WAVES) {
+        const int f = 4 * q;
+        int ts[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ts[e] = tend_src[f + e];
+        const bool al = ts[0] >= 0 && (ts[0] & 3) == 0 && ts[1] == ts[0] + 1 && ts[2] == ts[0] + 2 && ts[3] == ts[0] + 3 && ts[0] + 3 < n_in;
+        float vy[CPL][4], vx[CPL][4];
+#pragma unroll
+        for (int j = 0; j < CPL; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { vy[j][e] = 0.f; vx[j][e] = 0.f; }
+        if (in_range) {
+            TV ro[4], ri[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                ro[e] = *reinterpret_cast<const TV*>(b + (int64_t)(f + e) * ncol + c);
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) ri[e][j] = (T)0;
+                if (ts[e] >= 0) ri[e] = *reinterpret_cast<const TV*>(a + (int64_t)ts[e] * ncol + c);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const double sc = scale[f + e];
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) vy[j][e] = loader_conv<true>((double)ro[e][j], (double)ri[e][j], ts[e] >= 0, sc, 1.0);
+                if (al) {
+                    const double k0 = sub[ts[e]], k1 = div[ts[e]];
+#pragma unroll
+                    for (int j = 0; j < CPL; ++j) vx[j][e] = loader_conv<false>((double)ri[e][j], 0.0, false, k0, k1);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+            *reinterpret_cast<float4*>(tile_y + (CPL * lane + j) * 128 + ((q ^ key) << 2)) = make_float4(vy[j][0], vy[j][1], vy[j][2], vy[j][3]);
+            if (al) *reinterpret_cast<float4*>(tile_x + (CPL * lane + j) * 128 + (((ts[0] >> 2) ^ key) << 2)) = make_float4(vx[j][0], vx[j][1], vx[j][2], vx[j][3]);
+        }
+    }
+    // ---- input groups nobody covered
+    for (int g = w; g < gi; g += WAVES) {
+        if (covered[g]) continue;                                     // (wave-uniform: g is)
+        const int f = 4 * g;
+        float vx[CPL][4];
+#pragma unroll
+        for (int j = 0; j < CPL; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) vx[j][e] = 0.f;
+        if (in_range) {
+            TV ri[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ri[e] = *reinterpret_cast<const TV*>(a + (int64_t)(f + e) * ncol + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const double k0 = sub[f + e], k1 = div[f + e];
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) vx[j][e] = loader_conv<false>((double)ri[e][j], 0.0, false, k0, k1);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < CPL; ++j)
+            *reinterpret_cast<float4*>(tile_x + (CPL * lane + j) * 128 + ((g ^ key) << 2)) = make_float4(vx[j][0], vx[j][1], vx[j][2], vx[j][3]);
+    }
+    __syncthreads();
+    {   // the tile's x rows and y rows are one block each
+        float4* dx = reinterpret_cast<float4*>(x_out + (t * ncol + c0) * (int64_t)n_in);
+        float4* dy = reinterpret_cast<float4*>(y_out + (t * ncol + c0) * (int64_t)n_out);
+        const int tx = ncols * gi, ty = ncols * go;
+        for (int i = tid; i < tx; i += THREADS) {
+            const int cc = i / gi, q = i - cc * gi;
+            dx[i] = *reinterpret_cast<const float4*>(tile_x + cc * 128 + ((q ^ ((cc / CPL) & 7)) << 2));
+        }
+        for (int i = tid; i < ty; i += THREADS) {
+            const int cc = i / go, q = i - cc * go;
+            dy[i] = *reinterpret_cast<const float4*>(tile_y + cc * 128 + ((q ^ ((cc / CPL) & 7)) << 2));
+        }
+    }
+}
