@@ -1223,21 +1223,24 @@ int cs_loader_stack(const void* mli_dev, const void* mlo_dev, int32_t src_f64, i
     // one pass over mli (loader.h, k_loader_stack5): both outputs wanted, widths <= 128; CS_LOADER_V5 = 0 off, 1 = 64 columns x 8 waves
     // (two workgroups per CU), 2 (default) = 128 columns x 16 waves (one per CU)
     static const int v5_mode = getenv("CS_LOADER_V5") ? atoi(getenv("CS_LOADER_V5")) : 2;
-    if (cpl && v5_mode && x_out_dev && y_out_dev && n_in <= 128 && n_out <= 128 && n_out % 4 == 0 && (cpl == 2 || v5_mode == 1)) {
+    if (cpl && v5_mode && x_out_dev && y_out_dev && n_in <= 128 && n_out <= 128 && n_out % 4 == 0 && (cpl == 2 || v5_mode != 2)) {
         static bool attr5 = false;
         if (!attr5) {
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_loader_stack5<double, 2, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 128 * 512 + 128));
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_loader_stack5<float, 2, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 128 * 512 + 128));
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_loader_stack5<double, 1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 512 + 128));
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_loader_stack5<float, 1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 512 + 128));
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_loader_stack5<double, 1, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 512 + 128));
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_loader_stack5<double, 1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 512 + 128));
             attr5 = true;
         }
-        const int c5 = v5_mode == 1 ? 1 : 2;
+        const int c5 = v5_mode != 2 ? 1 : 2;
         const dim3 grid5((unsigned)((ncol + 64 * c5 - 1) / (64 * c5)), (unsigned)n_steps);
         const size_t lds5 = (size_t)2 * 64 * c5 * 512 + 128;
 #define CS_LD5(TT, CC, WW) CS_LAUNCH((k_loader_stack5<TT, CC, WW>), grid5, dim3(64 * WW), lds5, st, (const TT*)mli_dev, (const TT*)mlo_dev, ncol, n_in, in_sub_dev, in_div_dev, \
                                      n_out, tend_src_dev, out_scale_dev, x_out_dev, y_out_dev)
-        if (src_f64 && c5 == 2) CS_LD5(double, 2, 16); else if (src_f64) CS_LD5(double, 1, 8); else if (c5 == 2) CS_LD5(float, 2, 16); else CS_LD5(float, 1, 8);
+        if (src_f64 && v5_mode == 3) CS_LD5(double, 1, 16); else if (src_f64 && v5_mode == 4) CS_LD5(double, 1, 4);      // (tuning runs)
+        else if (src_f64 && c5 == 2) CS_LD5(double, 2, 16); else if (src_f64) CS_LD5(double, 1, 8); else if (c5 == 2) CS_LD5(float, 2, 16); else CS_LD5(float, 1, 8);
 #undef CS_LD5
     }
     else if (cpl) {
