@@ -305,43 +305,53 @@ __global__ __launch_bounds__(64 * WAVES) void k_loader_stack5(const T* __restric
     }
     __syncthreads();
     const bool in_range = c < ncol;
-    // ---- target groups (and the input groups they cover)
-    for (int q = w; q < go; q += WAVES) {
-        const int f = 4 * q;
-        int ts[4];
+    // ---- target groups (and the input groups they cover); LD5_U groups per trip: all their loads (8 per group) fly together
+#ifndef LD5_U
+#define LD5_U 2
+#endif
+    for (int q0 = w; q0 < go; q0 += LD5_U * WAVES) {
+        int ts[LD5_U][4];
+        bool al[LD5_U];
+        TV ro[LD5_U][4], ri[LD5_U][4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) ts[e] = tend_src[f + e];
-        const bool al = ts[0] >= 0 && (ts[0] & 3) == 0 && ts[1] == ts[0] + 1 && ts[2] == ts[0] + 2 && ts[3] == ts[0] + 3 && ts[0] + 3 < n_in;
-        float vy[CPL][4], vx[CPL][4];
+        for (int u = 0; u < LD5_U; ++u) {
+            const int q = min(q0 + u * WAVES, go - 1), f = 4 * q;       // (a group past the end repeats the last one: loaded, not stored)
 #pragma unroll
-        for (int j = 0; j < CPL; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { vy[j][e] = 0.f; vx[j][e] = 0.f; }
-        if (in_range) {
-            TV ro[4], ri[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                ro[e] = *reinterpret_cast<const TV*>(b + (int64_t)(f + e) * ncol + c);
-#pragma unroll
-                for (int j = 0; j < CPL; ++j) ri[e][j] = (T)0;
-                if (ts[e] >= 0) ri[e] = *reinterpret_cast<const TV*>(a + (int64_t)ts[e] * ncol + c);
-            }
+            for (int e = 0; e < 4; ++e) ts[u][e] = tend_src[f + e];
+            al[u] = ts[u][0] >= 0 && (ts[u][0] & 3) == 0 && ts[u][1] == ts[u][0] + 1 && ts[u][2] == ts[u][0] + 2 && ts[u][3] == ts[u][0] + 3 && ts[u][0] + 3 < n_in;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const double sc = scale[f + e];
 #pragma unroll
-                for (int j = 0; j < CPL; ++j) vy[j][e] = loader_conv<true>((double)ro[e][j], (double)ri[e][j], ts[e] >= 0, sc, 1.0);
-                if (al) {
-                    const double k0 = sub[ts[e]], k1 = div[ts[e]];
-#pragma unroll
-                    for (int j = 0; j < CPL; ++j) vx[j][e] = loader_conv<false>((double)ri[e][j], 0.0, false, k0, k1);
+                for (int j = 0; j < CPL; ++j) { ro[u][e][j] = (T)0; ri[u][e][j] = (T)0; }
+                if (in_range) {
+                    ro[u][e] = *reinterpret_cast<const TV*>(b + (int64_t)(f + e) * ncol + c);
+                    if (ts[u][e] >= 0) ri[u][e] = *reinterpret_cast<const TV*>(a + (int64_t)ts[u][e] * ncol + c);
                 }
             }
         }
 #pragma unroll
-        for (int j = 0; j < CPL; ++j) {
-            *reinterpret_cast<float4*>(tile_y + (CPL * lane + j) * 128 + ((q ^ key) << 2)) = make_float4(vy[j][0], vy[j][1], vy[j][2], vy[j][3]);
-            if (al) *reinterpret_cast<float4*>(tile_x + (CPL * lane + j) * 128 + (((ts[0] >> 2) ^ key) << 2)) = make_float4(vx[j][0], vx[j][1], vx[j][2], vx[j][3]);
+        for (int u = 0; u < LD5_U; ++u) {
+            const int q = q0 + u * WAVES, f = 4 * q;
+            if (q >= go) continue;
+            float vy[CPL][4], vx[CPL][4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const double sc = scale[f + e];
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) vy[j][e] = in_range ? loader_conv<true>((double)ro[u][e][j], (double)ri[u][e][j], ts[u][e] >= 0, sc, 1.0) : 0.f;
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) vx[j][e] = 0.f;
+                if (al[u]) {
+                    const double k0 = sub[ts[u][e]], k1 = div[ts[u][e]];
+#pragma unroll
+                    for (int j = 0; j < CPL; ++j) vx[j][e] = in_range ? loader_conv<false>((double)ri[u][e][j], 0.0, false, k0, k1) : 0.f;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) {
+                *reinterpret_cast<float4*>(tile_y + (CPL * lane + j) * 128 + ((q ^ key) << 2)) = make_float4(vy[j][0], vy[j][1], vy[j][2], vy[j][3]);
+                if (al[u]) *reinterpret_cast<float4*>(tile_x + (CPL * lane + j) * 128 + (((ts[u][0] >> 2) ^ key) << 2)) = make_float4(vx[j][0], vx[j][1], vx[j][2], vx[j][3]);
+            }
         }
     }
     // ---- input groups nobody covered
