@@ -1221,7 +1221,7 @@ int cs_loader_stack(const void* mli_dev, const void* mlo_dev, int32_t src_f64, i
     const int cpl = (v3 && (v4_cpl == 2 || v4_cpl == 4) && ncol % v4_cpl == 0 && (uintptr_t)mli_dev % ((src_f64 ? 8 : 4) * v4_cpl) == 0 &&
                      (uintptr_t)mlo_dev % ((src_f64 ? 8 : 4) * v4_cpl) == 0) ? v4_cpl : 0;
     // one pass over mli (loader.h, k_loader_stack5): both outputs wanted, widths <= 128; CS_LOADER_V5 = 0 off, 3 (default) = 64 columns x 16
-    // waves (two workgroups per CU), 1 = x 8 waves, 4 = x 4 waves, 2 = 128 columns x 16 waves (one workgroup per CU)
+    // waves (two workgroups per CU), 1 = x 8 waves, 2 = 128 columns x 16 waves (one workgroup per CU)
     static const int v5_mode = getenv("CS_LOADER_V5") ? atoi(getenv("CS_LOADER_V5")) : 3;
     if (cpl && v5_mode && x_out_dev && y_out_dev && n_in <= 128 && n_out <= 128 && n_out % 4 == 0 && (cpl == 2 || v5_mode != 2)) {
         static bool attr5 = false;
@@ -1231,7 +1231,7 @@ int cs_loader_stack(const void* mli_dev, const void* mlo_dev, int32_t src_f64, i
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_loader_stack5<double, 1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 512 + 128));
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_loader_stack5<float, 1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 512 + 128));
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_loader_stack5<double, 1, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 512 + 128));
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_loader_stack5<double, 1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 512 + 128));
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_loader_stack5<float, 1, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 512 + 128));
             attr5 = true;
         }
         const int c5 = v5_mode != 2 ? 1 : 2;
@@ -1239,7 +1239,7 @@ int cs_loader_stack(const void* mli_dev, const void* mlo_dev, int32_t src_f64, i
         const size_t lds5 = (size_t)2 * 64 * c5 * 512 + 128;
 #define CS_LD5(TT, CC, WW) CS_LAUNCH((k_loader_stack5<TT, CC, WW>), grid5, dim3(64 * WW), lds5, st, (const TT*)mli_dev, (const TT*)mlo_dev, ncol, n_in, in_sub_dev, in_div_dev, \
                                      n_out, tend_src_dev, out_scale_dev, x_out_dev, y_out_dev)
-        if (src_f64 && v5_mode == 3) CS_LD5(double, 1, 16); else if (src_f64 && v5_mode == 4) CS_LD5(double, 1, 4);      // (tuning runs)
+        if (v5_mode == 3 && src_f64) CS_LD5(double, 1, 16); else if (v5_mode == 3) CS_LD5(float, 1, 16);
         else if (src_f64 && c5 == 2) CS_LD5(double, 2, 16); else if (src_f64) CS_LD5(double, 1, 8); else if (c5 == 2) CS_LD5(float, 2, 16); else CS_LD5(float, 1, 8);
 #undef CS_LD5
     }

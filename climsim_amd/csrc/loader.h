@@ -279,6 +279,9 @@ __global__ __launch_bounds__(256 * CPL) void k_loader_stack4(const T* __restrict
 // 0-119) the same registers also give that group's four normalised inputs.  Input groups no target group covers (the v1 scalars
 // 120-123) take a short second loop.  x and y tiles sit side by side in LDS ([64 CPL][128] floats each) and leave as two contiguous
 // blocks.  Same arithmetic per element, same bits.  Needs both outputs, n_in, n_out <= 128 and multiples of 4; k_loader_stack4 otherwise.
+// Measured (profiles/r04_loader_v5.txt, ms per 64 x 21,600 float64 columns, same box): two passes 0.83 | one pass, 64 columns x 8 waves
+// 0.78 | x 16 waves (two workgroups per CU; the default) 0.76 = 0.68-0.70 of the HBM peak on the algorithmic 3,024 B per column | 128
+// columns x 16 waves (one workgroup per CU) 0.81; four waves 0.85.  8-timestep chunks (the streamed trainer's): 0.119 -> 0.102 ms.
 template <typename T, int CPL, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void k_loader_stack5(const T* __restrict__ mli, const T* __restrict__ mlo, int ncol, int n_in,
                                                               const double* __restrict__ sub, const double* __restrict__ div, int n_out,
