@@ -1217,12 +1217,12 @@ int cs_loader_stack(const void* mli_dev, const void* mlo_dev, int32_t src_f64, i
     // whole rows staged in LDS, 16-byte contiguous stores (loader.h, round 3): widths that are multiples of 4 and 16-byte aligned outputs
     static const bool v3_off = getenv("CS_LOADER_V3") && atoi(getenv("CS_LOADER_V3")) == 0;
     const bool v3 = !v3_off && n_in % 4 == 0 && (n_out % 4 == 0 || !y_out_dev) && ((uintptr_t)x_out_dev % 16 == 0) && ((uintptr_t)y_out_dev % 16 == 0);
-    static const int v4_cpl = getenv("CS_LOADER_V4") ? atoi(getenv("CS_LOADER_V4")) : 2;      // columns per lane: 0 = the 64-column kernel, 2, 4
+    const int v4_cpl = getenv("CS_LOADER_V4") ? atoi(getenv("CS_LOADER_V4")) : 2;      // columns per lane: 0 = the 64-column kernel, 2, 4
     const int cpl = (v3 && (v4_cpl == 2 || v4_cpl == 4) && ncol % v4_cpl == 0 && (uintptr_t)mli_dev % ((src_f64 ? 8 : 4) * v4_cpl) == 0 &&
                      (uintptr_t)mlo_dev % ((src_f64 ? 8 : 4) * v4_cpl) == 0) ? v4_cpl : 0;
     // one pass over mli (loader.h, k_loader_stack5): both outputs wanted, widths <= 128; CS_LOADER_V5 = 0 off, 3 (default) = 64 columns x 16
     // waves (two workgroups per CU), 1 = x 8 waves, 2 = 128 columns x 16 waves (one workgroup per CU)
-    static const int v5_mode = getenv("CS_LOADER_V5") ? atoi(getenv("CS_LOADER_V5")) : 3;
+    const int v5_mode = getenv("CS_LOADER_V5") ? atoi(getenv("CS_LOADER_V5")) : 3;            // (read per call: the tests run every kernel)
     if (cpl && v5_mode && x_out_dev && y_out_dev && n_in <= 128 && n_out <= 128 && n_out % 4 == 0 && (cpl == 2 || v5_mode != 2)) {
         static bool attr5 = false;
         if (!attr5) {

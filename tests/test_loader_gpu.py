@@ -115,6 +115,34 @@ def test_device_loader_rounding_boundaries(L, raw_tree, lowres_assets):
     np.testing.assert_array_equal(y.cpu().numpy(), np.float32(yr))
 
 
+@pytest.mark.parametrize("env", [{"CS_LOADER_V5": "0"}, {"CS_LOADER_V5": "1"}, {"CS_LOADER_V5": "2"}, {"CS_LOADER_V5": "0", "CS_LOADER_V4": "4"},
+                                 {"CS_LOADER_V5": "0", "CS_LOADER_V4": "0"}])
+def test_every_loader_kernel_gives_the_same_bits(L, raw_tree, lowres_assets, monkeypatch, env):
+    """Round 4 added kernels to the device loader: two columns per lane (`k_loader_stack4`), one pass over the input state rows
+    (`k_loader_stack5`, the default).  Every one of them, and round 3's, must return the bits of the default - which the other tests of this
+    file hold to the host path - on float64 and float32 fields, ragged tiles (ncol = 21,600 and 778) and each output alone."""
+    root, _ = raw_tree
+    du = make(lowres_assets, "pytorch", root)
+    ld = L.GpuColumnLoader(du)
+    rng = np.random.default_rng(3)
+    for ncol, dt in ((21600, np.float64), (778, np.float32)):
+        a = (rng.normal(0, 1, (3, 124, ncol)) * 10.0 ** rng.integers(-6, 4, (1, 124, 1))).astype(dt)
+        b = (rng.normal(0, 1, (3, 128, ncol)) * 10.0 ** rng.integers(-6, 4, (1, 128, 1))).astype(dt)
+        a[0, 5, 7] = np.inf
+        b[1, 3, 9] = np.nan
+        with np.errstate(all="ignore"):
+            x0, y0 = ld.stack_raw(a, b)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            x1, y1 = ld.stack_raw(a, b)
+            x2, _ = ld.stack_raw(a, b, want_y=False)
+            _, y2 = ld.stack_raw(a, b, want_x=False)
+            for k in env:
+                monkeypatch.delenv(k)
+        for p, q in ((x0, x1), (y0, y1), (x0, x2), (y0, y2)):
+            assert torch.equal(p.view(torch.int32), q.view(torch.int32))
+
+
 def test_device_loader_from_netcdf4_files(L, lowres_assets, tmp_path):
     """NetCDF-4 (= HDF5) timestep files, read by the native reader (climsim_amd/hdf5.py), through the device loader:
     the rows are bit-identical to what the host path writes from the same files."""
