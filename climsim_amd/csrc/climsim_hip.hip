@@ -1283,12 +1283,16 @@ int cs_metrics_columns(const float* pred_dev, const float* target_dev, int64_t n
     hipStream_t st = (hipStream_t)stream;
     const int64_t items = (int64_t)ncol * n_out;
     HIP_TRY(hipMemsetAsync(stats_dev, 0, sizeof(double) * 6 * items, st));
-    int tsplit = (int)((4096 + (int64_t)ncol * ((n_out + 127) / 128) - 1) / ((int64_t)ncol * ((n_out + 127) / 128)));   // ~4096 workgroups
-    tsplit = std::max(1, std::min<int>(tsplit, (int)(n_steps / 64)));     // >= 64 time steps per slice: 6 float64 atomics per (column, output, slice)
-    static const bool v4_off = getenv("CS_METRICS_V4") && atoi(getenv("CS_METRICS_V4")) == 0;
+    const bool v4_off = getenv("CS_METRICS_V4") && atoi(getenv("CS_METRICS_V4")) == 0;
     const bool v4 = !v4_off && n_out % 4 == 0 && (uintptr_t)pred_dev % 16 == 0 && (uintptr_t)target_dev % 16 == 0;
+    const int mwaves = v4 ? (getenv("CS_METRICS_WAVES") ? atoi(getenv("CS_METRICS_WAVES")) : 16) : 4;      // 16 (default) or 4 waves per workgroup
+    const int64_t col_wgs = (int64_t)ncol * ((n_out + 127) / 128);
+    const int64_t want = mwaves == 16 ? 1024 : 4096;                                      // workgroups to aim for
+    int tsplit = (int)((want + col_wgs - 1) / col_wgs);
+    tsplit = std::max(1, std::min<int>(tsplit, (int)(n_steps / (mwaves == 16 ? 256 : 64))));     // >= 64 (256) time steps per slice: 6 float64 atomics per (column, output, slice)
     const dim3 mgrid((unsigned)ncol, (unsigned)((n_out + 127) / 128), (unsigned)tsplit);
-    if (v4) CS_LAUNCH(k_metrics_partial4<2>, mgrid, dim3(256), 0, st, pred_dev, target_dev, (int)n_steps, ncol, n_out, ps_dev, wa_dev, wb_dev, area_dev, stats_dev);
+    if (v4 && mwaves == 16) CS_LAUNCH((k_metrics_partial4<2, 16>), mgrid, dim3(1024), 0, st, pred_dev, target_dev, (int)n_steps, ncol, n_out, ps_dev, wa_dev, wb_dev, area_dev, stats_dev);
+    else if (v4) CS_LAUNCH((k_metrics_partial4<2, 4>), mgrid, dim3(256), 0, st, pred_dev, target_dev, (int)n_steps, ncol, n_out, ps_dev, wa_dev, wb_dev, area_dev, stats_dev);
     else CS_LAUNCH(k_metrics_partial, mgrid, dim3(256), 0, st, pred_dev, target_dev, (int)n_steps, ncol, n_out, ps_dev, wa_dev, wb_dev, area_dev, stats_dev);
     CS_LAUNCH(k_metrics_finish, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, stats_dev, items, (int)n_steps);
     HIP_TRY(hipGetLastError());

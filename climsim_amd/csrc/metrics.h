@@ -68,14 +68,19 @@ __global__ __launch_bounds__(256) void k_metrics_partial(const float* __restrict
 // flight measure the same (0.421-0.436), and 0.055 ms of the call are the 6 float64 atomics per (column, output, time slice)
 // (0.381 ms without them: profiles/r04_metrics_v4.txt).  Two adjacent grid columns per workgroup (1 KiB per wave load, what paid in
 // the loader) measured slower here: 0.461-0.466 against 0.433 ms (half the workgroups).
-template <int MT4_U>
-__global__ __launch_bounds__(256) void k_metrics_partial4(const float* __restrict__ pred, const float* __restrict__ target, int T, int ncol,
-                                                          int n_out, const double* __restrict__ ps, const double* __restrict__ wa,
-                                                          const double* __restrict__ wb, const double* __restrict__ area,
-                                                          double* __restrict__ acc /*[ncol][n_out][6], zeroed*/) {
-    __shared__ double red[3][128][6];
+// WAVES = waves per workgroup (4 or 16).  The float64 atomics that merge the time slices of a (column, output) are 13 % of the call at
+// 4 waves (eleven slices on the 384-column scoring split: 0.055 of 0.434 ms, and 104 MB of the launch's write traffic -
+// profiles/r04_metrics_v4.txt, r04_metrics_traffic.txt): sixteen waves per workgroup cover four times the time steps, the slices
+// shrink to three, and the waves of a workgroup meet in LDS (ds_add_f64) instead of a [waves][128][6] staging array.
+template <int MT4_U, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_metrics_partial4(const float* __restrict__ pred, const float* __restrict__ target, int T, int ncol,
+                                                                  int n_out, const double* __restrict__ ps, const double* __restrict__ wa,
+                                                                  const double* __restrict__ wb, const double* __restrict__ area,
+                                                                  double* __restrict__ acc /*[ncol][n_out][6], zeroed*/) {
+    __shared__ double red[128][6];
+    constexpr int TL = 2 * WAVES;                                                       // time-step lanes of the workgroup
     const int c = blockIdx.x;
-    const int q = threadIdx.x & 31, tr = threadIdx.x >> 5, wid = threadIdx.x >> 6;      // 4 outputs, time-step lane 0..7
+    const int q = threadIdx.x & 31, tr = threadIdx.x >> 5;                              // 4 outputs, time-step lane
     const int f0 = blockIdx.y * 128 + 4 * q;
     const bool live = f0 < n_out;                                                       // n_out % 4 == 0: all four or none
     const int t0 = (int)((int64_t)T * blockIdx.z / gridDim.z), t1 = (int)((int64_t)T * (blockIdx.z + 1) / gridDim.z);
@@ -86,17 +91,18 @@ __global__ __launch_bounds__(256) void k_metrics_partial4(const float* __restric
     for (int e = 0; e < 4; ++e)
 #pragma unroll
         for (int k = 0; k < 6; ++k) s[e][k] = 0.0;
+    for (int i = threadIdx.x; i < 128 * 6; i += 64 * WAVES) (&red[0][0])[i] = 0.0;
     if (live) {
         const float4 tf = *reinterpret_cast<const float4*>(target + (int64_t)c * n_out + f0);      // sample t = 0 of this (c, f)
         const float tfv[4] = {tf.x, tf.y, tf.z, tf.w};
         const double ps0 = ps[c];
 #pragma unroll
         for (int e = 0; e < 4; ++e) { a[e] = wa[f0 + e]; b[e] = wb[f0 + e]; shift[e] = (double)tfv[e] * ((a[e] + b[e] * ps0) * ar); }
-        for (int tb = t0 + tr; tb < t1; tb += 8 * MT4_U) {
+        for (int tb = t0 + tr; tb < t1; tb += TL * MT4_U) {
             float4 pv[MT4_U], tv[MT4_U]; double psv[MT4_U];
 #pragma unroll
             for (int u = 0; u < MT4_U; ++u) {
-                const int t = tb + 8 * u;
+                const int t = tb + TL * u;
                 const int64_t n = (int64_t)(t < t1 ? t : t0) * ncol + c;
                 psv[u] = ps[n];
                 pv[u] = *reinterpret_cast<const float4*>(pred + n * n_out + f0);
@@ -104,7 +110,7 @@ __global__ __launch_bounds__(256) void k_metrics_partial4(const float* __restric
             }
 #pragma unroll
             for (int u = 0; u < MT4_U; ++u) {
-                if (tb + 8 * u >= t1) continue;
+                if (tb + TL * u >= t1) continue;
                 const float pe[4] = {pv[u].x, pv[u].y, pv[u].z, pv[u].w}, te[4] = {tv[u].x, tv[u].y, tv[u].z, tv[u].w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -116,25 +122,22 @@ __global__ __launch_bounds__(256) void k_metrics_partial4(const float* __restric
             }
         }
     }
-    // the two time-step lanes of a wave (lanes l, l + 32), then the four waves
+    // the two time-step lanes of a wave (lanes l, l + 32), then the waves of the workgroup in LDS
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
         for (int k = 0; k < 6; ++k) s[e][k] += __shfl_xor(s[e][k], 32, 64);
-    if (wid > 0 && (threadIdx.x & 63) < 32) {
+    __syncthreads();                                                                    // red is zeroed
+    if ((threadIdx.x & 63) < 32 && live) {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int k = 0; k < 6; ++k) red[wid - 1][4 * q + e][k] = s[e][k];
+            for (int k = 0; k < 6; ++k) atomicAdd(&red[4 * q + e][k], s[e][k]);
     }
     __syncthreads();
-    if (wid == 0 && (threadIdx.x & 63) < 32 && live) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            double* o = acc + ((int64_t)c * n_out + f0 + e) * 6;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) atomicAdd(o + k, s[e][k] + red[0][4 * q + e][k] + red[1][4 * q + e][k] + red[2][4 * q + e][k]);
-        }
+    for (int i = threadIdx.x; i < 128 * 6; i += 64 * WAVES) {
+        const int fl = i / 6, k = i - fl * 6, f = blockIdx.y * 128 + fl;
+        if (f < n_out) atomicAdd(acc + ((int64_t)c * n_out + f) * 6 + k, red[fl][k]);
     }
 }
 
