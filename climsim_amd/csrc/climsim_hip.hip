@@ -1285,7 +1285,7 @@ int cs_metrics_columns(const float* pred_dev, const float* target_dev, int64_t n
     HIP_TRY(hipMemsetAsync(stats_dev, 0, sizeof(double) * 6 * items, st));
     const bool v4_off = getenv("CS_METRICS_V4") && atoi(getenv("CS_METRICS_V4")) == 0;
     const bool v4 = !v4_off && n_out % 4 == 0 && (uintptr_t)pred_dev % 16 == 0 && (uintptr_t)target_dev % 16 == 0;
-    const int mwaves = v4 ? (getenv("CS_METRICS_WAVES") ? atoi(getenv("CS_METRICS_WAVES")) : 16) : 4;      // 16 (default) or 4 waves per workgroup
+    const int mwaves = v4 ? (getenv("CS_METRICS_WAVES") ? atoi(getenv("CS_METRICS_WAVES")) : 4) : 4;       // 4 (default) or 16 waves per workgroup
     const int64_t col_wgs = (int64_t)ncol * ((n_out + 127) / 128);
     const int64_t want = mwaves == 16 ? 1024 : 4096;                                      // workgroups to aim for
     int tsplit = (int)((want + col_wgs - 1) / col_wgs);

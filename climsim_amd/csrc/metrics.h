@@ -68,10 +68,10 @@ __global__ __launch_bounds__(256) void k_metrics_partial(const float* __restrict
 // flight measure the same (0.421-0.436), and 0.055 ms of the call are the 6 float64 atomics per (column, output, time slice)
 // (0.381 ms without them: profiles/r04_metrics_v4.txt).  Two adjacent grid columns per workgroup (1 KiB per wave load, what paid in
 // the loader) measured slower here: 0.461-0.466 against 0.433 ms (half the workgroups).
-// WAVES = waves per workgroup (4 or 16).  The float64 atomics that merge the time slices of a (column, output) are 13 % of the call at
-// 4 waves (eleven slices on the 384-column scoring split: 0.055 of 0.434 ms, and 104 MB of the launch's write traffic -
-// profiles/r04_metrics_v4.txt, r04_metrics_traffic.txt): sixteen waves per workgroup cover four times the time steps, the slices
-// shrink to three, and the waves of a workgroup meet in LDS (ds_add_f64) instead of a [waves][128][6] staging array.
+// WAVES = waves per workgroup (4, the default, or 16).  The waves of a workgroup meet in LDS (ds_add_f64 into one [128][6] array) and
+// the workgroup sends 768 coalesced float64 atomics: 0.39 against 0.43 ms for the per-thread atomics behind a [3][128][6] staging array
+// (profiles/r04_metrics_v4.txt).  Sixteen waves per workgroup (three time slices instead of eleven, a quarter of the atomics - they are
+// 104 MB of write traffic per call, r04_metrics_traffic.txt) measured 0.41: fewer, longer workgroups cost more than the atomics.
 template <int MT4_U, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void k_metrics_partial4(const float* __restrict__ pred, const float* __restrict__ target, int T, int ncol,
                                                                   int n_out, const double* __restrict__ ps, const double* __restrict__ wa,
