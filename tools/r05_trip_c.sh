@@ -1,0 +1,10 @@
+#!/bin/bash
+# round 5, trip c: k_conv3 ablation variants (-DCV3_ABL), stamps per phase
+mkdir -p gpurun_out
+{
+for v in "" 1 2 4 5 8 16 32 40; do
+  if [ -z "$v" ]; then L=$PWD/climsim_amd/libclimsim_hip.so; else L=$PWD/climsim_amd/variants/abl$v.so; fi
+  echo "== CV3_ABL=${v:-0}"; BRIEF=1 CLIMSIM_HIP_LIB=$L timeout 120 python tools/cnn_stamps.py 512 2>&1 | grep -v amdgpu.ids
+done
+} > gpurun_out/r05_c.log 2>&1
+cat gpurun_out/r05_c.log
