@@ -51,41 +51,6 @@ __device__ __forceinline__ int cv3_chunk(int i, int kc) {
     return kc == 13 ? (int)((o13 >> (4 * i)) & 15u) : kc == 14 ? (int)((o14 >> (4 * i)) & 15u) : i;
 }
 
-// The loader waves' operand queue: three sets of 4 weight + 4 row-tile pieces (16 bytes per lane each) in FIXED registers v72..v167.
-// A piece is a plain 16-byte load into its register (asm: the compiler never sees the data, so it neither waits for it nor moves it)
-// and, once the counted `vmcnt` says it has landed, a `ds_write_b128` into the ring.  tools/conv3_audit.py checks the compiled kernels:
-// between the loader's markers no compiler instruction names v72..v167.
-#define CV3_RB_0_0 "v[72:75]"
-#define CV3_RA_0_0 "v[88:91]"
-#define CV3_RB_0_1 "v[76:79]"
-#define CV3_RA_0_1 "v[92:95]"
-#define CV3_RB_0_2 "v[80:83]"
-#define CV3_RA_0_2 "v[96:99]"
-#define CV3_RB_0_3 "v[84:87]"
-#define CV3_RA_0_3 "v[100:103]"
-#define CV3_RB_1_0 "v[104:107]"
-#define CV3_RA_1_0 "v[120:123]"
-#define CV3_RB_1_1 "v[108:111]"
-#define CV3_RA_1_1 "v[124:127]"
-#define CV3_RB_1_2 "v[112:115]"
-#define CV3_RA_1_2 "v[128:131]"
-#define CV3_RB_1_3 "v[116:119]"
-#define CV3_RA_1_3 "v[132:135]"
-#define CV3_RB_2_0 "v[136:139]"
-#define CV3_RA_2_0 "v[152:155]"
-#define CV3_RB_2_1 "v[140:143]"
-#define CV3_RA_2_1 "v[156:159]"
-#define CV3_RB_2_2 "v[144:147]"
-#define CV3_RA_2_2 "v[160:163]"
-#define CV3_RB_2_3 "v[148:151]"
-#define CV3_RA_2_3 "v[164:167]"
-#define CV3_QCLOB "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167"
-#define CV3_GLB(R, k, ptr) asm volatile("global_load_dwordx4 " CV3_RB_##R##_##k ", %0, off" :: "v"(ptr) : "memory", CV3_QCLOB);
-#define CV3_GLA(R, k, ptr) asm volatile("global_load_dwordx4 " CV3_RA_##R##_##k ", %0, off sc1" :: "v"(ptr) : "memory", CV3_QCLOB);
-#define CV3_DWB(R, k, addr) asm volatile("ds_write_b128 %0, " CV3_RB_##R##_##k :: "v"(addr) : "memory");
-#define CV3_DWA(R, k, addr) asm volatile("ds_write_b128 %0, " CV3_RA_##R##_##k :: "v"(addr) : "memory");
-#define CV3_SET3(r, BODY) { if ((r) == 0) { BODY(0) } else if ((r) == 1) { BODY(1) } else { BODY(2) } }
-
 template <int MODE>
 __global__ __launch_bounds__(CV2_THREADS) void k_conv3(const ConvProg P) {
     const ConvArgs& p0 = P.st[0];      // geometry (row tiles, channel tiles, seq, zero page) is that of every stage
@@ -130,8 +95,8 @@ __global__ __launch_bounds__(CV2_THREADS) void k_conv3(const ConvProg P) {
             a_row[k] = pa * 16 + prow;
             b_row[k] = pb * 16 + prow;
         }
-        // ---- the weight stream: its own walk over (stage, pass, chunk, tap); it never stops at a pass or conv boundary
-        int b_stage = 0, b_second = 0, b_it = 0, b_ic = 0, b_kc = 1, b_taps = 1, b_live = 1;
+        // ---- the weight stream: its own walk over (stage, pass, chunk, tap), always four slabs ahead of the barrier index
+        int b_stage = 0, b_second = 0, b_it = 0, b_ic = 0, b_kc = 1, b_taps = 1, bs = 0, b_live = 1;
         const char* bsrc[4];
         auto b_setup = [&]() __attribute__((always_inline)) {
             const ConvArgs& p = P.st[b_stage];
@@ -142,11 +107,11 @@ __global__ __launch_bounds__(CV2_THREADS) void k_conv3(const ConvProg P) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) bsrc[k] = reinterpret_cast<const char*>(qB + (int64_t)(n0 + b_row[k]) * ldb + cl);
         };
-        auto issue_b = [&](int r) __attribute__((always_inline)) {       // the weight slab of the next slab of the stream -> set r
+        auto b_issue = [&]() __attribute__((always_inline)) {
             const int boff_ = (b_it * b_kc + cv3_chunk(b_ic, b_kc)) * 64;
-#define CV3_BODY(R) CV3_GLB(R, 0, bsrc[0] + boff_) CV3_GLB(R, 1, bsrc[1] + boff_) CV3_GLB(R, 2, bsrc[2] + boff_) CV3_GLB(R, 3, bsrc[3] + boff_)
-            if (!(CV3_ABL & 16)) CV3_SET3(r, CV3_BODY)
-#undef CV3_BODY
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (!(CV3_ABL & 16)) dma16(bsrc[k] + boff_, bdst[k] + (unsigned)bs * CV2_B_SLOT);
+            bs = bs + 1 == CV2_NSLOT ? 0 : bs + 1;
             if (++b_it == b_taps) {
                 b_it = 0;
                 if (++b_ic == b_kc) {
@@ -159,7 +124,7 @@ __global__ __launch_bounds__(CV2_THREADS) void k_conv3(const ConvProg P) {
         };
         // ---- the row-tile stream of the pass the compute waves are in
         const u16 *qA0 = nullptr, *qA3 = nullptr;
-        int a_it = 0, a_ic = 0, a_kc = 1, a_taps = 1;
+        int a_it = 0, a_ic = 0, a_kc = 1, a_taps = 1, as = CV2_NSLOT - 1;
         unsigned dep0 = 0u, dep3 = 0u, rdy0 = 0u, rdy3 = 0u;
         int64_t arow[4];
         auto a_setup = [&](const ConvArgs& p, int second) __attribute__((always_inline)) {
@@ -198,48 +163,28 @@ __global__ __launch_bounds__(CV2_THREADS) void k_conv3(const ConvProg P) {
                 __builtin_amdgcn_s_sleep(2);
             }
         };
-        // the next slab of this pass: if it opens a row tile (tap 0, tap 3), its four pieces -> row-tile half of set r; returns the pieces
-        auto issue_a = [&](int r) __attribute__((always_inline)) -> int {
+        auto a_issue = [&]() __attribute__((always_inline)) -> int {     // the row tile of the next slab of this pass, if that slab opens one
             int n = 0;
             if ((a_it == 0) | (a_it == 3)) {
                 const int ch = cv3_chunk(a_ic, a_kc);
                 if (a_it == 3) { if (dep3) wait_ready(dep3, ch, rdy3); }
                 else if (dep0) wait_ready(dep0, ch, rdy0);
+                as = as + 1 == CV2_NSLOT ? 0 : as + 1;
                 const char* Sb_ = reinterpret_cast<const char*>(a_it == 3 ? qA3 : qA0) + ch * 64;
-                const char *s0_ = (oka & 1u) ? Sb_ + arow[0] : zsrc, *s1_ = (oka & 2u) ? Sb_ + arow[1] : zsrc,
-                           *s2_ = (oka & 4u) ? Sb_ + arow[2] : zsrc, *s3_ = (oka & 8u) ? Sb_ + arow[3] : zsrc;
-#define CV3_BODY(R) CV3_GLA(R, 0, s0_) CV3_GLA(R, 1, s1_) CV3_GLA(R, 2, s2_) CV3_GLA(R, 3, s3_)
-                if (!(CV3_ABL & 16)) CV3_SET3(r, CV3_BODY)
-#undef CV3_BODY
+#pragma unroll
+                for (int k = 0; k < 4; ++k) if (!(CV3_ABL & 16)) dma16_sc1(((oka >> k) & 1u) ? Sb_ + arow[k] : zsrc, adst[k] + (unsigned)as * CV2_A_SLOT);
                 n = 4;
             }
             if (++a_it == a_taps) { a_it = 0; ++a_ic; }
             return n;
         };
-        // ---- registers -> rings (slot counters of the WRITE side; the compute waves count the same way)
-        int bs_w = 0, as_w = CV2_NSLOT - 1;
-        const unsigned lane16 = (unsigned)lane * 16u;
-        auto write_b = [&](int r) __attribute__((always_inline)) {
-            const unsigned o_ = (unsigned)bs_w * CV2_B_SLOT + lane16;
-#define CV3_BODY(R) CV3_DWB(R, 0, bdst[0] + o_) CV3_DWB(R, 1, bdst[1] + o_) CV3_DWB(R, 2, bdst[2] + o_) CV3_DWB(R, 3, bdst[3] + o_)
-            if (!(CV3_ABL & 16)) CV3_SET3(r, CV3_BODY)
-#undef CV3_BODY
-            bs_w = bs_w + 1 == CV2_NSLOT ? 0 : bs_w + 1;
-        };
-        auto write_a = [&](int r) __attribute__((always_inline)) {
-            as_w = as_w + 1 == CV2_NSLOT ? 0 : as_w + 1;
-            const unsigned o_ = (unsigned)as_w * CV2_A_SLOT + lane16;
-#define CV3_BODY(R) CV3_DWA(R, 0, adst[0] + o_) CV3_DWA(R, 1, adst[1] + o_) CV3_DWA(R, 2, adst[2] + o_) CV3_DWA(R, 3, adst[3] + o_)
-            if (!(CV3_ABL & 16)) CV3_SET3(r, CV3_BODY)
-#undef CV3_BODY
-        };
-        auto bits_issue = [&](const ConvArgs& p) __attribute__((always_inline)) {      // 8 KiB, 2 LDS-DMA pieces per loader
+        auto bits_issue = [&](const ConvArgs& p) __attribute__((always_inline)) {      // 8 KiB, 2 pieces per loader
             const char* bsrc_ = reinterpret_cast<const char*>(p.bits_in + (int64_t)work * 512) + lw * 2048 + lane * 16;
             dma16(bsrc_, lds0 + CV3_BITS_OFF + (unsigned)lw * 2048u);
             dma16(bsrc_ + 1024, lds0 + CV3_BITS_OFF + (unsigned)lw * 2048u + 1024u);
         };
-        // "the oldest slab in flight has landed": everything but the pieces of the two slabs requested behind it (a lower bound where the
-        // mask bits ride along: a smaller count only waits for more)
+        // "slab s+1 has landed": everything but the pieces of the two slabs requested behind it (np1 + np2 of them, a lower bound where
+        // the mask bits ride along: a smaller count only waits for more).
         auto wait_vm = [&](int n) __attribute__((always_inline)) {
             if (n >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
             else if (n >= 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
@@ -251,22 +196,9 @@ __global__ __launch_bounds__(CV2_THREADS) void k_conv3(const ConvProg P) {
         int dslot = 0;
         unsigned long long* const dbg_ = P.dbg ? P.dbg + ((int64_t)blockIdx.x * 2 + 1) * 128 : nullptr;
 #define CV3_LSTAMP() if (dbg_ && lw == 0 && lane == 0 && dslot < 128) dbg_[dslot++] = __builtin_amdgcn_s_memrealtime();
-        asm volatile("; CV3_LOADER_BEGIN" ::: "memory");
-        // Schedule.  In LDS: the slab the compute waves are in and the next four (five slots); in registers: the three behind those.
-        // Behind barrier s of a pass: slab s+4 leaves its set for the ring slot that slab s-1 held, slab s+7 is requested into the set.
-        // n_iss / n_wr count the slabs of the WEIGHT stream requested / written; r_i / r_w are their sets.  The row-tile half of a set
-        // is filled with its slab when the slab belongs to the pass in progress; slabs of the NEXT pass get their row tiles at the pass
-        // boundary (their flags come out of the epilogue that is running then).
-        int n_iss = 0, n_wr = 0, r_i = 0, r_w = 0, np1 = 0, np2 = 0;
         b_setup();
-        for (int i = 0; i < 3; ++i) if (b_live) { issue_b(r_i); r_i = r_i == 2 ? 0 : r_i + 1; ++n_iss; }
-        for (int i = 0; i < 4; ++i)
-            if (n_wr < n_iss) {
-                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");        // (at most two younger weight slabs of 4 pieces)
-                if (n_iss - n_wr < 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                write_b(r_w); r_w = r_w == 2 ? 0 : r_w + 1; ++n_wr;
-                if (b_live) { issue_b(r_i); r_i = r_i == 2 ? 0 : r_i + 1; ++n_iss; }
-            }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (b_live) b_issue();
         for (int stage = 0; stage < P.n; ++stage) {
             const ConvArgs& p = P.st[stage];
             const int npass = (MODE != CONV_BWD && p.A2nd) ? 2 : 1;
@@ -274,66 +206,27 @@ __global__ __launch_bounds__(CV2_THREADS) void k_conv3(const ConvProg P) {
                 CV3_LSTAMP()
                 a_setup(p, ps);
                 const int nt = a_taps * a_kc;
-                // ---- pass boundary.  Weight slabs 0..3 of the pass are in the ring, 4..6 in flight.  Row tiles of slabs 0..3: request
-                // (as soon as their flags allow) into the row-tile halves of sets 0, 1, 2 in turn, wait, write; then those of slabs
-                // 4..6 into the halves of the sets their weight slabs are in.
-                int w_it = 0;                                   // tap of the next slab of this pass to be WRITTEN
-                {
-                    int c_ = 0;
-                    for (int l = 0; l < 4 && l < nt; ++l) {
-                        const bool opens_ = (w_it == 0) | (w_it == 3);
-                        w_it = w_it + 1 == a_taps ? 0 : w_it + 1;
-                        if (!opens_) { (void)issue_a(0); continue; }            // (advances the walk; nothing requested)
-                        if (c_ == 3) {
-                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                            write_a(0); write_a(1); write_a(2); c_ = 0;
-                        }
-                        (void)issue_a(c_); ++c_;
-                    }
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    for (int c = 0; c < c_; ++c) write_a(c);
-                }
-                np1 = np2 = 0;
-                {
-                    int r_ = r_w;
-                    for (int l = 4; l < 7 && l < nt; ++l) {
-                        const int n_ = issue_a(r_);
-                        r_ = r_ == 2 ? 0 : r_ + 1;
-                        np2 = np1; np1 = n_;
-                    }
-                    // (np1, np2) now describe the two slabs behind slab 4 - their weight pieces landed under the wait above)
-                    if (nt > 6) { /* slabs 5, 6 */ } else if (nt == 6) { np2 = np1; np1 = 0; } else { np1 = np2 = 0; }
-                }
+                // pass boundary: the row tiles of the pass's first four slabs (their weight slabs are in flight or here already)
+                for (int s = 0; s < 4; ++s) if (s < nt) (void)a_issue();
                 const bool bits = MODE == CONV_BWD && p.bits_in != nullptr;
                 if (bits && nt < 2) bits_issue(p);          // (the compute waves read the previous conv's bits before they arrive at X)
                 CV3_LSTAMP()
-                if (bits && nt < 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 CV3_LSTAMP()
                 __builtin_amdgcn_s_barrier();               // X: the pass can start
                 CV3_LSTAMP()
+                int np1 = 0, np2 = 0;
                 for (int s = 0; s < nt; ++s) {
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // my ring writes of the last step are done
-                    __builtin_amdgcn_s_barrier();           // slab s+1 is in the ring (written three steps ago); the slots of slab s-1 are free
+                    wait_vm(np1 + np2);
+                    __builtin_amdgcn_s_barrier();           // slab s+1 has landed, the slots of slab s-1 are free
                     int n = 0;
-                    if (n_wr < n_iss) {
-                        wait_vm(np1 + np2);                 // the oldest set has landed
-                        if (s + 4 < nt) {
-                            if ((w_it == 0) | (w_it == 3)) write_a(r_w);
-                            w_it = w_it + 1 == a_taps ? 0 : w_it + 1;
-                        }
-                        write_b(r_w); r_w = r_w == 2 ? 0 : r_w + 1; ++n_wr;
-                    }
-                    if (b_live) {
-                        if (s + 7 < nt) n += issue_a(r_i);
-                        issue_b(r_i); r_i = r_i == 2 ? 0 : r_i + 1; ++n_iss; n += 4;
-                    }
+                    if (s + 4 < nt) n += a_issue();
+                    if (b_live) { b_issue(); n += 4; }
                     if (bits && s == 0 && nt >= 2) bits_issue(p);       // every compute wave is inside this conv's loop: the old bits are in registers
                     np2 = np1; np1 = n;
                 }
             }
         }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\t; CV3_LOADER_END" ::: "memory");
 #undef CV3_LSTAMP
         return;
     }
@@ -488,7 +381,8 @@ __global__ __launch_bounds__(CV2_THREADS) void k_conv3(const ConvProg P) {
         const auto s0 = __builtin_amdgcn_permlane16_swap(a.x, b.x, false, false);
         const auto s1 = __builtin_amdgcn_permlane16_swap(a.y, b.y, false, false);
         char* sb_ = reinterpret_cast<char*>(dst + (m0 + r0w + 16 * i) * ld + n0 + CV3_CT(ja));
-        const unsigned vo_ = (unsigned)((l15e * ld + (qe & 1) * 16 + (qe >> 1) * 8) * 2);
+        const unsigned vo_ = (CV3_ABL & 64) ? (unsigned)(((le >> 3) * ld + (le & 7) * 8) * 2)      /* timing only: 8 rows x 128 B per store */
+                                            : (unsigned)((l15e * ld + (qe & 1) * 16 + (qe >> 1) * 8) * 2);
         if (!(CV3_ABL & 1)) *reinterpret_cast<uint4*>(sb_ + vo_) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
         else asm volatile("" :: "v"(s0[0]), "v"(s1[0]), "v"(s0[1]), "v"(s1[1]), "v"(sb_ + vo_));
     };
