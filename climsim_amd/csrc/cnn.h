@@ -38,9 +38,6 @@ struct ConvArgs {
     // (bits_out), read by the BWD launch that masks with that tensor (bits_in, instead of 28 eight-byte loads of `mask` per lane).
     uint4* bits_out; const uint4* bits_in;
     int ablate;                                      // development (CS_CONV_ABLATE): 1 no DMA in the loop, 2 no MFMA, 4 no epilogue, 8 epilogue without its global stores
-    // k_conv3 only (conv3.h): the stage of the same launch (index + 1; 0 = none: the tensor was complete before the launch) that writes
-    // the tensor taps 0-2 read / tap 3 reads / the second pass reads - cnn_flush fills them from the pointers
-    int dep0, dep3, dep2nd;
 };
 
 // (lowbias32: kernels.h)

@@ -2,7 +2,6 @@
 #pragma once
 #include "cnn_train.h"
 #include "conv2.h"
-#include "conv3.h"
 #include "conv_wgrad2.h"
 
 struct CnnConv {
@@ -43,9 +42,6 @@ struct cs_cnn {
     int fuse_max = CV2_MAX_STAGES;       // CS_CNN_FUSE (1 = one conv per launch)
     int spin_limit = 1 << 22;            // CS_CNN_SPIN_LIMIT: polls before a stage hand-off gives up (read at creation)
     unsigned* pair_flags = nullptr; unsigned gen = 0; int flag_tiles = 0;
-    unsigned long long* dbg_dev = nullptr; const char* dbg_path = nullptr;      // CS_CNN_DBG=<file>: k_conv3 phase stamps, written at destroy
-    int stagger_groups = 1, stagger_ticks = 0;          // CS_CNN_STAGGER="groups,microseconds"
-    bool stream_convs = true;            // CS_CNN_STREAM=0: k_conv2 (one flag per conv, rings refilled from empty) instead of k_conv3 (conv3.h)
     unsigned *err_host = nullptr, *err_dev = nullptr;      // pinned, host-mapped: bounded waits that ran out / partners on another XCD
 };
 
@@ -148,26 +144,7 @@ void cnn_flush(cs_cnn* h, hipStream_t st) {
     P.flags = h->pair_flags; P.error = h->err_dev; P.n_row_tiles = h->flag_tiles;
     P.spin_limit = h->spin_limit;
     P.tiles = (int)h->prog_grid;
-    P.stagger_groups = h->stagger_groups; P.stagger_ticks = h->stagger_ticks;
-    P.dbg = h->dbg_dev ? h->dbg_dev + (size_t)h->prog_mode * 1024 * 256 : nullptr;
     const dim3 grid((unsigned)round_up((int64_t)h->prog_grid, 8) * P.st[0].n_tiles), block(CV2_THREADS);
-    if (h->stream_convs) {
-        // k_conv3 hands a conv's output to the next chunk by chunk: name, per operand tensor, the stage of this launch that writes it
-        for (int s = 0; s < P.n; ++s) {
-            ConvArgs& a = P.st[s];
-            auto writer = [&](const u16* t) {
-                for (int w = s - 1; w >= 0; --w)
-                    if (t && (P.st[w].out == t || P.st[w].out2 == t)) return w + 1;
-                return 0;
-            };
-            a.dep0 = writer(a.A0); a.dep3 = a.taps == 4 ? writer(a.A3) : 0; a.dep2nd = writer(a.A2nd);
-        }
-        if (h->prog_mode == CONV_PREDICT) hipLaunchKernelGGL((k_conv3<CONV_PREDICT>), grid, block, CV3_LDS_BYTES, st, P);
-        else if (h->prog_mode == CONV_TRAIN_FWD) hipLaunchKernelGGL((k_conv3<CONV_TRAIN_FWD>), grid, block, CV3_LDS_BYTES, st, P);
-        else hipLaunchKernelGGL((k_conv3<CONV_BWD>), grid, block, CV3_LDS_BYTES, st, P);
-        P.n = 0;
-        return;
-    }
     if (h->prog_mode == CONV_PREDICT) hipLaunchKernelGGL((k_conv2<CONV_PREDICT>), grid, block, CV2_LDS_BYTES, st, P);
     else if (h->prog_mode == CONV_TRAIN_FWD) hipLaunchKernelGGL((k_conv2<CONV_TRAIN_FWD>), grid, block, CV2_LDS_BYTES, st, P);
     else hipLaunchKernelGGL((k_conv2<CONV_BWD>), grid, block, CV2_LDS_BYTES, st, P);
@@ -317,19 +294,6 @@ int cs_cnn_create(cs_cnn_t** out, const cs_cnn_cfg* cfg) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv2<CONV_PREDICT>), hipFuncAttributeMaxDynamicSharedMemorySize, CV2_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv2<CONV_TRAIN_FWD>), hipFuncAttributeMaxDynamicSharedMemorySize, CV2_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv2<CONV_BWD>), hipFuncAttributeMaxDynamicSharedMemorySize, CV2_LDS_BYTES));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3<CONV_PREDICT>), hipFuncAttributeMaxDynamicSharedMemorySize, CV3_LDS_BYTES));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3<CONV_TRAIN_FWD>), hipFuncAttributeMaxDynamicSharedMemorySize, CV3_LDS_BYTES));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3<CONV_BWD>), hipFuncAttributeMaxDynamicSharedMemorySize, CV3_LDS_BYTES));
-    if (const char* e = getenv("CS_CNN_STREAM")) h->stream_convs = atoi(e) != 0;
-    if (const char* e = getenv("CS_CNN_STAGGER")) {
-        int g = 1; float us = 0.f;
-        if (sscanf(e, "%d,%f", &g, &us) == 2 && g >= 1) { h->stagger_groups = g; h->stagger_ticks = (int)(us * 100.f); }
-    }
-    if (const char* e = getenv("CS_CNN_DBG")) {
-        h->dbg_path = e;
-        HIP_TRY(hipMalloc((void**)&h->dbg_dev, sizeof(unsigned long long) * 3 * 1024 * 256));
-        HIP_TRY(hipMemset(h->dbg_dev, 0, sizeof(unsigned long long) * 3 * 1024 * 256));
-    }
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wgrad2<8>), hipFuncAttributeMaxDynamicSharedMemorySize, CW2_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wgrad2<4>), hipFuncAttributeMaxDynamicSharedMemorySize, CW2_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wgrad2l), hipFuncAttributeMaxDynamicSharedMemorySize, CW2_LDS_BYTES));
@@ -371,12 +335,10 @@ int cs_cnn_create(cs_cnn_t** out, const cs_cnn_cfg* cfg) {
     A((void**)&h->bd, sizeof(float) * 16);
     A((void**)&h->zeros, 4096);
     h->flag_tiles = (int)((h->m_pad_max + CV2_BM - 1) / CV2_BM);
-    A((void**)&h->pair_flags, sizeof(unsigned) * CV3_FLAG_WORDS * (size_t)h->flag_tiles);     // conv3.h: [tiles][32]; conv2.h uses [tiles][4] + [tiles][4] of it
+    A((void**)&h->pair_flags, sizeof(unsigned) * 8 * (size_t)h->flag_tiles);     // [tiles][4] stage words + [tiles][4] XCC ids (conv2.h)
     A((void**)&h->A0, sizeof(u16) * h->m_pad_max * CNN_A0_LD);
     A((void**)&h->O10, sizeof(u16) * h->m_pad_max * 128);
-    // trunk tensors hold one 240-row tile more than the padded batch: k_conv3 stores whole tiles (no lane predicated), the last tile's
-    // rows past the batch land there and nobody reads them
-    const size_t trunk_bytes = sizeof(u16) * (size_t)(h->m_pad_max + CV2_BM) * CNN_CP;
+    const size_t trunk_bytes = sizeof(u16) * (size_t)h->m_pad_max * CNN_CP;
     for (u16** b : {&h->X, &h->A1, &h->R, &h->XN}) A((void**)b, trunk_bytes);
     A((void**)&h->P, sizeof(float) * np);
     h->n_seg = (int)h->convs.size() * 2 + 4;
@@ -483,12 +445,6 @@ int cs_cnn_create(cs_cnn_t** out, const cs_cnn_cfg* cfg) {
 
 void cs_cnn_destroy(cs_cnn_t* h) {
     if (!h) return;
-    if (h->dbg_dev) {
-        std::vector<unsigned long long> st((size_t)3 * 1024 * 256);
-        if (hipDeviceSynchronize() == hipSuccess && hipMemcpy(st.data(), h->dbg_dev, st.size() * 8, hipMemcpyDeviceToHost) == hipSuccess)
-            if (FILE* f = fopen(h->dbg_path, "wb")) { fwrite(st.data(), 8, st.size(), f); fclose(f); }
-        (void)hipFree(h->dbg_dev);
-    }
     for (void* p : h->allocs) (void)hipFree(p);
     if (h->err_host) (void)hipHostFree(h->err_host);
     delete h;

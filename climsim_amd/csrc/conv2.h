@@ -72,9 +72,7 @@ struct ConvProg {
     unsigned gen0;               // a workgroup publishes gen0 + s + 1 behind stage s (one counter per model, never reset)
     unsigned* flags;             // [row tile][4]: flag word of each channel tile ; [row tile][4] XCC ids behind them (+ 4 * tiles)
     unsigned* error;             // host-mapped
-    unsigned long long* dbg;     // development (CS_CNN_DBG=<file>): k_conv3 phase stamps [workgroup][compute wave 0 | loader 0][128] (100 MHz), null in production
     int spin_limit, n_row_tiles;
-    int stagger_groups, stagger_ticks;      // k_conv3: row tile t starts (t / 8 % groups) * ticks x 10 ns late (see conv3.h)
     int tiles;                   // row tiles of this launch; the grid is round_up(tiles, 8) * n_tiles workgroups
 };
 

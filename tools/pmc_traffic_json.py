@@ -1,4 +1,4 @@
-"""Fold the FETCH_SIZE / WRITE_SIZE passes of tools/gpu_diag.sh into profiles/r04_pmc_hbm_traffic.json (what
+"""Fold the FETCH_SIZE / WRITE_SIZE passes of tools/gpu_diag.sh into profiles/rNN_pmc_hbm_traffic.json (NN = $CS_ROUND, default 05; what
 bench.py's `roofline.traffic` reads).  Units and correction as /opt/skills/guides/MI355X_MICROARCH.md prescribes:
 counters in KiB, FETCH_SIZE counts half the bytes of wide coalesced streams on gfx950 -> traffic = (2*FETCH + WRITE) KiB.
     python tools/pmc_traffic_json.py 8192 [65536 ...]"""
@@ -10,7 +10,7 @@ import re
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OUT = os.path.join(REPO, "profiles", "r04_pmc_hbm_traffic.json")
+OUT = os.path.join(REPO, "profiles", f"r{os.environ.get('CS_ROUND', '05')}_pmc_hbm_traffic.json")
 
 
 def norm(name):
