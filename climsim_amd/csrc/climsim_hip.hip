@@ -142,7 +142,9 @@ struct cs_mlp {
     bool use_chainw = false;   // wide-model chain (chainw.h): widths any multiple of 128 up to 1024, batches up to chainw_max_n
     int64_t chainw_max_n = (int64_t)1 << 40;   // no limit: with the forward+backward launch the wide chain beats one GEMM per layer at every
                                                // batch (published model: 16384 columns 0.402 vs 0.498 ms, 131072: 2.79 vs 3.56); CS_CHAINW_MAX_N lowers it
-    bool grads_dirty = true;   // G may hold non-zero values (cleared by cs_mlp_apply)
+    bool grads_dirty = true;   // G may hold non-zero values (cleared by cs_mlp_apply where its kernel zeroes G)
+    bool g_stored = false;     // the last weight-gradient launch STORED every element of G (+ Gx): the optimiser need not zero it
+    bool g_need_zero = false;  // train_step: G is dirty and the weight-gradient launch must find zeros if it accumulates
     unsigned long long* dbg = nullptr;   // CS_CHAIN_DBG: [2][grid_max][64] stamps (fwd, bwd)
     int chain_ablate = 0;      // CS_CHAIN_ABLATE env, timing experiments only
     int64_t chain_nt_min = 24576;   // CS_CHAIN_NT_MIN: batch from which the tuned chain's activation / gradient stores are non-temporal (chain.h)
@@ -223,7 +225,8 @@ OptArgs fill_opt_args(cs_mlp* h, float lr, float grad_scale, bool recast_only) {
     OptArgs a{};
     a.P = h->P; a.M = h->M; a.V = h->V; a.G = h->G;
     a.Gx = h->Gx; a.gx_stride = h->n_params; a.gx_n = recast_only ? 0 : h->gx_parts;
-    if (!recast_only) h->gx_parts = 0;
+    a.zero_g = (recast_only || h->g_stored) ? 0 : 1;
+    if (!recast_only) { h->gx_parts = 0; h->g_stored = false; }
     a.n_seg = h->n_seg; a.seg = h->seg_dev;
     a.kind = h->cfg.optimizer; a.lr = lr; a.grad_scale = grad_scale;
     a.recast_only = recast_only ? 1 : 0;
@@ -633,6 +636,12 @@ int run_backward(cs_mlp* h, int64_t n, bool atomics_needed, hipStream_t st) {
             d.tiles_k = (ly.Kp + tdim - 1) / tdim; d.tiles_n = (ly.N + tdim - 1) / tdim; d.wg_begin = wg;
             wg += d.tiles_k * d.tiles_n * splitk;
         }
+        if (h->g_need_zero && w.use_atomics) {             // (train_step leaves this to the launch that knows how the gradients arrive)
+            ProfScope psz(CS_K_MEMSET, st);
+            HIP_TRY(hipMemsetAsync(h->G, 0, sizeof(float) * h->n_params, st));
+        }
+        h->g_need_zero = false;
+        h->g_stored = w.plain != 0;
         ProfScope ps(CS_K_WGRAD, st);
         static const bool wg2_loaders = !(getenv("CS_WGRAD2_LOADERS") && atoi(getenv("CS_WGRAD2_LOADERS")) == 0);
         if (big && wg2_loaders) CS_LAUNCH(k_wgrad2l, dim3((unsigned)wg), dim3(768), WG2L_LDS_BYTES, st, w);
@@ -1080,8 +1089,9 @@ int cs_mlp_set_grad_buffer(cs_mlp_t* h, void* dev_ptr) {
 int cs_mlp_apply(cs_mlp_t* h, float lr, float grad_scale, void* stream) {
     if (!h) return fail(CS_ERR_INVALID, "null handle");
     if (int rc = coop_poll(h)) return rc;
+    const bool stored = h->g_stored;       // the kernel leaves G as it found it then (every element is stored again by the next step)
     int rc = launch_optimizer(h, lr, grad_scale, false, (hipStream_t)stream);
-    if (rc == CS_OK) { h->iterations += 1; h->grads_dirty = false; }
+    if (rc == CS_OK) { h->iterations += 1; h->grads_dirty = stored; }
     return rc;
 }
 
@@ -1094,10 +1104,7 @@ int cs_mlp_train_step(cs_mlp_t* h, const float* x_dev, const float* y_dev, const
     hipStream_t st = (hipStream_t)stream;
     // No memset launch in the steady state: the loss sums accumulate in an internal slot that the PREVIOUS step's
     // optimiser kernel zeroed; this step's optimiser kernel copies them to loss_dev and zeroes the other slot.
-    if (h->grads_dirty) {
-        ProfScope ps(CS_K_MEMSET, st);
-        HIP_TRY(hipMemsetAsync(h->G, 0, sizeof(float) * h->n_params, st));
-    }
+    h->g_need_zero = h->grads_dirty;       // (run_backward clears G if this step's weight-gradient launch adds to it)
     h->grads_dirty = true;
     float* slot = h->loss_ring + LOSS_STRIPES * LOSS_STRIPE_FLOATS * h->loss_cur;
     h->loss_striped = true;
@@ -1108,7 +1115,7 @@ int cs_mlp_train_step(cs_mlp_t* h, const float* x_dev, const float* y_dev, const
     h->in_step = true;
     rc = run_backward(h, n, false, st);
     h->in_step = false;
-    if (rc) { h->gx_parts = 0; return rc; }
+    if (rc) { h->gx_parts = 0; h->g_stored = false; h->g_need_zero = false; return rc; }
     h->opt_loss_src = slot; h->opt_loss_dst = loss_dev; h->opt_loss_zero = h->loss_ring + LOSS_STRIPES * LOSS_STRIPE_FLOATS * (h->loss_cur ^ 1);
     h->loss_cur ^= 1;
     return cs_mlp_apply(h, lr, 1.0f / ((float)h->n_out * (float)n), stream);
@@ -1506,15 +1513,8 @@ int cs_mlp_group_train_step(cs_mlp_group_t* g, const float* const* x_dev, const 
     if (na == 0) return CS_OK;
     if (int rc = group_sync_members(g, st)) return rc;
     bool tables_stale = false;
-    for (int a = 0; a < na; ++a) {
-        cs_mlp* h = g->m[(size_t)act[a]];
-        if (h->grads_dirty) {
-            ProfScope ps(CS_K_MEMSET, st);
-            HIP_TRY(hipMemsetAsync(h->G, 0, sizeof(float) * h->n_params, st));
-        }
-        h->grads_dirty = true;
-        if (g->opt_G[(size_t)act[a]] != h->G) tables_stale = true;
-    }
+    for (int a = 0; a < na; ++a)
+        if (g->opt_G[(size_t)act[a]] != g->m[(size_t)act[a]]->G) tables_stale = true;
     // ---- weight-gradient split count for THIS set of members; per-member tables are rebuilt when a batch size, the split
     // count or a gradient buffer changed (rare: a blocking upload after the stream has drained)
     int tiles = 0;
@@ -1525,6 +1525,15 @@ int cs_mlp_group_train_step(cs_mlp_group_t* g, const float* const* x_dev, const 
     if (n_min < 2048) splitk = std::min(splitk, 2); else if (n_min < 6144) splitk = std::min(splitk, 3);
     splitk = (int)std::min<int64_t>(splitk, round_up(n_min, 128) / WG2_ROWS);
     if (splitk != g->wg_splitk) tables_stale = true;
+    // one split STORES the gradients (no atomics): nothing has to be zero before and the optimiser launch leaves G as it is
+    for (int a = 0; a < na; ++a) {
+        cs_mlp* h = g->m[(size_t)act[a]];
+        if (h->grads_dirty && splitk > 1) {
+            ProfScope ps(CS_K_MEMSET, st);
+            HIP_TRY(hipMemsetAsync(h->G, 0, sizeof(float) * h->n_params, st));
+        }
+        h->grads_dirty = true;
+    }
     for (int a = 0; a < na; ++a)
         if (g->wg_n[(size_t)act[a]] != n[act[a]]) tables_stale = true;
     if (tables_stale) {
@@ -1538,6 +1547,7 @@ int cs_mlp_group_train_step(cs_mlp_group_t* g, const float* const* x_dev, const 
             g->wg_n[(size_t)i] = n[i] ? n[i] : g->wg_n[(size_t)i];
             const float* ls = h->opt_loss_src; float* ld = h->opt_loss_dst; float* lz = h->opt_loss_zero;
             oa[(size_t)i] = fill_opt_args(h, 0.f, 0.f, false);
+            oa[(size_t)i].zero_g = splitk > 1 ? 1 : 0;
             h->opt_loss_src = ls; h->opt_loss_dst = ld; h->opt_loss_zero = lz;
             g->opt_G[(size_t)i] = h->G;
         }
@@ -1601,7 +1611,7 @@ int cs_mlp_group_train_step(cs_mlp_group_t* g, const float* const* x_dev, const 
         const OptArgs o = fill_opt_args(h, lr[i], 1.0f / ((float)h->n_out * (float)n[i]), false);
         od.d[a] = OptDyn{h->G, o.loss_src, o.loss_dst, o.loss_zero, o.lr, o.grad_scale, o.alpha, o.bc1, o.bc2, o.radam_r, o.radam_rect};
         h->iterations += 1;
-        h->grads_dirty = false;
+        h->grads_dirty = splitk == 1;
     }
     {
         ProfScope ps(CS_K_OPTIMIZER, st);

@@ -534,7 +534,7 @@ struct Segment {          // one parameter tensor of the flat buffer
     int blk_begin;        // first workgroup of this tensor in the optimiser launch (32x32 tiles, or 1024-float slices of a bias)
 };
 struct OptArgs {
-    float* P; float* M; float* V; float* G;   // G is consumed: zeroed after the update (no memset launch per step)
+    float* P; float* M; float* V; float* G;   // G is consumed; zeroed after the update where the next weight-gradient launch ADDS to it (zero_g)
     int n_seg; const Segment* seg;
     int kind; float lr, grad_scale;
     // scalars prepared on the host in float32 arithmetic, at the points where TF casts:
@@ -550,6 +550,9 @@ struct OptArgs {
     const float* loss_src; float* loss_dst; float* loss_zero;
     // partial sums that k_wgrad3 stored beside the gradient buffer (WgradArgs.plain): g = G[i] + sum_p Gx[p * gx_stride + i]
     const float* Gx; int64_t gx_stride; int gx_n;
+    // 1: leave G zeroed (the next weight-gradient launch accumulates with atomics and no memset launch precedes it); 0: the launch that
+    // filled G STORED every element (row splits into G + Gx, or a single split) and so will the next one - 4 bytes per parameter less
+    int zero_g;
 };
 
 // Update rules (float32, one thread = 4 parameters):
@@ -615,7 +618,7 @@ __device__ __forceinline__ void opt_update4(const OptArgs& a, int64_t i0, float 
         g.x += e.x; g.y += e.y; g.z += e.z; g.w += e.w;
     }
     opt_rule4(a, i0, g, wv);
-    *reinterpret_cast<float4*>(a.G + i0) = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.zero_g) *reinterpret_cast<float4*>(a.G + i0) = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 // train_step's loss sums: add the stripes the chain kernels accumulated (loss_flush), hand them to the caller, zero the other slot

@@ -150,7 +150,9 @@ int cs_mlp_get_grads(cs_mlp_t* h, float* host, int64_t n, void* stream);
  * operand copies of the weights. */
 int cs_mlp_apply(cs_mlp_t* h, float lr, float grad_scale, void* stream);
 
-/* Model.train_step: loss_grads + apply(lr, 1/(128 n)). */
+/* Model.train_step: loss_grads + apply(lr, 1/(128 n)).  What the gradient buffer holds AFTER a train_step is unspecified (the step may
+ * keep its row splits' partial sums in separate buffers and leave the buffer un-zeroed: 4 bytes per parameter less per step); a
+ * later cs_mlp_loss_grads starts from a clean buffer either way. */
 int cs_mlp_train_step(cs_mlp_t* h, const float* x_dev, const float* y_dev, const int64_t* row_idx_dev,
                       int64_t n, int normalise, float lr, float* loss_dev, void* stream);
 

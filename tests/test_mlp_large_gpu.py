@@ -83,7 +83,9 @@ def test_training_step_without_gradient_atomics_equals_the_two_call_form(M, n, o
     """cs_mlp_train_step lets k_wgrad3 STORE its row splits into separate buffers that the optimiser kernel adds up
     (WgradArgs.plain, 2 or 3 splits); cs_mlp_loss_grads + cs_mlp_apply - what data-parallel training calls - accumulates with
     float atomics into one buffer.  Same gradients up to the order of float additions, so the same weights after several
-    steps (every optimiser family reads the extra buffers), and the gradient buffer is handed back zeroed either way."""
+    steps (every optimiser family reads the extra buffers).  The two-call form hands the gradient buffer back zeroed (its next
+    launch adds to it); after a train_step its content is unspecified (round 5: every element is stored again by the next step, so
+    the optimiser kernel no longer zeroes it) - what must hold is that a gradient read afterwards sees one clean buffer."""
     cfg = O.MLPConfig(hidden=CFG)
     ws = O.glorot_init(cfg, 5)
     a = M.MLPEmulator(units=CFG, optimizer=opt, max_batch=n, seed=None)
@@ -97,7 +99,7 @@ def test_training_step_without_gradient_atomics_equals_the_two_call_form(M, n, o
         lb = b.loss_grads(xd, yd, row_idx=perm).cpu().numpy()
         b.apply_gradients(1e-3, 1.0 / (128 * n))
         np.testing.assert_allclose(la, lb, rtol=2e-3)
-    assert float(a.gradient_tensor().abs().max()) == 0.0 and float(b.gradient_tensor().abs().max()) == 0.0
+    assert float(b.gradient_tensor().abs().max()) == 0.0
     for wa, wb, w0 in zip(a.get_weights(), b.get_weights(), ws):
         assert rel(wa - w0, wb - w0) <= 2e-3, rel(wa - w0, wb - w0)
     # and a gradient read after a training step still sees one clean buffer

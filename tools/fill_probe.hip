@@ -20,7 +20,17 @@ __global__ void k_fill(uint4* p, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = make_uint4(i, 1, 2, 3);
 }
 // tensors: L layers x {H, Z}, each [m][512] bf16 (1 KiB rows) or 4 panels [m][128]
-__global__ __launch_bounds__(256) void k_stream(const char* base, size_t tensor_bytes, int m, int splits, int panel, unsigned* sink) {
+// round 5: `mode` 0 = every piece an LDS-DMA request (the kernels' way), 1 = every piece a plain 16-byte load into a register (no LDS
+// write: what the vector-memory path alone delivers for this address pattern), 2 = H pieces by LDS-DMA and Z pieces by plain loads
+// (do the two paths add up?), 3 = plain loads + a ds_write_b128 of the register into the piece's place
+__device__ __forceinline__ void ld16(const void* gsrc) {
+    asm volatile("global_load_dwordx4 v[200:203], %0, off" :: "v"(gsrc) : "memory", "v200", "v201", "v202", "v203");
+}
+__device__ __forceinline__ void st16(unsigned lds_dst, int lane) {
+    const unsigned a = lds_dst + (unsigned)lane * 16u;
+    asm volatile("ds_write_b128 %0, v[200:203]" :: "v"(a) : "memory");
+}
+__global__ __launch_bounds__(256) void k_stream(const char* base, size_t tensor_bytes, int m, int splits, int panel, unsigned* sink, int mode) {
     extern __shared__ char ring[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int b = blockIdx.x, nwg = gridDim.x;
@@ -44,7 +54,10 @@ __global__ __launch_bounds__(256) void k_stream(const char* base, size_t tensor_
     }
     const unsigned mine = (unsigned)__builtin_amdgcn_readfirstlane(2 * wid) * 1024u;
 #define ISSUE(st) { const int sc = (st) < nst ? (st) : nst - 1; const size_t ro = (size_t)sc * 32 * rstride; const unsigned bb = ((st) & 3) * 16384u + mine; \
-        dma16(hs[0] + ro, bb); dma16(hs[1] + ro, bb + 1024u); dma16(zs[0] + ro, bb + 8192u); dma16(zs[1] + ro, bb + 8192u + 1024u); }
+        if (mode == 0) { dma16(hs[0] + ro, bb); dma16(hs[1] + ro, bb + 1024u); dma16(zs[0] + ro, bb + 8192u); dma16(zs[1] + ro, bb + 8192u + 1024u); } \
+        else if (mode == 2) { dma16(hs[0] + ro, bb); dma16(hs[1] + ro, bb + 1024u); ld16(zs[0] + ro); ld16(zs[1] + ro); } \
+        else { ld16(hs[0] + ro); ld16(hs[1] + ro); ld16(zs[0] + ro); ld16(zs[1] + ro); \
+               if (mode == 3) { st16(bb, lane); st16(bb + 1024u, lane); st16(bb + 8192u, lane); st16(bb + 8192u + 1024u, lane); } } }
     ISSUE(0) ISSUE(1) ISSUE(2)
     unsigned acc = 0;
     for (int s = 0; s < nst; ++s) {
@@ -65,21 +78,22 @@ int main(int argc, char** argv) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_stream), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     printf("m = %d: 5 layers x {H, Z} [m][512] bf16 = %.1f MB unique; every slab is read by 4 tiles (reuse through one XCD's L2)\n", m, tensor * 2 * L / 1e6);
-    for (int panel = 0; panel < 2; ++panel)
-        for (int splits : {3, 5, 7, 16}) {
+    for (int mode = 0; mode < 4; ++mode)
+    for (int panel = 0; panel < 1; ++panel)
+        for (int splits : {3, 16}) {
             if (m / splits / 32 < 4) continue;
             float best = 1e9, sum = 0;
             const int grid = L * 16 * splits;
             for (int rep = 0; rep < 6; ++rep) {
                 hipLaunchKernelGGL(k_fill, dim3(1024), dim3(256), 0, 0, (uint4*)buf, tensor * 2 * L / 16);   // fresh data, written by other CUs
                 hipEventRecord(e0);
-                hipLaunchKernelGGL(k_stream, dim3(grid), dim3(256), 65536, 0, buf, tensor, m, splits, panel, sink);
+                hipLaunchKernelGGL(k_stream, dim3(grid), dim3(256), 65536, 0, buf, tensor, m, splits, panel, sink, mode);
                 hipEventRecord(e1); hipEventSynchronize(e1);
                 float ms; hipEventElapsedTime(&ms, e0, e1);
                 if (rep) { best = ms < best ? ms : best; sum += ms; }
             }
             const double l2lds = (double)grid * (m / splits / 32) * 16384.0;
-            printf("%s splits %d (%3d workgroups): %.1f us best, %.1f mean | L2->LDS %.0f MB = %.2f TB/s | unique %.2f TB/s\n", panel ? "panel    " : "row-major",
+            printf("mode %d %s splits %d (%3d workgroups): %.1f us best, %.1f mean | L2->LDS %.0f MB = %.2f TB/s | unique %.2f TB/s\n", mode, panel ? "panel    " : "row-major",
                    splits, grid, best * 1e3, sum / 5 * 1e3, l2lds / 1e6, l2lds / (best * 1e-3) / 1e12, tensor * 2 * L / (best * 1e-3) / 1e12);
         }
     printf("%s\n", hipGetErrorString(hipGetLastError()));
