@@ -478,8 +478,18 @@ template <int BM, int EPI, bool ELU>
 __device__ __forceinline__ void chain_trunk(u16* X, const float* bias_lds, const ChainArgs& p, int bid, const int i0, const int cnt,
                                             const int64_t m0, const int wid, const int tid, int& slot, ChainPending& pend) {
     static_assert(BM == 32 && !ELU, "the counted window below is written for 32-row tiles without ELU");
+    static_assert(EPI == EPI_HIDDEN || EPI == EPI_DGRAD, "a run is made of training-pass stages: each issues exactly one sign-mask operation");
     constexpr int MT = BM / 32, NT = 2, D = 8;
-    constexpr int EXTRA = BM / 8 + 1;                          // asm memory operations between a stage's tail loads and the next stage's first wait
+    // THE INVARIANT OF THE COUNTED WINDOW.  Between the tail loads of stage s (which carry steps 0..7 of stage s + 1) and the first
+    // `vmcnt` of stage s + 1, this wave issues EXACTLY these asm memory operations, unconditionally, on every path:
+    //   forward  (EPI_HIDDEN): 1 sign-mask STORE (epilogue of stage s)            + BM / 8 copy-out stores (head of stage s + 1)
+    //   backward (EPI_DGRAD):  1 sign-mask LOAD  (head of stage s + 1)            + BM / 8 copy-out stores (head of stage s + 1)
+    // = EXTRA.  chain_find_trunk (host) only admits stages that have both an output tensor and a sign mask, so none of them is
+    // conditional.  An edit that makes one of them conditional (edge tiles, an ablation, a null mask) issues FEWER operations than
+    // the waits count: the MFMAs would read queue registers whose loads have not landed, silently.  The chain_stamp stores of
+    // CS_CHAIN_DBG only make the wait stricter.  tests/test_mlp_large_gpu.py::test_continuous_run_equals_one_queue_per_stage holds the
+    // run to the per-stage form bit for bit (CS_CHAIN_TRUNK=0) at row counts that are and are not multiples of 32.
+    constexpr int EXTRA = BM / 8 + 1;
     constexpr unsigned STEPB = 16 * 64 * 16;                   // bytes per k16-step of a 512-wide stage (16 column tiles of 1 KiB)
     const int jt0 = wid * 2;
     ChainQ Q;

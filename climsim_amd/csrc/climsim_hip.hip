@@ -20,6 +20,7 @@
 #include <dlfcn.h>
 #include <string>
 #include <utility>
+#include <mutex>
 #include <vector>
 
 namespace {
@@ -157,6 +158,8 @@ struct cs_mlp {
     unsigned* coop_error = nullptr;    // device address of coop_error_host
     unsigned* coop_error_host = nullptr;   // pinned, host-mapped, coherent: bounded waits of cooperative launches that ran out (counted by the kernel)
     int coop_spin_limit = COOP_SPIN_LIMIT;
+    bool chain_trunk_off = false;  // CS_CHAIN_TRUNK=0 (read at creation): one weight queue per stage instead of the continuous run (A/B, tests)
+    int coop_warm = 0;             // CS_COOP_WARM (development, read at creation): 4 = write-through exchange even on one XCD, 8 = members of a tile dealt ACROSS the XCDs
     unsigned* coop_xcc = nullptr;      // [tiles] XCC ids seen per tile (roll call of the members)
     unsigned coop_epoch = 0;
     char* coop_ll = nullptr;           // tagged exchange blocks of the cooperative chain (coop.h, "LL exchange"); CS_COOP_LL=0: flag protocol
@@ -335,8 +338,7 @@ int chain_bm(const cs_mlp* h, int64_t n) { return chain_bm_of(h->cfg.flags, h->n
 // first (its first 8 k16-steps are requested by the stage in front, the next 8 by its own head block).
 void chain_find_trunk(const cs_mlp* h, ChainArgs& c) {
     c.trunk_i0 = 0; c.trunk_n = 0;
-    static const bool off = getenv("CS_CHAIN_TRUNK") && atoi(getenv("CS_CHAIN_TRUNK")) == 0;
-    if (off || h->cfg.act == CS_ACT_ELU || (c.ablate & ~128) || c.mask_bm64) return;
+    if (h->chain_trunk_off || h->cfg.act == CS_ACT_ELU || (c.ablate & ~128) || c.mask_bm64) return;
     int best0 = 0, bestn = 0;
     for (int i = 0; i < c.n_stages;) {
         int n = 0;
@@ -456,7 +458,7 @@ int run_forward(cs_mlp* h, const float* x, const int64_t* row_idx, int64_t n, in
                 if (h->coop_ll) HIP_TRY(hipMemsetAsync(h->coop_ll, 0, h->coop_ll_bytes, st));
                 h->coop_epoch = 0;
             }
-            static const int warm = getenv("CS_COOP_WARM") ? atoi(getenv("CS_COOP_WARM")) : 0;
+            const int warm = h->coop_warm;
             const int n_seq = c.n_stages + cb.n_stages;
             const bool ll_fits = h->coop_ll && m_pad / 32 <= 64 && n_seq <= 2 * h->L;
             CoopArgs co{coop_c, ++h->coop_epoch, h->coop_arrive, h->coop_arrive + 256, h->coop_xcc, h->coop_error, h->coop_spin_limit, warm, h->dbg,
@@ -871,6 +873,8 @@ int cs_mlp_create(cs_mlp_t** out, const cs_mlp_cfg* cfg) {
         memset(h->coop_error_host, 0, 64);
         HIP_TRY(hipHostGetDevicePointer((void**)&h->coop_error, h->coop_error_host, 0));
         if (const char* e = getenv("CS_COOP_SPIN_LIMIT")) h->coop_spin_limit = atoi(e);
+        if (const char* e = getenv("CS_COOP_WARM")) h->coop_warm = atoi(e);
+        if (const char* e = getenv("CS_CHAIN_TRUNK")) h->chain_trunk_off = atoi(e) == 0;
     }
     guard.p = nullptr;
     *out = h;
@@ -1211,6 +1215,30 @@ int cs_permutation(int64_t n, uint64_t seed, int64_t* out_dev, void* stream) {
     return CS_OK;
 }
 
+// Dynamic-LDS limits of the loader kernels, once per DEVICE (the attribute belongs to the function on the current device; a process
+// that runs the loader on a second device used to launch there without it: round-4 advisor finding).
+static int loader_set_attrs() {
+    static std::mutex mu;
+    static bool done[64] = {};
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return fail(CS_ERR_INVALID, "device %d out of range", dev);
+    std::lock_guard<std::mutex> lk(mu);
+    if (done[dev]) return CS_OK;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_loader_stack5<double, 2, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 128 * 512 + 128));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_loader_stack5<float, 2, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 128 * 512 + 128));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_loader_stack5<double, 1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 512 + 128));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_loader_stack5<float, 1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 512 + 128));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_loader_stack5<double, 1, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 512 + 128));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_loader_stack5<float, 1, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 512 + 128));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_loader_stack4<double, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_loader_stack4<float, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_loader_stack4<double, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_loader_stack4<float, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    done[dev] = true;
+    return CS_OK;
+}
+
 int cs_loader_stack(const void* mli_dev, const void* mlo_dev, int32_t src_f64, int64_t n_steps, int32_t ncol, int32_t n_in,
                     const double* in_sub_dev, const double* in_div_dev, int32_t n_out, const int32_t* tend_src_dev,
                     const double* out_scale_dev, float* x_out_dev, float* y_out_dev, void* stream) {
@@ -1230,17 +1258,10 @@ int cs_loader_stack(const void* mli_dev, const void* mlo_dev, int32_t src_f64, i
     // one pass over mli (loader.h, k_loader_stack5): both outputs wanted, widths <= 128; CS_LOADER_V5 = 0 off, 3 (default) = 64 columns x 16
     // waves (two workgroups per CU), 1 = x 8 waves, 2 = 128 columns x 16 waves (one workgroup per CU)
     const int v5_mode = getenv("CS_LOADER_V5") ? atoi(getenv("CS_LOADER_V5")) : 3;            // (read per call: the tests run every kernel)
-    if (cpl && v5_mode && x_out_dev && y_out_dev && n_in <= 128 && n_out <= 128 && n_out % 4 == 0 && (cpl == 2 || v5_mode != 2)) {
-        static bool attr5 = false;
-        if (!attr5) {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_loader_stack5<double, 2, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 128 * 512 + 128));
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_loader_stack5<float, 2, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 128 * 512 + 128));
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_loader_stack5<double, 1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 512 + 128));
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_loader_stack5<float, 1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 512 + 128));
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_loader_stack5<double, 1, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 512 + 128));
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_loader_stack5<float, 1, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 512 + 128));
-            attr5 = true;
-        }
+    // (the one-column-per-lane forms - modes 1 and 3 - load scalars and mask their lanes: any ncol, natural alignment; only the
+    // two-column form needs an even ncol and 16-byte-aligned raw fields)
+    if (v3 && v5_mode && x_out_dev && y_out_dev && n_in <= 128 && n_out <= 128 && n_out % 4 == 0 && (v5_mode != 2 || cpl == 2)) {
+        if (int rc = loader_set_attrs()) return rc;
         const int c5 = v5_mode != 2 ? 1 : 2;
         const dim3 grid5((unsigned)((ncol + 64 * c5 - 1) / (64 * c5)), (unsigned)n_steps);
         const size_t lds5 = (size_t)2 * 64 * c5 * 512 + 128;
@@ -1253,14 +1274,7 @@ int cs_loader_stack(const void* mli_dev, const void* mlo_dev, int32_t src_f64, i
     else if (cpl) {
         const dim3 grid4((unsigned)((ncol + 64 * cpl - 1) / (64 * cpl)), (unsigned)n_steps);
         const size_t lds = (size_t)64 * cpl * 128 * sizeof(float);
-        static bool attr_done = false;
-        if (!attr_done) {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_loader_stack4<double, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_loader_stack4<float, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_loader_stack4<double, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_loader_stack4<float, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
-            attr_done = true;
-        }
+        if (int rc = loader_set_attrs()) return rc;
 #define CS_LD4(TT, CC) CS_LAUNCH((k_loader_stack4<TT, CC>), grid4, dim3(256 * CC), lds, st, (const TT*)mli_dev, (const TT*)mlo_dev, ncol, n_in, in_sub_dev, in_div_dev, \
                                  n_out, tend_src_dev, out_scale_dev, x_out_dev, y_out_dev)
         if (src_f64 && cpl == 4) CS_LD4(double, 4); else if (src_f64) CS_LD4(double, 2); else if (cpl == 4) CS_LD4(float, 4); else CS_LD4(float, 2);

@@ -46,7 +46,7 @@ struct CoopArgs {
     unsigned* error;             // HOST-MAPPED word (hipHostMalloc): counts the bounded waits that ran out; system-scope atomic, so the
                                  // host sees it without a copy or a synchronisation (cs_mlp_* calls test it on entry, cs_mlp_check at a sync)
     int spin_limit;              // polls before a wait gives up
-    int warm;                    // development (CS_COOP_WARM): 4 = take the write-through (sc1) path even when the members share an XCD
+    int warm;                    // development (CS_COOP_WARM): 4 = take the write-through (sc1) path even when the members share an XCD, 8 = deal a tile's members across the XCDs
     unsigned long long* dbg;     // development (CS_CHAIN_DBG): [workgroup][128] s_memtime stamps, null in production
     char* ll;                    // round 4: [tile][n_seq][32 rows][COOP_LL_PITCH] tagged exchange lines (see "LL exchange"); null = flag protocol
     int n_seq;                   // exchanges per step (stages of the forward chain + of the backward chain)
@@ -394,7 +394,9 @@ __global__ __launch_bounds__(512) void k_chain_coop_fb(const ChainArgs pf, const
     float* bias_lds = red + COOP_RED_FLOATS;
     int64_t* rows_lds = reinterpret_cast<int64_t*>(bias_lds + CHAIN_MAX_BIAS);
     const int tid = threadIdx.x;
-    const int w = xcd_work_id((int)blockIdx.x, (int)gridDim.x);  // the members of a tile: consecutive work ids, one XCD
+    // the members of a tile: consecutive work ids, one XCD.  (co.warm & 8, tests: the raw block id instead - consecutive blocks run on
+    // consecutive XCDs, so every tile's members sit on 4 or 8 DIFFERENT XCDs and the exchange really crosses the fabric)
+    const int w = (co.warm & 8) ? (int)blockIdx.x : xcd_work_id((int)blockIdx.x, (int)gridDim.x);
     const int tile = w / C, member = w - tile * C;
     const int64_t m0 = (int64_t)tile * 32;
 

@@ -459,18 +459,22 @@ class MLPEmulator:
         acc_count = torch.zeros(1, dtype=torch.int64, device=self.device) if want_acc else None
         if want_acc:
             history["accuracy"] = []
-            _lib.check(self.lib.cs_mlp_set_train_accuracy(self._h, _ptr(acc_count)))
         csv_keys = sorted({"accuracy", *history.keys()})
         best, wait = math.inf, 0
-        writer = None
-        if csv_log and rank == 0:
-            new = not os.path.exists(csv_log)
-            f = open(csv_log, "a", newline="")
-            writer = csv.writer(f)
-            if new:
-                writer.writerow(["epoch", *csv_keys])
+        writer = f = None
         self.stop_training = False
         try:
+            # everything that can raise sits inside the try: the engine holds the counter's DEVICE POINTER from here on, and the
+            # `finally` below takes it back before `acc_count` can be freed (a log file that cannot be opened used to leave it
+            # dangling: the next train_on_batch would have added to freed memory)
+            if want_acc:
+                _lib.check(self.lib.cs_mlp_set_train_accuracy(self._h, _ptr(acc_count)))
+            if csv_log and rank == 0:
+                new = not os.path.exists(csv_log)
+                f = open(csv_log, "a", newline="")
+                writer = csv.writer(f)
+                if new:
+                    writer.writerow(["epoch", *csv_keys])
             for epoch in range(epochs):
                 gen.manual_seed(seed + epoch)            # identical permutation on every rank
                 perm = torch.randperm(n, device=self.device, generator=gen) if shuffle else torch.arange(n, device=self.device)
@@ -523,10 +527,9 @@ class MLPEmulator:
                         self.stop_training = True
                         break
         finally:
-            if writer:
+            if f is not None:
                 f.close()
-            if want_acc:
-                self.lib.cs_mlp_set_train_accuracy(self._h, None)
+            self.lib.cs_mlp_set_train_accuracy(self._h, None)      # unconditionally: no pointer of this call survives it
             dp.close()                     # the engine's RCCL communicator never outlives the call, also on an exception
         return history
 

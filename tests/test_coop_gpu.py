@@ -83,6 +83,32 @@ def test_tagged_exchange_and_flag_protocol_give_the_same_bits(M, monkeypatch, n,
     assert np.array_equal(out["1"][2], out["0"][2])
 
 
+@pytest.mark.parametrize("warm", ["8", "4"])
+def test_tagged_exchange_across_xcds_matches_the_flag_protocol_over_many_steps(M, monkeypatch, warm):
+    """The tagged exchange assumes that an aligned 8-byte {data, tag} unit of a 16-byte write-through store is seen whole by an
+    `sc1` load on another XCD (no drain, no flag, no fence: observed on gfx950, not an architectural guarantee - INTEGRATION.md).
+    A torn unit would be silent: wrong activations reach the next layer.  CS_COOP_WARM=8 deals the members of every tile ACROSS the
+    XCDs (raw block ids), so that every exchange of every layer crosses the fabric with write-through stores; = 4 keeps them on one XCD
+    but still writes through.  300 steps of two models per protocol: weights must end bit-identical, no wait may time out."""
+    monkeypatch.setenv("CS_COOP_WARM", warm)
+    n, units = 1024, (512, 512, 512, 512, 512)
+    x, y = O.synth_columns(n, seed=31)
+    xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    ends = {}
+    for ll in ("1", "0"):
+        monkeypatch.setenv("CS_COOP_LL", ll)
+        m, cfg, ws = make(M, units, "leakyrelu")
+        for it in range(300):
+            perm = torch.randperm(n, device="cuda", generator=torch.Generator(device="cuda").manual_seed(it))
+            m.train_on_batch(xd, yd, 1e-3, row_idx=perm)
+        m.check()
+        assert m.coop_timeouts == 0
+        ends[ll] = [w.copy() for w in m.get_weights()]
+        m.close()
+    for a, b in zip(ends["1"], ends["0"]):
+        assert np.array_equal(a, b)
+
+
 def test_coop_training_tracks_oracle_and_the_plain_chain(M):
     units, n = (512, 512, 512), 1024
     a, cfg, ws = make(M, units, "leakyrelu", cooperative=True)

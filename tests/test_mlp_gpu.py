@@ -287,6 +287,13 @@ def test_fit_predict_evaluate_api(M, tmp_path):
     assert "accuracy" not in m.fit(x[:1024], y[:1024], batch_size=256, epochs=1, learning_rate=0.0)      # off without a CSV log
     pred = m.predict(xv, batch_size=300)
     assert np.mean((pred - yv) ** 2) == pytest.approx(after["mse"], rel=1e-3)
+    # a fit that fails before its first step (the CSV log cannot be opened) must not leave the engine with the device pointer of its
+    # accuracy counter: the next steps would add to freed memory (round-4 advisor finding).  Afterwards the model trains as before.
+    with pytest.raises(OSError):
+        m.fit(x[:1024], y[:1024], batch_size=256, epochs=1, csv_log=str(tmp_path / "no_such_dir" / "log.csv"))
+    w0 = m.get_weights()
+    h1 = m.fit(x[:1024], y[:1024], batch_size=256, epochs=1, learning_rate=0.0)
+    assert "accuracy" not in h1 and all(np.array_equal(a, b) for a, b in zip(w0, m.get_weights()))
 
 
 # ----------------------------------------------------------------------- BASELINE-size properties

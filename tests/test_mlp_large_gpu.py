@@ -109,3 +109,35 @@ def test_training_step_without_gradient_atomics_equals_the_two_call_form(M, n, o
     b.loss_grads(xd, yd)
     for u, v in zip(ga, b.get_gradients(1.0)):
         assert rel(u, v) <= 1e-4
+
+
+@pytest.mark.parametrize("n", [8192, 4096 + 17, 100, 33])
+def test_continuous_run_equals_one_queue_per_stage(M, monkeypatch, n):
+    """chain_trunk (csrc/chain.h) carries the weight queue from one 512-wide stage into the next behind waits that COUNT the memory
+    operations issued in between (round-4 advisor finding: nothing but the code's shape enforces that count).  CS_CHAIN_TRUNK=0
+    runs the same stages with one queue per stage (every wait sized by chain_mma): same arithmetic, same order - loss sums,
+    every gradient (to rounding: see below), the weights after three steps and the predictions (bit for bit), also for row counts that leave the last
+    32-row tile partly empty."""
+    cfg = O.MLPConfig(hidden=CFG)
+    ws = O.glorot_init(cfg, 7)
+    x, y = O.synth_columns(n, seed=13)
+    xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    out = {}
+    for trunk in ("1", "0"):
+        monkeypatch.setenv("CS_CHAIN_TRUNK", trunk)
+        m = M.MLPEmulator(units=CFG, max_batch=max(n, 128), seed=None)
+        m.set_weights(ws)
+        sums = m.loss_grads(xd, yd).cpu().numpy()
+        g = [a.copy() for a in m.get_gradients(1.0)]
+        for _ in range(3):
+            m.train_on_batch(xd, yd, 1e-3)
+        out[trunk] = (sums, g, [w.copy() for w in m.get_weights()], np.asarray(m.predict(xd)))
+        m.close()
+    # (the two-call form adds its row splits and the workgroups' loss sums with float atomics: their ORDER is not fixed, so these two
+    #  agree to rounding; the one-call steps store their splits and add them in a fixed order: bit for bit)
+    np.testing.assert_allclose(out["1"][0], out["0"][0], rtol=1e-6)
+    for a, b in zip(out["1"][1], out["0"][1]):
+        assert rel(a, b) <= 1e-6
+    for a, b in zip(out["1"][2], out["0"][2]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(out["1"][3], out["0"][3])
