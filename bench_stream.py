@@ -101,6 +101,8 @@ def run(nch=8, T=8, B=8192, reps=5):
                                "whole_batches = the full batches alone, no permutation kernels (%d steps): %.1f columns/s of its own rows" % (
                                    sum(x.shape[0] // B for x, _ in xs), sum((x.shape[0] // B) * B for x, _ in xs) / t_whole),
             "serial_sum_columns_per_s": round(rows / (t_train + t_load), 1),
+            # the two yardsticks as fields (round 5): < 1 against training alone is the loader's time showing; > 1 against the serial sum is overlap
+            "ratio_to_train_only": round(t_train / t_stream, 4), "ratio_to_serial_sum": round((t_train + t_load) / t_stream, 4),
             "loader_share_hidden": round(1.0 - (t_stream - t_train) / t_load, 3),
             "timing": {"reps": reps, "value_from": "median pass, passes of the three kinds taken in rotation",
                        "stream_ms": [round(t * 1e3, 2) for t in t_s], "train_only_ms": [round(t * 1e3, 2) for t in t_t], "loader_ms": [round(t * 1e3, 2) for t in t_l]}}

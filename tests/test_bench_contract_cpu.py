@@ -127,3 +127,27 @@ def test_failure_reporter_prints_one_error_line_when_rank_zero_is_blocked(tmp_pa
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["value"] is None and d["n_gpus"] == 2 and "SIGTERM" in d["error"] and "boom on rank 1" in d["failed_ranks"]["1"]
+
+
+def test_acceptance_check_of_the_bench_line():
+    """bench.acceptance_check (round 5): the engine's order-averaged per-variable MAE against the CPU restatement's, held to 2 % + the
+    spread that the data order alone makes inside either implementation.  Driven here on made-up tables: it passes where the
+    difference is inside the spread, fails where the engine is off by more, and reports the fields the line promises."""
+    import importlib
+    import sys
+    sys.path.insert(0, REPO)
+    bench = importlib.import_module("bench")
+    cpu = [{"a": 1.00, "b": 2.00}, {"a": 1.04, "b": 2.02}, {"a": 0.98, "b": 1.99}]
+    eng = [{"a": 1.03, "b": 2.01}, {"a": 0.99, "b": 2.03}, {"a": 1.02, "b": 2.00}]
+    c = bench.acceptance_check({"engine_bf16": eng, "cpu_fp32": cpu})
+    assert c["passed"] and c["margin"] > 0
+    assert set(c) >= {"engine_vs_cpu", "cpu_vs_cpu_other_order", "engine_vs_engine_other_order", "allowed", "worst_variable", "tolerance"}
+    assert c["cpu_vs_cpu_other_order"]["a"] == round((1.04 - 0.98) / 0.98, 4)
+    assert abs(c["engine_vs_cpu"]["of_the_order_means"]["a"] - abs(1.0133333 - 1.0066667) / 1.0066667) < 1e-3
+    off = [{"a": 1.00, "b": 2.30}, {"a": 1.01, "b": 2.31}, {"a": 1.02, "b": 2.29}]          # b off by 15 %, spreads of ~1 %
+    c = bench.acceptance_check({"engine_bf16": off, "cpu_fp32": cpu})
+    assert not c["passed"] and c["worst_variable"] == "b" and c["margin"] < 0
+    # the same numbers inside a spread of 20 % are not evidence of anything: passes, and says why (allowed = 0.02 + spread)
+    wide = [{"a": 1.00, "b": 2.00}, {"a": 1.04, "b": 2.45}, {"a": 0.98, "b": 2.10}]
+    c = bench.acceptance_check({"engine_bf16": off, "cpu_fp32": wide})
+    assert c["passed"] and c["allowed"]["b"] > 0.2

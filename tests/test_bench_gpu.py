@@ -52,9 +52,13 @@ def test_one_gpu_line_with_the_cpu_legs():
     d = run(["--steps", "5", "--warmup", "2", "--min-seconds", "0.05", "--rows", "65536", "--cpu-budget", "3", "--no-profile", "--extras", "pub_mlp"])
     a = d["heldout"]["against_cpu_restatement"]
     assert "error" not in a, a
-    # a REPORT, not the parity bar (tests/test_mlp_gpu.py::test_heldout_per_variable_mae_r2_match_cpu_training holds 2 % / 5 %
-    # on a settled run): two chaotic trajectories of a 5 x 512 model after 1200 steps; measured 0.014 % / 3.4 % for this schedule
-    assert a["rel_diff_mae_all_outputs"] < 0.05 and a["max_rel_diff_MAE"] < 0.15
+    # round 5: a CHECK - the order-averaged per-variable MAE of the engine against the CPU restatement's, held to 2 % + the spread
+    # that the data order alone makes inside either implementation (bench.acceptance_check; SURVEY 8(d) states 2 % for bf16)
+    c = a["check"]
+    assert c["passed"], c
+    assert set(c) >= {"engine_vs_cpu", "cpu_vs_cpu_other_order", "engine_vs_engine_other_order", "allowed", "margin"}
+    assert all(c["engine_vs_cpu"]["of_the_order_means"][v] <= c["allowed"][v] for v in c["allowed"])
+    assert a["rel_diff_mae_all_outputs"] < 0.05
     assert a["min_R2"]["engine_bf16"] > 0.5 and a["min_R2"]["cpu_fp32"] > 0.5       # both sides learned every variable
     p = d["pub_mlp"]
     assert "error" not in p, p
