@@ -95,6 +95,7 @@ SIGNATURES = {
     "cs_normalise_rows": (C.c_int, [_P, _P, _I64, _I32, _P, _P, _P, _P]),
     "cs_permutation": (C.c_int, [_I64, C.c_uint64, _P, _P]),
     "cs_metrics_columns": (C.c_int, [_P, _P, _I64, _I32, _I32, _P, _P, _P, _P, _P, _P]),
+    "cs_metrics_columns_x": (C.c_int, [_P, _P, _I64, _I32, _I32, _P, _I32, _I32, C.c_double, C.c_double, _P, _P, _P, _P, _P]),
     "cs_mlp_kernel_family": (C.c_int, [_P]),
     "cs_mlp_forward_limit": (_I64, [_P]),
     "cs_mlp_group_create": (C.c_int, [C.POINTER(_P), C.POINTER(_P), _I32]),

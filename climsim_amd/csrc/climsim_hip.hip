@@ -1296,11 +1296,12 @@ int cs_loader_stack(const void* mli_dev, const void* mlo_dev, int32_t src_f64, i
     return CS_OK;
 }
 
-int cs_metrics_columns(const float* pred_dev, const float* target_dev, int64_t n_steps, int32_t ncol, int32_t n_out,
-                       const double* ps_dev, const double* wa_dev, const double* wb_dev, const double* area_dev,
-                       double* stats_dev, void* stream) {
-    if (!pred_dev || !target_dev || !ps_dev || !wa_dev || !wb_dev || !area_dev || !stats_dev) return fail(CS_ERR_INVALID, "null argument");
+static int metrics_columns(const float* pred_dev, const float* target_dev, int64_t n_steps, int32_t ncol, int32_t n_out,
+                           const double* ps_dev, const float* x_dev, int32_t n_in, int32_t ps_index, double ps_mul, double ps_add,
+                           const double* wa_dev, const double* wb_dev, const double* area_dev, double* stats_dev, void* stream) {
+    if (!pred_dev || !target_dev || (!ps_dev && !x_dev) || !wa_dev || !wb_dev || !area_dev || !stats_dev) return fail(CS_ERR_INVALID, "null argument");
     if (n_steps <= 0 || n_steps > 0x7fffffff || ncol <= 0 || n_out <= 0) return fail(CS_ERR_INVALID, "bad sizes");
+    if (!ps_dev && (n_in <= 0 || ps_index < 0 || ps_index >= n_in)) return fail(CS_ERR_INVALID, "ps_index %d outside the %d input features", ps_index, n_in);
     hipStream_t st = (hipStream_t)stream;
     const int64_t items = (int64_t)ncol * n_out;
     HIP_TRY(hipMemsetAsync(stats_dev, 0, sizeof(double) * 6 * items, st));
@@ -1311,6 +1312,24 @@ int cs_metrics_columns(const float* pred_dev, const float* target_dev, int64_t n
     const int64_t want = mwaves == 16 ? 1024 : 4096;                                      // workgroups to aim for
     int tsplit = (int)((want + col_wgs - 1) / col_wgs);
     tsplit = std::max(1, std::min<int>(tsplit, (int)(n_steps / (mwaves == 16 ? 256 : 64))));     // >= 64 (256) time steps per slice: 6 float64 atomics per (column, output, slice)
+    // round 5 (default): column blocks - a wave loads 1 KiB of two adjacent columns per tensor and time step (metrics.h, k_metrics_partial5);
+    // CS_METRICS_V5=0 keeps the one-column workgroups.  Time split: about one round of three 256-thread workgroups per CU.
+    const bool v5 = v4 && !(getenv("CS_METRICS_V5") && atoi(getenv("CS_METRICS_V5")) == 0);
+    if (!ps_dev && !v5) return fail(CS_ERR_INVALID, "the surface pressure is read from the input rows by the column-block kernel only (n_out % 4 == 0, 16-byte aligned rows)");
+    if (v5) {
+        constexpr int W5 = 4;
+        const int64_t blocks = (int64_t)((ncol + 2 * W5 - 1) / (2 * W5)) * ((n_out + 127) / 128);
+        int dev = 0, ncu = 256;
+        if (hipGetDevice(&dev) == hipSuccess) { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ncu = v; }
+        int ts5 = (int)std::max<int64_t>(1, (3LL * ncu + blocks / 2) / blocks);
+        ts5 = std::max(1, std::min<int>(ts5, (int)(n_steps / 32)));                       // >= 32 time steps per slice
+        const dim3 g5((unsigned)((ncol + 2 * W5 - 1) / (2 * W5)), (unsigned)((n_out + 127) / 128), (unsigned)ts5);
+        CS_LAUNCH((k_metrics_partial5<4, W5>), g5, dim3(64 * W5), (size_t)W5 * 2 * 128 * 6 * sizeof(double), st, pred_dev, target_dev, (int)n_steps, ncol, n_out,
+                  ps_dev, wa_dev, wb_dev, area_dev, stats_dev, x_dev, (int)n_in, (int)ps_index, ps_mul, ps_add);
+        CS_LAUNCH(k_metrics_finish, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, stats_dev, items, (int)n_steps);
+        HIP_TRY(hipGetLastError());
+        return CS_OK;
+    }
     const dim3 mgrid((unsigned)ncol, (unsigned)((n_out + 127) / 128), (unsigned)tsplit);
     if (v4 && mwaves == 16) CS_LAUNCH((k_metrics_partial4<2, 16>), mgrid, dim3(1024), 0, st, pred_dev, target_dev, (int)n_steps, ncol, n_out, ps_dev, wa_dev, wb_dev, area_dev, stats_dev);
     else if (v4) CS_LAUNCH((k_metrics_partial4<2, 4>), mgrid, dim3(256), 0, st, pred_dev, target_dev, (int)n_steps, ncol, n_out, ps_dev, wa_dev, wb_dev, area_dev, stats_dev);
@@ -1318,6 +1337,20 @@ int cs_metrics_columns(const float* pred_dev, const float* target_dev, int64_t n
     CS_LAUNCH(k_metrics_finish, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, stats_dev, items, (int)n_steps);
     HIP_TRY(hipGetLastError());
     return CS_OK;
+}
+
+int cs_metrics_columns(const float* pred_dev, const float* target_dev, int64_t n_steps, int32_t ncol, int32_t n_out,
+                       const double* ps_dev, const double* wa_dev, const double* wb_dev, const double* area_dev,
+                       double* stats_dev, void* stream) {
+    if (!ps_dev) return fail(CS_ERR_INVALID, "null argument");
+    return metrics_columns(pred_dev, target_dev, n_steps, ncol, n_out, ps_dev, nullptr, 0, 0, 1.0, 0.0, wa_dev, wb_dev, area_dev, stats_dev, stream);
+}
+
+int cs_metrics_columns_x(const float* pred_dev, const float* target_dev, int64_t n_steps, int32_t ncol, int32_t n_out,
+                         const float* x_dev, int32_t n_in, int32_t ps_index, double ps_mul, double ps_add,
+                         const double* wa_dev, const double* wb_dev, const double* area_dev, double* stats_dev, void* stream) {
+    if (!x_dev) return fail(CS_ERR_INVALID, "null argument");
+    return metrics_columns(pred_dev, target_dev, n_steps, ncol, n_out, nullptr, x_dev, n_in, ps_index, ps_mul, ps_add, wa_dev, wb_dev, area_dev, stats_dev, stream);
 }
 
 int cs_categorical_accuracy(const float* pred_dev, const float* target_dev, int64_t n, int32_t width,

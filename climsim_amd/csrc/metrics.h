@@ -141,6 +141,81 @@ __global__ __launch_bounds__(64 * WAVES) void k_metrics_partial4(const float* __
     }
 }
 
+// Round 5: the same sums by COLUMN BLOCKS.  k_metrics_partial4 gives a workgroup one grid column: every 512-byte row it reads sits
+// ncol rows (196 KB at low resolution) from the next, and a wave's load is two such pieces from two time steps.  Here a wave owns TWO
+// ADJACENT columns of one time step - one contiguous 1-KiB load per tensor - and a workgroup of WAVES waves 2 * WAVES adjacent columns
+// (8 KiB per time step and tensor at four waves), walking its slice of the time axis with MT5_U steps in flight.  A thread keeps the
+// six sums of its four outputs of ITS column for the whole slice (no exchange between lanes or waves: 24 float64 registers), then
+// the wave's 2 x 128 x 6 sums go through its own 12 KiB of LDS so that the float64 atomics leave as whole lines.  Grid: column blocks
+// x 128-output slices x time slices; the host picks the time split so that the launch is about one round of three workgroups per CU.
+template <int MT5_U, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_metrics_partial5(const float* __restrict__ pred, const float* __restrict__ target, int T, int ncol,
+                                                                  int n_out, const double* __restrict__ ps, const double* __restrict__ wa,
+                                                                  const double* __restrict__ wb, const double* __restrict__ area,
+                                                                  double* __restrict__ acc /*[ncol][n_out][6], zeroed*/,
+                                                                  const float* __restrict__ xin, int n_in, int ps_index, double ps_mul, double ps_add) {
+    // surface pressure of a row: ps[row] (float64, prepared by the caller), or - ps == null - straight from the normalised input rows:
+    // x[row][ps_index] * ps_mul + ps_add in float64, multiply and add rounded separately (what the host pipeline computes)
+    auto ps_of = [&](int64_t n) __attribute__((always_inline)) { return ps ? ps[n] : __dadd_rn(__dmul_rn((double)xin[n * n_in + ps_index], ps_mul), ps_add); };
+    extern __shared__ __attribute__((aligned(16))) double red5[];                      // [WAVES][2][128][6]
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q = lane & 31, cw = lane >> 5;
+    const int c = (int)blockIdx.x * (2 * WAVES) + 2 * w + cw;
+    const int f0 = blockIdx.y * 128 + 4 * q;
+    const bool live = c < ncol && f0 < n_out;                                           // n_out % 4 == 0: all four outputs or none
+    const int t0 = (int)((int64_t)T * blockIdx.z / gridDim.z), t1 = (int)((int64_t)T * (blockIdx.z + 1) / gridDim.z);
+    double s[4][6];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) s[e][k] = 0.0;
+    if (live) {
+        const double ar = area[c];
+        double a[4], b[4], shift[4];
+        const float4 tf = *reinterpret_cast<const float4*>(target + (int64_t)c * n_out + f0);      // sample t = 0 of this (c, f)
+        const float tfv[4] = {tf.x, tf.y, tf.z, tf.w};
+        const double ps0 = ps_of(c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a[e] = wa[f0 + e]; b[e] = wb[f0 + e]; shift[e] = (double)tfv[e] * ((a[e] + b[e] * ps0) * ar); }
+        for (int tb = t0; tb < t1; tb += MT5_U) {
+            float4 pv[MT5_U], tv[MT5_U]; double psv[MT5_U];
+#pragma unroll
+            for (int u = 0; u < MT5_U; ++u) {
+                const int t = tb + u;
+                const int64_t n = (int64_t)(t < t1 ? t : t0) * ncol + c;
+                psv[u] = ps_of(n);
+                pv[u] = *reinterpret_cast<const float4*>(pred + n * n_out + f0);
+                tv[u] = *reinterpret_cast<const float4*>(target + n * n_out + f0);
+            }
+#pragma unroll
+            for (int u = 0; u < MT5_U; ++u) {
+                if (tb + u >= t1) continue;
+                const float pe[4] = {pv[u].x, pv[u].y, pv[u].z, pv[u].w}, te[4] = {tv[u].x, tv[u].y, tv[u].z, tv[u].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const double wgt = (a[e] + b[e] * psv[u]) * ar;
+                    const double pw = (double)pe[e] * wgt, tw = (double)te[e] * wgt;
+                    const double d = pw - tw, ts = tw - shift[e];
+                    s[e][0] += fabs(d); s[e][1] += d * d; s[e][2] += pw; s[e][3] += tw; s[e][4] += ts; s[e][5] += ts * ts;
+                }
+            }
+        }
+    }
+    // this wave's sums -> its own LDS block [2 columns][128 outputs][6] -> float64 atomics on consecutive addresses (a wave reads back
+    // what it wrote itself: the LDS operations of one wave complete in order, no barrier)
+    double* mine = red5 + (size_t)w * (2 * 128 * 6);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) mine[(cw * 128 + 4 * q + e) * 6 + k] = s[e][k];
+    const int c_first = (int)blockIdx.x * (2 * WAVES) + 2 * w;
+    for (int i = lane; i < 2 * 128 * 6; i += 64) {
+        const int cc = i / (128 * 6), r = i - cc * (128 * 6), fl = r / 6, k = r - fl * 6;
+        const int col = c_first + cc, f = blockIdx.y * 128 + fl;
+        if (col < ncol && f < n_out) atomicAdd(acc + ((int64_t)col * n_out + f) * 6 + k, mine[i]);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_metrics_finish(double* __restrict__ acc, int64_t n_items, int T) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_items) return;

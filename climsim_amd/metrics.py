@@ -63,9 +63,17 @@ class GpuMetrics:
         n = p.shape[0]
         if tuple(t.shape) != (n, self.n_out) or tuple(p.shape) != (n, self.n_out) or x.shape[0] != n or n % self.ncol:
             raise ValueError(f"expected (T*{self.ncol}, {self.n_out}) predictions and targets and matching inputs")
-        ps = (x[:, self.du.ps_index].double() * self._ps_mul + self._ps_add).contiguous()
         out = torch.empty((self.ncol, self.n_out, 6), dtype=torch.float64, device=self.device)
         st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        import os
+        if (x.dtype == torch.float32 and x.is_contiguous() and self.n_out % 4 == 0 and p.data_ptr() % 16 == 0 and t.data_ptr() % 16 == 0
+                and os.environ.get("CS_METRICS_V5", "1") != "0" and os.environ.get("CS_METRICS_V4", "1") != "0"):
+            # round 5: the kernel reads the surface pressure from the input rows itself (no gather / conversion passes over the rows)
+            _lib.check(self.lib.cs_metrics_columns_x(_ptr(p), _ptr(t), n // self.ncol, self.ncol, self.n_out, _ptr(x), int(x.shape[1]),
+                                                     int(self.du.ps_index), float(self._ps_mul), float(self._ps_add), _ptr(self._wa),
+                                                     _ptr(self._wb), _ptr(self._area), _ptr(out), st))
+            return out[:, :, :4]
+        ps = (x[:, self.du.ps_index].double() * self._ps_mul + self._ps_add).contiguous()
         _lib.check(self.lib.cs_metrics_columns(_ptr(p), _ptr(t), n // self.ncol, self.ncol, self.n_out, _ptr(ps), _ptr(self._wa),
                                                _ptr(self._wb), _ptr(self._area), _ptr(out), st))
         return out[:, :, :4]

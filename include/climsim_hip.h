@@ -223,6 +223,12 @@ int cs_loader_stack(const void* mli_dev, const void* mlo_dev, int32_t src_f64, i
 int cs_metrics_columns(const float* pred_dev, const float* target_dev, int64_t n_steps, int32_t ncol, int32_t n_out,
                        const double* ps_dev, const double* wa_dev, const double* wb_dev, const double* area_dev,
                        double* stats_dev, void* stream);
+/* The same with the surface pressure taken inside the kernel from the (normalised) input rows x_dev (n_steps*ncol, n_in) float32:
+ * ps[row] = x[row][ps_index] * ps_mul + ps_add in float64 - data_utils.set_pressure_grid reads state_ps from the input rows
+ * (data_utils.py:1037-1086); saves the caller's gather + conversion passes over the rows.  Needs n_out % 4 == 0 and 16-byte aligned rows. */
+int cs_metrics_columns_x(const float* pred_dev, const float* target_dev, int64_t n_steps, int32_t ncol, int32_t n_out,
+                         const float* x_dev, int32_t n_in, int32_t ps_index, double ps_mul, double ps_add,
+                         const double* wa_dev, const double* wb_dev, const double* area_dev, double* stats_dev, void* stream);
 
 /* ---- many trials per GPU / ensembles: K members, ONE grouped launch per kernel kind --------------------------------
  * The reference searches ~8k small MLPs, five worker processes per GPU (hpo_baseline_v1.py:221-245, 255-260, batch

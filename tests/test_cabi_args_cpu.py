@@ -90,6 +90,7 @@ def test_group_loader_metrics_dp_and_cnn_entries(lib):
     bad(lib, lib.cs_loader_stack(f8, None, 1, 1, 1, 1, f8, f8, 0, None, None, None, None, None), b"no output")
     bad(lib, lib.cs_loader_stack(f8, None, 1, 70000, 1, 1, f8, f8, 0, None, None, f8, None, None), b"bad sizes")
     bad(lib, lib.cs_metrics_columns(None, None, 1, 1, 1, None, None, None, None, None, None))
+    bad(lib, lib.cs_metrics_columns_x(None, None, 1, 1, 1, None, 124, 120, 1.0, 0.0, None, None, None, None, None))
     bad(lib, lib.cs_normalise_rows(None, None, 1, 1, None, None, None, None))
     bad(lib, lib.cs_categorical_accuracy(None, None, 1, 1, None, 0, None))
     bad(lib, lib.cs_dp_unique_id(b"/nonexistent/librccl.so", C.create_string_buffer(128)), b"cannot load RCCL")

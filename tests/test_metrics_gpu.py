@@ -35,6 +35,13 @@ def test_device_metrics_match_host_pipeline(lowres_assets, T):
         d.create_metrics_df("scoring")
     gm = GpuMetrics(d)
     stats = gm.column_stats(p, y, x).cpu().numpy()                 # (384, 128, 4)
+    # round 5: float32 input rows take cs_metrics_columns_x (surface pressure read inside the kernel); float64 rows the entry that is
+    # handed a prepared float64 pressure array - the same float64 arithmetic either way
+    assert x.dtype == np.float32
+    via_ps = gm.column_stats(p, y, x.astype(np.float64)).cpu().numpy()
+    both = np.isfinite(stats) & np.isfinite(via_ps)
+    np.testing.assert_allclose(stats[both], via_ps[both], rtol=1e-10, atol=1e-13)      # (float64 atomics arrive in any order)
+    assert np.array_equal(np.isfinite(stats), np.isfinite(via_ps))
     at = 0
     for v in d.target_vars:
         ln = d.var_lens[v]
