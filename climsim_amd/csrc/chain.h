@@ -68,7 +68,7 @@ struct ChainArgs {
     int fused;               // forward half: dz of the heads also goes to LDS, loss scratch moves to the bias block;
                              // backward half: no prologue load (dz is in X) and no L2 warm-up (a prefetch of Wb issued during
                              // the forward half would sit in front of that half's weight stream: memory operations complete in order)
-    int ablate;              // timing experiments only (CS_CHAIN_ABLATE): 4 no global stores, 8 no warm-up, 128 no contraction split in 128-wide stages
+    int ablate;              // timing experiments only (CS_CHAIN_ABLATE): 4 no global stores, 8 no warm-up, 128 no contraction split in 128-wide stages, 256 half the weight bytes from L2 (chain_trunk)
     int store_nt;            // activations / gradients leave with the non-temporal policy (host: batches the L2s cannot hold anyway)
     int trunk_i0, trunk_n;   // stages trunk_i0 .. trunk_i0 + trunk_n - 1 run as ONE continuous weight stream (chain_trunk; 0 / 0: off)
     unsigned long long* dbg; // optional [grid][64] s_memtime stamps (CS_CHAIN_DBG), null in production
@@ -520,12 +520,15 @@ __device__ __forceinline__ void chain_trunk(u16* X, const float* bias_lds, const
         }                                                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
         {                                                                                                      \
-            const unsigned long long rb_ = refill ? rbase + (unsigned long long)((d) * STEPB) : 0ull;          \
+            const unsigned long long rb_ = refill ? rbase + (unsigned long long)(((d) & dmask) * STEPB) : 0ull;  \
             asm volatile("s_cmp_eq_u64 %3, 0\n\ts_cbranch_scc1 1f\n\ts_nop 2\n\t"                              \
                          "global_load_dwordx4 %0, %2, %3" CHAIN_LOAD_MOD "\n\tglobal_load_dwordx4 %1, %2, %3 offset:1024" CHAIN_LOAD_MOD "\n1:" \
                          : "+v"(Q0), "+v"(Q1) : "v"(voff), "s"(rb_) : "memory", "scc");                        \
         }                                                                                                      \
     }
+    // (CS_CHAIN_ABLATE & 256, timing only: every odd k16-step re-reads the even step's fragments - an L1 hit - so a workgroup pulls HALF
+    //  the weight bytes from L2 for the same MFMAs: what a stage would cost if two CUs shared its weight stream, before any hand-off)
+    const unsigned dmask = (p.ablate & 256) ? ~1u : ~0u;
     for (int st = 0; st < cnt; ++st) {
         const ChainStage& S = p.st[i0 + st];
         const bool cont = st > 0, has_next = st + 1 < cnt, last = (i0 + st + 1 == p.n_stages);

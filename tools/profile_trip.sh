@@ -10,9 +10,9 @@ echo "== sweep"; rm -f gpurun_out/${R}_bench_sweep.jsonl
 for b in 1024 3072 4096 8192 16384 32768 65536; do
   timeout 600 python bench.py --batch $b --steps 100 --warmup 10 --cpu-budget 0 --no-extras 2>&1 | tail -1 >> gpurun_out/${R}_bench_sweep.jsonl
 done
-python - <<'PY'
-import json
-for line in open('gpurun_out/${R}_bench_sweep.jsonl'):
+R=$R python - <<'PY'
+import json, os
+for line in open('gpurun_out/%s_bench_sweep.jsonl' % os.environ['R']):
     try: d=json.loads(line)
     except Exception: print(line[:200]); continue
     print(d['config']['per_gpu_batch'], d['value'], d['ms_per_step'], {k:round(v['ms_per_step']*1e3,1) for k,v in d['kernels'].items()})

@@ -1,7 +1,6 @@
 #!/bin/bash
 mkdir -p gpurun_out
 {
-echo "== metrics tests"; timeout 600 python -m pytest tests/test_metrics_gpu.py tests/test_accept_real_gpu.py -x -q -m gpu 2>&1 | tail -5
-for v in 1 1 0; do echo "== CS_METRICS_V5=$v"; CS_METRICS_V5=$v timeout 120 python bench_metrics.py 2>&1 | tail -1 | cut -c1-220; done
-} > gpurun_out/r05_metrics.log 2>&1
-cat gpurun_out/r05_metrics.log
+for ab in 0 4 16 20 0 4; do echo "== CS_CHAIN_ABLATE=$ab"; CS_CHAIN_ABLATE=$ab timeout 120 python tools/step_time.py 8192 2>&1 | grep -v amdgpu | tail -1; done
+} > gpurun_out/r05_chain_ablate.log 2>&1
+cat gpurun_out/r05_chain_ablate.log
