@@ -412,9 +412,13 @@ __device__ __forceinline__ void wgrad3_body(const WgradArgs& pa, const int work,
     }
 #pragma unroll
         for (int st = 0; st < SLOTS - 1; ++st) WG3_ISSUE(st)
+        // Barrier protocol (round 5, the same count in both roles): [stage 0 landed] then one per stage t: [stage t + 1 landed; the slot of
+        // stage t - 1 is free] - the compute waves read the fragments of stage t + 1's first steps under the last MFMAs of stage t.
+        asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * PPL * (SLOTS - 2)) : "memory");
+        __builtin_amdgcn_s_barrier();
         for (int t = 0; t < nst; ++t) {
-            // stage t has landed: SLOTS - 2 younger stages (2 * PPL pieces each from this wave) may still be in flight
-            asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * PPL * (SLOTS - 2)) : "memory");
+            // stage t + 1 has landed: SLOTS - 3 younger stages (2 * PPL pieces each from this wave) may still be in flight
+            asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * PPL * (SLOTS - 3)) : "memory");
             __builtin_amdgcn_s_barrier();                             // ... and the compute waves are done with stage t - 1
             WG3_ISSUE(t + SLOTS - 1)                                  // into its slot
         }
@@ -443,25 +447,76 @@ __device__ __forceinline__ void wgrad3_body(const WgradArgs& pa, const int work,
 #pragma unroll
     for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
 
-    for (int s = 0; s < nst; ++s) {
-        __builtin_amdgcn_s_barrier();
-        if (pa.ablate & 4) continue;                                  // timing experiment: requests and barriers only
-        const u16* Hs = ring + (s & (SLOTS - 1)) * STAGE_ELEMS;
-        const u16* Zs = Hs + R * 128;
+    // Compute loop, written out in `asm volatile` (round 5).  hipcc's schedule of the builtin form read the eight fragment pieces of a
+    // 16-row step, waited for them and only then issued the step's four MFMAs - with ONE compute wave per SIMD every step paid a full
+    // LDS latency (contraction alone, operands stale in LDS: 21.9 us for 11-13 us of MFMAs at 8192 columns).  Here two fragment sets
+    // alternate (even / odd steps); a fragment takes the rows of step + 2 right behind its last MFMA of this step, so a set has a whole
+    // step of MFMAs to land, and the last two steps of a stage fetch the first two of the NEXT stage (the barrier in front of a stage
+    // says that the next one has landed: see the loader).  LDS returns in order: `lgkmcnt(8)` = the set about to be used is there
+    // (the eight younger reads are the other set's).  A fragment = two transposing 64-bit reads, 4 rows (1 KiB) apart.
+    if (nst > 0 && !(pa.ablate & 4)) {
+        typedef unsigned long long u64_t;
+        union Frag { bf16x8_t v; u64_t h[2]; };
+        Frag ah_[2], az_[2], bh_[2], bz_[2];
+        unsigned adh[2], adz[2];                        // byte addresses of this lane's fragment pieces, step 0 of the slot being read
+        {
+            const int col = 16 * ((lane >> 4) & 1) + (lane & 3) * 4, m = 8 * (lane >> 5) + ((lane & 15) >> 2);
 #pragma unroll
-        for (int kk = 0; kk < R / 16; ++kk) {
-            bf16x8_t fh[2], fz[2];
+            for (int i = 0; i < 2; ++i) adh[i] = lds0 + 2u * (unsigned)swz_tn(m, wk * 64 + i * 32 + col);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) fh[i] = frag_w3(Hs, kk * 16, wk * 64 + i * 32, lane);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) fz[j] = frag_w3(Zs, kk * 16, wn * 64 + j * 32, lane);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[i], fz[j], acc[i][j], 0, 0, 0);
-            if (do_bias) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, wk ? fz[1] : fz[0], accb, 0, 0, 0);
+            for (int j = 0; j < 2; ++j) adz[j] = lds0 + (unsigned)(R * 256) + 2u * (unsigned)swz_tn(m, wn * 64 + j * 32 + col);
         }
+        constexpr int S = R / 16;                       // 16-row steps per stage (4 or 2)
+#define W3_RD(F, A, OFF) asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4" \
+                                      : "=v"((F).h[0]), "=v"((F).h[1]) : "v"(A), "n"(OFF), "n"((OFF) + 1024));
+#define W3_MM(i, j, FH, FZ) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"((FH).v), "v"((FZ).v));
+        // (`ones` is an in/out operand: as a plain input hipcc re-created it in front of every bias MFMA and used one of its registers as a
+        //  scratch in between - while the MFMA issued just before, still waiting behind two others in the pipe, had not read it yet)
+#define W3_MB(FZ) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(accb), "+v"(ones) : "v"((FZ).v));
+        // one step on set (H0, H1, Z0, Z1); its fragments then take the rows at byte offset NOFF from the addresses (step + 2).
+        // The bias MFMA sits where ANOTHER MFMA that reads the same dZ fragment still follows it (an MFMA issued while others are in the
+        // pipe reads its operands when it starts, not when it is issued: nothing may rewrite them right behind it).
+#define W3_STEP(H0, H1, Z0, Z1, NOFF)                                                                  \
+        asm volatile("s_waitcnt lgkmcnt(8)");                                                           \
+        W3_MM(0, 0, H0, Z0)                                                                             \
+        if (do_bias && !wk) { W3_MB(Z0) }                                                               \
+        W3_MM(0, 1, H0, Z1)                                                                             \
+        if (do_bias && wk) { W3_MB(Z1) }                                                                \
+        W3_RD(H0, adh[0], NOFF)                                                                         \
+        W3_MM(1, 0, H1, Z0)                                                                             \
+        W3_RD(Z0, adz[0], NOFF)                                                                         \
+        W3_MM(1, 1, H1, Z1)                                                                             \
+        W3_RD(Z1, adz[1], NOFF) W3_RD(H1, adh[1], NOFF)
+        __builtin_amdgcn_s_barrier();                   // stage 0 has landed
+        W3_RD(ah_[0], adh[0], 0) W3_RD(az_[0], adz[0], 0) W3_RD(az_[1], adz[1], 0) W3_RD(ah_[1], adh[1], 0)
+        W3_RD(bh_[0], adh[0], 4096) W3_RD(bz_[0], adz[0], 4096) W3_RD(bz_[1], adz[1], 4096) W3_RD(bh_[1], adh[1], 4096)
+        int slot = 0;
+        for (int s = 0; s < nst; ++s) {
+            __builtin_amdgcn_s_barrier();               // stage s + 1 has landed; the slot of stage s - 1 is the loaders'
+            if (S == 4) {
+                W3_STEP(ah_[0], ah_[1], az_[0], az_[1], 2 * 4096)
+                W3_STEP(bh_[0], bh_[1], bz_[0], bz_[1], 3 * 4096)
+            }
+            const int nslot = slot + 1 == SLOTS ? 0 : slot + 1;
+            const unsigned delta = (unsigned)((nslot - slot) * (STAGE_ELEMS * 2));
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { adh[i] += delta; adz[i] += delta; }
+            slot = nslot;
+            W3_STEP(ah_[0], ah_[1], az_[0], az_[1], 0)          // the stage's last two steps: reloads fetch steps 0, 1 of stage s + 1
+            W3_STEP(bh_[0], bh_[1], bz_[0], bz_[1], 4096)
+        }
+        // the fragments read past the last stage are never used: operands here so that their registers stay theirs until the reads have
+        // retired; the last MFMA's result is written (no hazard check sees an asm MFMA)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7"
+                     : "+v"(ah_[0].v), "+v"(ah_[1].v), "+v"(az_[0].v), "+v"(az_[1].v), "+v"(bh_[0].v), "+v"(bh_[1].v), "+v"(bz_[0].v), "+v"(bz_[1].v)
+                     :: "memory");
+#undef W3_RD
+#undef W3_MM
+#undef W3_MB
+#undef W3_STEP
+    } else if (nst > 0) {
+        __builtin_amdgcn_s_barrier();
+        for (int s = 0; s < nst; ++s) __builtin_amdgcn_s_barrier();  // timing experiment (CS_WGRAD_ABLATE & 4): requests and barriers only
     }
     if (nst > 0) __builtin_amdgcn_s_barrier();                        // pairs with the loaders' last barrier
     if (pa.ablate & 1) {

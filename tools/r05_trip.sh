@@ -1,6 +1,3 @@
 #!/bin/bash
 mkdir -p gpurun_out
-{
-for ab in 0 4 16 20 0 4; do echo "== CS_CHAIN_ABLATE=$ab"; CS_CHAIN_ABLATE=$ab timeout 120 python tools/step_time.py 8192 2>&1 | grep -v amdgpu | tail -1; done
-} > gpurun_out/r05_chain_ablate.log 2>&1
-cat gpurun_out/r05_chain_ablate.log
+timeout 2400 python -m pytest tests/test_mlp_gpu.py tests/test_mlp_large_gpu.py tests/test_group_gpu.py tests/test_hpo_gpu.py tests/test_coop_gpu.py tests/test_dp_gpu.py tests/test_online_mlp_gpu.py tests/test_stream_gpu.py tests/test_dp_two_ranks_gpu.py -x -q -m gpu 2>&1 | grep -E "passed|failed|Error|error" | tail -5 > gpurun_out/r05_parity.log; cat gpurun_out/r05_parity.log
