@@ -94,6 +94,32 @@ class GpuColumnLoader:
                                                 _ptr(x[lo * ncol:]) if want_x else None, _ptr(y[lo * ncol:]) if want_y else None, st))
         return x, y
 
+    def stack_raw_sliced(self, mli_raw, mlo_raw, extra_rows: int = 0):
+        """The rows of `stack_raw` produced a few timesteps at a time: returns (x, y, run) with x, y allocated (uninitialised) and
+        `run(t_lo, t_hi)` launching the loader for timesteps [t_lo, t_hi) on the CURRENT stream into their rows.  The streamed trainer
+        (stream.py, loader_on="gaps") spreads a chunk's loader over the steps of the chunk in front.  Device tensors only."""
+        import torch
+        a, b = mli_raw, mlo_raw
+        if isinstance(a, np.ndarray) or isinstance(b, np.ndarray):
+            raise ValueError("stack_raw_sliced takes device tensors")
+        a, b = a.contiguous(), b.contiguous()
+        if a.dtype not in (torch.float64, torch.float32) or b.dtype != a.dtype:
+            raise ValueError("raw fields must be float64 or float32 (both the same)")
+        T, fin, ncol = a.shape
+        if fin != self.n_in or tuple(b.shape) != (T, self.n_out, ncol):
+            raise ValueError(f"expected (T,{self.n_in},ncol) and (T,{self.n_out},ncol)")
+        x = torch.empty((T * ncol + extra_rows, self.n_in), dtype=torch.float32, device=self.device)
+        y = torch.empty((T * ncol + extra_rows, self.n_out), dtype=torch.float32, device=self.device)
+        f64 = int(a.dtype == torch.float64)
+
+        def run(t_lo: int, t_hi: int):
+            st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            _lib.check(self.lib.cs_loader_stack(_ptr(a[t_lo:t_hi]), _ptr(b[t_lo:t_hi]), f64, t_hi - t_lo, ncol, self.n_in, _ptr(self._sub),
+                                                _ptr(self._div), self.n_out, _ptr(self._tend), _ptr(self._scale),
+                                                _ptr(x[t_lo * ncol:]), _ptr(y[t_lo * ncol:]), st))
+        run.keep = (a, b)
+        return x, y, run
+
     def load_files(self, files: Sequence[str]):
         """The rows `save_as_npy` would write for these mli files, as float32 device tensors."""
         raws = [self.read_raw(f) for f in files]

@@ -43,13 +43,21 @@ class StreamedTrainer:
         import os
         import torch
         self.loader_on = loader_on or os.environ.get("CS_STREAM_LOADER", "main")
-        if self.loader_on not in ("main", "side"):
-            raise ValueError("loader_on must be 'main' or 'side'")
+        if self.loader_on not in ("main", "side", "gaps"):
+            raise ValueError("loader_on must be 'main', 'side' or 'gaps'")
+        # "gaps" (round 5, an experiment that is kept for its measurement - profiles/r05_stream_gaps.txt): the loader of chunk k + 1
+        # is cut into `gap_slices` launches of a few timesteps each, and launch j goes out on the side stream gated on an event of the
+        # training stream inside step j of chunk k: `gap_at` = "opt" (between the weight-gradient kernel and the optimiser: the slice
+        # runs beside k_optimizer) or "chain" (in front of the step: the slice runs beside the layer chain).
+        self.gap_at = os.environ.get("CS_STREAM_GAP", "opt")
+        self.gap_slices = int(os.environ.get("CS_STREAM_SLICES", "0"))        # 0 = one slice per timestep
+        if self.gap_at not in ("opt", "chain"):
+            raise ValueError("CS_STREAM_GAP must be 'opt' or 'chain'")
         if slots < 2:
             raise ValueError("need at least two chunk slots (one being produced while one is consumed)")
         if batch_size > model.max_batch:
             raise ValueError(f"batch {batch_size} exceeds the engine's max_batch {model.max_batch}")
-        if getattr(model, "cooperative", False) and self.loader_on == "side":
+        if getattr(model, "cooperative", False) and self.loader_on != "main":
             # the loader kernel on the side stream occupies compute units while the step runs: a cooperative launch
             # (CS_FLAG_COOP), whose workgroups wait for one another, could be starved into a time-out
             raise ValueError("StreamedTrainer drives a side stream: build the model with cooperative=False")
@@ -93,7 +101,7 @@ class StreamedTrainer:
                 a = torch.from_numpy(np.ascontiguousarray(a)).pin_memory()
                 return a.to(self.device, non_blocking=True)
             return a
-        if self.loader_on == "main":
+        if self.loader_on in ("main", "gaps"):
             # Host chunks: staged and copied on the side stream NOW (gated on the chunk that used this slot: at most `slots` raw
             # chunks are ever staged, however far the host runs ahead), so the copy overlaps the steps of the chunk in front.  The
             # loader kernel and the wait for the copy are issued by _consume, behind those steps (`ready` = None marks the
@@ -158,6 +166,7 @@ class StreamedTrainer:
             self.rows_dropped += n_have - n
             if n <= 0:
                 raise ValueError("a rank produced an empty chunk")
+        gap = self._gap_open() if self.loader_on == "gaps" else None
         step = step0
         # one [sum sq err, sum abs err] slot per step: the engine writes them, nothing is launched to add them up
         sums = torch.zeros((passes * ((n + self.batch - 1) // self.batch), 2), dtype=torch.float32, device=self.device)
@@ -189,7 +198,15 @@ class StreamedTrainer:
             for lo in range(0, n_train, self.batch):
                 idx = perm[lo:lo + self.batch]
                 lr = lr_of_step(step)
-                if self.dist is None:
+                if gap is not None and gap["next"] < len(gap["cuts"]) - 1 and self.dist is None:
+                    if self.gap_at == "chain":
+                        self._gap_slice(gap, main)
+                        self.model.train_on_batch(x, y, lr, row_idx=idx, loss=sums[k])
+                    else:
+                        self.model.loss_grads(x, y, row_idx=idx, loss=sums[k])
+                        self._gap_slice(gap, main)
+                        self.model.apply_gradients(lr, 1.0 / (self.model.output_length * idx.numel()))
+                elif self.dist is None:
                     self.model.train_on_batch(x, y, lr, row_idx=idx, loss=sums[k])
                 else:
                     self.model.loss_grads(x, y, row_idx=idx, loss=sums[k])
@@ -197,11 +214,45 @@ class StreamedTrainer:
                     self.model.apply_gradients(lr, 1.0 / (self.model.output_length * idx.numel() * self.world))
                 step += 1
                 k += 1
+        if gap is not None:                          # slices the chunk's steps did not reach, then the promise the next _consume waits for
+            while gap["next"] < len(gap["cuts"]) - 1:
+                self._gap_slice(gap, main)
+            ready2 = torch.cuda.Event()
+            ready2.record(self.side)
+            self._ring[0] = (gap["x"], gap["y"], ready2)
         self._mark("steps")
         done = torch.cuda.Event()
         done.record(main)
         self.rows_seen += n_train * passes
         return done, step
+
+    # ---- loader_on == "gaps": the next chunk's loader in slices beside this chunk's steps
+    def _gap_open(self):
+        ring = self._ring
+        if not ring or ring[0][2] is not None:
+            return None
+        (mli, mlo), copied, _ = ring[0]
+        if mlo is None:
+            return None
+        if copied is not None:                       # a host chunk: its copy runs on the side stream, in front of the slices
+            pass
+        x2, y2, run = self.loader.stack_raw_sliced(mli, mlo, extra_rows=self.batch if self._carrying else 0)
+        for a in (x2, y2, mli, mlo):
+            a.record_stream(self.side)
+        T = int(mli.shape[0])
+        ns = min(T, self.gap_slices) if self.gap_slices > 0 else T
+        cuts = [T * i // ns for i in range(ns + 1)]
+        return {"x": x2, "y": y2, "run": run, "cuts": cuts, "next": 0}
+
+    def _gap_slice(self, gap, main):
+        torch = self.torch
+        e = torch.cuda.Event()
+        e.record(main)
+        self.side.wait_event(e)
+        j = gap["next"]
+        with torch.cuda.stream(self.side):
+            gap["run"](gap["cuts"][j], gap["cuts"][j + 1])
+        gap["next"] = j + 1
 
     def _flush_carry(self, lr_of_step, step):
         """The rows still carried when the pass ends: its one short batch (the reference's last batch of an epoch)."""
@@ -236,7 +287,7 @@ class StreamedTrainer:
         self._carrying = self.carry and passes_per_chunk == 1
         self._carry_n = 0
         it = iter(chunks)
-        ring = []                                  # [(x, y, ready)] produced, not yet consumed
+        ring = self._ring = []                     # [(x, y, ready)] produced, not yet consumed
         free = []                                  # `done` events of consumed chunks, oldest first
         step = step_start = self.model.iterations
         produced = 0

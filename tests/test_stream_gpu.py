@@ -10,10 +10,16 @@ pytestmark = pytest.mark.gpu
 from test_loader_cpu import make, raw_tree  # noqa: E402,F401
 
 
-@pytest.mark.parametrize("loader_on", ["main", "side"])
-def test_streamed_training_equals_materialised_training(raw_tree, lowres_assets, loader_on):
+@pytest.mark.parametrize("loader_on", ["main", "side", "gaps", "gaps-chain", "gaps-opt-3"])
+def test_streamed_training_equals_materialised_training(raw_tree, lowres_assets, loader_on, monkeypatch):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
+    if loader_on.startswith("gaps-"):               # the next chunk's loader in slices beside this chunk's steps (round 5)
+        parts = loader_on.split("-")
+        monkeypatch.setenv("CS_STREAM_GAP", parts[1])
+        if len(parts) > 2:
+            monkeypatch.setenv("CS_STREAM_SLICES", parts[2])
+        loader_on = "gaps"
     from climsim_amd import build
     build.build()
     from climsim_amd.loader import GpuColumnLoader

@@ -1,3 +1,14 @@
 #!/bin/bash
+# scratch: streamed training with the next chunk's loader in slices inside the steps' gaps
 mkdir -p gpurun_out
-timeout 2400 python -m pytest tests/test_mlp_gpu.py tests/test_mlp_large_gpu.py tests/test_group_gpu.py tests/test_hpo_gpu.py tests/test_coop_gpu.py tests/test_dp_gpu.py tests/test_online_mlp_gpu.py tests/test_stream_gpu.py tests/test_dp_two_ranks_gpu.py -x -q -m gpu 2>&1 | grep -E "passed|failed|Error|error" | tail -5 > gpurun_out/r05_parity.log; cat gpurun_out/r05_parity.log
+timeout 900 python -m pytest tests/test_stream_gpu.py -x -q 2>&1 | tail -5
+O=gpurun_out/r05_stream_gaps.txt; : > $O
+for rep in 1 2; do
+for cfg in "main opt 0" "gaps opt 0" "gaps opt 4" "gaps chain 0" "gaps chain 4" "side opt 0"; do
+  set -- $cfg
+  echo "== CS_STREAM_LOADER=$1 CS_STREAM_GAP=$2 CS_STREAM_SLICES=$3" >> $O
+  CS_STREAM_LOADER=$1 CS_STREAM_GAP=$2 CS_STREAM_SLICES=$3 timeout 300 python bench_stream.py 2>&1 | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print({k:d[k] for k in ('value','ratio_to_train_only','ratio_to_serial_sum','loader_share_hidden')}, d.get('passes',{}).get('stream_ms'))" >> $O
+done; done
+cat $O
