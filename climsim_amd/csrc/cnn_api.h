@@ -21,7 +21,6 @@ struct cs_cnn {
     u16 *A0 = nullptr, *X = nullptr, *A1 = nullptr, *R = nullptr, *XN = nullptr, *O10 = nullptr, *DZO = nullptr;
     float *wd = nullptr, *bd = nullptr;  // fused heads: [10][10], [10]
     u16* zeros = nullptr;                // zero page (k_conv2 fetches out-of-column rows from it)
-    int cw_waves = 8;                    // waves per workgroup of k_conv_wgrad2 (CS_CW2_WAVES=4: 128 x 112 wave tiles, measured slower)
     bool tile128 = false;                // CS_CNN_FLAG_TILE128: the 128x128 kernels everywhere (A/B and parity runs)
     int conv_ablate = 0;                 // CS_CONV_ABLATE (development)
     int cpw = 0;                         // contraction pad of the trunk channels (32- or 64-granular)
@@ -29,7 +28,13 @@ struct cs_cnn {
     CnnSeg* seg_dev = nullptr; int n_seg = 0, opt_blocks = 0, opt_blocks2 = 0, opt_pitch = 40; bool opt_tiles = false;
     ConvWgradItem* items_dev = nullptr; int n_items = 0, total_tiles = 0;
     CwTile* cw_tiles_dev = nullptr; int n_cw_tiles = 0, n_cu = 256;      // conv_wgrad2.h
-    int* cw_prefix_dev = nullptr; int n_cw_convs = 0, cw_splits = 0;
+    int n_cw_convs = 0, cw_splits = 0;
+    std::vector<int> cw_prefix;          // tiles of conv c: [cw_prefix[c], cw_prefix[c + 1])
+    CwWork* cw_work_dev = nullptr; int cw_work_slabs = -1;   // work queues of k_conv_wgrad2l for cw_work_slabs slabs of 32 rows
+    std::vector<CwWork> cw_work; int cw_qbegin[9] = {0}; int cw_longest = 0;
+    int* cw_counters = nullptr;          // [8] queue heads of the persistent launch
+    int cw_rounds = 4; float cw_taper = 0.8f; bool cw_persist = true;   // CS_CNN_WGRAD_ROUNDS, CS_CNN_WGRAD_TAPER, CS_CW2_PERSIST
+    unsigned long long* cw_dbg = nullptr; int cw_dbg_grid = 0;   // CS_CNN_DBG: [CW_DBG_GRID][CW_DBG_SLOTS] stamps of k_conv_wgrad2l, grid of the last launch
     std::vector<CnnBlockBufs> blk;
     std::vector<u16*> Wd_a, Wd_b;    // per block data-gradient packs: [512][4*cp] (a flipped + r), [512][3*cp]
     u16* Wd_o = nullptr;             // [512][64]
@@ -51,6 +56,75 @@ constexpr int CNN_A0_LD = 128;       // pitch of the 6-channel input rows
 inline unsigned host_lowbias32(unsigned x) {
     x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
     return x;
+}
+
+// Work table of the conv weight-gradient launch (conv_wgrad2.h) for a batch of `slabs` 32-row slabs.
+//   * a GROUP = the tiles of one conv over one row range (10 tiles for a 3-tap trunk conv): consecutive workgroups of ONE XCD, so
+//     that the five tiles with the same dZ columns and the two with the same H columns meet in that L2;
+//   * about cw_rounds entries per CU in all, but ranges of unequal length - per conv `s` ranges whose lengths fall linearly by
+//     +-cw_taper around the mean, shifted from conv to conv so that the lengths of all groups form a ramp, not s levels - and every
+//     queue runs longest first: the CUs do not finish in rounds (equal workgroups: 4.34 rounds cost 5, and all 256 flushes of a
+//     round met in the memory system), the short ranges fill the end;
+//   * eight queues, one per XCD (block b runs on XCD b % 8); the persistent workgroups of an XCD take its entries in order.
+// CS_CNN_WGRAD_SPLITS=s: s equal ranges per tile (rounds 2-4) in the same queue form.
+#define CW_MAX_WORK 16384
+#define CW_DBG_GRID 2048
+static void cnn_build_cw_work(cs_cnn* h, int slabs) {
+    struct Group { int conv, s0, s1; };
+    std::vector<Group> groups;
+    const int nconv = h->n_cw_convs;
+    const int min_len = 8;
+    if (h->cw_splits > 0) {
+        const int s = std::max(1, std::min(h->cw_splits, std::max(1, slabs / min_len)));
+        for (int c = 0; c < nconv; ++c)
+            for (int i = 0; i < s; ++i) groups.push_back({c, (int)((int64_t)slabs * i / s), (int)((int64_t)slabs * (i + 1) / s)});
+    } else {
+        const double per_wg = (double)h->n_cw_tiles * slabs / ((double)h->cw_rounds * h->n_cu);   // mean slabs per workgroup
+        const double sf = std::max(1.0, slabs / std::max(per_wg, 1.0));                              // ranges per conv, fractional
+        double want = 0, given = 0;
+        for (int c = 0; c < nconv; ++c) {
+            const int tiles = h->cw_prefix[c + 1] - h->cw_prefix[c];
+            want += sf * tiles;
+            int s = (int)std::floor((want - given) / tiles + 0.5);
+            s = std::max((int)std::floor(sf), std::min(s, (int)std::ceil(sf)));
+            s = std::max(1, std::min(s, std::max(1, slabs / min_len)));
+            given += (double)s * tiles;
+            // lengths proportional to 1 + taper * (1 - 2 (i + phase) / s), i = 0 the longest; phase in [0, 1) differs from conv to conv
+            double tot = 0, run = 0;
+            const double phase = std::fmod(0.5 + c * 0.6180339887, 1.0);
+            std::vector<double> w(s);
+            for (int i = 0; i < s; ++i) { w[i] = s > 1 ? 1.0 + h->cw_taper * (1.0 - 2.0 * (i + phase) / s) : 1.0; tot += w[i]; }
+            int lo = 0;
+            for (int i = 0; i < s; ++i) {
+                run += w[i];
+                int hi = i == s - 1 ? slabs : (int)std::floor(slabs * run / tot + 0.5);
+                hi = std::max(hi, std::min(slabs, lo + 1));
+                if (hi > lo) groups.push_back({c, lo, hi});
+                lo = hi;
+            }
+        }
+    }
+    // longest first, each group to the queue with the least work so far (work = tiles x (slabs + the ~20 slabs an entry costs besides
+    // its loop)): the queues end together, and each runs its long entries first
+    std::stable_sort(groups.begin(), groups.end(), [](const Group& a, const Group& b) { return a.s1 - a.s0 > b.s1 - b.s0; });
+    std::vector<std::vector<CwWork>> q(8);
+    double load[8] = {0};
+    for (size_t g = 0; g < groups.size(); ++g) {
+        const Group& G = groups[g];
+        const int tiles = h->cw_prefix[G.conv + 1] - h->cw_prefix[G.conv];
+        int x = 0;
+        for (int i = 1; i < 8; ++i) if (load[i] < load[x]) x = i;
+        load[x] += (double)tiles * (G.s1 - G.s0 + 20);
+        for (int t = h->cw_prefix[G.conv]; t < h->cw_prefix[G.conv + 1]; ++t) q[x].push_back({t, G.s0, G.s1, 0});
+    }
+    h->cw_work.clear();
+    h->cw_longest = 0;
+    for (int x = 0; x < 8; ++x) {
+        h->cw_qbegin[x] = (int)h->cw_work.size();
+        h->cw_work.insert(h->cw_work.end(), q[x].begin(), q[x].end());
+        h->cw_longest = std::max(h->cw_longest, (int)q[x].size());
+    }
+    h->cw_qbegin[8] = (int)h->cw_work.size();
 }
 
 int cnn_upload_items(cs_cnn* h) {
@@ -104,7 +178,8 @@ int cnn_upload_items(cs_cnn* h) {
         h->n_cw_convs = (int)prefix.size();
         prefix.push_back((int)cw.size());
         HIP_TRY(hipMemcpy(h->cw_tiles_dev, cw.data(), cw.size() * sizeof(CwTile), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(h->cw_prefix_dev, prefix.data(), prefix.size() * sizeof(int), hipMemcpyHostToDevice));
+        h->cw_prefix = prefix;
+        h->cw_work_slabs = -1;
     }
     return CS_OK;
 }
@@ -287,6 +362,9 @@ int cs_cnn_create(cs_cnn_t** out, const cs_cnn_cfg* cfg) {
     h->tile128 = (cfg->flags & CS_CNN_FLAG_TILE128) != 0 || CV2_BM % cfg->seq != 0;
     if (const char* e = getenv("CS_CONV_ABLATE")) h->conv_ablate = atoi(e);
     if (const char* e = getenv("CS_CNN_WGRAD_SPLITS")) h->cw_splits = atoi(e);
+    if (const char* e = getenv("CS_CNN_WGRAD_ROUNDS")) h->cw_rounds = std::max(1, std::min(atoi(e), 16));
+    if (const char* e = getenv("CS_CNN_WGRAD_TAPER")) h->cw_taper = std::max(0.0f, std::min((float)atof(e), 0.9f));
+    if (const char* e = getenv("CS_CNN_DBG")) if (atoi(e)) { HIP_TRY(hipMalloc(&h->cw_dbg, sizeof(unsigned long long) * CW_DBG_GRID * CW_DBG_SLOTS)); h->allocs.push_back(h->cw_dbg); }
     const int kgran = h->tile128 ? 64 : 32;                       // contraction slab of the trunk kernels
     const int C = cfg->channels, cp = (int)round_up(C, kgran), depth = cfg->depth;
     h->cpw = cp;
@@ -294,10 +372,8 @@ int cs_cnn_create(cs_cnn_t** out, const cs_cnn_cfg* cfg) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv2<CONV_PREDICT>), hipFuncAttributeMaxDynamicSharedMemorySize, CV2_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv2<CONV_TRAIN_FWD>), hipFuncAttributeMaxDynamicSharedMemorySize, CV2_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv2<CONV_BWD>), hipFuncAttributeMaxDynamicSharedMemorySize, CV2_LDS_BYTES));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wgrad2<8>), hipFuncAttributeMaxDynamicSharedMemorySize, CW2_LDS_BYTES));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wgrad2<4>), hipFuncAttributeMaxDynamicSharedMemorySize, CW2_LDS_BYTES));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wgrad2l), hipFuncAttributeMaxDynamicSharedMemorySize, CW2_LDS_BYTES));
-    if (const char* e = getenv("CS_CW2_WAVES")) h->cw_waves = atoi(e) == 4 ? 4 : 8;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wgrad2l), hipFuncAttributeMaxDynamicSharedMemorySize, CW2L_LDS_BYTES));
+    if (const char* e = getenv("CS_CW2_PERSIST")) h->cw_persist = atoi(e) != 0;
     {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, cfg->device));
@@ -350,7 +426,8 @@ int cs_cnn_create(cs_cnn_t** out, const cs_cnn_cfg* cfg) {
         A((void**)&h->DZO, sizeof(u16) * h->m_pad_max * 128);
         A((void**)&h->items_dev, sizeof(ConvWgradItem) * (7 * depth + 1));
         A((void**)&h->cw_tiles_dev, sizeof(CwTile) * (32 * depth));
-        A((void**)&h->cw_prefix_dev, sizeof(int) * (3 * depth + 2));
+        A((void**)&h->cw_work_dev, sizeof(CwWork) * CW_MAX_WORK);
+        A((void**)&h->cw_counters, sizeof(int) * 8);
         h->blk.resize(depth);
         h->Wd_a.assign(depth, nullptr);
         h->Wd_b.assign(depth, nullptr);
@@ -581,18 +658,34 @@ int cs_cnn_loss_grads(cs_cnn_t* h, const float* x_dev, int x3d, const float* y_d
     // ---- weight gradients: stream-K over every conv of the step (conv_wgrad2.h) + the 10-channel conv
     if (h->n_cw_tiles > 0) {
         CwArgs ca{};
-        ca.tiles = h->cw_tiles_dev; ca.n_tiles = h->n_cw_tiles; ca.m_rows = m_rows; ca.slabs = (int)(m_pad / 32); ca.seq = seq;
+        ca.tiles = h->cw_tiles_dev; ca.n_tiles = h->n_cw_tiles; ca.m_rows = m_rows; ca.seq = seq;
         ca.zeros = h->zeros;
-        ca.conv_prefix = h->cw_prefix_dev; ca.n_convs = h->n_cw_convs;
-        // row splits: enough workgroups for >= 4 rounds of the CUs (tail loss <= ~1/8), at least 8 slabs each
-        int splits = h->cw_splits > 0 ? h->cw_splits : (4 * h->n_cu + ca.n_tiles - 1) / ca.n_tiles;
-        splits = std::max(1, std::min(splits, ca.slabs / 8 > 0 ? ca.slabs / 8 : 1));
-        ca.splits = splits;
-        const int grid = ca.n_tiles * splits;
-        static const bool loaders = !(getenv("CS_CW2_LOADERS") && atoi(getenv("CS_CW2_LOADERS")) == 0);
-        if (h->cw_waves == 8 && loaders) hipLaunchKernelGGL(k_conv_wgrad2l, dim3((unsigned)grid), dim3(512 + 64 * CW2L_LOADERS), CW2_LDS_BYTES, st, ca);
-        else if (h->cw_waves == 8) hipLaunchKernelGGL(k_conv_wgrad2<8>, dim3((unsigned)grid), dim3(512), CW2_LDS_BYTES, st, ca);
-        else hipLaunchKernelGGL(k_conv_wgrad2<4>, dim3((unsigned)grid), dim3(256), CW2_LDS_BYTES, st, ca);
+        ca.dbg = nullptr;
+        const int slabs = (int)(m_pad / 32);
+        if (slabs != h->cw_work_slabs) {
+            cnn_build_cw_work(h, slabs);
+            // (pageable source: the copy has left the vector when the call returns; earlier launches that read the old table are
+            //  in front of it on the same stream)
+            HIP_TRY(hipMemcpyAsync(h->cw_work_dev, h->cw_work.data(), h->cw_work.size() * sizeof(CwWork), hipMemcpyHostToDevice, st));
+            h->cw_work_slabs = slabs;
+        }
+        ca.work = h->cw_work_dev;
+        for (int x = 0; x < 9; ++x) ca.q_begin[x] = h->cw_qbegin[x];
+        int grid;
+        if (h->cw_persist) {                                   // one workgroup per CU (158 KB of LDS each), entries taken from the queues
+            HIP_TRY(hipMemsetAsync(h->cw_counters, 0, sizeof(int) * 8, st));
+            ca.counters = h->cw_counters;
+            grid = std::min(h->n_cu, (int)h->cw_work.size());
+            grid = std::max(8, (grid + 7) / 8 * 8);
+        } else {
+            ca.counters = nullptr;
+            grid = 8 * h->cw_longest;
+        }
+        if (h->cw_dbg && grid <= CW_DBG_GRID) {
+            HIP_TRY(hipMemsetAsync(h->cw_dbg, 0, sizeof(unsigned long long) * grid * CW_DBG_SLOTS, st));
+            ca.dbg = h->cw_dbg; h->cw_dbg_grid = grid;
+        }
+        hipLaunchKernelGGL(k_conv_wgrad2l, dim3((unsigned)grid), dim3(512 + 64 * CW2L_LOADERS), CW2L_LDS_BYTES, st, ca);
     }
     ConvWgradArgs wa{};
     wa.items = h->items_dev; wa.n_items = h->n_items; wa.m_rows = m_rows; wa.m_pad = m_pad; wa.seq = seq;
@@ -604,6 +697,16 @@ int cs_cnn_loss_grads(cs_cnn_t* h, const float* x_dev, int x3d, const float* y_d
     wa.splitk = splitk; wa.use_atomics = 1;
     hipLaunchKernelGGL(k_conv_wgrad, dim3((unsigned)(h->total_tiles * splitk)), dim3(256), 0, st, wa);
     HIP_TRY(hipGetLastError());
+    return CS_OK;
+}
+
+int cs_cnn_debug_stamps(cs_cnn_t* h, unsigned long long* host, int64_t n_words, int32_t* grid) {
+    if (!h || !host || !grid) return fail(CS_ERR_INVALID, "null argument");
+    if (!h->cw_dbg) return fail(CS_ERR_STATE, "set CS_CNN_DBG=1 before cs_cnn_create");
+    const int64_t have = (int64_t)h->cw_dbg_grid * CW_DBG_SLOTS;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(host, h->cw_dbg, sizeof(unsigned long long) * (n_words < have ? n_words : have), hipMemcpyDeviceToHost));
+    *grid = h->cw_dbg_grid;
     return CS_OK;
 }
 

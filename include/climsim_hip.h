@@ -326,6 +326,10 @@ int  cs_cnn_loss_grads(cs_cnn_t* h, const float* x_dev, int x3d, const float* y_
 /* Restart the dropout stream: call k of cs_cnn_loss_grads uses seed + k.  Under data parallelism every rank takes its
  * own stream (climsim_amd.cnn.CNNEmulator.fit: seed + 1000003 * rank). */
 int  cs_cnn_set_seed(cs_cnn_t* h, uint64_t seed);
+/* Development aid (CS_CNN_DBG=1 at create time): stamps of the last conv weight-gradient launch, [workgroup][16] words
+ * (csrc/conv_wgrad2.h: entry, set-up, ring fill, loop, flush in shader clocks; slabs; 100 MHz entry / exit; hardware id);
+ * *grid = workgroups of that launch.  Not for production use. */
+int  cs_cnn_debug_stamps(cs_cnn_t* h, unsigned long long* host, int64_t n_words, int32_t* grid);
 int  cs_cnn_grad_buffer(cs_cnn_t* h, void** grad_dev, int64_t* n_floats);     /* payload of the DP all-reduce */
 int  cs_cnn_set_grad_buffer(cs_cnn_t* h, float* grad_dev, int64_t n_floats);  /* bind a caller-owned buffer (NULL: own) */
 /* optimizer.apply_gradients: w -= update(grad_scale * G); grad_scale = 1/(n*seq*world_size); zeroes G. */

@@ -272,6 +272,34 @@ def test_cnn_chained_launches_match_one_conv_per_launch(CNN, monkeypatch):
             assert c >= 0.999999 and abs(ratio - 1) <= 1e-5
         np.testing.assert_allclose(res[0][1], other[1], rtol=1e-6)
 
+def test_cnn_weight_gradient_queue_forms_agree(CNN, monkeypatch):
+    """k_conv_wgrad2l takes (tile, row range) entries from eight queues laid out by the host (cnn_api.h, cnn_build_cw_work): the default
+    is one persistent workgroup per CU and ranges of unequal length; CS_CW2_PERSIST=0 runs one entry per workgroup,
+    CS_CNN_WGRAD_SPLITS / ROUNDS / TAPER change how the batch's rows are cut.  Every cut covers every row once: the gradients agree
+    to the order of the float atomics.  A batch of 100 columns = 6000 rows = 188 slabs, the last one partial."""
+    depth, width, n = 3, 406, 100
+    ws = CO.glorot_cnn(seed=8, bias_scale=0.05, depth=depth, channels=width)
+    x3, y3 = make_xy(n, 9)
+    res = []
+    forms = [{}, {"CS_CW2_PERSIST": "0"}, {"CS_CNN_WGRAD_SPLITS": "3"}, {"CS_CNN_WGRAD_ROUNDS": "9", "CS_CNN_WGRAD_TAPER": "0.9"},
+             {"CS_CW2_PERSIST": "0", "CS_CNN_WGRAD_SPLITS": "1"}]
+    for env in forms:
+        for k in ("CS_CW2_PERSIST", "CS_CNN_WGRAD_SPLITS", "CS_CNN_WGRAD_ROUNDS", "CS_CNN_WGRAD_TAPER"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        m = CNN.CNNEmulator(depth=depth, channel_width=width, max_batch=128, trainable=True, loss="mse", dropout=0.0, seed=3)
+        m.set_weights(ws)
+        for _ in range(2):                           # the second call reuses the queues (and the queue heads must have been reset)
+            m.loss_grads(x3, y3)
+        res.append(m.get_gradients(1.0 / (n * 60)))
+        m.close()
+    for other in res[1:]:
+        for a, b in zip(res[0], other):
+            c, ratio = cos_rel(a, b)
+            assert c >= 0.999999 and abs(ratio - 1) <= 1e-5
+
+
 def test_cnn_handoff_timeout_fails_the_next_call(CNN, monkeypatch):
     """A stage hand-off of a chained conv launch that gives up (CS_CNN_SPIN_LIMIT=0: the first poll that finds the partner not
     ready) is counted by the kernel in host-mapped memory; the NEXT call on the model fails - a healthy model never does."""

@@ -30,7 +30,7 @@ __device__ __forceinline__ void st16(unsigned lds_dst, int lane) {
     const unsigned a = lds_dst + (unsigned)lane * 16u;
     asm volatile("ds_write_b128 %0, v[200:203]" :: "v"(a) : "memory");
 }
-__global__ __launch_bounds__(256) void k_stream(const char* base, size_t tensor_bytes, int m, int splits, int panel, unsigned* sink, int mode) {
+__global__ __launch_bounds__(256) void k_stream(const char* base, size_t tensor_bytes, int m, int splits, int panel, unsigned* sink, int mode, int passes) {
     extern __shared__ char ring[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int b = blockIdx.x, nwg = gridDim.x;
@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void k_stream(const char* base, size_t tensor_
     const int layer = work / per_layer, rel = work % per_layer;
     const int split = rel / 16, tile = rel % 16;
     const int kt = tile & 3, nt = tile >> 2;
-    const int rows = m / splits, row0 = split * rows, nst = rows / 32;
+    const int rows = m / splits, row0 = split * rows, nst1 = rows / 32, nst = nst1 * passes;   // passes > 1: the range again and again (L2-resident)
     const char* H = base + (size_t)(2 * layer) * tensor_bytes;
     const char* Z = base + (size_t)(2 * layer + 1) * tensor_bytes;
     // a 1-KiB piece = 4 rows x 256 B; pieces 2*wid, 2*wid+1 of each operand per wave
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void k_stream(const char* base, size_t tensor_
         else { hs[j] = H + (size_t)(row0 + ml) * 1024 + kt * 256 + pch * 16; zs[j] = Z + (size_t)(row0 + ml) * 1024 + nt * 256 + pch * 16; rstride = 1024; }
     }
     const unsigned mine = (unsigned)__builtin_amdgcn_readfirstlane(2 * wid) * 1024u;
-#define ISSUE(st) { const int sc = (st) < nst ? (st) : nst - 1; const size_t ro = (size_t)sc * 32 * rstride; const unsigned bb = ((st) & 3) * 16384u + mine; \
+#define ISSUE(st) { const int sc = ((st) < nst ? (st) : nst - 1) % nst1; const size_t ro = (size_t)sc * 32 * rstride; const unsigned bb = ((st) & 3) * 16384u + mine; \
         if (mode == 0) { dma16(hs[0] + ro, bb); dma16(hs[1] + ro, bb + 1024u); dma16(zs[0] + ro, bb + 8192u); dma16(zs[1] + ro, bb + 8192u + 1024u); } \
         else if (mode == 2) { dma16(hs[0] + ro, bb); dma16(hs[1] + ro, bb + 1024u); ld16(zs[0] + ro); ld16(zs[1] + ro); } \
         else { ld16(hs[0] + ro); ld16(hs[1] + ro); ld16(zs[0] + ro); ld16(zs[1] + ro); \
@@ -72,6 +72,7 @@ __global__ __launch_bounds__(256) void k_stream(const char* base, size_t tensor_
 
 int main(int argc, char** argv) {
     const int m = argc > 1 ? atoi(argv[1]) : 8192, L = 5;      // round 4: ./fill_probe 65536 = tensors that no cache holds
+    const int passes = argc > 2 ? atoi(argv[2]) : 1;           // round 5: ./fill_probe 1024 16 = every workgroup streams its range 16 times (from L2)
     const size_t tensor = (size_t)m * 1024;
     char* buf; unsigned* sink;
     hipMalloc(&buf, tensor * 2 * L); hipMalloc(&sink, 4);
@@ -87,14 +88,14 @@ int main(int argc, char** argv) {
             for (int rep = 0; rep < 6; ++rep) {
                 hipLaunchKernelGGL(k_fill, dim3(1024), dim3(256), 0, 0, (uint4*)buf, tensor * 2 * L / 16);   // fresh data, written by other CUs
                 hipEventRecord(e0);
-                hipLaunchKernelGGL(k_stream, dim3(grid), dim3(256), 65536, 0, buf, tensor, m, splits, panel, sink, mode);
+                hipLaunchKernelGGL(k_stream, dim3(grid), dim3(256), 65536, 0, buf, tensor, m, splits, panel, sink, mode, passes);
                 hipEventRecord(e1); hipEventSynchronize(e1);
                 float ms; hipEventElapsedTime(&ms, e0, e1);
                 if (rep) { best = ms < best ? ms : best; sum += ms; }
             }
-            const double l2lds = (double)grid * (m / splits / 32) * 16384.0;
-            printf("mode %d %s splits %d (%3d workgroups): %.1f us best, %.1f mean | L2->LDS %.0f MB = %.2f TB/s | unique %.2f TB/s\n", mode, panel ? "panel    " : "row-major",
-                   splits, grid, best * 1e3, sum / 5 * 1e3, l2lds / 1e6, l2lds / (best * 1e-3) / 1e12, tensor * 2 * L / (best * 1e-3) / 1e12);
+            const double l2lds = (double)grid * (m / splits / 32) * 16384.0 * passes;
+            printf("mode %d %s splits %d (%3d workgroups): %.1f us best, %.1f mean | L2->LDS %.0f MB = %.2f TB/s = %.1f B/clk per workgroup at 2.1 GHz | unique %.2f TB/s\n", mode, panel ? "panel    " : "row-major",
+                   splits, grid, best * 1e3, sum / 5 * 1e3, l2lds / 1e6, l2lds / (best * 1e-3) / 1e12, l2lds / grid / (best * 1e-3) / 2.1e9, tensor * 2 * L / (best * 1e-3) / 1e12);
         }
     printf("%s\n", hipGetErrorString(hipGetLastError()));
     return 0;

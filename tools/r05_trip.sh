@@ -1,14 +1,14 @@
 #!/bin/bash
-# scratch: streamed training with the next chunk's loader in slices inside the steps' gaps
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_stream_gpu.py -x -q 2>&1 | tail -5
-O=gpurun_out/r05_stream_gaps.txt; : > $O
-for rep in 1 2; do
-for cfg in "main opt 0" "gaps opt 0" "gaps opt 4" "gaps chain 0" "gaps chain 4" "side opt 0"; do
+timeout 900 python -m pytest tests/test_cnn_gpu.py -x -q 2>&1 | tail -3
+O=gpurun_out/r05_cnn_wgrad_ab.txt; : > $O
+for rep in 1 2 3; do
+for cfg in "0 4 0 S4" "1 4 0.8 -" "1 5 0.6 -" "0 4 0.5 -" "1 4 0.6 -" "1 5 0.8 -"; do
   set -- $cfg
-  echo "== CS_STREAM_LOADER=$1 CS_STREAM_GAP=$2 CS_STREAM_SLICES=$3" >> $O
-  CS_STREAM_LOADER=$1 CS_STREAM_GAP=$2 CS_STREAM_SLICES=$3 timeout 300 python bench_stream.py 2>&1 | tail -1 | python -c "
-import json,sys
-d=json.loads(sys.stdin.read()); print({k:d[k] for k in ('value','ratio_to_train_only','ratio_to_serial_sum','loader_share_hidden')}, d.get('passes',{}).get('stream_ms'))" >> $O
+  unset CS_CNN_WGRAD_SPLITS
+  export CS_CW2_PERSIST=$1 CS_CNN_WGRAD_ROUNDS=$2 CS_CNN_WGRAD_TAPER=$3
+  [ $4 = S4 ] && export CS_CNN_WGRAD_SPLITS=4
+  echo -n "persist $1 rounds $2 taper $3 $4: " >> $O
+  timeout 300 python bench_cnn.py 512 60 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'])" >> $O
 done; done
-cat $O
+sort $O | awk '{k=$1" "$2" "$3" "$4" "$5" "$6" "$7; s[k]=s[k]" "$NF} END{for(k in s) print k, s[k]}' | sort
