@@ -149,6 +149,11 @@ int cnn_upload_items(cs_cnn* h) {
                 CwTile t{};
                 t.H = H; t.Z = Z; t.dW = h->G + c.w_off; t.db = h->G + c.b_off; t.ldh = ldh; t.ldz = CNN_CP;
                 t.cin = c.cin; t.cout = c.cout; t.taps = c.taps; t.kpt = kpt; t.k0 = k0; t.n0 = n0;
+                // development (timing only, wrong sums): 1 = every conv reads the first block's tensors (62 MB: beyond the L2s, inside the
+                // memory-side cache), 2 = every row of a slab is the same row (the CU's own L1 serves it)
+                static const int src_hack = getenv("CS_CW_SRC_HACK") ? atoi(getenv("CS_CW_SRC_HACK")) : 0;
+                if (src_hack >= 1 && ldh == CNN_CP) { t.H = h->blk[0].A1; t.Z = h->blk[0].DZ2; }
+                if (src_hack >= 2) { t.ldh = 0; t.ldz = 0; }
                 cw.push_back(t);
             }
     };

@@ -63,7 +63,10 @@ __device__ __forceinline__ void cw_stamp(const CwArgs& pa, int tid, int& slot, i
 }
 
 #define CW2_SLAB_BYTES 32768     // H [32][256] + Z [32][256] bf16
-#define CW2_LDS_BYTES (4 * CW2_SLAB_BYTES)
+#ifndef CW2_SLOTS
+#define CW2_SLOTS 4              // ring depth (slabs): CW2_SLOTS - 1 in flight
+#endif
+#define CW2_LDS_BYTES (CW2_SLOTS * CW2_SLAB_BYTES)
 
 // [32][256] bf16 slab, 512-B rows.  A half-wave of ds_read_b64_tr_b16 in the 16x16x32 fragment form touches 8 rows
 // ({0-3} and {8-11}, or +4) x 32 B: the 64-B units are XOR-ed with (m & 3) as in swz_w2 and the 32-B half of the
@@ -98,7 +101,13 @@ __device__ __forceinline__ bf16x8_t frag_cw(const u16* tile, int mb, int cb, int
 // pa.counters == null: one entry per workgroup, entry blockIdx.x >> 3 of queue blockIdx.x & 7 (A/B: CS_CW2_PERSIST=0).
 #define CW2L_LOADERS 4
 #define CW2L_STAGE_BYTES (8 * 8 * 112 * 4)                // flush staging: per compute wave 8 rows x 112 floats
+#if CW2_SLOTS <= 4
 #define CW2L_LDS_BYTES (CW2_LDS_BYTES + CW2L_STAGE_BYTES + 16)
+#define CW2L_STAGE_OFF CW2_LDS_BYTES
+#else                            // timing experiment only: five slots fill the LDS, staging and the queue word overlay the last slot (wrong sums)
+#define CW2L_LDS_BYTES CW2_LDS_BYTES
+#define CW2L_STAGE_OFF (CW2_LDS_BYTES - CW2L_STAGE_BYTES - 16)
+#endif
 __global__ __launch_bounds__(512 + 64 * CW2L_LOADERS) void k_conv_wgrad2l(const CwArgs pa) {
     constexpr int IT = 4;
     extern __shared__ __attribute__((aligned(16))) u16 cw_ring[];
@@ -107,7 +116,7 @@ __global__ __launch_bounds__(512 + 64 * CW2L_LOADERS) void k_conv_wgrad2l(const 
     const int wm = (wid >> 1) & 3, wn = wid & 1;
     typedef u16 __attribute__((address_space(3))) * lds_p;
     const unsigned lds0 = (unsigned)(uintptr_t)((lds_p)cw_ring);
-    int* next_slot = reinterpret_cast<int*>(reinterpret_cast<char*>(cw_ring) + CW2_LDS_BYTES + CW2L_STAGE_BYTES);   // [2]: entry k + 1 of the queue, by parity
+    int* next_slot = reinterpret_cast<int*>(reinterpret_cast<char*>(cw_ring) + CW2L_STAGE_OFF + CW2L_STAGE_BYTES);   // [2]: entry k + 1 of the queue, by parity
     const int q = blockIdx.x & 7;
     const int qb = pa.q_begin[q], qn = pa.q_begin[q + 1] - qb;
     int dslot = 2;                                                      // stamps: four per entry (CS_CNN_DBG)
@@ -173,6 +182,7 @@ __global__ __launch_bounds__(512 + 64 * CW2L_LOADERS) void k_conv_wgrad2l(const 
     {                                                                                                   \
         const unsigned base_ = lds0 + (unsigned)(slot) * CW2_SLAB_BYTES + my_piece;                     \
         _Pragma("unroll") for (int j = 0; j < PL; ++j) {                                                \
+            if (CW_ABL & 16) { dma16(hp[j], base_ + 1024u * j); dma16(zp[j], base_ + 1024u * j + 16384u); hp[j] += 32 * ldh2; zp[j] += 32 * ldz2; continue; } \
             const bool in_ = mi[j] < (int)pa.m_rows;                                                    \
             const char* hs_ = hk[j] == 0 ? ((in_ && lv[j] >= 0 && lv[j] < pa.seq) ? hp[j] : zpage) : ((hk[j] == 1 && in_) ? opage : zpage); \
             const char* zs_ = in_ ? zp[j] : zpage;                                                      \
@@ -187,8 +197,9 @@ __global__ __launch_bounds__(512 + 64 * CW2L_LOADERS) void k_conv_wgrad2l(const 
             int nxt = -1;
             const bool fetch = pa.counters && wid == 8 && lane == 0;
             if (fetch) asm volatile("global_atomic_add %0, %1, %2, off sc0" : "+v"(nxt) : "v"(pa.counters + q), "v"(1) : "memory");
-            CW2L_ISSUE(0) CW2L_ISSUE(1) CW2L_ISSUE(2) CW2L_ISSUE(3)
-            asm volatile("s_waitcnt vmcnt(%0)" ::"i"(3 * 2 * PL) : "memory");   // slab 0 has landed (three younger slabs x 2 PL pieces of this wave)
+#pragma unroll
+            for (int i_ = 0; i_ < CW2_SLOTS; ++i_) CW2L_ISSUE(i_)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"i"((CW2_SLOTS - 1) * 2 * PL) : "memory");   // slab 0 has landed (the younger slabs x 2 PL pieces of this wave are in flight)
             if (fetch) {
                 asm volatile("" : "+v"(nxt));
                 if (nxt < 0) asm volatile("s_waitcnt vmcnt(0)" : "+v"(nxt) :: "memory");   // (not in order after all: wait for everything)
@@ -196,10 +207,12 @@ __global__ __launch_bounds__(512 + 64 * CW2L_LOADERS) void k_conv_wgrad2l(const 
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
+            int isl = 0;
             for (int s = 0; s < nsl; ++s) {
-                asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * 2 * PL) : "memory");   // slab s + 1 has landed
-                __builtin_amdgcn_s_barrier();                           // ... and slab s is out of use: its slot takes slab s + 4
-                CW2L_ISSUE(__builtin_amdgcn_readfirstlane(s & 3))
+                asm volatile("s_waitcnt vmcnt(%0)" ::"i"((CW2_SLOTS - 2) * 2 * PL) : "memory");   // slab s + 1 has landed
+                __builtin_amdgcn_s_barrier();                           // ... and slab s is out of use: its slot takes slab s + CW2_SLOTS
+                CW2L_ISSUE(isl)
+                isl = isl + 1 == CW2_SLOTS ? 0 : isl + 1;
             }
 #undef CW2L_ISSUE
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the run-ahead pieces must not land in the next entry's slabs (or outlive the kernel)
@@ -226,10 +239,12 @@ __global__ __launch_bounds__(512 + 64 * CW2L_LOADERS) void k_conv_wgrad2l(const 
             for (int i = 0; i < IT; ++i) CW2_FRAG(fh[i], cw_ring, fo_h[i])
 #pragma unroll
             for (int j = 0; j < 7; ++j) CW2_FRAG(fz[j], cw_ring, fo_z[j])
+            int rsl = 1 % CW2_SLOTS;
             for (int s = 0; s < nsl; ++s) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // my reads of slab s are done
                 __builtin_amdgcn_s_barrier();
-                const u16* nx = cw_ring + ((s + 1) & 3) * (CW2_SLAB_BYTES / 2);
+                const u16* nx = cw_ring + rsl * (CW2_SLAB_BYTES / 2);
+                rsl = rsl + 1 == CW2_SLOTS ? 0 : rsl + 1;
 #pragma unroll
                 for (int j = 0; j < 6; ++j) {
 #pragma unroll
@@ -251,7 +266,7 @@ __global__ __launch_bounds__(512 + 64 * CW2L_LOADERS) void k_conv_wgrad2l(const 
             // 128-byte lines) instead of 16 floats of four rows (four half lines; round 3: 247 MB of partial sums per step in 64-byte
             // pieces cost 0.18 ms).  A wave reads back what it wrote itself: LDS operations of one wave complete in order, no barrier.
             if (!(CW_ABL & 8)) {
-                float* stg = reinterpret_cast<float*>(reinterpret_cast<char*>(cw_ring) + CW2_LDS_BYTES) + wid * (8 * 112);
+                float* stg = reinterpret_cast<float*>(reinterpret_cast<char*>(cw_ring) + CW2L_STAGE_OFF) + wid * (8 * 112);
 #pragma unroll
                 for (int i = 0; i < IT; ++i) {
                     const int kf = T.k0 + wm * (16 * IT) + i * 16;      // first kk row of the group: one tap (kpt is a multiple of 16)

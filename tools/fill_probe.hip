@@ -44,7 +44,10 @@ __global__ __launch_bounds__(256) void k_stream(const char* base, size_t tensor_
     const char* H = base + (size_t)(2 * layer) * tensor_bytes;
     const char* Z = base + (size_t)(2 * layer + 1) * tensor_bytes;
     // a 1-KiB piece = 4 rows x 256 B; pieces 2*wid, 2*wid+1 of each operand per wave
-    const int prow = lane >> 4, pch = lane & 15;
+    // mode 4 (round 5): LDS-DMA with the lane -> 16-byte chunk map permuted the way the kernels swizzle their slabs on the SOURCE side
+    // (64-byte units XOR-ed with the row, 32-byte halves swapped on odd row groups): does the permutation cost request throughput?
+    const int prow = lane >> 4, pch0 = lane & 15;
+    const int pch = mode == 4 ? ((((pch0 >> 2) ^ (prow & 3)) << 2) | ((pch0 & 3) ^ ((wid & 1) << 1))) : pch0;
     const char* hs[2]; const char* zs[2];
     size_t rstride;
     for (int j = 0; j < 2; ++j) {
@@ -54,7 +57,7 @@ __global__ __launch_bounds__(256) void k_stream(const char* base, size_t tensor_
     }
     const unsigned mine = (unsigned)__builtin_amdgcn_readfirstlane(2 * wid) * 1024u;
 #define ISSUE(st) { const int sc = ((st) < nst ? (st) : nst - 1) % nst1; const size_t ro = (size_t)sc * 32 * rstride; const unsigned bb = ((st) & 3) * 16384u + mine; \
-        if (mode == 0) { dma16(hs[0] + ro, bb); dma16(hs[1] + ro, bb + 1024u); dma16(zs[0] + ro, bb + 8192u); dma16(zs[1] + ro, bb + 8192u + 1024u); } \
+        if (mode == 0 || mode == 4) { dma16(hs[0] + ro, bb); dma16(hs[1] + ro, bb + 1024u); dma16(zs[0] + ro, bb + 8192u); dma16(zs[1] + ro, bb + 8192u + 1024u); } \
         else if (mode == 2) { dma16(hs[0] + ro, bb); dma16(hs[1] + ro, bb + 1024u); ld16(zs[0] + ro); ld16(zs[1] + ro); } \
         else { ld16(hs[0] + ro); ld16(hs[1] + ro); ld16(zs[0] + ro); ld16(zs[1] + ro); \
                if (mode == 3) { st16(bb, lane); st16(bb + 1024u, lane); st16(bb + 8192u, lane); st16(bb + 8192u + 1024u, lane); } } }
@@ -79,7 +82,7 @@ int main(int argc, char** argv) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_stream), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     printf("m = %d: 5 layers x {H, Z} [m][512] bf16 = %.1f MB unique; every slab is read by 4 tiles (reuse through one XCD's L2)\n", m, tensor * 2 * L / 1e6);
-    for (int mode = 0; mode < 4; ++mode)
+    for (int mode = 0; mode < 5; ++mode)
     for (int panel = 0; panel < 1; ++panel)
         for (int splits : {3, 16}) {
             if (m / splits / 32 < 4) continue;
