@@ -921,7 +921,7 @@ def run(args, world, rank):
                     # there: every workgroup streams all 4.65 MB of weights through its CU for 32 rows.
                     "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
-                    "limited_by": ("L2->CU weight stream: 1.19 GB of L2 traffic per launch at 8192 columns (26 FLOP per L2 byte), ~85 % of the XCDs' L2 bandwidth while it runs"
+                    "limited_by": ("each CU's vector-memory return path: a 32-row tile pulls all 4.65 MB of weights through its own CU (1.19 GB per launch, 26 FLOP per byte) at ~53 of the path's 64 B/clk; halving the L2 traffic alone buys 4 % (profiles/r05_chain_probes.txt)"
                                    if dom == "chain_fb" and B == 8192 else "see DESIGN.md section 4"),
                     "avg_us_per_launch": round(kernels[dom]["avg_us_per_launch"], 2),
                     "launches_per_step": kernels[dom]["launches_per_step"],

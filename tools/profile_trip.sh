@@ -35,3 +35,5 @@ timeout 300 python bench_hpo.py 2>&1 | tail -1 > gpurun_out/${R}_hpo_bench.json;
 echo "== CNN"; bash tools/cnn_trip.sh ${1:-05} 2>&1 | tail -30
 echo "== chain stamps"
 timeout 300 python tools/chain_stamps.py 8192 2>&1 | grep -v amdgpu.ids | tail -12 > gpurun_out/${R}_chain_stamps.txt; cat gpurun_out/${R}_chain_stamps.txt
+echo "== CNN weight-gradient stamps"
+timeout 300 python tools/cnn_wgrad_stamps.py 512 2>&1 | grep -v amdgpu.ids | tail -16 > gpurun_out/${R}_cnn_wgrad_stamps_final.txt; head -8 gpurun_out/${R}_cnn_wgrad_stamps_final.txt
