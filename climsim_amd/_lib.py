@@ -92,6 +92,7 @@ SIGNATURES = {
     "cs_profile_end": (C.c_int, [C.POINTER(CsKernelTimes)]),
     "cs_mlp_profile_step": (C.c_int, [_P, _P, _P, _P, _I64, C.c_int, _F, _P, _P, C.POINTER(CsKernelTimes)]),
     "cs_mlp_debug_stamps": (C.c_int, [_P, _P, _I64]),
+    "cs_mlp_debug_stamps_wgrad": (C.c_int, [_P, _P, _I64, _P]),
     "cs_cnn_debug_stamps": (C.c_int, [_P, _P, _I64, _P]),
     "cs_normalise_rows": (C.c_int, [_P, _P, _I64, _I32, _P, _P, _P, _P]),
     "cs_permutation": (C.c_int, [_I64, C.c_uint64, _P, _P]),

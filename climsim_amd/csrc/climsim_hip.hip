@@ -147,6 +147,7 @@ struct cs_mlp {
     bool g_stored = false;     // the last weight-gradient launch STORED every element of G (+ Gx): the optimiser need not zero it
     bool g_need_zero = false;  // train_step: G is dirty and the weight-gradient launch must find zeros if it accumulates
     unsigned long long* dbg = nullptr;   // CS_CHAIN_DBG: [2][grid_max][64] stamps (fwd, bwd)
+    unsigned long long* wg_dbg = nullptr; int wg_dbg_grid = 0;   // CS_CHAIN_DBG: [4096][8] stamps of the last k_wgrad3 launch
     int chain_ablate = 0;      // CS_CHAIN_ABLATE env, timing experiments only
     int64_t chain_nt_min = 24576;   // CS_CHAIN_NT_MIN: batch from which the tuned chain's activation / gradient stores are non-temporal (chain.h)
     bool wgrad3 = true;        // small-batch wgrad through the LDS-DMA ring (CS_WGRAD3=0: register-staged k_wgrad)
@@ -652,6 +653,7 @@ int run_backward(cs_mlp* h, int64_t n, bool atomics_needed, hipStream_t st) {
             // one round of workgroups: 64-row stages (the whole LDS as ring); more: 32-row stages, two workgroups per CU
             static const int rows_env = getenv("CS_WGRAD3_ROWS") ? atoi(getenv("CS_WGRAD3_ROWS")) : 0;
             const bool r64 = (rows_env ? rows_env == 64 : wg <= ncu) && (m_pad / 64) >= splitk;
+            if (h->wg_dbg && wg <= 4096) { w.dbg = h->wg_dbg; h->wg_dbg_grid = (int)wg; }
             if (r64) CS_LAUNCH((k_wgrad3<4, 64>), dim3((unsigned)wg), dim3(WG3_THREADS), WG3_LDS_BYTES_64, st, w);
             else CS_LAUNCH((k_wgrad3<4, 32>), dim3((unsigned)wg), dim3(WG3_THREADS), WG3_LDS_BYTES, st, w);
         }
@@ -830,6 +832,7 @@ int cs_mlp_create(cs_mlp_t** out, const cs_mlp_cfg* cfg) {
         }
     }
     // stamps: the chain kernels write [fwd|bwd][workgroup][64], the cooperative chain [workgroup][128] for up to 256 workgroups
+    if (getenv("CS_CHAIN_DBG")) A((void**)&h->wg_dbg, (size_t)4096 * 8 * 8);
     if (getenv("CS_CHAIN_DBG")) A((void**)&h->dbg, (size_t)std::max<int64_t>(2 * (h->m_pad_max / 32) * 64, 256 * 128) * 8);
     // sign masks of the hidden activations: tuned chain (16 B per thread and 32..128-row tile) and wide chain (8 B per thread and
     // 32-row tile; ReLU / LeakyReLU - ELU differentiates through the stored activations)
@@ -1189,6 +1192,16 @@ int cs_mlp_debug_stamps(cs_mlp_t* h, unsigned long long* host, int64_t n_words) 
     const int64_t have = 2 * (h->m_pad_max / 32) * 64;
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(host, h->dbg, sizeof(unsigned long long) * (n_words < have ? n_words : have), hipMemcpyDeviceToHost));
+    return CS_OK;
+}
+
+int cs_mlp_debug_stamps_wgrad(cs_mlp_t* h, unsigned long long* host, int64_t n_words, int32_t* grid) {
+    if (!h || !host || !grid) return fail(CS_ERR_INVALID, "null argument");
+    if (!h->wg_dbg) return fail(CS_ERR_STATE, "set CS_CHAIN_DBG=1 before cs_mlp_create");
+    const int64_t have = (int64_t)h->wg_dbg_grid * 8;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(host, h->wg_dbg, sizeof(unsigned long long) * (n_words < have ? n_words : have), hipMemcpyDeviceToHost));
+    *grid = h->wg_dbg_grid;
     return CS_OK;
 }
 

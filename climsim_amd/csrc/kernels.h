@@ -361,6 +361,7 @@ struct WgradArgs {               // ALL layers of the step in one launch: grid.x
     // follows adds them up while it reads the gradient (OptArgs.Gx).  With one round of workgroups every tile's atomics used
     // to leave at the same moment at the end of the launch: 8 us of a 38 us kernel at 8192 columns.
     int plain; float* g_base; float* part; int64_t part_stride;
+    unsigned long long* dbg;     // development (CS_CHAIN_DBG): [workgroup][8] stamps of k_wgrad3 (tools/wgrad_stamps.py), null in production
 };
 
 // LDS tile [64 m][128 cols] bf16 (256-B rows).  The four 64-B units of a row are XOR-swizzled with

@@ -365,9 +365,15 @@ __device__ __forceinline__ bf16x8_t frag_w3(const u16* tile, int mb, int cb, int
 // (8 such slots, one workgroup per CU with seven stages requested ahead, measured 40.0 against 38.1 us at 8192 columns).
 // R = 64: 32 KiB stages, 128 KiB ring, one workgroup per CU - half the barriers, and the fragment reads of a stage's second
 // half run under the MFMAs of its first (with one compute wave per SIMD nothing else hides the LDS latency).
+// stamp words of a workgroup (CS_CHAIN_DBG): 0 entry, 1 stage 0 landed, 2 contraction done, 3 result stores issued, 4 ... acknowledged
+// (s_memtime); 5, 6 s_memrealtime at entry / exit (100 MHz); 7 stages of the workgroup
+__device__ __forceinline__ void wg3_stamp(const WgradArgs& pa, int tid, int slot) {
+    if (pa.dbg && tid == 0) pa.dbg[(int64_t)blockIdx.x * 8 + slot] = slot == 5 || slot == 6 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime();
+}
 template <int SLOTS, int R>
 __device__ __forceinline__ void wgrad3_body(const WgradArgs& pa, const int work, u16* ring) {
     const int tid = threadIdx.x, lane = tid & 63;
+    wg3_stamp(pa, tid, 0); wg3_stamp(pa, tid, 5);
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wk = (wid >> 1) & 1, wn = wid & 1;
     int li = 0;
@@ -488,6 +494,7 @@ __device__ __forceinline__ void wgrad3_body(const WgradArgs& pa, const int work,
         W3_MM(1, 1, H1, Z1)                                                                             \
         W3_RD(Z1, adz[1], NOFF) W3_RD(H1, adh[1], NOFF)
         __builtin_amdgcn_s_barrier();                   // stage 0 has landed
+        wg3_stamp(pa, tid, 1);
         W3_RD(ah_[0], adh[0], 0) W3_RD(az_[0], adz[0], 0) W3_RD(az_[1], adz[1], 0) W3_RD(ah_[1], adh[1], 0)
         W3_RD(bh_[0], adh[0], 4096) W3_RD(bz_[0], adz[0], 4096) W3_RD(bz_[1], adz[1], 4096) W3_RD(bh_[1], adh[1], 4096)
         int slot = 0;
@@ -519,6 +526,8 @@ __device__ __forceinline__ void wgrad3_body(const WgradArgs& pa, const int work,
         for (int s = 0; s < nst; ++s) __builtin_amdgcn_s_barrier();  // timing experiment (CS_WGRAD_ABLATE & 4): requests and barriers only
     }
     if (nst > 0) __builtin_amdgcn_s_barrier();                        // pairs with the loaders' last barrier
+    wg3_stamp(pa, tid, 2);
+    if (pa.dbg && tid == 0) pa.dbg[(int64_t)blockIdx.x * 8 + 7] = (unsigned long long)nst;
     if (pa.ablate & 1) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -572,6 +581,11 @@ __device__ __forceinline__ void wgrad3_body(const WgradArgs& pa, const int work,
     if (do_bias && lane < 32) {                                       // row 0 of the ones product: lanes 0..31, element 0
         float* dst = db + n0 + wn * 64 + wk * 32 + lane;
         if (pa.use_atomics) atomicAdd(dst, accb[0]); else *dst = accb[0];
+    }
+    if (pa.dbg) {
+        wg3_stamp(pa, tid, 3);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wg3_stamp(pa, tid, 4); wg3_stamp(pa, tid, 6);
     }
 }
 

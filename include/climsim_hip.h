@@ -186,6 +186,9 @@ int cs_mlp_profile_step(cs_mlp_t* h, const float* x_dev, const float* y_dev, con
 /* Development aid: s_memtime stamps of the chain kernels (needs CS_CHAIN_DBG=1 at create time):
  * [fwd|bwd][workgroup][64 slots] shader-clock ticks.  Not for production use. */
 int cs_mlp_debug_stamps(cs_mlp_t* h, unsigned long long* host, int64_t n_words);
+/* ... and of the last k_wgrad3 launch: [workgroup][8] words (csrc/wgrad2.h: entry, stage 0 landed, contraction done, stores issued,
+ * stores acknowledged in shader clocks; 100 MHz entry / exit; stages); *grid = its workgroups. */
+int cs_mlp_debug_stamps_wgrad(cs_mlp_t* h, unsigned long long* host, int64_t n_words, int32_t* grid);
 
 /* The shuffle of the input pipeline (`.unbatch().shuffle(buffer, reshuffle_each_iteration).batch(bs)`, step2_retrain.py:266-277) for
  * rows that live in HBM: out_dev[0..n) = a permutation of 0..n-1 keyed by `seed` (4-round Feistel network over the index bits,

@@ -47,6 +47,7 @@ def test_mlp_entries_refuse_null_handles_and_buffers(lib):
     assert lib.cs_mlp_forward_limit(None) == 0
     bad(lib, lib.cs_mlp_profile_step(None, f4, f4, None, 4, 0, 1e-3, f4, None, None))
     bad(lib, lib.cs_mlp_debug_stamps(None, None, 0))
+    bad(lib, lib.cs_mlp_debug_stamps_wgrad(None, None, 0, None))
     bad(lib, lib.cs_cnn_debug_stamps(None, None, 0, None))
     bad(lib, lib.cs_profile_end(None))
     bad(lib, lib.cs_mlp_set_train_accuracy(None, None), b"null handle")
