@@ -336,7 +336,7 @@ __device__ __forceinline__ void chain_heads(const float* __restrict__ bias_lds, 
                           acc[a][0][4 * q + 3] + b4.w};
             const bool valid = m < d_.n_rows;
             float d[4];
-            head4(v, d, n >= p.n_lin, p.keep, n, (have_y && valid) ? &tgt[a][q] : nullptr, p.loss_kind, sq, ab);
+            head4(v, d, n >= p.n_lin, p.keep, n, have_y && valid, tgt[a][q], p.loss_kind, sq, ab);
             if (valid && d_.yhat) *reinterpret_cast<float4*>(d_.yhat + m * S.Nc + n) = make_float4(v[0], v[1], v[2], v[3]);
             const uint2 dpk = make_uint2(cvt_pk_bf16(d[0], d[1]), cvt_pk_bf16(d[2], d[3]));
             if (p.dz_out) *reinterpret_cast<uint2*>(p.dz_out + m * p.ld_dz_out + n) = dpk;

@@ -137,9 +137,9 @@ __device__ __forceinline__ void chainw_body(const ChainArgs& p, const ChainDyn& 
                     const float4 b4 = *reinterpret_cast<const float4*>(bias_lds + S.bias_off + n);
                     float v[4] = {acc[4 * q + 0] + b4.x, acc[4 * q + 1] + b4.y, acc[4 * q + 2] + b4.z, acc[4 * q + 3] + b4.w};
                     float d[4];
-                    float4 t4;
+                    float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (d_.y && valid) t4 = *reinterpret_cast<const float4*>(d_.y + yrow * p.n_real + n);
-                    head4(v, d, n >= p.n_lin, p.keep, n, (d_.y && valid) ? &t4 : nullptr, p.loss_kind, sq, ab);
+                    head4(v, d, n >= p.n_lin, p.keep, n, d_.y && valid, t4, p.loss_kind, sq, ab);
                     if (valid && d_.yhat) *reinterpret_cast<float4*>(d_.yhat + m * p.n_real + n) = make_float4(v[0], v[1], v[2], v[3]);
                     if (p.dz_out) *reinterpret_cast<uint2*>(p.dz_out + m * p.ld_dz_out + n) = make_uint2(cvt_pk_bf16(d[0], d[1]), cvt_pk_bf16(d[2], d[3]));
                 }

@@ -368,10 +368,10 @@ __device__ __forceinline__ void coop_stage(const ChainArgs& p, const ChainStage&
                 for (int hlf = 0; hlf < 2; ++hlf) {
                     float vv[4] = {v[4 * hlf] + bb[4 * hlf], v[4 * hlf + 1] + bb[4 * hlf + 1], v[4 * hlf + 2] + bb[4 * hlf + 2], v[4 * hlf + 3] + bb[4 * hlf + 3]};
                     float dd[4];
-                    float4 t4;
+                    float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
                     const bool have = p.y && valid;
                     if (have) t4 = it == it_a ? (hlf ? pre_t1 : pre_t0) : *reinterpret_cast<const float4*>(p.y + (yr >= 0 ? yr : 0) * S.Nc + n + 4 * hlf);
-                    head4(vv, dd, n + 4 * hlf >= p.n_lin, p.keep, n + 4 * hlf, have ? &t4 : nullptr, p.loss_kind, sq, ab);
+                    head4(vv, dd, n + 4 * hlf >= p.n_lin, p.keep, n + 4 * hlf, have, t4, p.loss_kind, sq, ab);
                     if (valid && p.yhat) *reinterpret_cast<float4*>(p.yhat + row * S.Nc + n + 4 * hlf) = make_float4(vv[0], vv[1], vv[2], vv[3]);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) d[4 * hlf + e] = dd[e];

@@ -109,9 +109,9 @@ __global__ __launch_bounds__(256) void k_gemm_nt2(const GemmNT p) {
                 v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
                 float d[4];
                 const bool valid = m < p.n_rows && n < p.n_real;
-                float4 t4;
+                float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (p.y && valid) t4 = *reinterpret_cast<const float4*>(p.y + (p.row_idx ? p.row_idx[m] : m) * p.n_real + n);
-                head4(v, d, n >= p.n_lin, p.keep, n, (p.y && valid) ? &t4 : nullptr, p.loss_kind, sq, ab);   // (n_lin is a multiple of 4)
+                head4(v, d, n >= p.n_lin, p.keep, n, p.y && valid, t4, p.loss_kind, sq, ab);   // (n_lin is a multiple of 4)
                 if (valid && p.yhat) *reinterpret_cast<float4*>(p.yhat + m * p.n_real + n) = make_float4(v[0], v[1], v[2], v[3]);
                 if (p.out) *reinterpret_cast<uint2*>(p.out + m * p.ldo + n) = pack4_hw(d[0], d[1], d[2], d[3]);
             }

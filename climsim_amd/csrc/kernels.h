@@ -148,9 +148,11 @@ __global__ __launch_bounds__(256) void k_normalise_rows(const float* __restrict_
 //   kind 0  mse   (keras 'mse' / nn.MSELoss):       d = 2e            s0 += e^2
 //   kind 1  mae   (nn.L1Loss):                      d = sign(e)       s0 += e^2
 //   kind 2  huber (nn.SmoothL1Loss, beta = 1):      d = clamp(e,-1,1) s0 += |e| < 1 ? e^2/2 : |e| - 1/2
-//   s1 += |e| always.  t4 == nullptr: prediction only.
+//   s1 += |e| always.  !have_t: prediction only.
+// (The targets come BY VALUE with a flag: as a pointer that is either the address of a local or null they - and with them a scratch
+//  round trip per call - lived in scratch memory in every kernel that calls this.)
 __device__ __forceinline__ void head4(float (&v)[4], float (&d)[4], bool relu_cols, const float* __restrict__ keep, int n,
-                                      const float4* t4, int kind, float& s0, float& s1) {
+                                      const bool have_t, const float4 t, int kind, float& s0, float& s1) {
     float kp[4] = {1.f, 1.f, 1.f, 1.f};
     if (keep) { const float4 k4 = *reinterpret_cast<const float4*>(keep + n); kp[0] = k4.x; kp[1] = k4.y; kp[2] = k4.z; kp[3] = k4.w; }
 #pragma unroll
@@ -159,8 +161,8 @@ __device__ __forceinline__ void head4(float (&v)[4], float (&d)[4], bool relu_co
         if (keep && kp[e] == 0.f) v[e] = 0.f;
         d[e] = 0.f;
     }
-    if (!t4) return;
-    const float e4[4] = {v[0] - t4->x, v[1] - t4->y, v[2] - t4->z, v[3] - t4->w};
+    if (!have_t) return;
+    const float e4[4] = {v[0] - t.x, v[1] - t.y, v[2] - t.z, v[3] - t.w};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const float a = fabsf(e4[e]);
@@ -321,9 +323,9 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const GemmNT p) {
                     v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
                     float d[4];
                     const bool valid = m < p.n_rows && n < p.n_real;
-                    float4 t4;
+                    float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (p.y && valid) t4 = *reinterpret_cast<const float4*>(p.y + (p.row_idx ? p.row_idx[m] : m) * p.n_real + n);
-                    head4(v, d, n >= p.n_lin, p.keep, n, (p.y && valid) ? &t4 : nullptr, p.loss_kind, sq, ab);   // (n_lin is a multiple of 4)
+                    head4(v, d, n >= p.n_lin, p.keep, n, p.y && valid, t4, p.loss_kind, sq, ab);   // (n_lin is a multiple of 4)
                     if (valid && p.yhat)
                         *reinterpret_cast<float4*>(p.yhat + m * p.n_real + n) = make_float4(v[0], v[1], v[2], v[3]);
                     if (p.out) *reinterpret_cast<uint2*>(p.out + m * p.ldo + n) = pack4(d[0], d[1], d[2], d[3]);
@@ -592,34 +594,39 @@ __device__ __forceinline__ void opt_elem(const OptArgs& a, const float gv, float
 }
 
 // The update rule on four consecutive parameters at flat offset i0, given their UNSCALED gradient sums g (reads and writes P,
-// M, V; leaves the new weights in wv).
-__device__ __forceinline__ void opt_rule4(const OptArgs& a, int64_t i0, const float4 g, float (&wv)[4]) {
+// M, V; returns the new weights).  (By VALUE: as a `float (&)[4]` out-parameter filled on two paths the four weights lived in scratch
+// memory - 28 bytes per thread, 8.6 MB of extra write traffic per launch at 1.2 M parameters, found in the WRITE_SIZE counter:
+// profiles/r05_optimizer_traffic.txt.)
+__device__ __forceinline__ float4 opt_rule4(const OptArgs& a, int64_t i0, const float4 g) {
     const float4 w = *reinterpret_cast<const float4*>(a.P + i0);
-    wv[0] = w.x; wv[1] = w.y; wv[2] = w.z; wv[3] = w.w;
-    const float gv[4] = {g.x * a.grad_scale, g.y * a.grad_scale, g.z * a.grad_scale, g.w * a.grad_scale};
-    float mv[4] = {0.f, 0.f, 0.f, 0.f}, vv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (a.kind != 3) { const float4 v4 = *reinterpret_cast<const float4*>(a.V + i0); vv[0] = v4.x; vv[1] = v4.y; vv[2] = v4.z; vv[3] = v4.w; }
-    if (a.kind != 3 && a.kind != 2) { const float4 m4 = *reinterpret_cast<const float4*>(a.M + i0); mv[0] = m4.x; mv[1] = m4.y; mv[2] = m4.z; mv[3] = m4.w; }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) opt_elem(a, gv[e], wv[e], mv[e], vv[e]);
-    if (a.kind != 3 && a.kind != 2) *reinterpret_cast<float4*>(a.M + i0) = make_float4(mv[0], mv[1], mv[2], mv[3]);
-    if (a.kind != 3) *reinterpret_cast<float4*>(a.V + i0) = make_float4(vv[0], vv[1], vv[2], vv[3]);
-    *reinterpret_cast<float4*>(a.P + i0) = make_float4(wv[0], wv[1], wv[2], wv[3]);
+    float w0 = w.x, w1 = w.y, w2 = w.z, w3 = w.w;
+    float4 m4 = make_float4(0.f, 0.f, 0.f, 0.f), v4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.kind != 3) v4 = *reinterpret_cast<const float4*>(a.V + i0);
+    if (a.kind != 3 && a.kind != 2) m4 = *reinterpret_cast<const float4*>(a.M + i0);
+    opt_elem(a, g.x * a.grad_scale, w0, m4.x, v4.x);
+    opt_elem(a, g.y * a.grad_scale, w1, m4.y, v4.y);
+    opt_elem(a, g.z * a.grad_scale, w2, m4.z, v4.z);
+    opt_elem(a, g.w * a.grad_scale, w3, m4.w, v4.w);
+#ifndef OPT_ABL
+#define OPT_ABL 0            // development (traffic accounting only): 1 = no bf16 operand copies, 2 = no M / V stores, 4 = no P store
+#endif
+    if (!(OPT_ABL & 2) && a.kind != 3 && a.kind != 2) *reinterpret_cast<float4*>(a.M + i0) = m4;
+    if (!(OPT_ABL & 2) && a.kind != 3) *reinterpret_cast<float4*>(a.V + i0) = v4;
+    const float4 out = make_float4(w0, w1, w2, w3);
+    if (!(OPT_ABL & 4)) *reinterpret_cast<float4*>(a.P + i0) = out;
+    return out;
 }
 
-__device__ __forceinline__ void opt_update4(const OptArgs& a, int64_t i0, float (&wv)[4]) {
-    if (a.recast_only) {
-        const float4 w = *reinterpret_cast<const float4*>(a.P + i0);
-        wv[0] = w.x; wv[1] = w.y; wv[2] = w.z; wv[3] = w.w;
-        return;
-    }
+__device__ __forceinline__ float4 opt_update4(const OptArgs& a, int64_t i0) {
+    if (a.recast_only) return *reinterpret_cast<const float4*>(a.P + i0);
     float4 g = *reinterpret_cast<const float4*>(a.G + i0);
     for (int q = 0; q < a.gx_n; ++q) {
         const float4 e = *reinterpret_cast<const float4*>(a.Gx + q * a.gx_stride + i0);
         g.x += e.x; g.y += e.y; g.z += e.z; g.w += e.w;
     }
-    opt_rule4(a, i0, g, wv);
+    const float4 out = opt_rule4(a, i0, g);
     if (a.zero_g) *reinterpret_cast<float4*>(a.G + i0) = make_float4(0.f, 0.f, 0.f, 0.f);
+    return out;
 }
 
 // train_step's loss sums: add the stripes the chain kernels accumulated (loss_flush), hand them to the caller, zero the other slot
@@ -644,18 +651,18 @@ __device__ __forceinline__ void optimizer_body(const OptArgs& a, const int bid, 
     while (s + 1 < a.n_seg && bid >= a.seg[s + 1].blk_begin) ++s;
     const Segment sg = a.seg[s];
     const int rel = bid - sg.blk_begin;
-    float wv[4] = {0.f, 0.f, 0.f, 0.f};
     if (sg.Kp == 0) {                                   // bias: 1024 floats per workgroup
         const int64_t i = (int64_t)rel * 1024 + tid * 4;
-        if (i < sg.size) opt_update4(a, sg.off + i, wv);
+        if (i < sg.size) (void)opt_update4(a, sg.off + i);
         return;
     }
     const int tiles_n = sg.N >> 5;
     const int kt = rel / tiles_n, nt = rel - kt * tiles_n;
     const int kk = tid >> 3, nq = tid & 7;
     const int k = kt * 32 + kk, n = nt * 32 + nq * 4;
-    if (k < sg.K) opt_update4(a, sg.off + (int64_t)k * sg.N + n, wv);
-    const uint2 pk = pack4_hw(wv[0], wv[1], wv[2], wv[3]);
+    float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (k < sg.K) w4 = opt_update4(a, sg.off + (int64_t)k * sg.N + n);
+    const uint2 pk = pack4_hw(w4.x, w4.y, w4.z, w4.w);
     *reinterpret_cast<uint2*>(&tile[kk][nq * 4]) = pk;
     if (sg.Wn && k < sg.K) *reinterpret_cast<uint2*>(sg.Wn + (int64_t)k * sg.N + n) = pk;
     __syncthreads();
@@ -665,6 +672,7 @@ __device__ __forceinline__ void optimizer_body(const OptArgs& a, const int bid, 
                                     (unsigned)tile[kq * 4 + 2][nl] | ((unsigned)tile[kq * 4 + 3][nl] << 16));
         *reinterpret_cast<uint2*>(sg.Wt + (int64_t)(nt * 32 + nl) * sg.Kp + kt * 32 + kq * 4) = t4;
     }
+    if (OPT_ABL & 1) return;
     if (sg.Wf && tid < 128) {                           // blocks (k/16, n/32): lane L holds W[16kb + 8(L>>5) + 0..7][n = L&31]
         const int kb = tid >> 6, L = tid & 63, nl = L & 31, k8 = kb * 16 + 8 * (L >> 5);
         unsigned q[4];
