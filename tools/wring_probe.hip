@@ -47,10 +47,11 @@ __device__ __forceinline__ const char* frag_ptr(const char* W, int step, int til
     return W + ((size_t)step * 16 + tile) * 1024 + lane * 16;
 }
 
-template <int M>
+// GAP (round 5): behind every layer (KSTEPS steps) the wave stops for ~GAP x 64 clocks and two workgroup barriers - a stage's epilogue -
+// while whatever the queue holds in flight keeps arriving.  Does a deeper queue carry the stream through the gap?
+template <int M, int D = 8, int GAP = 0>
 __global__ __launch_bounds__(512) void k_queue(const char* __restrict__ W, float* __restrict__ sink) {
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    constexpr int D = 8;
     u32x4_t q[D][2];
     f32x16_t acc[M][2];
 #pragma unroll
@@ -80,6 +81,12 @@ __global__ __launch_bounds__(512) void k_queue(const char* __restrict__ W, float
 #pragma unroll
             for (int t = 0; t < 2; ++t)
                 asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(q[d][t]) : "v"(frag_ptr(W, sn, 2 * wid + t, lane)) : "memory");
+            if (GAP > 0 && ((s0 + d + 1) % KSTEPS) == 0) {
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_s_sleep(GAP > 127 ? 127 : GAP);
+                if (GAP > 127) __builtin_amdgcn_s_sleep(GAP - 127 > 127 ? 127 : GAP - 127);
+                __builtin_amdgcn_s_barrier();
+            }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -202,6 +209,17 @@ int main() {
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring<2>), hipFuncAttributeMaxDynamicSharedMemorySize, ring_lds));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring<4>), hipFuncAttributeMaxDynamicSharedMemorySize, ring_lds));
     printf("weights per workgroup %.2f MB, %d steps x 2 fragments per compute wave, 256 workgroups\n", bytes / 1e6, STEPS);
+    // round 5: how does the queue's depth change the stream?  (in flight per CU: D x 16 KiB)
+    printf("M=1, queue depth 4 / 8 / 16 steps: %.1f / %.1f / %.1f us\n",
+           time_us([&] { hipLaunchKernelGGL((k_queue<1, 4>), dim3(256), dim3(512), 0, 0, W, sink); }, 20),
+           time_us([&] { hipLaunchKernelGGL((k_queue<1, 8>), dim3(256), dim3(512), 0, 0, W, sink); }, 20),
+           time_us([&] { hipLaunchKernelGGL((k_queue<1, 16>), dim3(256), dim3(512), 0, 0, W, sink); }, 20));
+    printf("M=1 with a gap of ~2300 clocks + two barriers behind every layer, depth 8 / 16: %.1f / %.1f us  (no gap: depth 8 above; 13 gaps of ~1.1 us = 14 us if nothing hides them)\n",
+           time_us([&] { hipLaunchKernelGGL((k_queue<1, 8, 36>), dim3(256), dim3(512), 0, 0, W, sink); }, 20),
+           time_us([&] { hipLaunchKernelGGL((k_queue<1, 16, 36>), dim3(256), dim3(512), 0, 0, W, sink); }, 20));
+    printf("M=1 with a gap of ~4600 clocks, depth 8 / 16: %.1f / %.1f us\n",
+           time_us([&] { hipLaunchKernelGGL((k_queue<1, 8, 72>), dim3(256), dim3(512), 0, 0, W, sink); }, 20),
+           time_us([&] { hipLaunchKernelGGL((k_queue<1, 16, 72>), dim3(256), dim3(512), 0, 0, W, sink); }, 20));
     printf("M=1 (32-row tiles): queue %.1f us   ring %.1f us\n", time_us([&] { hipLaunchKernelGGL(k_queue<1>, dim3(256), dim3(512), 0, 0, W, sink); }, 20),
            time_us([&] { hipLaunchKernelGGL(k_ring<1>, dim3(256), dim3(768), ring_lds, 0, W, sink); }, 20));
     printf("M=2 (64-row tiles): queue %.1f us   ring %.1f us\n", time_us([&] { hipLaunchKernelGGL(k_queue<2>, dim3(256), dim3(512), 0, 0, W, sink); }, 20),
