@@ -74,8 +74,9 @@ static void cnn_build_cw_work(cs_cnn* h, int slabs) {
     std::vector<Group> groups;
     const int nconv = h->n_cw_convs;
     const int min_len = 8;
+    const int s_cap = std::max(1, CW_MAX_WORK / std::max(1, h->n_cw_tiles));       // the table holds CW_MAX_WORK entries
     if (h->cw_splits > 0) {
-        const int s = std::max(1, std::min(h->cw_splits, std::max(1, slabs / min_len)));
+        const int s = std::max(1, std::min(std::min(h->cw_splits, s_cap), std::max(1, slabs / min_len)));
         for (int c = 0; c < nconv; ++c)
             for (int i = 0; i < s; ++i) groups.push_back({c, (int)((int64_t)slabs * i / s), (int)((int64_t)slabs * (i + 1) / s)});
     } else {
@@ -87,7 +88,7 @@ static void cnn_build_cw_work(cs_cnn* h, int slabs) {
             want += sf * tiles;
             int s = (int)std::floor((want - given) / tiles + 0.5);
             s = std::max((int)std::floor(sf), std::min(s, (int)std::ceil(sf)));
-            s = std::max(1, std::min(s, std::max(1, slabs / min_len)));
+            s = std::max(1, std::min(std::min(s, s_cap), std::max(1, slabs / min_len)));
             given += (double)s * tiles;
             // lengths proportional to 1 + taper * (1 - 2 (i + phase) / s), i = 0 the longest; phase in [0, 1) differs from conv to conv
             double tot = 0, run = 0;

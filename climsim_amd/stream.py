@@ -231,11 +231,10 @@ class StreamedTrainer:
         ring = self._ring
         if not ring or ring[0][2] is not None:
             return None
-        (mli, mlo), copied, _ = ring[0]
+        (mli, mlo), _, _ = ring[0]
         if mlo is None:
             return None
-        if copied is not None:                       # a host chunk: its copy runs on the side stream, in front of the slices
-            pass
+        # (a host chunk's copy was issued on the side stream by _produce: the slices queue behind it there)
         x2, y2, run = self.loader.stack_raw_sliced(mli, mlo, extra_rows=self.batch if self._carrying else 0)
         for a in (x2, y2, mli, mlo):
             a.record_stream(self.side)

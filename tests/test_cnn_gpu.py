@@ -159,8 +159,11 @@ def test_cnn_adam_steps_follow_oracle(CNN):
         _, g = CO.loss_and_grads(cur, x3, y3, depth=depth, loss="mae", rate=0.175, seed=9 + step, bf16=True)
         cur = opt.apply(cur, g, 1e-3)
     got = m.get_weights()
+    from conftest import record_margin
     for i, (a, b, w0) in enumerate(zip(got, cur, ws)):
         moved = np.linalg.norm(b - w0)
+        if moved > 1e-6:
+            record_margin("cnn_adam5_movement_vs_oracle_rel", float(np.linalg.norm(a - b) / moved))
         assert np.linalg.norm(a - b) <= 0.15 * moved + 1e-7, (i, np.linalg.norm(a - b), moved)
         if moved > 1e-6:
             assert cos_rel(a - w0, b - w0)[0] >= 0.98, i

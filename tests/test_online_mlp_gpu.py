@@ -92,8 +92,12 @@ def test_five_adam_steps(OM, name, path):
         # total movement after 5 steps is <= 5*lr per weight: compare the MOVEMENT with the oracle's
         mv, omv = sd[k] - init[k], osd[k] - init[k]
         assert rel(mv, omv) <= 5e-2, (k, rel(mv, omv))
+    from conftest import record_margin
+    for k in sd:
+        record_margin(f"online_{name}_movement_vs_oracle_rel", rel(sd[k] - init[k], osd[k] - init[k]))
     for k in [f for f in GOLD.files if f.startswith(f"{name}/after5/")]:
         kk = k.split("/after5/")[1]
+        record_margin(f"online_{name}_movement_vs_reference_rel", rel(sd[kk] - init[kk], GOLD[k] - init[kk]))
         assert rel(sd[kk] - init[kk], GOLD[k] - init[kk]) <= 0.35, (kk, rel(sd[kk] - init[kk], GOLD[k] - init[kk]))   # Adam's first steps are ~lr*sign(g)
 
 
