@@ -164,7 +164,7 @@ def test_cnn_adam_steps_follow_oracle(CNN):
         moved = np.linalg.norm(b - w0)
         if moved > 1e-6:
             record_margin("cnn_adam5_movement_vs_oracle_rel", float(np.linalg.norm(a - b) / moved))
-        assert np.linalg.norm(a - b) <= 0.15 * moved + 1e-7, (i, np.linalg.norm(a - b), moved)
+        assert np.linalg.norm(a - b) <= 0.06 * moved + 1e-7, (i, np.linalg.norm(a - b), moved)   # measured 0.026 (profiles/r05_test_margins.json; 0.15 until round 5)
         if moved > 1e-6:
             assert cos_rel(a - w0, b - w0)[0] >= 0.98, i
     mm, vv, it = m.get_optimizer_state()

@@ -91,14 +91,16 @@ def test_five_adam_steps(OM, name, path):
     for k in sd:
         # total movement after 5 steps is <= 5*lr per weight: compare the MOVEMENT with the oracle's
         mv, omv = sd[k] - init[k], osd[k] - init[k]
-        assert rel(mv, omv) <= 5e-2, (k, rel(mv, omv))
+        assert rel(mv, omv) <= 5e-3, (k, rel(mv, omv))       # measured 1e-6 (profiles/r05_test_margins.json; the bar was 5e-2 until round 5)
     from conftest import record_margin
     for k in sd:
         record_margin(f"online_{name}_movement_vs_oracle_rel", rel(sd[k] - init[k], osd[k] - init[k]))
     for k in [f for f in GOLD.files if f.startswith(f"{name}/after5/")]:
         kk = k.split("/after5/")[1]
         record_margin(f"online_{name}_movement_vs_reference_rel", rel(sd[kk] - init[kk], GOLD[k] - init[kk]))
-        assert rel(sd[kk] - init[kk], GOLD[k] - init[kk]) <= 0.35, (kk, rel(sd[kk] - init[kk], GOLD[k] - init[kk]))   # Adam's first steps are ~lr*sign(g)
+        # Adam's first steps are ~lr*sign(g): a bf16-sized difference in a near-zero gradient flips a whole step.  Measured against the
+        # reference's fp32 vectors: 0.054 / 0.091 / 0.130 over the three configurations (profiles/r05_test_margins.json); bar 0.2 (0.35 until round 5)
+        assert rel(sd[kk] - init[kk], GOLD[k] - init[kk]) <= 0.2, (kk, rel(sd[kk] - init[kk], GOLD[k] - init[kk]))
 
 
 @pytest.mark.parametrize("flags", [0, 2])
