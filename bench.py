@@ -921,7 +921,7 @@ def run(args, world, rank):
                     # there: every workgroup streams all 4.65 MB of weights through its CU for 32 rows.
                     "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
-                    "limited_by": ("each CU's own request path: a 32-row tile pulls all 4.65 MB of weights through its CU (1.19 GB per launch, 26 FLOP per byte) at ~52 B/clk = what a CU holds in flight (~64 KB, whatever the software queue's depth) over the loaded L2 latency; halving the L2 traffic alone buys 4 % (profiles/r05_chain_probes.txt, r05_wring_depth.txt)"
+                    "limited_by": ("each CU's own request path: a 32-row tile pulls all 4.65 MB of weights through its CU (1.19 GB per launch, 26 FLOP per byte) at ~52 of the path's 64 B/clk, where the stream saturates once 64 KB per CU are in flight (a deeper queue changes nothing); halving the L2 traffic alone buys 4 % (profiles/r05_chain_probes.txt, r05_wring_depth.txt)"
                                    if dom == "chain_fb" and B == 8192 else "see DESIGN.md section 4"),
                     "avg_us_per_launch": round(kernels[dom]["avg_us_per_launch"], 2),
                     "launches_per_step": kernels[dom]["launches_per_step"],

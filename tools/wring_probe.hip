@@ -210,6 +210,9 @@ int main() {
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring<4>), hipFuncAttributeMaxDynamicSharedMemorySize, ring_lds));
     printf("weights per workgroup %.2f MB, %d steps x 2 fragments per compute wave, 256 workgroups\n", bytes / 1e6, STEPS);
     // round 5: how does the queue's depth change the stream?  (in flight per CU: D x 16 KiB)
+    printf("M=1, queue depth 1 / 2 steps (16 / 32 KiB in flight per CU): %.1f / %.1f us\n",
+           time_us([&] { hipLaunchKernelGGL((k_queue<1, 1>), dim3(256), dim3(512), 0, 0, W, sink); }, 20),
+           time_us([&] { hipLaunchKernelGGL((k_queue<1, 2>), dim3(256), dim3(512), 0, 0, W, sink); }, 20));
     printf("M=1, queue depth 4 / 8 / 16 steps: %.1f / %.1f / %.1f us\n",
            time_us([&] { hipLaunchKernelGGL((k_queue<1, 4>), dim3(256), dim3(512), 0, 0, W, sink); }, 20),
            time_us([&] { hipLaunchKernelGGL((k_queue<1, 8>), dim3(256), dim3(512), 0, 0, W, sink); }, 20),
