@@ -157,16 +157,31 @@ __device__ __forceinline__ void chainw_copy_out(const u16* __restrict__ X, u16* 
 // stage between the two halves of a 32-row tile's waves), `ks_total` the number of steps it takes from there.
 template <int BMROWS, int MT, int NT, int D, bool SELF_PRIME, int PITCH = CHAIN_PITCH, bool WIDE_PEND = false>
 __device__ __forceinline__ void chain_mma(const u16* __restrict__ X, const u16* __restrict__ wfrag, int ks_total, int ntiles,
-                                          int jt0, int mrow0, int tid, f32x16_t (&acc)[MT][NT], ChainPending& pend, int64_t m0, const int kofs = 0) {
+                                          int jt0, int mrow0, int tid, f32x16_t (&acc)[MT][NT], ChainPending& pend, int64_t m0, const int kofs = 0,
+                                          const float* bias0 = nullptr) {
     const int lane = tid & 63;
     ChainQ Q;
     static_assert(D == 4 || D == 8, "queue slots are written out for depth 4 and 8");
-#pragma unroll
-    for (int a = 0; a < MT; ++a)
+    // `bias0` (LDS: the bias of column jt0 * 32): the accumulators START from the bias - element 4 q + e of a tile is column
+    // 8 q + 4 (lane >> 5) + e - so the fetch flies under the queue's priming loads instead of standing in the epilogue (round 5: a
+    // forward epilogue took 2.35k clocks where a backward one took 1.56k, a wait behind each of its eight 16-byte bias fetches).
+    if (bias0) {
 #pragma unroll
         for (int b = 0; b < NT; ++b)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+            for (int q = 0; q < 4; ++q) {
+                const float4 b4 = *reinterpret_cast<const float4*>(bias0 + b * 32 + 8 * q + 4 * (lane >> 5));
+#pragma unroll
+                for (int a = 0; a < MT; ++a) { acc[a][b][4 * q] = b4.x; acc[a][b][4 * q + 1] = b4.y; acc[a][b][4 * q + 2] = b4.z; acc[a][b][4 * q + 3] = b4.w; }
+            }
+    } else {
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+            for (int b = 0; b < NT; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    }
     const int sstride = ntiles * 64;             // uint4 per k16 step
     const uint4* wp0 = reinterpret_cast<const uint4*>(wfrag) + jt0 * 64 + lane + kofs * sstride;
     // The weight stream is issued with inline-asm loads and waited for with COUNTED vmcnt: hipcc's own
@@ -266,6 +281,9 @@ __device__ __forceinline__ void chain_mma(const u16* __restrict__ X, const u16* 
 //   forward : h = max(z, slope*z)  (ReLU: slope 0, LeakyReLU: slope alpha; valid for 0 <= slope <= 1)
 //   backward: dz *= bit ? 1 : slope
 // ELU keeps a generic path (needs expm1 forward and the activation value backward).
+template <int MT, bool ELU>
+__device__ __forceinline__ constexpr bool chain_bias_in_acc() { return !(ELU && MT == 4); }
+
 template <int MT, int NT, int EPI, bool ELU>
 __device__ __forceinline__ void chain_epilogue(u16* __restrict__ X, const float* __restrict__ bias_lds,
                                                const ChainArgs& p, const ChainStage& S, bool last, int64_t m0, int jt0,
@@ -282,15 +300,16 @@ __device__ __forceinline__ void chain_epilogue(u16* __restrict__ X, const float*
         for (int q = 0; q < 4; ++q) {
             const int c = (jt0 + b) * 4 + q;                        // 16-B chunk index of these columns
             const int ldsoff = ((c ^ r15) << 3);                    // (row & 15) == (lane & 15) for every tile row
-            float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (EPI == EPI_HIDDEN) b4 = *reinterpret_cast<const float4*>(bias_lds + S.bias_off + c * 8 + hi4);
 #pragma unroll
             for (int a = 0; a < MT; ++a) {
                 const int t = a * NT + b;                           // tile index within the wave
                 const int sh = (t & 1) * 16 + 4 * q;                // bit position of element e = 0
                 float v[4] = {acc[a][b][4 * q + 0], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
-                if (EPI == EPI_HIDDEN) {
-                    v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+                if (EPI == EPI_HIDDEN) {                            // (the bias is in the accumulators since the top of the stage: chain_mma, chain_trunk)
+                    if (!chain_bias_in_acc<MT, ELU>()) {           // ... except ELU on 128-row tiles, where the early fetch spilled
+                        const float4 b4 = *reinterpret_cast<const float4*>(bias_lds + S.bias_off + c * 8 + hi4);
+                        v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+                    }
                     if (ELU) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : __expf(v[e]) - 1.f;   // abs err 6e-8, below bf16 resolution
@@ -392,8 +411,10 @@ __device__ __forceinline__ void chain_stage(u16* X, const float* bias_lds, const
     //  registers then live across the stage dispatch, hipcc copies / spills them - 140-300 B of scratch per lane - and a
     //  copy of a register whose asm load has not landed yet is garbage.  The queue stays local to chain_mma.)
     const int ks_all = S.Kc >> 4, ks_mine = ksplit ? ks_all >> 1 : ks_all, kofs = (ksplit && upper) ? ks_all >> 1 : 0;
-    if (MT <= 2 && (S.Kc & 127) == 0 && (!ksplit || (ks_mine & 7) == 0)) chain_mma<BMROWS, MT, NT, 8, true>(X, S.wfrag, ks_mine, S.Nc >> 5, jt0, mrow0, tid, acc, pend, m0, kofs);
-    else chain_mma<BMROWS, MT, NT, 4, true>(X, S.wfrag, ks_mine, S.Nc >> 5, jt0, mrow0, tid, acc, pend, m0, kofs);
+    // forward hidden stages start their accumulators from the bias (of a split contraction: the half that the epilogue's waves own)
+    const float* bias0 = (EPI == EPI_HIDDEN && chain_bias_in_acc<MT, ELU>() && !(ksplit && upper)) ? bias_lds + S.bias_off + jt0 * 32 : nullptr;
+    if (MT <= 2 && (S.Kc & 127) == 0 && (!ksplit || (ks_mine & 7) == 0)) chain_mma<BMROWS, MT, NT, 8, true>(X, S.wfrag, ks_mine, S.Nc >> 5, jt0, mrow0, tid, acc, pend, m0, kofs, bias0);
+    else chain_mma<BMROWS, MT, NT, 4, true>(X, S.wfrag, ks_mine, S.Nc >> 5, jt0, mrow0, tid, acc, pend, m0, kofs, bias0);
     if (EPI == EPI_DGRAD && !ELU && remap) {
         const int a0 = bid & 1;
         msk[0] = S.Nc == 512 ? (a0 ? msk[1] : msk[0]) : (S.Nc == 256 ? msk[0] >> (16 * a0) : msk[0]);
@@ -547,12 +568,24 @@ __device__ __forceinline__ void chain_trunk(u16* X, const float* bias_lds, const
         const unsigned voff = (unsigned)(jt0 * 64 + lane) * 16u;                               // this lane's 16 bytes inside a k16-step
         const unsigned long long own = (unsigned long long)(uintptr_t)S.wfrag;
         const unsigned long long nxt = has_next ? (unsigned long long)(uintptr_t)p.st[i0 + st + 1].wfrag : 0ull;
-#pragma unroll
-        for (int a = 0; a < MT; ++a)
+        if (EPI == EPI_HIDDEN) {                               // accumulators start from the bias (see chain_mma)
+            const float* bias0 = bias_lds + S.bias_off + jt0 * 32;
 #pragma unroll
             for (int b = 0; b < NT; ++b)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+                for (int q = 0; q < 4; ++q) {
+                    const float4 b4 = *reinterpret_cast<const float4*>(bias0 + b * 32 + 8 * q + 4 * ahalf);
+#pragma unroll
+                    for (int a = 0; a < MT; ++a) { acc[a][b][4 * q] = b4.x; acc[a][b][4 * q + 1] = b4.y; acc[a][b][4 * q + 2] = b4.z; acc[a][b][4 * q + 3] = b4.w; }
+                }
+        } else {
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int b = 0; b < NT; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+        }
         unsigned* mword = reinterpret_cast<unsigned*>(S.mask) + (int64_t)bid * 512 + tid;      // 32-row tiles: one sign word per thread and stage
         unsigned mskw = 0u;
         if (EPI == EPI_DGRAD) asm volatile("global_load_dword %0, %1, off" : "=v"(mskw) : "v"(mword) : "memory");   // (1 operation)

@@ -18,6 +18,12 @@ for kern in sys.argv[2:]:
         else: clusters[-1].append(i)
     for c in clusters:
         a,b=c[0]-120,c[-1]+450
+        # the region ends at the stage loop's BACK EDGE (a branch to a label defined in front of the cluster): behind the loop the run
+        # is over, the queue is empty and its registers are anybody's (round 5: the +450 window reached into the code behind the loop)
+        labels={L[i].split(':')[0].strip():i for i in range(max(0,a-4000),c[0]) if re.match(r'^\.LBB\w+:', L[i])}
+        for i in range(c[-1],min(len(L),c[-1]+450)):
+            mm=re.match(r'\ts_branch (\.LBB\w+)', L[i])
+            if mm and mm.group(1) in labels: b=i+1; break
         dest=set(); inasm=False
         for i in range(a,b):
             if 'ASMSTART' in L[i]: inasm=True
