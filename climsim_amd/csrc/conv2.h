@@ -381,12 +381,15 @@ __global__ __launch_bounds__(CV2_THREADS) void k_conv2(const ConvProg P) {
             // mask from the forward pass's bits, applied where the tile is packed for the second tensor (nothing holds 112 masked
             // values beside the accumulators: 168 VGPRs): no memory operation between the two store tiles
             const unsigned mwb[4] = {mbits.x, mbits.y, mbits.z, mbits.w};
+            unsigned msc_ = __builtin_bit_cast(unsigned, p.mscale);
+            asm volatile("" : "+s"(msc_));                  // (an opaque scalar, as the dropout parameters of the forward epilogue below)
+            const float mscale_f = __builtin_bit_cast(float, msc_);
             auto masked = [&](int i, int j) __attribute__((always_inline)) {
                 const int t = (i * 7 + j) * 4;
                 const unsigned b4 = mwb[t >> 5] >> (t & 31);
                 f32x4_t r;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) r[e] = (b4 & (1u << e)) ? acc[i][j][e] * p.mscale : 0.f;
+                for (int e = 0; e < 4; ++e) r[e] = (b4 & (1u << e)) ? acc[i][j][e] * mscale_f : 0.f;
                 return r;
             };
             CV2_STORE_TILE_X(p.out2, p.ldo2, masked)
@@ -401,6 +404,15 @@ __global__ __launch_bounds__(CV2_THREADS) void k_conv2(const ConvProg P) {
         // transform(i, j): bias, activation, dropout of one tile, IN PLACE (the second pass accumulates on top), and its bit of the
         // mask the backward pass uses (>= 0 everywhere after ReLU: one bit per element, this thread's 112 in one 16-byte store).
         const float act_floor = p.act == CACT_RELU ? 0.f : -__builtin_huge_valf();
+        // The stage's dropout parameters as OPAQUE scalars: read through `p` (the stage record in the kernel-argument segment) hipcc
+        // re-fetched them for every one of a thread's 28 tiles - two s_load + `lgkmcnt(0)` per tile, each of which also waited for the
+        // tile's bias fetch from LDS (round 5, read off the compiled epilogue).
+        unsigned dthr_ = 0u, dkey_ = 0u, dscale_ = 0u;
+        if (MODE == CONV_TRAIN_FWD) {
+            dthr_ = p.drop_thr; dkey_ = p.drop_key; dscale_ = __builtin_bit_cast(unsigned, p.drop_scale);
+            asm volatile("" : "+s"(dthr_), "+s"(dkey_), "+s"(dscale_));
+        }
+        const float dscale_f = __builtin_bit_cast(float, dscale_);
         unsigned mwb[4] = {0u, 0u, 0u, 0u};
         auto transform = [&](int i, int j) __attribute__((always_inline)) {
             const int n = nw + j * 16 + 4 * (le >> 4);
@@ -413,12 +425,12 @@ __global__ __launch_bounds__(CV2_THREADS) void k_conv2(const ConvProg P) {
             float v[4] = {acc[i][j][0] + b4.x, acc[i][j][1] + b4.y, acc[i][j][2] + b4.z, acc[i][j][3] + b4.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], act_floor);      // ReLU | identity, branch-free
-            if (MODE == CONV_TRAIN_FWD && p.drop_thr) {
-                const unsigned h0 = drop_hash2(m, n, p.drop_key), h1 = drop_hash2(m, n + 2, p.drop_key);
-                v[0] = (h0 & 0xffffu) >= p.drop_thr ? v[0] * p.drop_scale : 0.f;
-                v[1] = (h0 >> 16) >= p.drop_thr ? v[1] * p.drop_scale : 0.f;
-                v[2] = (h1 & 0xffffu) >= p.drop_thr ? v[2] * p.drop_scale : 0.f;
-                v[3] = (h1 >> 16) >= p.drop_thr ? v[3] * p.drop_scale : 0.f;
+            if (MODE == CONV_TRAIN_FWD && dthr_) {
+                const unsigned h0 = drop_hash2(m, n, dkey_), h1 = drop_hash2(m, n + 2, dkey_);
+                v[0] = (h0 & 0xffffu) >= dthr_ ? v[0] * dscale_f : 0.f;
+                v[1] = (h0 >> 16) >= dthr_ ? v[1] * dscale_f : 0.f;
+                v[2] = (h1 & 0xffffu) >= dthr_ ? v[2] * dscale_f : 0.f;
+                v[3] = (h1 >> 16) >= dthr_ ? v[3] * dscale_f : 0.f;
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[i][j][e] = v[e];
