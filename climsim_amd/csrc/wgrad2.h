@@ -142,17 +142,23 @@ __global__ __launch_bounds__(512) void k_wgrad2(const WgradArgs pa) {
         if (lane < 32 && n < p.N) atomicAdd(p.db + n, accb[0]);       // row 0 of the ones product
     }
     if (!(k_live && n_live)) return;
-    // D[i = k][j = n]: lane owns column n = ..+(lane&31), rows k = ..+(r&3)+8*(r>>2)+4*(lane>>5)
+    // D[i = k][j = n]: lane owns column n = ..+(lane&31), rows k = ..+(r&3)+8*(r>>2)+4*(lane>>5).
+    // (The layer record's fields as OPAQUE scalars: read through `p` hipcc re-fetched the pointer in front of every one of a lane's
+    //  128 atomics - s_load + `lgkmcnt(0)` each; round 5, read off the compiled kernel.)
+    unsigned long long dwp_ = (unsigned long long)(uintptr_t)p.dW;
+    int pN_ = p.N, kreal_ = p.k_real;
+    asm volatile("" : "+s"(dwp_), "+s"(pN_), "+s"(kreal_));
+    float* const dWb = reinterpret_cast<float*>((uintptr_t)dwp_);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int n = n0 + wn * 128 + j * 32 + (lane & 31);
-            if (n >= p.N) continue;
+            if (n >= pN_) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int k = k0 + wk * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (k < p.k_real) atomicAdd(p.dW + (int64_t)k * p.N + n, acc[i][j][r]);
+                if (k < kreal_) atomicAdd(dWb + (int64_t)k * pN_ + n, acc[i][j][r]);
             }
         }
 }
@@ -323,17 +329,21 @@ __global__ __launch_bounds__(768) void k_wgrad2l(const WgradArgs pa) {
 #undef W2L_STEP
     }
     if (!(k_live && n_live)) return;
-    // D[i = k][j = n]: lane owns column n = ..+(lane&31), rows k = ..+(r&3)+8*(r>>2)+4*(lane>>5)
+    // D[i = k][j = n]: lane owns column n = ..+(lane&31), rows k = ..+(r&3)+8*(r>>2)+4*(lane>>5)  (opaque scalars: see k_wgrad2)
+    unsigned long long dwp_ = (unsigned long long)(uintptr_t)p.dW;
+    int pN_ = p.N, kreal_ = p.k_real;
+    asm volatile("" : "+s"(dwp_), "+s"(pN_), "+s"(kreal_));
+    float* const dWb = reinterpret_cast<float*>((uintptr_t)dwp_);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int n = n0 + wn * 128 + j * 32 + (lane & 31);
-            if (n >= p.N) continue;
+            if (n >= pN_) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int k = k0 + wk * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (k < p.k_real) atomicAdd(p.dW + (int64_t)k * p.N + n, acc[i][j][r]);
+                if (k < kreal_) atomicAdd(dWb + (int64_t)k * pN_ + n, acc[i][j][r]);
             }
         }
 }
