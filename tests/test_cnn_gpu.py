@@ -81,7 +81,10 @@ def make_xy(n, seed):
 
 
 @pytest.mark.parametrize("depth,width,n,loss,rate", [(1, 64, 6, "mse", 0.0), (2, 128, 9, "mae", 0.0), (2, 406, 11, "mse", 0.175),
-                                                      (3, 406, 7, "mae", 0.175)])
+                                                      (3, 406, 7, "mae", 0.175),
+                                                      # one and two columns = 2 and 4 slabs of 32 rows: row ranges SHORTER than the
+                                                      # weight-gradient kernel's four-slab prologue (round 5: queue entries of any length)
+                                                      (2, 406, 1, "mse", 0.0), (1, 128, 2, "mae", 0.175)])
 def test_cnn_loss_and_gradients_match_oracle(CNN, depth, width, n, loss, rate):
     """Training-mode pass: loss sums and every gradient tensor against torch autograd on the CPU (bf16 rounding
     points emulated, same dropout hash).  Tolerance: per tensor, cosine >= 0.999 and norm ratio within 1 % of
