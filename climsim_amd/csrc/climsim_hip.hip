@@ -146,6 +146,8 @@ struct cs_mlp {
     bool grads_dirty = true;   // G may hold non-zero values (cleared by cs_mlp_apply where its kernel zeroes G)
     bool g_stored = false;     // the last weight-gradient launch STORED every element of G (+ Gx): the optimiser need not zero it
     bool g_need_zero = false;  // train_step: G is dirty and the weight-gradient launch must find zeros if it accumulates
+    bool g_stale = true;       // G holds the gradients of a step that was APPLIED and left un-zeroed (or was just rebound): even an
+                               // accumulating cs_mlp_loss_grads must clear it first (round-5 advisor finding)
     unsigned long long* dbg = nullptr;   // CS_CHAIN_DBG: [2][grid_max][64] stamps (fwd, bwd)
     unsigned long long* wg_dbg = nullptr; int wg_dbg_grid = 0;   // CS_CHAIN_DBG: [4096][8] stamps of the last k_wgrad3 launch
     int chain_ablate = 0;      // CS_CHAIN_ABLATE env, timing experiments only
@@ -1061,13 +1063,16 @@ int cs_mlp_loss_grads(cs_mlp_t* h, const float* x_dev, const float* y_dev, const
     if (!x_dev || !y_dev || !loss_dev) return fail(CS_ERR_INVALID, "x_dev, y_dev and loss_dev are required");
     if (normalise && !h->have_norm) return fail(CS_ERR_STATE, "normalise requested before cs_mlp_set_norm");
     hipStream_t st = (hipStream_t)stream;
-    if (!accumulate) {
+    h->g_need_zero = false;                // (a failed train_step may have left it set: this call zeroes by itself)
+    if (!accumulate || h->g_stale) {
         ProfScope ps(CS_K_MEMSET, st);
-        HIP_TRY(hipMemsetAsync(loss_dev, 0, 2 * sizeof(float), st));
-        // the optimiser kernel leaves G zeroed; a memset is only needed when the last gradients were
-        // never applied (or the buffer was just rebound)
-        if (h->grads_dirty) HIP_TRY(hipMemsetAsync(h->G, 0, sizeof(float) * h->n_params, st));
+        if (!accumulate) HIP_TRY(hipMemsetAsync(loss_dev, 0, 2 * sizeof(float), st));
+        // the optimiser kernel leaves G zeroed; a memset is only needed when the last gradients were never applied, when the last
+        // step left its (applied) gradients in place, or when the buffer was just rebound - the last two also for accumulate != 0:
+        // what is in G then is not a micro-batch of this accumulation
+        if (h->grads_dirty || h->g_stale) HIP_TRY(hipMemsetAsync(h->G, 0, sizeof(float) * h->n_params, st));
     }
+    h->g_stale = false;
     h->grads_dirty = true;
     rc = run_forward(h, x_dev, row_idx_dev, n, normalise, h->acc_count ? h->yhat_train : nullptr, y_dev, loss_dev, true, st);
     if (rc) return rc;
@@ -1090,15 +1095,17 @@ int cs_mlp_set_grad_buffer(cs_mlp_t* h, void* dev_ptr) {
     h->G = (float*)dev_ptr;
     h->own_G = false;
     h->grads_dirty = true;
+    h->g_stale = true;
     return CS_OK;
 }
 
 int cs_mlp_apply(cs_mlp_t* h, float lr, float grad_scale, void* stream) {
     if (!h) return fail(CS_ERR_INVALID, "null handle");
-    if (int rc = coop_poll(h)) return rc;
+    if (int rc = coop_poll(h)) { h->gx_parts = 0; h->g_stored = false; h->g_need_zero = false; h->grads_dirty = true; return rc; }
     const bool stored = h->g_stored;       // the kernel leaves G as it found it then (every element is stored again by the next step)
     int rc = launch_optimizer(h, lr, grad_scale, false, (hipStream_t)stream);
-    if (rc == CS_OK) { h->iterations += 1; h->grads_dirty = stored; }
+    if (rc == CS_OK) { h->iterations += 1; h->grads_dirty = stored; h->g_stale = stored; }
+    else { h->gx_parts = 0; h->g_stored = false; h->grads_dirty = true; }
     return rc;
 }
 
@@ -1113,11 +1120,12 @@ int cs_mlp_train_step(cs_mlp_t* h, const float* x_dev, const float* y_dev, const
     // optimiser kernel zeroed; this step's optimiser kernel copies them to loss_dev and zeroes the other slot.
     h->g_need_zero = h->grads_dirty;       // (run_backward clears G if this step's weight-gradient launch adds to it)
     h->grads_dirty = true;
+    h->g_stale = false;                    // (this step's launch stores every element, or finds the buffer zeroed)
     float* slot = h->loss_ring + LOSS_STRIPES * LOSS_STRIPE_FLOATS * h->loss_cur;
     h->loss_striped = true;
     rc = run_forward(h, x_dev, row_idx_dev, n, normalise, h->acc_count ? h->yhat_train : nullptr, y_dev, slot, true, st);
     h->loss_striped = false;
-    if (rc) return rc;
+    if (rc) { h->g_need_zero = false; return rc; }
     if (h->acc_count) train_accuracy(h, y_dev, row_idx_dev, n, st);
     h->in_step = true;
     rc = run_backward(h, n, false, st);
@@ -1593,6 +1601,7 @@ int cs_mlp_group_train_step(cs_mlp_group_t* g, const float* const* x_dev, const 
             HIP_TRY(hipMemsetAsync(h->G, 0, sizeof(float) * h->n_params, st));
         }
         h->grads_dirty = true;
+        h->g_stale = false;
     }
     for (int a = 0; a < na; ++a)
         if (g->wg_n[(size_t)act[a]] != n[act[a]]) tables_stale = true;
@@ -1672,6 +1681,7 @@ int cs_mlp_group_train_step(cs_mlp_group_t* g, const float* const* x_dev, const 
         od.d[a] = OptDyn{h->G, o.loss_src, o.loss_dst, o.loss_zero, o.lr, o.grad_scale, o.alpha, o.bc1, o.bc2, o.radam_r, o.radam_rect};
         h->iterations += 1;
         h->grads_dirty = splitk == 1;
+        h->g_stale = splitk == 1;
     }
     {
         ProfScope ps(CS_K_OPTIMIZER, st);

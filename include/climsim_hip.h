@@ -152,7 +152,8 @@ int cs_mlp_apply(cs_mlp_t* h, float lr, float grad_scale, void* stream);
 
 /* Model.train_step: loss_grads + apply(lr, 1/(128 n)).  What the gradient buffer holds AFTER a train_step is unspecified (the step may
  * keep its row splits' partial sums in separate buffers and leave the buffer un-zeroed: 4 bytes per parameter less per step); a
- * later cs_mlp_loss_grads starts from a clean buffer either way. */
+ * later cs_mlp_loss_grads starts from a clean buffer either way - ALSO with accumulate != 0: gradients that were already applied
+ * (or a buffer that was just rebound) are never the first micro-batch of an accumulation. */
 int cs_mlp_train_step(cs_mlp_t* h, const float* x_dev, const float* y_dev, const int64_t* row_idx_dev,
                       int64_t n, int normalise, float lr, float* loss_dev, void* stream);
 

@@ -204,7 +204,7 @@ def cyclical_lr(it, init_lr=2.5e-4, max_lr=2.5e-3, step_size=16):
 
 @dataclass
 class Optimizer:
-    """Keras 2.11 Adam / RMSprop / SGD and tfa 0.19 RectifiedAdam update rules, float32 state."""
+    """Keras 2.11 Adam / RMSprop / SGD, tfa 0.19 RectifiedAdam and torch.optim.Adam ('AdamTorch') update rules, float32 state."""
     kind: str = "Adam"
     beta1: float = 0.9
     beta2: float = 0.999
@@ -240,6 +240,16 @@ class Optimizer:
                 self.v[i] = self.v[i] + (g * g - self.v[i]) * F32(1 - self.beta2)
                 alpha = lr * np.sqrt(one - p2) / (one - p1)
                 w = w - (self.m[i] * alpha) / (np.sqrt(self.v[i]) + eps)
+            elif self.kind == "AdamTorch":
+                # torch.optim.Adam (_single_tensor_adam; online_testing/baseline_models/MLP_v2rh/training/train_mlp_h5loader.py:210-211):
+                # the bias corrections are Python doubles, eps sits INSIDE the correction of v (default 1e-8).  Pinned by reference
+                # output: tests/test_hot_mlp_cpu.py (five steps of the reference's own optimiser on the benchmarked topologies).
+                td = float(self.it + 1)
+                step = F32(float(lr) / (1.0 - self.beta1 ** td))
+                bc2_sqrt = F32(np.sqrt(1.0 - self.beta2 ** td))
+                self.m[i] = (self.m[i] + F32(1 - self.beta1) * (g - self.m[i])).astype(F32)
+                self.v[i] = (self.v[i] * b2 + (F32(1 - self.beta2) * g) * g).astype(F32)
+                w = w - (step * self.m[i]) / (np.sqrt(self.v[i]) / bc2_sqrt + eps)
             elif self.kind == "RAdam":
                 self.m[i] = b1 * self.m[i] + (one - b1) * g
                 self.v[i] = b2 * self.v[i] + (one - b2) * (g * g)

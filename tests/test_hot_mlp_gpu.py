@@ -1,0 +1,143 @@
+"""The BENCHMARKED kernels against vectors the REFERENCE computed (tests/golden/hot_mlp_golden.npz: the reference's torch MLP
+- online_testing/baseline_models/MLP_v2rh/training/mlp.py:28-67 - in the cfg-MLP topology at batch 8192 and in the published
+topology at batch 3072, nn.MSELoss, autograd, five torch.optim.Adam steps; made by tests/golden/make_online_mlp_golden.py).
+
+`MLPEmulator(units=(512,)*5, activation="relu", optimizer="AdamTorch", epsilon=1e-8)` with DEFAULT flags at 8192 rows is the
+bench line's step: k_chain_fb<32> + k_wgrad3<4,64> + k_optimizer (three launches, asserted through cs_mlp_profile_step); the
+published widths at 3072 rows run k_chainw_fb.  Two comparisons per quantity:
+  (a) against the reference's float32 vectors at bf16-operand tolerance: predictions 3e-2 of the largest, loss / mae 2 %, every
+      gradient tensor 5 % in norm / projections (bf16 operands through seven layers; measured: profiles/r06_test_margins.json),
+  (b) against oracle/mlp_oracle.py with the engine's rounding points emulated (pinned to the same vectors at float32 tolerance by
+      tests/test_hot_mlp_cpu.py) at accumulation-order tolerance: predictions 1e-3 in norm, loss 2e-3, gradients 5e-3 in norm."""
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from oracle import mlp_oracle as O  # noqa: E402
+from online_mlp_inputs import HOT_CASES, LR, hot_batches, hot_init_state, hot_pred_rows, hot_summary  # noqa: E402
+from test_hot_mlp_cpu import cfg_of, keras_list, state_dict  # noqa: E402
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "hot_mlp_golden.npz"))
+FAMILY = {"cfg_mlp_b8192": 1, "pub_mlp_b3072": 2}             # cs_mlp_kernel_family: 1 = tuned chain (k_chain_fb), 2 = wide chain (k_chainw_fb)
+
+
+@pytest.fixture(scope="module")
+def M():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from climsim_amd import build
+    build.build()
+    from climsim_amd import mlp
+    return mlp
+
+
+def rel(a, b):
+    return float(np.linalg.norm(np.asarray(a, np.float64) - np.asarray(b, np.float64)) / (np.linalg.norm(b) + 1e-30))
+
+
+def make(M, name):
+    n_in, n_out, hidden, loss, nb = HOT_CASES[name]
+    m = M.MLPEmulator(units=tuple(hidden[:-1]), activation="relu", optimizer="AdamTorch", epsilon=1e-8, max_batch=nb, seed=None)
+    m.set_weights(keras_list(hot_init_state(name), len(hidden)))
+    return m
+
+
+def summary_vs_reference(name, prefix, key, t):
+    """Norm and projections of a weight-shaped tensor against the reference's, relative to the reference's norm; corner + sample
+    entries relative to the rms entry."""
+    got = hot_summary(name, key, t)
+    fro = float(GOLD[f"{prefix}/{key}/fro"])
+    rms = fro / np.sqrt(np.asarray(t).size)
+    return (abs(got["fro"] - fro) / fro, float(np.abs(got["proj"] - GOLD[f"{prefix}/{key}/proj"]).max() / fro),
+            float(max(np.abs(got[f] - GOLD[f"{prefix}/{key}/{f}"]).max() for f in ("corner", "sample")) / rms))
+
+
+@pytest.mark.parametrize("name", list(HOT_CASES))
+def test_default_kernels_match_the_reference_vectors(M, name):
+    from climsim_amd.group import kernel_family
+    from conftest import record_margin
+    n_in, n_out, hidden, loss, nb = HOT_CASES[name]
+    m = make(M, name)
+    assert kernel_family(m) == FAMILY[name]
+    cfg = cfg_of(name)
+    ws = keras_list(hot_init_state(name), len(hidden))
+    x, y = hot_batches(name)[0]
+    xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    ol, omae, og, opred = O.loss_and_grads(ws, x, y, cfg, bf16=True)
+    # forward
+    pred = m.predict(xd, as_numpy=False).cpu().numpy()
+    rows = hot_pred_rows(name)
+    amax = float(GOLD[f"{name}/pred_absmax"])
+    record_margin(f"hot_{name}_pred_vs_reference_max", float(np.abs(pred[rows] - GOLD[f"{name}/pred_rows"]).max() / amax))
+    record_margin(f"hot_{name}_pred_vs_oracle_rel", rel(pred, opred))
+    assert np.abs(pred[rows] - GOLD[f"{name}/pred_rows"]).max() <= 3e-2 * amax
+    assert rel(pred[rows], GOLD[f"{name}/pred_rows"]) <= 1e-2
+    assert rel(pred, opred) <= 1e-3 and np.abs(pred - opred).max() <= 6e-3 * np.abs(opred).max()
+    assert (pred[:, 120:] >= 0).all()
+    # loss + backward (the two-call form: k_chain_fb + the weight-gradient kernel)
+    sums = m.loss_grads(xd, yd).cpu().numpy().astype(np.float64) / (128 * nb)
+    assert abs(sums[0] - float(GOLD[f"{name}/loss"])) <= 2e-2 * float(GOLD[f"{name}/loss"])
+    assert abs(sums[1] - float(GOLD[f"{name}/mae"])) <= 2e-2 * float(GOLD[f"{name}/mae"])
+    assert abs(sums[0] - ol) <= 2e-3 * ol and abs(sums[1] - omae) <= 2e-3 * omae
+    g = state_dict(m.get_gradients(1.0 / (128 * nb)), len(hidden))
+    osd = state_dict(og, len(hidden))
+    for k in g:
+        assert rel(g[k], osd[k]) <= 5e-3, (k, rel(g[k], osd[k]))
+        record_margin(f"hot_{name}_grad_vs_oracle_rel", rel(g[k], osd[k]))
+        if k.endswith("bias"):
+            r = rel(g[k], GOLD[f"{name}/grad/{k}"])
+            record_margin(f"hot_{name}_bias_grad_vs_reference_rel", r)
+            assert r <= 5e-2, (k, r)
+        else:
+            dfro, dproj, dentry = summary_vs_reference(name, f"{name}/grad", k, g[k])
+            record_margin(f"hot_{name}_weight_grad_vs_reference_fro", dfro)
+            record_margin(f"hot_{name}_weight_grad_vs_reference_proj", dproj)
+            record_margin(f"hot_{name}_weight_grad_vs_reference_entry", dentry)
+            assert dfro <= 2e-2 and dproj <= 5e-2 and dentry <= 0.25, (k, dfro, dproj, dentry)
+    m.close()
+
+
+@pytest.mark.parametrize("name", list(HOT_CASES))
+def test_five_adam_steps_of_the_default_step_match_the_reference(M, name):
+    """cs_mlp_train_step (the bench's one-call step: the row splits of the weight gradients are stored and added by k_optimizer) on
+    the reference's five batches with the reference's optimiser rule."""
+    from conftest import record_margin
+    n_in, n_out, hidden, loss, nb = HOT_CASES[name]
+    m = make(M, name)
+    cfg = cfg_of(name)
+    init = hot_init_state(name)
+    ws = keras_list(init, len(hidden))
+    opt = O.Optimizer(kind="AdamTorch", eps=1e-8)
+    losses, olosses = [], []
+    for i, (x, y) in enumerate(hot_batches(name)):
+        xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+        if i == 0:                                                   # the launches of the step, by kind
+            kt = m.profile_step(xd, yd, LR)
+            launched = {k: v[1] for k, v in kt.items() if v[1]}
+            assert launched == {"chain_fb": 1, "wgrad": 1, "optimizer": 1}, launched
+            losses.append(float(m._loss.cpu().numpy()[0]) / (128 * nb))
+        else:
+            losses.append(float(m.train_on_batch(xd, yd, LR).cpu().numpy()[0]) / (128 * nb))
+        ws, ol, _ = O.train_step(ws, opt, x, y, cfg, LR, bf16=True)
+        olosses.append(ol)
+    np.testing.assert_allclose(losses, GOLD[f"{name}/losses"], rtol=2e-2)
+    np.testing.assert_allclose(losses, olosses, rtol=3e-3)
+    sd, osd = state_dict(m.get_weights(), len(hidden)), state_dict(ws, len(hidden))
+    for k in sd:
+        mv, omv = sd[k] - init[k], osd[k] - init[k]
+        record_margin(f"hot_{name}_movement_vs_oracle_rel", rel(mv, omv))
+        assert rel(mv, omv) <= 2e-2, (k, rel(mv, omv))
+        if k.endswith("bias"):
+            r = rel(mv, GOLD[f"{name}/after5/{k}"] - init[k])
+            record_margin(f"hot_{name}_bias_movement_vs_reference_rel", r)
+            assert r <= 0.1, (k, r)
+        else:
+            dfro, dproj, dentry = summary_vs_reference(name, f"{name}/moved5", k, sd[k].astype(np.float64) - init[k])
+            record_margin(f"hot_{name}_weight_movement_vs_reference_fro", dfro)
+            record_margin(f"hot_{name}_weight_movement_vs_reference_proj", dproj)
+            assert dfro <= 2e-2 and dproj <= 0.1, (k, dfro, dproj)
+    m.close()

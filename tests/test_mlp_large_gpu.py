@@ -141,3 +141,50 @@ def test_continuous_run_equals_one_queue_per_stage(M, monkeypatch, n):
     for a, b in zip(out["1"][2], out["0"][2]):
         assert np.array_equal(a, b)
     assert np.array_equal(out["1"][3], out["0"][3])
+
+
+@pytest.mark.parametrize("n", [8192, 1024])
+def test_accumulating_gradient_call_after_a_step_starts_clean(M, n):
+    """Round-5 advisor finding: a one-call step may leave its (applied) gradients in the flat buffer; `loss_grads(accumulate=True)` as
+    the FIRST micro-batch after such a step - or after a grouped step, or on a fresh handle - must not add onto them.  Two
+    accumulated micro-batches after a step == the same two on a model that was never stepped but holds the same weights."""
+    from climsim_amd.group import MLPGroup
+    cfg = O.MLPConfig(hidden=CFG)
+    ws = O.glorot_init(cfg, 9)
+    x, y = O.synth_columns(n, seed=17)
+    xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    h = n // 2
+
+    def two_micro_batches(m):
+        m.loss_grads(xd[:h], yd[:h], accumulate=True)
+        m.loss_grads(xd[h:], yd[h:], accumulate=True)
+        return m.get_gradients(1.0)
+
+    a = M.MLPEmulator(units=CFG, max_batch=n, seed=None)
+    a.set_weights(ws)
+    a.train_on_batch(xd, yd, 1e-3)
+    got = two_micro_batches(a)
+    b = M.MLPEmulator(units=CFG, max_batch=n, seed=None)
+    b.set_weights(a.get_weights())
+    b.set_optimizer_state(*a.get_optimizer_state())
+    b.loss_grads(xd[:h], yd[:h])
+    b.loss_grads(xd[h:], yd[h:], accumulate=True)
+    want = b.get_gradients(1.0)
+    for u, v in zip(got, want):
+        assert rel(u, v) <= 1e-4, rel(u, v)
+    # fresh handle, first call accumulating
+    c = M.MLPEmulator(units=CFG, max_batch=n, seed=None)
+    c.set_weights(a.get_weights())
+    for u, v in zip(two_micro_batches(c), want):
+        assert rel(u, v) <= 1e-4, rel(u, v)
+    # after a grouped step (one row split stores the gradients and leaves them in place)
+    g = MLPGroup([a, c])
+    g.train_on_batch(xd[:h], yd[:h], 1e-3)
+    b.set_weights(a.get_weights())
+    b.loss_grads(xd[:h], yd[:h])
+    b.loss_grads(xd[h:], yd[h:], accumulate=True)
+    for u, v in zip(two_micro_batches(a), b.get_gradients(1.0)):
+        assert rel(u, v) <= 1e-4, rel(u, v)
+    g.close()
+    for m in (a, b, c):
+        m.close()
