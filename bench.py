@@ -217,40 +217,72 @@ def heldout_per_variable(model, xv, yv):
             "note": "energy-weighted units (W/m2) as in the reference's evaluation; R2 is null where a level has zero target variance"}
 
 
-def acceptance_check(tables):
-    """The check of the acceptance leg, separated from the runs so that it can be driven on made-up tables (tests/test_bench_cpu.py).
-    `tables[side][order]` = {variable: MAE} for side in ("engine_bf16", "cpu_fp32") and >= 2 data orders each.  Per variable: the
-    engine's MAE averaged over the orders must sit within (2 % + the largest difference that changing NOTHING BUT THE DATA ORDER makes
-    inside either implementation) of the CPU restatement's - SURVEY 8(d) states 2 % for bf16 after equal steps; the measured
-    same-implementation spread says how much of a difference between two training runs is not about the implementation at all."""
+def acceptance_check(tables, overall=None):
+    """The check of the acceptance leg, separated from the runs so that it can be driven on made-up tables
+    (tests/test_bench_contract_cpu.py).  `tables[side][order]` = {variable: MAE} for side in ("engine_bf16", "cpu_fp32"); order o of
+    both sides saw the same batches in the same sequence, so the orders are PAIRS.  Round 6 - a statistic instead of a maximum
+    over three pairs: per variable the paired differences d_o = engine_o - cpu_o give delta = mean(d_o) and its standard error
+    se = std(d_o, ddof=1) / sqrt(n); asserted is |delta| <= 2 % (bf16 after equal steps) + 2 se, both relative to
+    the CPU restatement's mean.  The engine's own run-to-run scatter enters through se only TOGETHER with the restatement's
+    (round-5 advisor finding: it must not widen its own bar), and is bounded separately: its order-to-order standard deviation
+    may not exceed 2.5 x the restatement's.  `overall[side][order]` (optional) = MAE over all 128 outputs, the one low-noise
+    quantity of the leg: its mean relative difference must stay within 2 % with no allowance."""
+    import math
     sides = ("engine_bf16", "cpu_fp32")
     names = list(tables["cpu_fp32"][0])
-    mean = {s_: {v: sum(t[v] for t in tables[s_]) / len(tables[s_]) for v in names} for s_ in sides}
+    n = len(tables["cpu_fp32"])
+    assert n >= 2 and len(tables["engine_bf16"]) == n, "the check needs the same >= 2 data orders on both sides"
+
+    def mean(xs):
+        return sum(xs) / len(xs)
+
+    def sd(xs):
+        m = mean(xs)
+        return math.sqrt(sum((x - m) ** 2 for x in xs) / (len(xs) - 1))
+    mu = {s_: {v: mean([t[v] for t in tables[s_]]) for v in names} for s_ in sides}
+    sig = {s_: {v: sd([t[v] for t in tables[s_]]) / max(abs(mu["cpu_fp32"][v]), 1e-30) for v in names} for s_ in sides}
+    ref = {v: max(abs(mu["cpu_fp32"][v]), 1e-30) for v in names}
+    d = {v: [e[v] - c[v] for e, c in zip(tables["engine_bf16"], tables["cpu_fp32"])] for v in names}
+    delta = {v: abs(mean(d[v])) / ref[v] for v in names}
+    se = {v: sd(d[v]) / math.sqrt(n) / ref[v] for v in names}
+    allowed = {v: 0.02 + 2.0 * se[v] for v in names}
+    same_order = {v: max(abs(x) for x in d[v]) / ref[v] for v in names}
 
     def pair_spread(ts, v):
         return max(abs(ts[i][v] - ts[j][v]) / max(abs(ts[j][v]), 1e-30) for i in range(len(ts)) for j in range(len(ts)) if i != j)
     spread = {s_: {v: pair_spread(tables[s_], v) for v in names} for s_ in sides}
-    diff = {v: abs(mean["engine_bf16"][v] - mean["cpu_fp32"][v]) / max(abs(mean["cpu_fp32"][v]), 1e-30) for v in names}
-    same_order = {v: max(abs(e[v] - c[v]) / max(abs(c[v]), 1e-30) for e, c in zip(tables["engine_bf16"], tables["cpu_fp32"])) for v in names}
-    allowed = {v: 0.02 + max(spread["engine_bf16"][v], spread["cpu_fp32"][v]) for v in names}
-    worst = max(names, key=lambda v: diff[v] - allowed[v])
-    r4 = lambda d: {v: round(x, 4) for v, x in d.items()}          # noqa: E731
-    return {"engine_vs_cpu": {"of_the_order_means": r4(diff), "same_order_worst": r4(same_order)},
-            "cpu_vs_cpu_other_order": r4(spread["cpu_fp32"]), "engine_vs_engine_other_order": r4(spread["engine_bf16"]),
-            "allowed": r4(allowed), "tolerance": "0.02 + the larger same-implementation spread, per variable",
-            "worst_variable": worst, "margin": round(allowed[worst] - diff[worst], 4), "passed": bool(all(diff[v] <= allowed[v] for v in names))}
+    worst = max(names, key=lambda v: delta[v] - allowed[v])
+    # the engine may not be more erratic than the restatement (floor: 0.5 % - two runs that agree to rounding have no scatter to compare)
+    scatter_ok = {v: sig["engine_bf16"][v] <= 2.5 * max(sig["cpu_fp32"][v], 0.005) for v in names}
+    r4 = lambda t: {v: round(x, 4) for v, x in t.items()}          # noqa: E731
+    out = {"orders": n,
+           "engine_vs_cpu": {"of_the_order_means": r4(delta), "se": r4(se), "same_order_worst": r4(same_order)},
+           "order_to_order_sd": {"engine_bf16": r4(sig["engine_bf16"]), "cpu_fp32": r4(sig["cpu_fp32"])},
+           "cpu_vs_cpu_other_order": r4(spread["cpu_fp32"]), "engine_vs_engine_other_order": r4(spread["engine_bf16"]),
+           "allowed": r4(allowed), "tolerance": "per variable |mean paired difference| <= 0.02 + 2 se, relative to the CPU restatement's mean; "
+                                                "engine order-to-order sd <= 2.5 x the restatement's; all-output MAE within 0.02",
+           "worst_variable": worst, "margin": round(allowed[worst] - delta[worst], 4),
+           "per_variable_passed": bool(all(delta[v] <= allowed[v] for v in names)),
+           "scatter_passed": bool(all(scatter_ok.values()))}
+    if overall is not None:
+        do = [e - c for e, c in zip(overall["engine_bf16"], overall["cpu_fp32"])]
+        mo = max(abs(mean(overall["cpu_fp32"])), 1e-30)
+        out["all_outputs"] = {"rel_diff_of_the_order_means": round(abs(mean(do)) / mo, 5), "se": round(sd(do) / math.sqrt(n) / mo, 5), "allowed": 0.02}
+        out["all_outputs_passed"] = bool(abs(mean(do)) / mo <= 0.02)
+    out["passed"] = bool(out["per_variable_passed"] and out["scatter_passed"] and out.get("all_outputs_passed", True))
+    return out
 
 
-def acceptance_vs_cpu(torch, device, steps=1200, bs=1024, lr0=1e-3, high_share=0.5, orders=3):
+def acceptance_vs_cpu(torch, device, steps=800, bs=1024, lr0=1e-3, high_share=0.5, orders=6):
     """SURVEY 8(d) "MAE acceptance", synthetic form, inside the bench line - a CHECK since round 5, not two numbers side by side.
     The cfg-MLP is trained for the SAME `steps` steps on the SAME batches (Adam, lr 1e-3, 1e-4 for the second half) by the HIP engine
     (bf16 operands) and by the fp32 torch-CPU restatement of the reference step (oracle/mlp_torch_cpu.py), both from
     synthetic_init(0), both scored on the same held-out rows through the reference's evaluation weighting - and that `orders`
     times, each time with the batches in another order (same rows, same init).  Two training runs of a 5 x 512 model differ by
     several per cent on single outputs from the data order alone, in EITHER implementation (round 4 measured 2.4 - 10 % between
-    schedules); the leg measures that spread (`cpu_vs_cpu_other_order`, `engine_vs_engine_other_order`) and holds the difference
-    of the order-averaged per-variable MAE to it: |engine - cpu| <= spread + 2 % (acceptance_check).  tests/test_bench_gpu.py asserts
-    `check.passed` on the line the driver's command prints."""
+    schedules); the leg measures that scatter and holds the mean paired difference of the per-variable MAE to 2 % + two standard
+    errors, and the all-output MAE to 2 % flat (acceptance_check; round 6: six orders of 800 steps instead of three of 1200 - the
+    leg's time is the CPU side's).  tests/test_bench_gpu.py asserts `check.passed` on the line the driver's command prints."""
     from climsim_amd.mlp import MLPEmulator
     from oracle.mlp_oracle import MLPConfig
     from oracle.mlp_torch_cpu import TorchMLP
@@ -263,6 +295,7 @@ def acceptance_vs_cpu(torch, device, steps=1200, bs=1024, lr0=1e-3, high_share=0
     xc, yc = x.cpu(), y.cpu()
     t0 = time.perf_counter()
     tables = {"engine_bf16": [], "cpu_fp32": []}
+    overall = {"engine_bf16": [], "cpu_fp32": []}
     first = {}
     for o in range(orders):
         ws = synthetic_init(0)
@@ -282,13 +315,14 @@ def acceptance_vs_cpu(torch, device, steps=1200, bs=1024, lr0=1e-3, high_share=0
             e = (pr - ys).double()
             t = per_variable_tables(pr, ys, xs)
             tables[name].append(t["MAE"])
+            overall[name].append(float(e.abs().mean()))
             if o == 0:
                 first[name] = {"mse": float((e * e).mean()), "mae": float(e.abs().mean()), **t}
         m.close()
     out = {"task": f"cfg-MLP from synthetic_init(0), {steps} steps of batch {bs} (fresh rows every step, the same batches in the same order on both sides), lr 1e-3 then 1e-4 for the second half; "
                    f"targets tanh(3 xA) * 0.3 + noise (the recipe with a stronger signal, as the acceptance test); held-out {12 * 384} rows; {orders} data orders per side",
            "seconds": round(time.perf_counter() - t0, 1), **first}
-    out["check"] = acceptance_check(tables)
+    out["check"] = acceptance_check(tables, overall)
     out["max_rel_diff_MAE"] = max(out["check"]["engine_vs_cpu"]["of_the_order_means"].values())
     out["rel_diff_mae_all_outputs"] = round(abs(first["engine_bf16"]["mae"] - first["cpu_fp32"]["mae"]) / first["cpu_fp32"]["mae"], 5)
     r2 = [(first["engine_bf16"]["R2"][v], first["cpu_fp32"]["R2"][v]) for v in first["cpu_fp32"]["R2"]]

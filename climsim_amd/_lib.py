@@ -120,6 +120,7 @@ SIGNATURES = {
     "cs_cnn_evaluate": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, _P, _I64, _P, C.c_int, _P]),
     "cs_cnn_loss_grads": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, _P, _I64, _P, _P]),
     "cs_cnn_set_seed": (C.c_int, [_P, C.c_uint64]),
+    "cs_cnn_set_metrics_buffer": (C.c_int, [_P, _P]),
     "cs_cnn_grad_buffer": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_I64)]),
     "cs_cnn_set_grad_buffer": (C.c_int, [_P, _P, _I64]),
     "cs_cnn_apply": (C.c_int, [_P, _F, _F, _P]),

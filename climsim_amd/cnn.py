@@ -84,6 +84,9 @@ class CNNEmulator:
         self._n_params = int(self.lib.cs_cnn_num_params(self._h))
         self._shapes = _shapes(depth, channel_width)
         self._loss = torch.zeros(4, dtype=torch.float32, device=self.device)
+        # running sums of the reference's two remaining compiled metrics (hpo_train.py:83-111, 231): [CRPS score terms, argmax matches]
+        self._metrics = torch.zeros(2, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.cs_cnn_set_metrics_buffer(self._h, _ptr(self._metrics)))
         self._grad_tensor = None
         if self.trainable:
             self.gradient_tensor()                   # bind the torch-owned gradient buffer before the first step
@@ -205,13 +208,20 @@ class CNNEmulator:
             return a, 0
         raise ValueError(f"expected (N,{shape3[0]},{shape3[1]}) or (N,{flat_cols}), got {tuple(a.shape)}")
 
-    def _losses(self, sums, n_cols):
+    def _losses(self, sums, n_cols, metrics=None):
+        """Loss sums (+ optionally the metric sums of `self._metrics`) of `n_cols` columns -> the values Keras logs for
+        compile(metrics=["mse", "mae", "accuracy", mse_adjusted, mae_adjusted, continuous_ranked_probability_score]), hpo_train.py:231."""
         s = np.asarray(sums, np.float64)
         dp, ds = n_cols * 60 * 2, n_cols * 60 * 8
         mae = s[0] / dp * (120 / 128) + s[1] / ds * (8 / 128)
         mse = s[2] / dp * (120 / 128) + s[3] / ds * (8 / 128)
-        return {"loss": float(mae if LOSSES[self.loss_name] == 0 else mse), "mae_adjusted": float(mae), "mse_adjusted": float(mse),
-                "mae": float((s[0] + s[1]) / (dp + ds)), "mse": float((s[2] + s[3]) / (dp + ds))}
+        out = {"loss": float(mae if LOSSES[self.loss_name] == 0 else mse), "mae_adjusted": float(mae), "mse_adjusted": float(mse),
+               "mae": float((s[0] + s[1]) / (dp + ds)), "mse": float((s[2] + s[3]) / (dp + ds))}
+        if metrics is not None:
+            q = np.asarray(metrics, np.float64)
+            out["continuous_ranked_probability_score"] = float(q[0] / (n_cols * 60))
+            out["accuracy"] = float(q[1] / (n_cols * 60))
+        return out
 
     def loss_grads(self, x, y, row_idx=None, n=None, loss=None, normalise=False, x3d=None, y3d=None):
         """Training-mode forward (dropout on) + backward of one batch; gradients (unscaled sums) land in
@@ -264,17 +274,22 @@ class CNNEmulator:
         return self._split(self.gradient_tensor().detach().cpu().numpy() * np.float32(grad_scale))
 
     def evaluate(self, x, y, batch_size: Optional[int] = None):
-        """model.evaluate: loss (the compiled one) plus mae/mse and their adjusted forms (hpo_train.py:227-231)."""
+        """model.evaluate: loss (the compiled one) plus every compiled metric: mae / mse and their adjusted forms, accuracy and
+        continuous_ranked_probability_score (hpo_train.py:227-231)."""
         import torch
         x, x3d = self._to_device(x, 124, (60, 6))
         y, y3d = self._to_device(y, 128, (60, 10))
         bs = min(batch_size or self.max_batch, self.max_batch)
         tot = torch.zeros(4, dtype=torch.float32, device=self.device)
+        kept = self._metrics.clone()                     # an evaluation inside fit() must not disturb the epoch's running sums
+        self._metrics.zero_()
         for i, lo in enumerate(range(0, x.shape[0], bs)):
             hi = min(lo + bs, x.shape[0])
             _lib.check(self.lib.cs_cnn_evaluate(self._h, _ptr(x[lo:hi]), x3d, _ptr(y[lo:hi]), y3d, None, hi - lo, _ptr(tot),
                                                 int(i > 0), self._stream()))
-        return self._losses(tot.cpu().numpy(), x.shape[0])
+        out = self._losses(tot.cpu().numpy(), x.shape[0], self._metrics.cpu().numpy())
+        self._metrics.copy_(kept)
+        return out
 
     def fit(self, x, y, batch_size: int = 512, epochs: int = 15, validation_data=None, learning_rate=None,
             shuffle: bool = True, seed: int = 0, steps_per_epoch: Optional[int] = None, checkpoint: Optional[str] = None,
@@ -309,7 +324,7 @@ class CNNEmulator:
         if steps < 1:
             raise ValueError("dataset smaller than one batch")
         gen = torch.Generator(device=self.device)
-        keys = ["loss", "mae_adjusted", "mse_adjusted", "mae", "mse"]
+        keys = ["loss", "mse", "mae", "accuracy", "mse_adjusted", "mae_adjusted", "continuous_ranked_probability_score"]   # Keras' order
         history = {k: [] for k in keys + ["lr"]}
         if validation_data is not None:
             history.update({"val_" + k: [] for k in keys})
@@ -322,6 +337,7 @@ class CNNEmulator:
                 gen.manual_seed(seed + epoch)
                 perm = torch.randperm(n, device=self.device, generator=gen) if shuffle else torch.arange(n, device=self.device)
                 epoch_sum.zero_()
+                self._metrics.zero_()
                 lr = sched(self.iterations)
                 for s in range(steps):
                     lr = sched(self.iterations)
@@ -336,7 +352,8 @@ class CNNEmulator:
                     epoch_sum += step_loss
                 if distributed:
                     dist.all_reduce(epoch_sum)
-                row = self._losses(epoch_sum.cpu().numpy(), batch_size * steps)
+                    dist.all_reduce(self._metrics)
+                row = self._losses(epoch_sum.cpu().numpy(), batch_size * steps, self._metrics.cpu().numpy())
                 row["lr"] = float(lr)
                 if validation_data is not None:
                     ev = self.evaluate(validation_data[0], validation_data[1])

@@ -20,6 +20,10 @@
 #define CWD_MAX_BIAS 7936         // floats of bias staged in LDS (sum of layer widths): what is left of the 160 KiB beside the two activation
                                   // buffers - e.g. 7 layers of 1024 + the two 128-wide ones (round 2 shared the tuned chain's 4096, which sent
                                   // 5 x 896 and 5 x 1024 - inside the reference's search space - to the one-GEMM-per-layer path)
+#ifndef CWD_BIAS_ACC
+#define CWD_BIAS_ACC 1            // forward hidden stages start their accumulators from the bias (as chain.h since round 5; round 6 here: the
+                                  // published model's step 0.1426 -> 0.1385 ms at batch 3072, LAB_NOTES round 5).  0 = bias added in the epilogue (A/B builds)
+#endif
 constexpr int chainw_lds_bytes() { return 2 * CWD_BM * CWD_PITCH * 2 + CWD_MAX_BIAS * 4 + CWD_BM * 8; }
 
 __device__ __forceinline__ int cwd_off(int row, int col) {        // element offset of (row, col): 16-B chunks XOR (row & 15)
@@ -173,9 +177,14 @@ __device__ __forceinline__ void chainw_body(const ChainArgs& p, const ChainDyn& 
                 const int n = tile * 32 + 8 * q + hi4;
                 float v[4] = {acc[4 * q + 0], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
                 if (!BWD) {
+#if CWD_BIAS_ACC
+                    v[0] = act_fwd(v[0], p.act, p.slope); v[1] = act_fwd(v[1], p.act, p.slope);        // (the bias is in the accumulators: chain_mma)
+                    v[2] = act_fwd(v[2], p.act, p.slope); v[3] = act_fwd(v[3], p.act, p.slope);
+#else
                     const float4 b4 = *reinterpret_cast<const float4*>(bias_lds + S.bias_off + n);
                     v[0] = act_fwd(v[0] + b4.x, p.act, p.slope); v[1] = act_fwd(v[1] + b4.y, p.act, p.slope);
                     v[2] = act_fwd(v[2] + b4.z, p.act, p.slope); v[3] = act_fwd(v[3] + b4.w, p.act, p.slope);
+#endif
                     if (p.drop_thr) {                            // training-mode nn.Dropout: relu(dropout(z)) == dropout(relu(z))
                         const unsigned h0 = mlp_drop_hash2(m0 + mrow, n, S.drop_key), h1 = mlp_drop_hash2(m0 + mrow, n + 2, S.drop_key);
                         v[0] = (h0 & 0xffffu) >= p.drop_thr ? v[0] * p.drop_scale : 0.f;
@@ -213,16 +222,17 @@ __device__ __forceinline__ void chainw_body(const ChainArgs& p, const ChainDyn& 
                         hh[b][q] = *reinterpret_cast<const uint2*>(S.hprev + (m0 + mrow) * S.ldh + (tile0 + (two ? b : 0)) * 32 + 8 * q + hi4);
             }
             // the weight stream of chain.h: inline-asm loads, counted vmcnt, 8 (or 4) k16-steps in flight
+            const float* bias0 = (!BWD && CWD_BIAS_ACC) ? bias_lds + S.bias_off + tile0 * 32 : nullptr;
             if (two) {
                 f32x16_t acc2[1][2];
-                if ((S.Kc & 127) == 0) chain_mma<CWD_BM, 1, 2, 8, true, CWD_PITCH, true>(Xin, S.wfrag, ks, ntiles, tile0, 0, tid, acc2, pend, m0);
-                else chain_mma<CWD_BM, 1, 2, 4, true, CWD_PITCH, true>(Xin, S.wfrag, ks, ntiles, tile0, 0, tid, acc2, pend, m0);
+                if ((S.Kc & 127) == 0) chain_mma<CWD_BM, 1, 2, 8, true, CWD_PITCH, true>(Xin, S.wfrag, ks, ntiles, tile0, 0, tid, acc2, pend, m0, 0, bias0);
+                else chain_mma<CWD_BM, 1, 2, 4, true, CWD_PITCH, true>(Xin, S.wfrag, ks, ntiles, tile0, 0, tid, acc2, pend, m0, 0, bias0);
                 epilogue(tile0, slot0, acc2[0][0], hh[0]);
                 epilogue(tile0 + 1, slot0 + 1, acc2[0][1], hh[1]);
             } else {
                 f32x16_t acc1[1][1];
-                if ((S.Kc & 127) == 0) chain_mma<CWD_BM, 1, 1, 8, true, CWD_PITCH, true>(Xin, S.wfrag, ks, ntiles, tile0, 0, tid, acc1, pend, m0);
-                else chain_mma<CWD_BM, 1, 1, 4, true, CWD_PITCH, true>(Xin, S.wfrag, ks, ntiles, tile0, 0, tid, acc1, pend, m0);
+                if ((S.Kc & 127) == 0) chain_mma<CWD_BM, 1, 1, 8, true, CWD_PITCH, true>(Xin, S.wfrag, ks, ntiles, tile0, 0, tid, acc1, pend, m0, 0, bias0);
+                else chain_mma<CWD_BM, 1, 1, 4, true, CWD_PITCH, true>(Xin, S.wfrag, ks, ntiles, tile0, 0, tid, acc1, pend, m0, 0, bias0);
                 epilogue(tile0, slot0, acc1[0][0], hh[0]);
             }
         }

@@ -41,6 +41,7 @@ struct cs_cnn {
     int64_t off_wl = 0, off_bl = 0, off_wr = 0, off_br = 0;
     int64_t iterations = 0, drop_calls = 0;
     bool grads_dirty = false;
+    float* metrics_dev = nullptr;      // caller's [sum of CRPS scores, argmax matches] accumulator (cs_cnn_set_metrics_buffer) or null
     std::vector<void*> allocs;
     // k_conv2 programs (conv2.h): trunk convs on the same row tiles are chained into one launch, flushed when another kernel follows
     ConvProg prog{}; int prog_mode = -1; unsigned prog_grid = 0;
@@ -595,6 +596,12 @@ int cs_cnn_forward(cs_cnn_t* h, const float* x_dev, int layout3d, int64_t n, flo
     return CS_OK;
 }
 
+int cs_cnn_set_metrics_buffer(cs_cnn_t* h, float* dev2) {
+    if (!h) return fail(CS_ERR_INVALID, "null handle");
+    h->metrics_dev = dev2;
+    return CS_OK;
+}
+
 int cs_cnn_evaluate(cs_cnn_t* h, const float* x_dev, int x3d, const float* y_dev, int y3d, const int64_t* row_idx_dev, int64_t n,
                     float* loss_dev, int accumulate, void* stream) {
     if (!h || !x_dev || !y_dev || !loss_dev) return fail(CS_ERR_INVALID, "null argument");
@@ -607,7 +614,7 @@ int cs_cnn_evaluate(cs_cnn_t* h, const float* x_dev, int x3d, const float* y_dev
     cnn_loss_factors(h, f_p, f_s);
     hipLaunchKernelGGL(k_cnn_loss_heads, dim3((unsigned)std::min<int64_t>((n + 3) / 4, 64)), dim3(256), 0, st, h->O10, 128, h->wd, h->bd, h->cfg.n_lin, h->cfg.seq, n,
                        y_dev, row_idx_dev, y3d, 0, f_p, f_s, loss_dev, (u16*)nullptr, 0, (float*)nullptr, (float*)nullptr,
-                       (float*)nullptr, (float*)nullptr);
+                       (float*)nullptr, (float*)nullptr, h->metrics_dev);
     HIP_TRY(hipGetLastError());
     return CS_OK;
 }
@@ -650,7 +657,7 @@ int cs_cnn_loss_grads(cs_cnn_t* h, const float* x_dev, int x3d, const float* y_d
     cnn_loss_factors(h, f_p, f_s);
     hipLaunchKernelGGL(k_cnn_loss_heads, dim3((unsigned)std::min<int64_t>((n + 3) / 4, 64)), dim3(256), 0, st, h->O10, 128, h->wd, h->bd, h->cfg.n_lin, seq, n, y_dev,
                        row_idx_dev, y3d, h->cfg.loss, f_p, f_s, loss_dev, h->DZO, 128, h->G + h->off_wl, h->G + h->off_bl,
-                       h->G + h->off_wr, h->G + h->off_br);
+                       h->G + h->off_wr, h->G + h->off_br, h->metrics_dev);
     // ---- data gradients, last block to first
     launch_conv_bwd(h, h->DZO, h->DZO, 128, kgran, h->Wd_o, 1, h->blk[depth - 1].A2, h->blk[depth - 1].GG, h->blk[depth - 1].DZ2,
                     m_rows, m_pad, st, h->blk[depth - 1].B2);

@@ -22,11 +22,13 @@ __global__ __launch_bounds__(256) void k_cnn_loss_heads(const u16* __restrict__ 
                                                         const float* __restrict__ y, const int64_t* __restrict__ row_idx, int y3d,
                                                         int loss_kind, float f_p, float f_s, float* __restrict__ loss,
                                                         u16* __restrict__ dzo, int lddz, float* __restrict__ g_wl,
-                                                        float* __restrict__ g_bl, float* __restrict__ g_wr, float* __restrict__ g_br) {
-    __shared__ float red[4][114];
+                                                        float* __restrict__ g_bl, float* __restrict__ g_wr, float* __restrict__ g_br,
+                                                        float* __restrict__ metrics) {
+    __shared__ float red[4][116];
     const int l = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const bool live = l < seq;
     float s4[4] = {0.f, 0.f, 0.f, 0.f};
+    float s2[2] = {0.f, 0.f};          // metrics: [sum of the per-(column, level) CRPS scores, number of argmax matches]
     float gw[100], gb[10];
 #pragma unroll
     for (int q = 0; q < 100; ++q) gw[q] = 0.f;
@@ -34,7 +36,7 @@ __global__ __launch_bounds__(256) void k_cnn_loss_heads(const u16* __restrict__ 
     for (int q = 0; q < 10; ++q) gb[q] = 0.f;
     for (int64_t b = (int64_t)blockIdx.x * 4 + wv; b < n_cols; b += (int64_t)gridDim.x * 4) {
         if (!live) continue;
-        float o[10], dy[10];
+        float o[10], dy[10], pr[10], tg[10];
         const u16* r = o10 + (b * seq + l) * ld;
 #pragma unroll
         for (int c = 0; c < 10; ++c) o[c] = bf2f(r[c]);
@@ -49,11 +51,29 @@ __global__ __launch_bounds__(256) void k_cnn_loss_heads(const u16* __restrict__ 
             const float t = y3d ? y[(yb * seq + l) * 10 + j]
                                 : (j < 2 ? y[yb * (2 * seq + 8) + j * seq + l] : y[yb * (2 * seq + 8) + 2 * seq + (j - 2)]);
             const float e = pred - t;
+            pr[j] = pred; tg[j] = t;
             if (lin) { s4[0] += fabsf(e); s4[2] += e * e; } else { s4[1] += fabsf(e); s4[3] += e * e; }
             float g = loss_kind == CNN_LOSS_MAE ? (e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f)) : 2.f * e;
             g *= lin ? f_p : f_s;
             if (!lin && !(s > 0.f)) g = 0.f;
             dy[j] = g;
+        }
+        if (metrics) {
+            // compile(metrics=[..., "accuracy", ..., continuous_ranked_probability_score]) (hpo_train.py:83-111, 231): per (column, level)
+            //   score = mean_j |p_j - t_j| - 1/2 mean_{i,j} |p_i - p_j|   over the 10 channels (the forecast "ensemble" of the metric),
+            //   accuracy = categorical: argmax_j t_j == argmax_j p_j (first index on ties, as tf.argmax)
+            float sabs = 0.f, spair = 0.f, mp = pr[0], mt = tg[0];
+            int ap = 0, at = 0;
+#pragma unroll
+            for (int j = 0; j < 10; ++j) {
+                sabs += fabsf(pr[j] - tg[j]);
+#pragma unroll
+                for (int i = 0; i < j; ++i) spair += fabsf(pr[i] - pr[j]);
+                if (pr[j] > mp) { mp = pr[j]; ap = j; }
+                if (tg[j] > mt) { mt = tg[j]; at = j; }
+            }
+            s2[0] += sabs * 0.1f - 0.5f * (2.f * spair) * 0.01f;
+            s2[1] += ap == at ? 1.f : 0.f;
         }
         if (!dzo) continue;
         float dz[16];
@@ -79,6 +99,10 @@ __global__ __launch_bounds__(256) void k_cnn_loss_heads(const u16* __restrict__ 
     // wave reductions -> LDS -> one atomic per value and workgroup
 #pragma unroll
     for (int q = 0; q < 4; ++q) { const float v = wave_sum(s4[q]); if (l == 0) red[wv][q] = v; }
+    if (metrics) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) { const float v = wave_sum(s2[q]); if (l == 0) red[wv][114 + q] = v; }
+    }
     if (dzo) {
 #pragma unroll
         for (int q = 0; q < 10; ++q) { const float v = wave_sum(gb[q]); if (l == 0) red[wv][4 + q] = v; }
@@ -94,6 +118,7 @@ __global__ __launch_bounds__(256) void k_cnn_loss_heads(const u16* __restrict__ 
         else if (t < 14) { const int j = t - 4; atomicAdd(j < n_lin ? g_bl + j : g_br + (j - n_lin), v); }
         else { const int c = (t - 14) / 10, j = (t - 14) % 10; atomicAdd(j < n_lin ? g_wl + c * n_lin + j : g_wr + c * n_relu + (j - n_lin), v); }
     }
+    if (metrics && t >= 114 && t < 116) atomicAdd(metrics + (t - 114), red[0][t] + red[1][t] + red[2][t] + red[3][t]);
 }
 
 // ---------------------------------------------------------------- grouped conv weight gradients

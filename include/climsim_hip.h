@@ -327,6 +327,12 @@ int  cs_cnn_evaluate(cs_cnn_t* h, const float* x_dev, int x3d, const float* y_de
  * the flat gradient buffer; loss_dev[4] as above. */
 int  cs_cnn_loss_grads(cs_cnn_t* h, const float* x_dev, int x3d, const float* y_dev, int y3d, const int64_t* row_idx_dev,
                        int64_t n, float* loss_dev, void* stream);
+/* The two remaining entries of the reference's compile(metrics=[...]) list (hpo_train.py:83-111, 231): while `dev2` (two floats of
+ * device memory owned by the caller, or NULL to switch this off) is set, every cs_cnn_evaluate / cs_cnn_loss_grads / cs_cnn_train_step
+ * ADDS [sum over (column, level) of the continuous_ranked_probability_score terms mean_j|p_j - y_j| - 1/2 mean_ij|p_i - p_j| over the
+ * 10 channels, number of (column, level) pairs whose argmax over the channels agrees between target and prediction ("accuracy" =
+ * Keras categorical accuracy)] to it; divide by n*seq.  The caller zeroes it (once per epoch: Keras metrics are running means). */
+int  cs_cnn_set_metrics_buffer(cs_cnn_t* h, float* dev2);
 /* Restart the dropout stream: call k of cs_cnn_loss_grads uses seed + k.  Under data parallelism every rank takes its
  * own stream (climsim_amd.cnn.CNNEmulator.fit: seed + 1000003 * rank). */
 int  cs_cnn_set_seed(cs_cnn_t* h, uint64_t seed);

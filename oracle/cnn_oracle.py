@@ -83,6 +83,22 @@ def mse_adjusted(y_true, y_pred):
     return float(se[:, :, 0:2].mean() * (120 / 128) + se[:, :, 2:10].mean() * (8 / 128))
 
 
+def continuous_ranked_probability_score(y_true, y_pred):
+    """hpo_train.py:83-111 restated in numpy: per (column, level) mean_j |p_j - y_j| - 1/2 mean_{i,j} |p_i - p_j| over the last axis
+    (the 10 channels play the role of the forecast ensemble there), then the mean over everything else.  float64."""
+    yt, yp = np.asarray(y_true, np.float64), np.asarray(y_pred, np.float64)
+    score = np.abs(yp - yt).mean(axis=-1)
+    diff = yp[..., :, None] - yp[..., None, :]
+    score = score - 0.5 * np.abs(diff).mean(axis=(-2, -1))
+    return float(score.mean())
+
+
+def categorical_accuracy(y_true, y_pred):
+    """metrics=["accuracy"] on (B, 60, 10) float targets resolves to Keras' categorical accuracy (hpo_train.py:231; keras 2.10
+    compile_utils: last-axis size > 1, dense targets): argmax over the channels agrees (np.argmax = first index on ties, as tf.argmax)."""
+    return float((np.argmax(np.asarray(y_true), axis=-1) == np.argmax(np.asarray(y_pred), axis=-1)).mean())
+
+
 # ------------------------------------------------------------------------------------------------
 # Training path (hpo_train.py:159-236 model + :114-121 losses; Keras autodiff restated with torch
 # autograd on CPU).  PARITY UNPINNED like the forward: Keras' Dropout draws from TF's own random

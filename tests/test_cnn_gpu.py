@@ -192,7 +192,44 @@ def test_cnn_fit_reduces_loss(CNN):
     assert h["loss"][-1] < 0.7 * h["loss"][0]
     assert h["val_loss"][-1] < h["val_loss"][0]
     assert set(h) >= {"loss", "mae_adjusted", "mse_adjusted", "val_loss", "lr"}
+    # every entry of the reference's compile(metrics=[...]) list (hpo_train.py:231), for the training pass and the validation pass
+    ref_metrics = ["mse", "mae", "accuracy", "mse_adjusted", "mae_adjusted", "continuous_ranked_probability_score"]
+    assert set(h) >= set(ref_metrics) | {"val_" + k for k in ref_metrics}
+    assert all(len(h[k]) == 6 for k in h)
+    assert all(0.0 <= a <= 1.0 for a in h["accuracy"] + h["val_accuracy"])
+    assert h["continuous_ranked_probability_score"][-1] < h["continuous_ranked_probability_score"][0]
+    # the validation columns of the last epoch are what evaluate() returns now (eval mode, weights unchanged since)
+    ev = m.evaluate(xv, yv)
+    for k in ref_metrics:
+        assert ev[k] == pytest.approx(h["val_" + k][-1], rel=1e-6, abs=1e-9), k
     assert m.iterations == 6 * 4
+
+
+@pytest.mark.parametrize("n,y3d", [(37, True), (64, False)])
+def test_cnn_accuracy_and_crps_match_the_numpy_restatement(CNN, n, y3d):
+    """`accuracy` (Keras categorical accuracy over the 10 channels) and `continuous_ranked_probability_score` (hpo_train.py:83-111)
+    come out of the loss kernel's pass (cs_cnn_set_metrics_buffer).  Against oracle/cnn_oracle.py's numpy restatements applied to
+    the engine's OWN predictions (isolates the metric arithmetic: float32 sums against float64, 1e-5), and applied to the oracle's
+    bf16-emulating forward (2e-3: a prediction that differs in the last bf16 digit may move an argmax between near-equal channels)."""
+    xf, yf, x3, y3 = CO.synth_cnn_columns(n, seed=21)
+    ws = CO.glorot_cnn(seed=4, bias_scale=0.05, depth=2, channels=64)
+    m = CNN.CNNEmulator(depth=2, channel_width=64, max_batch=64, trainable=True, seed=5)
+    m.set_weights(ws)
+    if y3d:
+        ev = m.evaluate(x3, y3, batch_size=16)                       # several calls: the sums accumulate across them
+    else:
+        ev = m.evaluate(xf, yf, batch_size=64)                       # flat (N,124) / (N,128) rows: the reshape happens in the kernels
+    pred = m.predict(x3)
+    assert ev["continuous_ranked_probability_score"] == pytest.approx(CO.continuous_ranked_probability_score(y3, pred), rel=1e-5)
+    assert ev["accuracy"] == pytest.approx(CO.categorical_accuracy(y3, pred), abs=1.5 / (n * 60))
+    ref = CO.forward(ws, x3, depth=2, bf16=True)
+    assert ev["continuous_ranked_probability_score"] == pytest.approx(CO.continuous_ranked_probability_score(y3, ref), rel=2e-3)
+    assert ev["accuracy"] == pytest.approx(CO.categorical_accuracy(y3, ref), abs=5e-3)
+    # the training pass adds to the same buffer (dropout on: another prediction, the same arithmetic): a step leaves n * 60 terms
+    m._metrics.zero_()
+    m.train_on_batch(x3, y3, 1e-4)
+    q = m._metrics.cpu().numpy()
+    assert 0 <= q[1] <= n * 60 and q[1] == round(q[1]) and abs(q[0] / (n * 60) - ev["continuous_ranked_probability_score"]) < 0.5 * abs(ev["continuous_ranked_probability_score"]) + 1e-3
 
 
 def test_cnn_error_paths(CNN):

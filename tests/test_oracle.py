@@ -221,3 +221,24 @@ def test_rmsprop_radam_sgd_against_torch_optim():
     t8 = _torch_opt_run("RAdam", [np.zeros(1, np.float32)], seq1[:-1], 1.0, betas=(0.9, 0.999), eps=eps)[0][0]
     t9 = _torch_opt_run("RAdam", [np.zeros(1, np.float32)], seq1, 1.0, betas=(0.9, 0.999), eps=eps)[0][0]
     assert (t9 - t8) == pytest.approx(torch_step, rel=2e-3)      # and torch.optim.RAdam indeed takes the other one
+
+
+def test_cnn_metric_restatements_against_a_loop():
+    """oracle/cnn_oracle.py: continuous_ranked_probability_score (hpo_train.py:83-111) and Keras' categorical accuracy, against
+    plain loops over a small tensor and against two closed forms."""
+    from oracle import cnn_oracle as CO
+    rs = np.random.RandomState(0)
+    yt, yp = rs.standard_normal((3, 5, 10)), rs.standard_normal((3, 5, 10))
+    tot = 0.0
+    for b in range(3):
+        for l in range(5):
+            a = sum(abs(yp[b, l, j] - yt[b, l, j]) for j in range(10)) / 10
+            d = sum(abs(yp[b, l, i] - yp[b, l, j]) for i in range(10) for j in range(10)) / 100
+            tot += a - 0.5 * d
+    assert abs(CO.continuous_ranked_probability_score(yt, yp) - tot / 15) < 1e-12
+    flat = np.full((2, 4, 10), 0.3)                              # a degenerate "ensemble": the score is the mean absolute error
+    assert abs(CO.continuous_ranked_probability_score(yt[:2, :4], flat) - np.abs(flat - yt[:2, :4]).mean()) < 1e-12
+    acc = np.mean([[np.argmax(yt[b, l]) == np.argmax(yp[b, l]) for l in range(5)] for b in range(3)])
+    assert CO.categorical_accuracy(yt, yp) == acc and CO.categorical_accuracy(yt, yt) == 1.0
+    tie = np.zeros((1, 1, 10))
+    assert CO.categorical_accuracy(tie, yp[:1, :1] * 0 + np.arange(10)[::-1]) == 1.0      # first index on ties: 0 == argmax of a decreasing row
