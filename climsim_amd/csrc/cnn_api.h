@@ -3,6 +3,7 @@
 #include "cnn_train.h"
 #include "conv2.h"
 #include "conv_wgrad2.h"
+#include "conv_wgrad3.h"
 
 struct CnnConv {
     int cin, cin_p, cout, taps;
@@ -29,6 +30,7 @@ struct cs_cnn {
     ConvWgradItem* items_dev = nullptr; int n_items = 0, total_tiles = 0;
     CwTile* cw_tiles_dev = nullptr; int n_cw_tiles = 0, n_cu = 256;      // conv_wgrad2.h
     int n_cw_convs = 0, cw_splits = 0;
+    Cw3Tile* cw3_tiles_dev = nullptr; bool cw3 = true;                   // conv_wgrad3.h: tap-shared tiles (CS_CW3=0: conv_wgrad2.h's)
     std::vector<int> cw_prefix;          // tiles of conv c: [cw_prefix[c], cw_prefix[c + 1])
     CwWork* cw_work_dev = nullptr; int cw_work_slabs = -1;   // work queues of k_conv_wgrad2l for cw_work_slabs slabs of 32 rows
     std::vector<CwWork> cw_work; int cw_qbegin[9] = {0}; int cw_longest = 0;
@@ -159,11 +161,54 @@ int cnn_upload_items(cs_cnn* h) {
                 cw.push_back(t);
             }
     };
+    // tap-shared tiles of one conv (conv_wgrad3.h): 16 group slots of 16 (tap, channel) rows x 224-wide slices of c_out
+    std::vector<Cw3Tile> cw3;
+    auto push_cw3 = [&](const u16* H, int ldh, const u16* Z, const CnnConv& c) {
+        const int ncb = (c.cin + 15) / 16;                           // 16-channel blocks
+        prefix.push_back((int)cw3.size());
+        struct Plan { int first, nmain, xcb, xtap; bool ones; };     // main blocks [first, first + nmain), the extra window's block / tap, the ones window
+        std::vector<Plan> plan;
+        if (c.taps == 3) {
+            const int nfull = ncb / 5, rem = ncb % 5;
+            const bool ride = rem > 0 && 3 * rem <= nfull - 1;       // the remainder's (tap, block) pairs fit the spare slots of tiles 1 ..
+            const int nt = ride ? nfull : (ncb + 4) / 5;
+            for (int t = 0; t < nt; ++t) plan.push_back({5 * t, std::min(5, ncb - 5 * t), -1, -1, t == 0});
+            if (ride) for (int e = 0; e < 3 * rem; ++e) { plan[(size_t)(1 + e)].xcb = 5 * nfull + e / 3; plan[(size_t)(1 + e)].xtap = e % 3; }
+        } else {
+            const int nt = (ncb + 1 + 15) / 16;                      // + the ones window
+            for (int t = 0; t < nt; ++t) plan.push_back({16 * t, std::max(0, std::min(16, ncb - 16 * t)), -1, -1, false});
+            plan.back().ones = true;                                 // (the last tile has a free window by construction)
+        }
+        for (int n0 = 0; n0 < c.cout; n0 += 224)
+            for (const Plan& pl : plan) {
+                Cw3Tile t{};
+                t.H = H; t.Z = Z; t.dW = h->G + c.w_off; t.db = h->G + c.b_off; t.ldh = ldh; t.ldz = CNN_CP;
+                t.cin = c.cin; t.cout = c.cout; t.n0 = n0; t.ntap = c.taps;
+                t.zchunks = (std::min(224, c.cout - n0) + 7) / 8;
+                for (int j = 0; j < 16; ++j) { t.win_c[j] = -1; t.slot_tap[j] = -1; t.slot_win[j] = 0; }
+                if (c.taps == 3) {
+                    for (int j = 0; j < pl.nmain; ++j) {
+                        t.win_c[j] = (short)(16 * (pl.first + j));
+                        for (int tap = 0; tap < 3; ++tap) { t.slot_tap[tap * 5 + j] = (signed char)tap; t.slot_win[tap * 5 + j] = (signed char)j; }
+                    }
+                    if (pl.ones) { t.win_c[5] = -2; t.slot_tap[15] = 1; t.slot_win[15] = 5; }
+                    else if (pl.xcb >= 0) { t.win_c[5] = (short)(16 * pl.xcb); t.slot_tap[15] = (signed char)pl.xtap; t.slot_win[15] = 5; }
+                } else {
+                    for (int j = 0; j < pl.nmain; ++j) { t.win_c[j] = (short)(16 * (pl.first + j)); t.slot_tap[j] = 0; t.slot_win[j] = (signed char)j; }
+                    if (pl.ones) { t.win_c[pl.nmain] = -2; t.slot_tap[pl.nmain] = 0; t.slot_win[pl.nmain] = (signed char)pl.nmain; }
+                }
+                cw3.push_back(t);
+            }
+    };
     for (int b = 0; b < depth; ++b) {
         const CnnConv &ca = h->convs[3 * b], &cb = h->convs[3 * b + 1], &cr = h->convs[3 * b + 2];
         const u16* xin = b == 0 ? h->A0 : h->blk[b - 1].XS;
         const int ldx = b == 0 ? CNN_A0_LD : CNN_CP;
-        if (h->tile128) {
+        if (!h->tile128 && h->cw3) {
+            push_cw3(xin, ldx, h->blk[b].DZ1, ca);
+            push_cw3(h->blk[b].A1, CNN_CP, h->blk[b].DZ2, cb);
+            push_cw3(xin, ldx, h->blk[b].GG, cr);
+        } else if (h->tile128) {
             for (int t = 0; t < 3; ++t)
                 push(xin, ldx, t - 1, h->blk[b].DZ1, CNN_CP, h->G + ca.w_off + (int64_t)t * ca.cin * C, C, ca.cin, C, t == 1 ? h->G + ca.b_off : nullptr);
             for (int t = 0; t < 3; ++t)
@@ -180,6 +225,16 @@ int cnn_upload_items(cs_cnn* h) {
     h->n_items = (int)it.size();
     h->total_tiles = tiles;
     HIP_TRY(hipMemcpy(h->items_dev, it.data(), it.size() * sizeof(ConvWgradItem), hipMemcpyHostToDevice));
+    if (!cw3.empty()) {
+        if (cw3.size() > (size_t)48 * depth) return fail(CS_ERR_INVALID, "conv weight-gradient tile table too small");
+        h->n_cw_tiles = (int)cw3.size();
+        h->n_cw_convs = (int)prefix.size();
+        prefix.push_back((int)cw3.size());
+        HIP_TRY(hipMemcpy(h->cw3_tiles_dev, cw3.data(), cw3.size() * sizeof(Cw3Tile), hipMemcpyHostToDevice));
+        h->cw_prefix = prefix;
+        h->cw_work_slabs = -1;
+        return CS_OK;
+    }
     h->n_cw_tiles = (int)cw.size();
     if (!cw.empty()) {
         h->n_cw_convs = (int)prefix.size();
@@ -380,7 +435,10 @@ int cs_cnn_create(cs_cnn_t** out, const cs_cnn_cfg* cfg) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv2<CONV_TRAIN_FWD>), hipFuncAttributeMaxDynamicSharedMemorySize, CV2_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv2<CONV_BWD>), hipFuncAttributeMaxDynamicSharedMemorySize, CV2_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wgrad2l), hipFuncAttributeMaxDynamicSharedMemorySize, CW2L_LDS_BYTES));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wgrad3l), hipFuncAttributeMaxDynamicSharedMemorySize, CW3_LDS_BYTES));
     if (const char* e = getenv("CS_CW2_PERSIST")) h->cw_persist = atoi(e) != 0;
+    if (const char* e = getenv("CS_CW3")) h->cw3 = atoi(e) != 0;
+    if (cfg->seq < 34) h->cw3 = false;       // (a 32-row slab must hold at most one column boundary: conv_wgrad3.h)
     {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, cfg->device));
@@ -433,6 +491,7 @@ int cs_cnn_create(cs_cnn_t** out, const cs_cnn_cfg* cfg) {
         A((void**)&h->DZO, sizeof(u16) * h->m_pad_max * 128);
         A((void**)&h->items_dev, sizeof(ConvWgradItem) * (7 * depth + 1));
         A((void**)&h->cw_tiles_dev, sizeof(CwTile) * (32 * depth));
+        A((void**)&h->cw3_tiles_dev, sizeof(Cw3Tile) * (48 * depth));
         A((void**)&h->cw_work_dev, sizeof(CwWork) * CW_MAX_WORK);
         A((void**)&h->cw_counters, sizeof(int) * 8);
         h->blk.resize(depth);
@@ -698,6 +757,13 @@ int cs_cnn_loss_grads(cs_cnn_t* h, const float* x_dev, int x3d, const float* y_d
             HIP_TRY(hipMemsetAsync(h->cw_dbg, 0, sizeof(unsigned long long) * grid * CW_DBG_SLOTS, st));
             ca.dbg = h->cw_dbg; h->cw_dbg_grid = grid;
         }
+        if (h->cw3) {
+            Cw3Args c3{};
+            c3.tiles = h->cw3_tiles_dev; c3.n_tiles = ca.n_tiles; c3.work = ca.work; c3.counters = ca.counters;
+            for (int x = 0; x < 9; ++x) c3.q_begin[x] = ca.q_begin[x];
+            c3.m_rows = m_rows; c3.seq = seq; c3.zeros = h->zeros; c3.dbg = ca.dbg;
+            hipLaunchKernelGGL(k_conv_wgrad3l, dim3((unsigned)grid), dim3(512 + 64 * CW2L_LOADERS), CW3_LDS_BYTES, st, c3);
+        } else
         hipLaunchKernelGGL(k_conv_wgrad2l, dim3((unsigned)grid), dim3(512 + 64 * CW2L_LOADERS), CW2L_LDS_BYTES, st, ca);
     }
     ConvWgradArgs wa{};

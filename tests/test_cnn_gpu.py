@@ -324,10 +324,12 @@ def test_cnn_weight_gradient_queue_forms_agree(CNN, monkeypatch):
     ws = CO.glorot_cnn(seed=8, bias_scale=0.05, depth=depth, channels=width)
     x3, y3 = make_xy(n, 9)
     res = []
+    # round 6: the default kernel is k_conv_wgrad3l (tap-shared operand tiles, conv_wgrad3.h); CS_CW3=0 = k_conv_wgrad2l (shifted rows
+    # per tap): other tiles, other fetches, the same sums
     forms = [{}, {"CS_CW2_PERSIST": "0"}, {"CS_CNN_WGRAD_SPLITS": "3"}, {"CS_CNN_WGRAD_ROUNDS": "9", "CS_CNN_WGRAD_TAPER": "0.9"},
-             {"CS_CW2_PERSIST": "0", "CS_CNN_WGRAD_SPLITS": "1"}]
+             {"CS_CW2_PERSIST": "0", "CS_CNN_WGRAD_SPLITS": "1"}, {"CS_CW3": "0"}, {"CS_CW3": "0", "CS_CW2_PERSIST": "0", "CS_CNN_WGRAD_SPLITS": "3"}]
     for env in forms:
-        for k in ("CS_CW2_PERSIST", "CS_CNN_WGRAD_SPLITS", "CS_CNN_WGRAD_ROUNDS", "CS_CNN_WGRAD_TAPER"):
+        for k in ("CS_CW2_PERSIST", "CS_CNN_WGRAD_SPLITS", "CS_CNN_WGRAD_ROUNDS", "CS_CNN_WGRAD_TAPER", "CS_CW3"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)

@@ -62,8 +62,6 @@ def run_case(G, specs, steps, skip=None, tag="tuned"):
         opts.append(O.Optimizer(opt))
         x, y = O.synth_columns(n, seed=dseed)
         data.append((x, y, torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()))
-    # the gradients of the first step, per member: which entries of a kernel carry signal (see the movement check below)
-    g_first = [O.loss_and_grads(wref[i], data[i][0], data[i][1], cfgs[i], bf16=True)[2] for i in range(len(specs))]
     g = group.MLPGroup(members)
     lrs = [s[3] for s in specs]
     curves_g = [[] for _ in specs]
@@ -83,22 +81,30 @@ def run_case(G, specs, steps, skip=None, tag="tuned"):
         np.testing.assert_allclose(curves_g[i], curves_r[i], rtol=CURVE_TOL, err_msg=f"member {i}")
         assert curves_g[i][0] == pytest.approx(curves_r[i][0], rel=2e-3)           # first step: same weights on both sides
         w0 = O.glorot_init(cfgs[i], 3 + i)
-        for a, b, z, g0 in zip(m.get_weights(), wref[i], w0, g_first[i]):
+        for a, b, z in zip(m.get_weights(), wref[i], w0):
             if z.ndim == 2:                                                            # (biases were re-drawn: compare kernels' movement)
                 record_margin(f"group_{tag}_weight_movement_rel", rel(a - z, b - z))
-                # Round 6: the asserted quantity is the movement of the entries whose gradient carries SIGNAL.  Adam-family rules move an
-                # entry by ~lr * g / (|g| + eps) per step whatever |g| is: where the gradient is rounding-level (units that are dead on
-                # most of a small batch) the step's sign is decided by the summation order, on either side - round 5 measured 0.0375
-                # against 0.058 on the wide family for two summation orders of the SAME arithmetic, all of it from such entries.
-                # Entries with |g| >= 1 % of the tensor's rms gradient at the first step (>= half of every tensor, asserted) are held
-                # to the bar; the all-entry figure stays recorded, and asserted where it always passed (tuned / ELU families).
-                sig = np.abs(g0) >= 1e-2 * np.sqrt(np.mean(g0.astype(np.float64) ** 2))
-                assert sig.mean() >= 0.5, (i, sig.mean())
-                r_sig = rel((a - z)[sig], (b - z)[sig])
-                record_margin(f"group_{tag}_weight_movement_significant_rel", r_sig)
-                assert r_sig <= (MOVE_TOL_WIDE if tag == "wide" else MOVE_TOL), (i, r_sig)
-                if tag != "wide":
-                    assert rel(a - z, b - z) <= MOVE_TOL, (i, rel(a - z, b - z))
+                # Round 6: a kernel's movement is held to the bar where float32 RESOLVES it.  The published widths under RAdam at lr
+                # 2.5e-4 move their first kernel by 9e-9 of its norm in four steps (tools/r06_group_wide_diag.py) - a fraction of one
+                # ulp per entry: fl(w - d) is then a threshold function of d, and whether an entry moves at all is decided by the last
+                # bit of the gradient sum (measured 0.037 against 0.058 for two summation orders of the SAME arithmetic, with
+                # first-step gradients at 3e-3 / 4e-3 of the oracle's).  What such a step computes is in the optimiser's moments,
+                # which are checked below for every member; the movement is asserted from 16 ulps (1e-6 of the norm) on.
+                resolved = np.linalg.norm(b - z) >= 1e-6 * np.linalg.norm(z)
+                if resolved:
+                    record_margin(f"group_{tag}_weight_movement_resolved_rel", rel(a - z, b - z))
+                    assert rel(a - z, b - z) <= (MOVE_TOL_WIDE if tag == "wide" else MOVE_TOL), (i, rel(a - z, b - z))
+        if specs[i][2] in ("Adam", "RAdam", "RMSprop"):                                # the optimiser's state after the steps: linear (m) and
+            ms, vs, it = m.get_optimizer_state()                                       # quadratic (v) in the gradients of every step taken
+            assert it == len(curves_r[i])
+            for k, z in enumerate(w0):
+                if z.ndim != 2:
+                    continue
+                if specs[i][2] != "RMSprop":
+                    record_margin(f"group_{tag}_first_moment_rel", rel(ms[k], opts[i].m[k]))
+                    assert rel(ms[k], opts[i].m[k]) <= 1e-2, (i, k, rel(ms[k], opts[i].m[k]))
+                record_margin(f"group_{tag}_second_moment_rel", rel(vs[k], opts[i].v[k]))
+                assert rel(vs[k], opts[i].v[k]) <= 2e-2, (i, k, rel(vs[k], opts[i].v[k]))
     g.close()
     for m in members:
         m.close()
