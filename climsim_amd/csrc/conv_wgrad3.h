@@ -14,16 +14,32 @@
 //     1..3 (one tap each, 16 more channels in their X tile), the spare slot of tile 0 is the column of ones whose product row is the
 //     bias gradient.  Per slab: X 34 x 96 channels (6.4 KB) + dZ 32 x 224 (14 KB) = 20.4 KB instead of 32;
 //   * rows whose shifted level leaves the column (level 0 under tap 0, level seq - 1 under tap 2) cannot be zeroed in the tile -
-//     the same row is valid under the other taps - so the READING lane is pointed at 8 zero bytes instead (one compare per
-//     fragment read and slab, only in slabs that hold a column boundary);
+//     the same row is valid under the other taps - so the READING lane is pointed at 8 zero bytes instead (a per-lane key per group
+//     slot, one compare + one select per read);
 //   * the loaders' fast path is pointer += constant: every lane's source is decided once per queue entry (real channels, zero page,
 //     ones page); the per-lane row tests run only in the first slab of the batch and from the last one on;
-//   * 1-tap (residual) convs use the same code with 16 windows of 16 channels (the old tile), shift 0.
-// Everything else - 8 compute waves of 64(kk) x 112(n) (4 x 7 v_mfma_f32_16x16x32_bf16), 4 loader waves, 4-slot LDS-DMA ring, one
-// persistent workgroup per CU taking (tile, row range) entries from eight host-built queues, partial sums out by float atomics
-// through a staging area - is conv_wgrad2.h's (hpo_train.py:159-200 is what the gradients belong to).
+//   * a slab stays in the ring while it is computed on and the seven dZ column groups stream through four fragment buffers (12 MFMAs
+//     between request and use) instead of all being fetched a slab ahead: 16 VGPRs less - no scratch access inside the loop at 168
+//     VGPRs (conv_wgrad2.h: 184 B per lane) - and the 20-KB slabs make room for a FIVE-slot ring;
+//   * 1-tap (residual) convs use the same code with 16 windows of 16 channels (the old tile), shift 0, four slots.
+// Everything else - 8 compute waves of 64(kk) x 112(n) (4 x 7 v_mfma_f32_16x16x32_bf16), 4 loader waves, LDS-DMA ring, one persistent
+// workgroup per CU taking (tile, row range) entries from eight host-built queues, partial sums out by float atomics through a staging
+// area - is conv_wgrad2.h's (hpo_train.py:159-200 is what the gradients belong to).
+//
+// Measured (profiles/r06_cnn_wgrad3.txt, batch 512, stamps in shader clocks per 32-row slab of a 3-tap tile; 896 = the MFMAs alone):
+// k_conv_wgrad2l 1596 -> 1357 here; kernel 0.915 -> ~0.80 ms, CNN step 3.17 -> 3.07 ms.  What is left, by ablation builds: MFMAs +
+// barrier 954; + the 22 fragment reads and their 17 address operations 1179; + the boundary selects (16 VALU) 1335 - a VALU
+// operation costs ~8 clocks here however it is placed or branched around (two waves per SIMD run the same code in step) - and the
+// operand requests ALONE take 1320 (566 .. 1876 from entry to entry): 20.4 KB per slab arrive at 15.5 B/clk per CU = 7.9 TB/s over the
+// chip through the L2s at 57 % hits.  More requests in flight make it slower, not faster (an L2 prefetch 4 / 8 slabs ahead: 1594 /
+// 2182 clocks per slab): the memory side is at its throughput for this access pattern, so a faster compute loop alone buys nothing.
 #pragma once
 #include "conv_wgrad2.h"
+#ifndef CW3_EXP
+#define CW3_EXP 0                // development (timing only): 1 = no sched_barriers in the loop, 2 = no column-boundary redirect (wrong sums), 8 = no per-slab
+#endif                           // barriers (races), 16 = the redirect's instructions with keys that never match (wrong sums)
+#define CW3_BAR() do { if (!(CW3_EXP & 8)) __builtin_amdgcn_s_barrier(); } while (0)
+#define CW3_SB() do { if (!(CW3_EXP & 1)) __builtin_amdgcn_sched_barrier(0); } while (0)
 
 struct Cw3Tile {
     const u16* H; const u16* Z;
@@ -132,9 +148,9 @@ __device__ __forceinline__ void cw3_loader(const Cw3Args& pa, const Cw3Tile* __r
         const bool fast = sl >= 1 && 32 * sl + 33 <= m_rows;
         if (fast) {
 #pragma unroll
-            for (int jj = 0; jj < NX; ++jj) { dma16(xp[jj], base + my_x + 1024u * jj); xp[jj] += xinc[jj]; }
+            for (int jj = 0; jj < NX; ++jj) { if (!(CW_ABL & 1)) dma16(xp[jj], base + my_x + 1024u * jj); xp[jj] += xinc[jj]; }
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) { dma16(zp[jj], base + my_z + 1024u * jj); zp[jj] += zinc[jj]; }
+            for (int jj = 0; jj < 4; ++jj) { if (!(CW_ABL & 1)) dma16(zp[jj], base + my_z + 1024u * jj); zp[jj] += zinc[jj]; }
         } else {
 #pragma unroll
             for (int jj = 0; jj < NX; ++jj) {
@@ -165,7 +181,7 @@ __device__ __forceinline__ void cw3_loader(const Cw3Args& pa, const Cw3Tile* __r
     int isl = SLOTS - 1;                                             // slab s + SLOTS - 1 goes where slab s - 1 was
     for (int s = 0; s < nsl; ++s) {
         asm volatile("s_waitcnt vmcnt(%0)" ::"i"((SLOTS - 3) * NI) : "memory");      // slab s + 1 has landed
-        __builtin_amdgcn_s_barrier();                                                // ... and slab s - 1 is out of use
+        CW3_BAR();                                                                   // ... and slab s - 1 is out of use
         issue(isl);
         isl = isl + 1 == SLOTS ? 0 : isl + 1;
     }
@@ -182,6 +198,8 @@ __device__ __forceinline__ void cw3_compute(const Cw3Args& pa, const Cw3Tile* __
     constexpr unsigned XB = Cw3Geo<W>::XB, SLAB = Cw3Geo<W>::SLAB;
     const int wm = (wid >> 1) & 3, wn = wid & 1;
     typedef s16x4_t __attribute__((address_space(3))) * lds_v4;
+    typedef char __attribute__((address_space(3))) * lds_c;
+    const lds_c ring_c = (lds_c)cw_ring;         // (LDS addresses below are byte offsets from the ring's base)
     // per slot: tap (row offset of the read), X-tile window, channel of the flush
     int tap[IT], cch[IT];
     int fo0[IT], fo1[IT];                       // byte offsets of the two transposing reads inside a slab (rows r0 + shift, r0 + 4 + shift)
@@ -198,7 +216,7 @@ __device__ __forceinline__ void cw3_compute(const Cw3Args& pa, const Cw3Tile* __
     }
     // dZ fragments: byte offset of (row r0, column 112 wn + 16 j + 4 (lane & 3)) = r0 * 512 + 8 (lane & 3) + (2 col_j ^ 2 P), P = the row's
     // swizzle bits (swz_cw): col_j touches bits 5..8 only, so ONE per-lane register and a scalar per column group address all seven
-    const unsigned az0 = lds0 + XB + (unsigned)(r0 * 512 + (lane & 3) * 8 + 2 * (((r0 & 3) << 5) | (((r0 >> 3) & 1) << 4)));
+    const unsigned az0 = XB + (unsigned)(r0 * 512 + (lane & 3) * 8 + 2 * (((r0 & 3) << 5) | (((r0 >> 3) & 1) << 4)));
     unsigned kz[7];
 #pragma unroll
     for (int j = 0; j < 7; ++j) kz[j] = (unsigned)__builtin_amdgcn_readfirstlane(2 * (wn * 112 + j * 16));
@@ -211,25 +229,30 @@ __device__ __forceinline__ void cw3_compute(const Cw3Args& pa, const Cw3Tile* __
     // tap 0 must not see row bnd (its shifted source is the previous column's last level), tap 2 must not see row bnd - 1
     int lv0 = (int)(((int64_t)s0 * 32) % pa.seq);
     auto next_bnd = [&]() __attribute__((always_inline)) { const int b = lv0 == 0 ? 0 : pa.seq - lv0; lv0 += 32; if (lv0 >= pa.seq) lv0 -= pa.seq; return b; };
-    const unsigned zaddr = lds0 + CW3_ZERO_OFF;
+    const unsigned zaddr = CW3_ZERO_OFF;
+    // Column boundaries.  Per slot a per-lane KEY: the slab-local row whose being level 0 makes this lane's FIRST read invalid - r0 under
+    // tap 0 (its source is the previous column's last level), r0 + 1 under tap 2 (the row itself is the last level), never under tap 1;
+    // the second read's key is 4 more.  A slab holds at most one level-0 row `bnd` (seq >= 34): one compare + one select per read.
+    // Empty slots read like any other: their sums are never flushed.
+    int key[IT];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) key[i] = (W == 6 && tap[i] == 0 && !(CW3_EXP & 16)) ? r0 : ((W == 6 && tap[i] == 2 && !(CW3_EXP & 16)) ? r0 + 1 : -1000 - (lane & 1));
     auto read_h = [&](bf16x8_t& dst, int i, unsigned slab, int bnd) __attribute__((always_inline)) {
         union { bf16x8_t v; s16x4_t h[2]; } u_;
         unsigned a0 = slab + (unsigned)fo0[i], a1 = slab + (unsigned)fo1[i];
-        if (tap[i] < 0) { a0 = zaddr; a1 = zaddr; }
-        else if (W == 6 && tap[i] != 1) {
-            const int bad = tap[i] == 0 ? bnd : bnd - 1;            // bnd in 0 .. seq - 1; rows >= 32 are not in this slab
-            if (r0 == bad) a0 = zaddr;
-            if (r0 + 4 == bad) a1 = zaddr;
+        if (W == 6 && !(CW3_EXP & 2)) {                              // (keys are <= 28: a slab whose level-0 row lies beyond 32 matches nothing)
+            if (key[i] == bnd) a0 = zaddr;
+            if (key[i] == bnd - 4) a1 = zaddr;
         }
-        u_.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)a0);
-        u_.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)a1);
+        u_.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(ring_c + a0));
+        u_.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(ring_c + a1));
         dst = u_.v;
     };
     auto read_z = [&](bf16x8_t& dst, int j, unsigned az) __attribute__((always_inline)) {     // az = az0 + the slab's offset
         union { bf16x8_t v; s16x4_t h[2]; } u_;
         const unsigned a = az ^ kz[j];
-        u_.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)a);
-        u_.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(a + 2048u));
+        u_.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(ring_c + a));
+        u_.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(ring_c + a + 2048u));
         dst = u_.v;
     };
     // Pipeline.  fh[i] (the wave's four group slots) stay in registers for a whole slab; the seven dZ column groups stream through FOUR
@@ -239,12 +262,12 @@ __device__ __forceinline__ void cw3_compute(const Cw3Args& pa, const Cw3Tile* __
     // that fh[i] of the next slab is requested behind the slot's last MFMA, 6 .. 0 MFMAs before the slab ends and i more before its use.
     bf16x8_t fh[IT], fz[4];
     __builtin_amdgcn_s_barrier();                                    // slab 0 has landed
-    cw3_stamp(pa, tid, dslot, 0);
+    cw3_stamp(pa, tid, dslot, W);                                    // (tag: the tile type, for tools/cnn_wgrad_stamps.py)
     int bnd_next;
     {
         const int bnd = next_bnd();
 #pragma unroll
-        for (int i = 0; i < IT; ++i) read_h(fh[i], i, lds0, bnd);
+        for (int i = 0; i < IT; ++i) read_h(fh[i], i, 0u, bnd);
 #pragma unroll
         for (int j = 0; j < 4; ++j) read_z(fz[j], j, az0);
         bnd_next = next_bnd();
@@ -254,13 +277,13 @@ __device__ __forceinline__ void cw3_compute(const Cw3Args& pa, const Cw3Tile* __
     _Pragma("unroll") for (int i = 0; i < IT; ++i)                                                                           \
         if (!(CW_ABL & 4)) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[i], fz[b], acc[i][j], 0, 0, 0);
     for (int s = 0; s < nsl; ++s) {
-        __builtin_amdgcn_s_barrier();                                // slab s + 1 has landed, slab s - 1 is free
-        const unsigned azc = az0 + cur_off, azn = az0 + nx_off, xn = lds0 + nx_off;
-        CW3_GROUP(0, 0) if (!(CW_ABL & 2)) read_z(fz[0], 4, azc); __builtin_amdgcn_sched_barrier(0);
-        CW3_GROUP(1, 1) if (!(CW_ABL & 2)) read_z(fz[1], 5, azc); __builtin_amdgcn_sched_barrier(0);
-        CW3_GROUP(2, 2) if (!(CW_ABL & 2)) read_z(fz[2], 6, azc); __builtin_amdgcn_sched_barrier(0);
-        CW3_GROUP(3, 3) if (!(CW_ABL & 2)) read_z(fz[3], 3, azn); __builtin_amdgcn_sched_barrier(0);
-        CW3_GROUP(4, 0) if (!(CW_ABL & 2)) read_z(fz[0], 0, azn); __builtin_amdgcn_sched_barrier(0);
+        CW3_BAR();                                                   // slab s + 1 has landed, slab s - 1 is free
+        const unsigned azc = az0 + cur_off, azn = az0 + nx_off, xn = nx_off;
+        CW3_GROUP(0, 0) if (!(CW_ABL & 2)) read_z(fz[0], 4, azc); CW3_SB();
+        CW3_GROUP(1, 1) if (!(CW_ABL & 2)) read_z(fz[1], 5, azc); CW3_SB();
+        CW3_GROUP(2, 2) if (!(CW_ABL & 2)) read_z(fz[2], 6, azc); CW3_SB();
+        CW3_GROUP(3, 3) if (!(CW_ABL & 2)) read_z(fz[3], 3, azn); CW3_SB();
+        CW3_GROUP(4, 0) if (!(CW_ABL & 2)) read_z(fz[0], 0, azn); CW3_SB();
 #pragma unroll
         for (int i = 0; i < IT; ++i) {
             if (!(CW_ABL & 4)) {
@@ -268,7 +291,7 @@ __device__ __forceinline__ void cw3_compute(const Cw3Args& pa, const Cw3Tile* __
                 acc[i][6] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[i], fz[2], acc[i][6], 0, 0, 0);
             }
             if (!(CW_ABL & 2)) read_h(fh[i], i, xn, bnd_next);
-            __builtin_amdgcn_sched_barrier(0);
+            CW3_SB();
         }
         if (!(CW_ABL & 2)) { read_z(fz[1], 1, azn); read_z(fz[2], 2, azn); }
         bnd_next = next_bnd();

@@ -44,7 +44,7 @@ for b in range(st.shape[0]):
     n = (e - 2) // 4
     for i in range(n):
         a = w[2 + 4 * i: 6 + 4 * i]
-        rows.append((b, i, int(a[0] >> np.uint64(48)), int(a[0] & MASK), int(a[1] & MASK), int(a[2] & MASK), int(a[3] & MASK)))
+        rows.append((b, i, int(a[0] >> np.uint64(48)), int(a[0] & MASK), int(a[1] & MASK), int(a[2] & MASK), int(a[3] & MASK), int(a[1] >> np.uint64(48))))
     wg.append((int(w[0]), int(w[e] & ~TOP), n, int((w[1] >> np.uint64(32)) & np.uint64(0xf))))
 rows = np.array(rows, dtype=np.int64)
 wg = np.array(wg, dtype=np.int64)
@@ -72,6 +72,11 @@ for nme, v in (("entry start -> slab 0 landed (set-up, ring fill)", fill), ("loo
     print(f"  {nme:50s} {v.mean():7.2f} us mean per entry ({v.min():.2f}-{v.max():.2f}) = {100 * v.sum() / tot:4.1f} %")
 per_slab = (rows[:, 5] - rows[:, 4]) / np.maximum(slabs, 1)
 print(f"  loop: {per_slab.mean():.0f} clocks per slab mean ({per_slab.min():.0f}-{per_slab.max():.0f}); the slab's 28 MFMAs per wave x 2 waves per SIMD = 896 clocks")
+for kind, label in ((6, "3-tap tiles (tap-shared X tile, 5 slots)"), (16, "1-tap tiles (16 windows, 4 slots)")):     # round 6: k_conv_wgrad3l tags the tile type
+    sel = rows[:, 7] == kind
+    if sel.any():
+        print(f"  {label}: {int(sel.sum())} entries, {per_slab[sel].mean():.0f} clocks per slab mean ({per_slab[sel].min():.0f}-{per_slab[sel].max():.0f}), "
+              f"set-up + fill {fill[sel].mean():.2f} us, flush {flush[sel].mean():.2f} us")
 print(f"  sum of loops / (workgroups x span) = {loop.sum() / (len(wg) * kernel):.3f}; slabs in all {int(slabs.sum())}")
 for x in range(8):
     sel = wg[:, 3] == x
