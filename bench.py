@@ -273,7 +273,7 @@ def acceptance_check(tables, overall=None):
     return out
 
 
-def acceptance_vs_cpu(torch, device, steps=800, bs=1024, lr0=1e-3, high_share=0.5, orders=6):
+def acceptance_vs_cpu(torch, device, steps=1200, bs=1024, lr0=1e-3, high_share=0.5, orders=6):
     """SURVEY 8(d) "MAE acceptance", synthetic form, inside the bench line - a CHECK since round 5, not two numbers side by side.
     The cfg-MLP is trained for the SAME `steps` steps on the SAME batches (Adam, lr 1e-3, 1e-4 for the second half) by the HIP engine
     (bf16 operands) and by the fp32 torch-CPU restatement of the reference step (oracle/mlp_torch_cpu.py), both from
@@ -281,8 +281,10 @@ def acceptance_vs_cpu(torch, device, steps=800, bs=1024, lr0=1e-3, high_share=0.
     times, each time with the batches in another order (same rows, same init).  Two training runs of a 5 x 512 model differ by
     several per cent on single outputs from the data order alone, in EITHER implementation (round 4 measured 2.4 - 10 % between
     schedules); the leg measures that scatter and holds the mean paired difference of the per-variable MAE to 2 % + two standard
-    errors, and the all-output MAE to 2 % flat (acceptance_check; round 6: six orders of 800 steps instead of three of 1200 - the
-    leg's time is the CPU side's).  tests/test_bench_gpu.py asserts `check.passed` on the line the driver's command prints."""
+    errors, and the all-output MAE to 2 % flat (acceptance_check; round 6: six orders instead of three - the leg's ~2 minutes are
+    the CPU side's.  Six orders of 800 steps were tried to stay near round 5's 63 s: the shorter anneal leaves the all-output MAE of
+    two runs 1.7 % +- 1.3 % apart instead of 0.1 %, too noisy for a flat 2 % bar).  tests/test_bench_gpu.py asserts `check.passed`
+    on the line the driver's command prints."""
     from climsim_amd.mlp import MLPEmulator
     from oracle.mlp_oracle import MLPConfig
     from oracle.mlp_torch_cpu import TorchMLP

@@ -153,6 +153,7 @@ struct cs_mlp {
     int chain_ablate = 0;      // CS_CHAIN_ABLATE env, timing experiments only
     int64_t chain_nt_min = 24576;   // CS_CHAIN_NT_MIN: batch from which the tuned chain's activation / gradient stores are non-temporal (chain.h)
     bool wgrad3 = true;        // small-batch wgrad through the LDS-DMA ring (CS_WGRAD3=0: register-staged k_wgrad)
+    bool wgrad3_asm = true;    // CS_WGRAD3_ASM=0: k_wgrad3's contraction through builtins (the asm loop's bit-for-bit reference)
     int wgrad2_mode = -1;      // CS_WGRAD2 env: 0 never, 1 always, -1 by batch size
     int wgrad_splitk = 0;      // 0 = automatic (CS_WGRAD_SPLITK env overrides, for tuning runs)
     // cooperative chain (coop.h): C workgroups per 32-row tile for batches of up to 4096 columns
@@ -604,7 +605,7 @@ int run_backward(cs_mlp* h, int64_t n, bool atomics_needed, hipStream_t st) {
         const int msteps = (big || dma_small) ? (int)(m_pad / WG2_ROWS) : steps;
         WgradArgs w{};
         w.n_layers = h->L; w.m_pad = m_pad;
-        { static const int ab = getenv("CS_WGRAD_ABLATE") ? atoi(getenv("CS_WGRAD_ABLATE")) : 0; w.ablate = ab; }
+        { static const int ab = getenv("CS_WGRAD_ABLATE") ? atoi(getenv("CS_WGRAD_ABLATE")) : 0; w.ablate = ab | (h->wgrad3_asm ? 0 : 32); }
         int tiles = 0;
         for (int l = 0; l < h->L; ++l)
             tiles += ((h->layers[l].Kp + tdim - 1) / tdim) * ((h->layers[l].N + tdim - 1) / tdim);
@@ -781,6 +782,7 @@ int cs_mlp_create(cs_mlp_t** out, const cs_mlp_cfg* cfg) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad3<4, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, WG3_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad3<4, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, WG3_LDS_BYTES_64));
     if (const char* e = getenv("CS_WGRAD3")) h->wgrad3 = atoi(e) != 0;
+    if (const char* e = getenv("CS_WGRAD3_ASM")) h->wgrad3_asm = atoi(e) != 0;
     if (cfg->flags & CS_FLAG_COOP) h->coop_mode = -1;
     if (const char* e = getenv("CS_COOP")) { const int v = atoi(e); h->coop_mode = v == 1 ? -1 : v; }
     if (h->use_chain) {

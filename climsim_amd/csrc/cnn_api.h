@@ -33,6 +33,11 @@ struct cs_cnn {
     Cw3Tile* cw3_tiles_dev = nullptr; bool cw3 = true;                   // conv_wgrad3.h: tap-shared tiles (CS_CW3=0: conv_wgrad2.h's)
     std::vector<int> cw_prefix;          // tiles of conv c: [cw_prefix[c], cw_prefix[c + 1])
     CwWork* cw_work_dev = nullptr; int cw_work_slabs = -1;   // work queues of k_conv_wgrad2l for cw_work_slabs slabs of 32 rows
+    // one device table per distinct batch size seen (the short last batch of an epoch alternates with the full one): uploaded ONCE with a
+    // blocking copy, never rewritten while launches that read it may be queued (round-5 advisor finding: the single table was refilled by
+    // hipMemcpyAsync from a pageable vector that the next size change rebuilt in place)
+    struct CwTable { int slabs; CwWork* dev; int n; int qbegin[9]; int longest; };
+    std::vector<CwTable> cw_tables; int cw_table_n = 0; CwWork* cw_work_cur = nullptr;
     std::vector<CwWork> cw_work; int cw_qbegin[9] = {0}; int cw_longest = 0;
     int* cw_counters = nullptr;          // [8] queue heads of the persistent launch
     int cw_rounds = 4; float cw_taper = 0.8f; bool cw_persist = true;   // CS_CNN_WGRAD_ROUNDS, CS_CNN_WGRAD_TAPER, CS_CW2_PERSIST
@@ -735,19 +740,38 @@ int cs_cnn_loss_grads(cs_cnn_t* h, const float* x_dev, int x3d, const float* y_d
         ca.dbg = nullptr;
         const int slabs = (int)(m_pad / 32);
         if (slabs != h->cw_work_slabs) {
-            cnn_build_cw_work(h, slabs);
-            // (pageable source: the copy has left the vector when the call returns; earlier launches that read the old table are
-            //  in front of it on the same stream)
-            HIP_TRY(hipMemcpyAsync(h->cw_work_dev, h->cw_work.data(), h->cw_work.size() * sizeof(CwWork), hipMemcpyHostToDevice, st));
+            const cs_cnn::CwTable* hit = nullptr;
+            for (const auto& t : h->cw_tables) if (t.slabs == slabs) hit = &t;
+            if (!hit) {
+                cnn_build_cw_work(h, slabs);
+                cs_cnn::CwTable t{};
+                t.slabs = slabs; t.n = (int)h->cw_work.size(); t.longest = h->cw_longest;
+                for (int x = 0; x < 9; ++x) t.qbegin[x] = h->cw_qbegin[x];
+                if (h->cw_tables.size() >= 8) {                       // (eight sizes cached; a ninth recycles the oldest table - behind a synchronise)
+                    HIP_TRY(hipStreamSynchronize(st));
+                    t.dev = h->cw_tables.front().dev;
+                    h->cw_tables.erase(h->cw_tables.begin());
+                } else if (h->cw_tables.empty()) {
+                    t.dev = h->cw_work_dev;
+                } else {
+                    HIP_TRY(hipMalloc(&t.dev, sizeof(CwWork) * CW_MAX_WORK));
+                    h->allocs.push_back(t.dev);
+                }
+                HIP_TRY(hipMemcpy(t.dev, h->cw_work.data(), h->cw_work.size() * sizeof(CwWork), hipMemcpyHostToDevice));
+                h->cw_tables.push_back(t);
+                hit = &h->cw_tables.back();
+            }
+            h->cw_work_cur = hit->dev; h->cw_table_n = hit->n; h->cw_longest = hit->longest;
+            for (int x = 0; x < 9; ++x) h->cw_qbegin[x] = hit->qbegin[x];
             h->cw_work_slabs = slabs;
         }
-        ca.work = h->cw_work_dev;
+        ca.work = h->cw_work_cur;
         for (int x = 0; x < 9; ++x) ca.q_begin[x] = h->cw_qbegin[x];
         int grid;
         if (h->cw_persist) {                                   // one workgroup per CU (158 KB of LDS each), entries taken from the queues
             HIP_TRY(hipMemsetAsync(h->cw_counters, 0, sizeof(int) * 8, st));
             ca.counters = h->cw_counters;
-            grid = std::min(h->n_cu, (int)h->cw_work.size());
+            grid = std::min(h->n_cu, h->cw_table_n);
             grid = std::max(8, (grid + 7) / 8 * 8);
         } else {
             ca.counters = nullptr;

@@ -470,7 +470,7 @@ __device__ __forceinline__ void wgrad3_body(const WgradArgs& pa, const int work,
     // step of MFMAs to land, and the last two steps of a stage fetch the first two of the NEXT stage (the barrier in front of a stage
     // says that the next one has landed: see the loader).  LDS returns in order: `lgkmcnt(8)` = the set about to be used is there
     // (the eight younger reads are the other set's).  A fragment = two transposing 64-bit reads, 4 rows (1 KiB) apart.
-    if (nst > 0 && !(pa.ablate & 4)) {
+    if (nst > 0 && !(pa.ablate & (4 | 32))) {
         typedef unsigned long long u64_t;
         union Frag { bf16x8_t v; u64_t h[2]; };
         Frag ah_[2], az_[2], bh_[2], bz_[2];
@@ -531,6 +531,34 @@ __device__ __forceinline__ void wgrad3_body(const WgradArgs& pa, const int work,
 #undef W3_MM
 #undef W3_MB
 #undef W3_STEP
+    } else if (nst > 0 && (pa.ablate & 32)) {
+        // CS_WGRAD3_ASM=0 - the same contraction through hipcc's own scheduling and hazard checks (builtins, nothing pipelined by hand):
+        // the reference the asm loop above is held to BIT FOR BIT (tests/test_mlp_large_gpu.py; round-5 advisor finding: no compiler
+        // check sees an asm MFMA, and the asm loop rewrites fragment registers right behind the MFMAs that read them).  Same barriers,
+        // same 16-row steps in the same order per accumulator.
+        constexpr int S = R / 16;
+        __builtin_amdgcn_s_barrier();                   // stage 0 has landed
+        wg3_stamp(pa, tid, 1);
+        int slot = 0;
+        for (int s = 0; s < nst; ++s) {
+            __builtin_amdgcn_s_barrier();               // stage s + 1 has landed; the slot of stage s - 1 is the loaders'
+            const u16* Hs = ring + slot * STAGE_ELEMS;
+            const u16* Zs = Hs + R * 128;
+#pragma unroll
+            for (int t = 0; t < S; ++t) {
+                bf16x8_t fh[2], fz[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) fh[i] = frag_w3(Hs, 16 * t, wk * 64 + i * 32, lane);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) fz[j] = frag_w3(Zs, 16 * t, wn * 64 + j * 32, lane);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[i], fz[j], acc[i][j], 0, 0, 0);
+                if (do_bias) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, wk ? fz[1] : fz[0], accb, 0, 0, 0);
+            }
+            slot = slot + 1 == SLOTS ? 0 : slot + 1;
+        }
     } else if (nst > 0) {
         __builtin_amdgcn_s_barrier();
         for (int s = 0; s < nst; ++s) __builtin_amdgcn_s_barrier();  // timing experiment (CS_WGRAD_ABLATE & 4): requests and barriers only

@@ -188,3 +188,33 @@ def test_accumulating_gradient_call_after_a_step_starts_clean(M, n):
     g.close()
     for m in (a, b, c):
         m.close()
+
+
+@pytest.mark.parametrize("units,n,exact", [(CFG, 8192, True), (CFG, 1000, True), (PUB, 3072, True), (CFG, 16384, False)])
+def test_wgrad3_asm_loop_equals_the_builtin_loop(M, monkeypatch, units, n, exact):
+    """k_wgrad3's contraction is hand-scheduled asm (round 5): no compiler hazard check sees its MFMAs, and it reloads fragment
+    registers right behind the MFMAs that read them (round-5 advisor finding).  CS_WGRAD3_ASM=0 runs the same contraction through
+    builtins - hipcc's own waits and hazard handling - with the same steps in the same order per accumulator.  Inside a one-call
+    step with up to three row splits every split STORES its tile and k_optimizer adds the buffers in a fixed order: the weights
+    after three SGD steps agree BIT FOR BIT (8192 rows = the bench's launch: 64-row stages, bias tiles; 1000 = a ragged last stage;
+    the published widths at their batch).  16384 rows run 32-row stages, two workgroups per CU, with seven splits added by float
+    atomics: equal to the order of those additions."""
+    cfg = O.MLPConfig(hidden=tuple(units))
+    ws = O.glorot_init(cfg, 21)
+    x, y = O.synth_columns(n, seed=23)
+    xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("CS_WGRAD3_ASM", mode)
+        m = M.MLPEmulator(units=units, optimizer="SGD", max_batch=max(n, 128), seed=None)
+        m.set_weights(ws)
+        for _ in range(3):
+            m.train_on_batch(xd, yd, 1e-2)
+        out[mode] = [w.copy() for w in m.get_weights()]
+        m.close()
+    for a, b, w0 in zip(out["1"], out["0"], ws):
+        if exact:
+            assert np.array_equal(a, b)
+        else:
+            assert rel(a - w0, b - w0) <= 1e-5
+        assert not np.array_equal(a, w0)                            # (the steps moved every tensor)
