@@ -116,6 +116,9 @@ static void cnn_build_cw_work(cs_cnn* h, int slabs) {
     // longest first, each group to the queue with the least work so far (work = tiles x (slabs + the ~20 slabs an entry costs besides
     // its loop)): the queues end together, and each runs its long entries first
     std::stable_sort(groups.begin(), groups.end(), [](const Group& a, const Group& b) { return a.s1 - a.s0 > b.s1 - b.s0; });
+    // (Round 6, measured no-go: the 10-tile groups first and 240 = 8 x 30 persistent workgroups, so that teams of ten take a group
+    //  together, keep it together and share its slabs in the L2 - 3.19 ms per step against 3.06: the queues lose their balance, and the
+    //  loop, compute-bound at ~1350 clocks per slab, does not get faster from a better hit rate.  profiles/r06_cnn_wgrad3.txt)
     std::vector<std::vector<CwWork>> q(8);
     double load[8] = {0};
     for (size_t g = 0; g < groups.size(); ++g) {

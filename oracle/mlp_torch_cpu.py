@@ -18,9 +18,39 @@ import torch
 from .mlp_oracle import MLPConfig, fuse_heads
 
 
+class _RoundSTE(torch.autograd.Function):
+    """bf16 rounding of a tensor, gradient passed through: fp32 master weights / activations, bf16 MFMA operands."""
+
+    @staticmethod
+    def forward(ctx, t):
+        return t.bfloat16().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+class _RoundGrad(torch.autograd.Function):
+    """identity forward, bf16 rounding of the gradient: where the engine stores dz as bf16 (operand of dgrad and wgrad)."""
+
+    @staticmethod
+    def forward(ctx, t):
+        return t
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.bfloat16().float()
+
+
 class TorchMLP:
-    def __init__(self, ws, cfg: MLPConfig):
+    """`bf16=True`: the ENGINE's arithmetic on the CPU - every contraction's operands rounded to bfloat16 (inputs, activations, the
+    weights' operand copies, dz), float32 accumulation, float32 master weights and optimiser - the rounding points of
+    oracle/mlp_oracle.py's `bf16=True` (which tests hold the engine to step by step), fast enough to TRAIN with: bench.py's
+    acceptance leg uses it to tell what bf16 operands cost after equal steps from what the engine would add on top."""
+
+    def __init__(self, ws, cfg: MLPConfig, bf16: bool = False):
         self.cfg = cfg
+        self.bf16 = bool(bf16)
         self.params = [torch.tensor(np.asarray(a), dtype=torch.float32, requires_grad=True)
                        for pair in fuse_heads(ws) for a in pair]
         self.m = [torch.zeros_like(p) for p in self.params]
@@ -30,8 +60,12 @@ class TorchMLP:
     def forward(self, x):
         cfg, h = self.cfg, x
         n = len(self.params) // 2
+        q = _RoundSTE.apply if self.bf16 else (lambda t: t)
+        h = q(h)
         for i in range(n):
-            z = torch.addmm(self.params[2 * i + 1], h, self.params[2 * i])
+            z = torch.addmm(self.params[2 * i + 1], h, q(self.params[2 * i]))
+            if self.bf16:
+                z = _RoundGrad.apply(z)
             if i < n - 1:
                 if cfg.act == "relu":
                     h = torch.relu(z)
@@ -39,6 +73,7 @@ class TorchMLP:
                     h = torch.nn.functional.elu(z)
                 else:
                     h = torch.nn.functional.leaky_relu(z, cfg.alpha)
+                h = q(h)
             else:
                 h = torch.cat([z[:, :cfg.n_out_lin], torch.relu(z[:, cfg.n_out_lin:])], dim=1)
         return h

@@ -130,10 +130,10 @@ def test_failure_reporter_prints_one_error_line_when_rank_zero_is_blocked(tmp_pa
 
 
 def test_acceptance_check_of_the_bench_line():
-    """bench.acceptance_check (round 6: a statistic): per variable the mean PAIRED difference engine - CPU restatement over the data
-    orders, held to 2 % + two standard errors; the engine's own scatter bounded by the restatement's; the all-output MAE within
-    2 % flat.  Driven here on made-up tables: it passes where the difference is inside the allowance, fails where the engine is
-    off by more, fails an erratic engine although its mean is right, and reports the fields the line promises."""
+    """bench.acceptance_check (round 6: a statistic): per variable - and for the all-output MAE - the mean PAIRED difference of two
+    sides over the data orders, held to 2 % + two standard errors; the first side's own scatter bounded by the second's.  Driven
+    here on made-up tables: it passes where the difference is inside the allowance, fails where the first side is off by more,
+    fails an erratic first side although its mean is right, and reports the fields the line promises."""
     import importlib
     import math
     import sys
@@ -142,7 +142,7 @@ def test_acceptance_check_of_the_bench_line():
     cpu = [{"a": 1.00, "b": 2.00}, {"a": 1.04, "b": 2.02}, {"a": 0.98, "b": 1.99}, {"a": 1.01, "b": 2.01}]
     eng = [{"a": 1.03, "b": 2.01}, {"a": 0.99, "b": 2.03}, {"a": 1.02, "b": 2.00}, {"a": 1.00, "b": 2.02}]
     c = bench.acceptance_check({"engine_bf16": eng, "cpu_fp32": cpu})
-    assert c["passed"] and c["margin"] > 0 and c["orders"] == 4
+    assert c["passed"] and c["margin"] > 0 and c["orders"] == 4 and c["sides"] == ["engine_bf16", "cpu_fp32"]
     assert set(c) >= {"engine_vs_cpu", "cpu_vs_cpu_other_order", "engine_vs_engine_other_order", "allowed", "worst_variable", "tolerance",
                       "order_to_order_sd", "per_variable_passed", "scatter_passed"}
     assert c["cpu_vs_cpu_other_order"]["a"] == round((1.04 - 0.98) / 0.98, 4)
@@ -151,17 +151,22 @@ def test_acceptance_check_of_the_bench_line():
     md = sum(d) / 4
     se = math.sqrt(sum((x - md) ** 2 for x in d) / 3) / 2 / mean_c
     assert abs(c["engine_vs_cpu"]["of_the_order_means"]["a"] - abs(md) / mean_c) < 1e-3
+    assert abs(c["engine_vs_cpu"]["signed"]["a"] - md / mean_c) < 1e-3
     assert abs(c["engine_vs_cpu"]["se"]["a"] - se) < 1e-3 and abs(c["allowed"]["a"] - (0.02 + 2 * se)) < 1e-3
     off = [{"a": 1.00, "b": 2.30}, {"a": 1.01, "b": 2.31}, {"a": 1.02, "b": 2.29}, {"a": 1.00, "b": 2.30}]   # b off by 15 %, scatter of ~1 %
     c = bench.acceptance_check({"engine_bf16": off, "cpu_fp32": cpu})
     assert not c["passed"] and not c["per_variable_passed"] and c["worst_variable"] == "b" and c["margin"] < 0
-    # an erratic engine: the mean of b is right, its scatter is ten times the restatement's - the standard error widens the bar
+    # an erratic first side: the mean of b is right, its scatter is ten times the second side's - the standard error widens the bar
     # (per variable passes), the scatter bound does not
     wild = [{"a": 1.00, "b": 1.60}, {"a": 1.04, "b": 2.45}, {"a": 0.98, "b": 1.75}, {"a": 1.01, "b": 2.22}]
     c = bench.acceptance_check({"engine_bf16": wild, "cpu_fp32": cpu})
     assert c["per_variable_passed"] and not c["scatter_passed"] and not c["passed"]
-    # the all-output MAE is held to 2 % with no allowance
+    # the all-output MAE is held to the same rule: 2 % + two standard errors of its own paired differences
     c = bench.acceptance_check({"engine_bf16": eng, "cpu_fp32": cpu}, {"engine_bf16": [1.0, 1.01, 1.0, 1.0], "cpu_fp32": [1.0, 1.0, 1.0, 1.0]})
-    assert c["passed"] and c["all_outputs"]["rel_diff_of_the_order_means"] == 0.0025
-    c = bench.acceptance_check({"engine_bf16": eng, "cpu_fp32": cpu}, {"engine_bf16": [1.03, 1.04, 1.03, 1.02], "cpu_fp32": [1.0, 1.0, 1.0, 1.0]})
+    assert c["passed"] and c["all_outputs"]["rel_diff_of_the_order_means"] == 0.0025 and c["all_outputs"]["signed"] == 0.0025
+    assert abs(c["all_outputs"]["allowed"] - (0.02 + 2 * 0.0025)) < 1e-4           # sd of (0, .01, 0, 0) = .005, / sqrt(4)
+    c = bench.acceptance_check({"engine_bf16": eng, "cpu_fp32": cpu}, {"engine_bf16": [1.05, 1.06, 1.05, 1.04], "cpu_fp32": [1.0, 1.0, 1.0, 1.0]})
     assert not c["passed"] and not c["all_outputs_passed"] and c["per_variable_passed"]
+    # any two sides of the leg can be compared (the line compares engine / bf16 emulation / float32 pairwise)
+    c = bench.acceptance_check({"x": eng, "y": cpu, "z": off}, None, ("x", "y"))
+    assert c["sides"] == ["x", "y"] and c["passed"]
