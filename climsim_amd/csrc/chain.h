@@ -68,7 +68,7 @@ struct ChainArgs {
     int fused;               // forward half: dz of the heads also goes to LDS, loss scratch moves to the bias block;
                              // backward half: no prologue load (dz is in X) and no L2 warm-up (a prefetch of Wb issued during
                              // the forward half would sit in front of that half's weight stream: memory operations complete in order)
-    int ablate;              // timing experiments only (CS_CHAIN_ABLATE): 4 no global stores, 8 no warm-up, 128 no contraction split in 128-wide stages, 256 half the weight bytes from L2 (chain_trunk)
+    int ablate;              // timing experiments only (CS_CHAIN_ABLATE): 4 no global stores, 8 no warm-up, 128 no contraction split in 128-wide stages, 256 half the weight bytes from L2 (chain_trunk), 512 the prologue warms two stages only, the rest behind stage 0 (round 6: no gain)
     int store_nt;            // activations / gradients leave with the non-temporal policy (host: batches the L2s cannot hold anyway)
     int trunk_i0, trunk_n;   // stages trunk_i0 .. trunk_i0 + trunk_n - 1 run as ONE continuous weight stream (chain_trunk; 0 / 0: off)
     unsigned long long* dbg; // optional [grid][64] s_memtime stamps (CS_CHAIN_DBG), null in production
@@ -654,15 +654,21 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const ChainDyn& d
     // share this XCD and which of them this one is: chain_warm_share for an ordinary launch.
     unsigned sink = 0;
     bool warmed = (p.ablate & 8) || (BWD && p.fused && !(p.ablate & 32));
-    auto warm_up = [&]() {
-        if (warmed) return;
-        warmed = true;
+    // (CS_CHAIN_ABLATE & 512, round-6 experiment: the prologue warms - and waits for - the first two stages only; the others' lines are
+    //  requested behind stage 0, to arrive under its epilogue instead of standing in front of the first MFMA)
+    const int warm_first = (!BWD && (p.ablate & 512)) ? min(2, p.n_stages) : p.n_stages;
+    auto warm_range = [&](int s_lo, int s_hi) {
         const int Q = wQ, q = wq;
-        for (int i = 0; i < p.n_stages; ++i) {
+        for (int i = s_lo; i < s_hi; ++i) {
             const unsigned* w = reinterpret_cast<const unsigned*>(p.st[i].wfrag);
             const int lines = (p.st[i].Kc * p.st[i].Nc) >> 6;            // 128-B lines of bf16
             for (int ln = q * 512 + tid; ln < lines; ln += Q * 512) sink ^= w[ln * 32];
         }
+    };
+    auto warm_up = [&]() {
+        if (warmed) return;
+        warmed = true;
+        warm_range(0, warm_first);
     };
     // Forward: the warm-up loads go out BEHIND the loads of the row indices and of the gathered input rows (memory
     // operations complete in order: in front of them they put their HBM / MALL latency into the indices -> rows
@@ -740,8 +746,20 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const ChainDyn& d
     chain_stamp(p, bid, tid, slot);
 
     float sq = 0.f, ab = 0.f;
+    unsigned sink2 = 0;
     ChainPending pend{nullptr, 0, 0, 0};
     for (int i = 0; i < p.n_stages; ++i) {
+        if (!BWD && i == 1 && warm_first < p.n_stages && !(p.ablate & 8)) {
+            // asm loads into ONE register that stays reserved to the end of the pass: nothing consumes them, nobody waits for them by
+            // name (they are older than every later weight load, whose counted waits cover them in order)
+            const int Q = wQ, q = wq;
+            for (int k = warm_first; k < p.n_stages; ++k) {
+                const unsigned* w = reinterpret_cast<const unsigned*>(p.st[k].wfrag);
+                const int lines = (p.st[k].Kc * p.st[k].Nc) >> 6;
+                for (int ln = q * 512 + tid; ln < lines; ln += Q * 512)
+                    asm volatile("global_load_dword %0, %1, off" : "+v"(sink2) : "v"(w + ln * 32) : "memory");
+            }
+        }
         if constexpr (BM == 32 && !ELU) {
             if (p.trunk_n > 1 && i == p.trunk_i0) {            // a run of 512-wide stages as one continuous weight stream (chain_trunk)
                 chain_trunk<BM, BWD ? EPI_DGRAD : EPI_HIDDEN, ELU>(X, bias_lds, p, bid, i, p.trunk_n, m0, wid, tid, slot, pend);
@@ -769,6 +787,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const ChainDyn& d
     // (scratch: X is free, the heads stage ended with a barrier - except under k_chain_fb, where X now holds dz of the
     //  heads and the bias block, which no later stage reads, takes its place)
     if (!BWD && d_.y) loss_flush(d_.loss, p.loss_stripes, bid, sq, ab, p.fused ? bias_lds : reinterpret_cast<float*>(X), tid, 8);
+    asm volatile("" :: "v"(sink2));          // (the deferred warm-up's destination register was reserved up to here)
     chain_stamp(p, bid, tid, slot);
     if (p.dbg && tid == 0) p.dbg[(int64_t)bid * 64 + 63] = __builtin_amdgcn_s_memrealtime();
 }

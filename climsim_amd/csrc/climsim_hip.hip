@@ -342,7 +342,7 @@ int chain_bm(const cs_mlp* h, int64_t n) { return chain_bm_of(h->cfg.flags, h->n
 // first (its first 8 k16-steps are requested by the stage in front, the next 8 by its own head block).
 void chain_find_trunk(const cs_mlp* h, ChainArgs& c) {
     c.trunk_i0 = 0; c.trunk_n = 0;
-    if (h->chain_trunk_off || h->cfg.act == CS_ACT_ELU || (c.ablate & ~(128 | 256)) || c.mask_bm64) return;
+    if (h->chain_trunk_off || h->cfg.act == CS_ACT_ELU || (c.ablate & ~(128 | 256 | 512)) || c.mask_bm64) return;
     int best0 = 0, bestn = 0;
     for (int i = 0; i < c.n_stages;) {
         int n = 0;

@@ -34,6 +34,14 @@ __device__ __forceinline__ bf16x8_t frag_w2(const u16* tile, int mb, int cb, int
 }
 
 // one 1-KiB LDS-DMA piece: lane i -> LDS byte lds_dst + 16*i  (M0 carries the wave-uniform base)
+#ifndef WG3_DMA_MOD
+#define WG3_DMA_MOD ""                   // cache-policy bits of k_wgrad3's operand requests (A/B builds: " nt", " sc1", " sc0 sc1": profiles/r06_wgrad3_policy.txt)
+#endif
+__device__ __forceinline__ void dma16w3(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" WG3_DMA_MOD "\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
 __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst) {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
@@ -422,8 +430,8 @@ __device__ __forceinline__ void wgrad3_body(const WgradArgs& pa, const int work,
         const int64_t roff = (int64_t)(s_begin + sc_) * R;                                              \
         const unsigned base = lds0 + (unsigned)((st) & (SLOTS - 1)) * (STAGE_ELEMS * 2) + mine;         \
         if (!(pa.ablate & 8)) _Pragma("unroll") for (int j = 0; j < PPL; ++j) {                         \
-            dma16(hb + (roff + 4 * j) * p.ldh, base + (unsigned)j * 1024u);                             \
-            dma16(zb + (roff + 4 * j) * p.ldz, base + R * 256u + (unsigned)j * 1024u);                  \
+            dma16w3(hb + (roff + 4 * j) * p.ldh, base + (unsigned)j * 1024u);                             \
+            dma16w3(zb + (roff + 4 * j) * p.ldz, base + R * 256u + (unsigned)j * 1024u);                  \
         }                                                                                               \
     }
 #pragma unroll
