@@ -39,7 +39,7 @@ PEAK_BF16_TFLOPS = 2500.0                   # dense MFMA peak, MI355X_MICROARCH.
 PEAK_HBM_GBS = 8000.0
 
 
-PMC_FILES = ("r05_pmc_hbm_traffic.json", "r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json")     # newest first
+PMC_FILES = ("r06_pmc_hbm_traffic.json", "r05_pmc_hbm_traffic.json", "r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json")     # newest first
 
 
 def pmc_traffic(kernel, batch):
