@@ -216,5 +216,5 @@ def test_wgrad3_asm_loop_equals_the_builtin_loop(M, monkeypatch, units, n, exact
         if exact:
             assert np.array_equal(a, b)
         else:
-            assert rel(a - w0, b - w0) <= 1e-5
+            assert rel(a - w0, b - w0) <= 1e-4                       # (float atomics: the order of seven partial sums; a wrong fragment would show at 1e-2)
         assert not np.array_equal(a, w0)                            # (the steps moved every tensor)
