@@ -341,7 +341,15 @@ def acceptance_vs_cpu(torch, device, steps=800, bs=1024, lr0=1e-3, high_share=0.
     # hence 800 steps, the emulation (the asserted side) for all six orders and float32 (information) for three: ~100 s.
     #   (Tried: both CPU models on two threads of this process, and two child processes side by side - 310 / 318 s for 2 x 6 x 1200 steps.)
     orders_fp32 = min(int(os.environ.get("CS_ACC_ORDERS_FP32", orders_fp32)), orders)
-    shm = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    need = (x.numel() + y.numel() + xs.numel()) * 4 + (64 << 20)
+    shm = None                                           # shared memory if it has room for the batches (a container's default /dev/shm is 64 MB), else the temp dir
+    for cand in ("/dev/shm", tempfile.gettempdir()):
+        try:
+            if os.path.isdir(cand) and os.access(cand, os.W_OK) and shutil.disk_usage(cand).free > need:
+                shm = cand
+                break
+        except OSError:
+            pass
     work = tempfile.mkdtemp(prefix="cs_acc_", dir=shm)
     children = {}
     try:
