@@ -6,7 +6,7 @@
 #     thread-local error string, handle teardown on failed creation.
 #   * the two C programs that write the HDF5 fixtures (tests/golden/hdf5/*.c) compiled with gcc -fsanitize=address,undefined
 #     and run into a scratch directory (they link the libhdf5 of /opt/conda when it is there; skipped otherwise).
-# Never on the GPU box (GPU AddressSanitizer / XNACK runs are refused there).  Writes profiles/r04_sanitizer_host.log.
+# Never on the GPU box (GPU AddressSanitizer / XNACK runs are refused there).  Writes profiles/r06_sanitizer_host.log.
 # Fails (exit 1) when the build fails, when pytest fails, or when a sanitizer report is found - a status file carries the group's outcome
 # out of the `{ ... } | tee` subshell (round-3 advisor: the old script printed 'clean' after a failed build).
 set -u
@@ -14,7 +14,7 @@ set -o pipefail
 cd "$(dirname "$0")/.."
 REPO=$(pwd)
 OUT=${TMPDIR:-/tmp}/climsim_asan
-LOG=$REPO/profiles/r04_sanitizer_host.log
+LOG=$REPO/profiles/r06_sanitizer_host.log
 mkdir -p "$OUT"
 STATUS=$OUT/status; echo fail > "$STATUS"
 {
