@@ -15,13 +15,18 @@ What it restates (numpy, float32 unless noted):
   * LR schedule: tfa.optimizers.CyclicalLearningRate, triangular2 (step2_retrain.py:140-148).
   * normalise  : climsim_utils/data_utils.py:807-809 and the inf/nan->0 rule :894-897.
 
-PARITY UNPINNED for the training arithmetic: the reference has no test, golden vector or fixture
-for forward/backward/optimiser results and TensorFlow/Keras cannot
-be installed here, so this restatement cannot be checked against reference outputs.  It is
-cross-checked against an independent torch-autograd implementation (oracle/mlp_torch_cpu.py) in
-tests/test_oracle.py, and the known answers that do exist (parameter count 1,753,472 and
-3,503,488 forward FLOPs for the published model, step1_results.csv:170 /
-FLOP_calculation.ipynb nb:231) are asserted there.
+PARITY: PINNED (round 6) for topology, head fusion, ReLU, MSE, the hand-derived backward and the torch-Adam rule: the reference's own
+torch MLP (online_testing/baseline_models/MLP_v2rh/training/mlp.py:28-67: Linear -> ReLU per hidden layer, a final Linear, ReLU on
+the last 8 outputs) instantiated as 124 -> [512]*5 + [128] -> 128 IS this model with act='relu' (the two heads = one 128 x 128 layer
+with ReLU on columns 120..127), and as 124 -> [768, 640, 512, 640, 640, 128] -> 128 the published one.  tests/golden/hot_mlp_golden.npz
+holds what the reference computes for them at batch 8192 / 3072 (loss, predictions, every gradient, five torch.optim.Adam steps;
+made by tests/golden/make_online_mlp_golden.py, which imports the reference in the build container); tests/test_hot_mlp_cpu.py holds
+`forward` / `loss_and_grads(bf16=False)` / `Optimizer('AdamTorch')` to those vectors at float32 accumulation-order tolerance (3e-6;
+loss 1e-6).  UNPINNED (TensorFlow / Keras cannot be installed here, the reference holds no vectors for them): the LeakyReLU / ELU
+epilogues and the Keras-2.11 / tfa-0.19 optimiser rules - restated from the published definitions, cross-checked
+against an independent torch-autograd implementation (oracle/mlp_torch_cpu.py) and against torch.optim with the documented
+epsilon-placement differences asserted (tests/test_oracle.py); the known answers that exist (parameter count 1,753,472 and 3,503,488
+forward FLOPs for the published model, step1_results.csv:170 / FLOP_calculation.ipynb nb:231) are asserted there.
 
 `bf16=True` reproduces the rounding points of the HIP engine (operands of every contraction
 rounded to bfloat16 round-to-nearest-even, fp32 accumulation, fp32 master weights) so that GPU
