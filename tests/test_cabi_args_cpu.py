@@ -124,7 +124,7 @@ def test_group_loader_metrics_dp_and_cnn_entries(lib):
     f4 = (C.c_float * 4)()
     for rc in (lib.cs_cnn_set_weights(None, f4, 4, None), lib.cs_cnn_get_weights(None, f4, 4, None), lib.cs_cnn_forward(None, f4, 0, 1, None, None, None),
                lib.cs_cnn_evaluate(None, f4, 0, f4, 0, None, 1, f4, 0, None), lib.cs_cnn_loss_grads(None, f4, 0, f4, 0, None, 1, f4, None),
-               lib.cs_cnn_set_seed(None, 1), lib.cs_cnn_apply(None, 1e-3, 1.0, None), lib.cs_cnn_train_step(None, f4, 0, f4, 0, None, 1, 1e-3, f4, None),
+               lib.cs_cnn_set_seed(None, 1), lib.cs_cnn_set_metrics_buffer(None, None), lib.cs_cnn_apply(None, 1e-3, 1.0, None), lib.cs_cnn_train_step(None, f4, 0, f4, 0, None, 1, 1e-3, f4, None),
                lib.cs_cnn_set_grad_buffer(None, None, 0), lib.cs_cnn_grad_buffer(None, None, None),
                lib.cs_cnn_get_opt_state(None, f4, f4, 4, None, None), lib.cs_cnn_set_opt_state(None, f4, f4, 4, 0, None)):
         bad(lib, rc)
