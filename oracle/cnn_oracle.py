@@ -5,9 +5,12 @@ float32 ops: hp_depth blocks of [Conv1D(C,3,'same') -> ReLU -> Dropout] x2 plus 
 projection of the block input added after the second activation; Conv1D(10,1, ELU); per-level
 Dense(10->2, linear) || Dense(10->8, relu); losses `mae_adjusted` / `mse_adjusted` (:114-121).
 Conv1D/Dense semantics come from un-vendored Keras (TF 2.10, CNN/env/tf2.yml:205-223): kernels
-(k, c_in, c_out), zero 'same' padding, glorot_uniform, zero biases.  PARITY UNPINNED: the reference
-holds no test or golden vector for the CNN (saved_model.pb has no variables); the known answer that
-exists - 13,215,420 parameters for depth 12 / width 406 - is asserted in tests.
+(k, c_in, c_out), zero 'same' padding, glorot_uniform, zero biases.  PARITY: the model's forward / backward is UNPINNED - the
+reference holds no test or golden vector for the CNN (saved_model.pb has no variables) and TensorFlow cannot run here; the known
+answer that exists - 13,215,420 parameters for depth 12 / width 406 - is asserted in tests.  PINNED (round 6): the
+loss / metric FUNCTIONS `mae_adjusted`, `mse_adjusted`, `continuous_ranked_probability_score` - tests/golden/cnn_loss_golden.npz is made
+by executing the reference's own three function bodies (hpo_train.py:83-121, taken out of the file by ast) over numpy namesakes of the
+backend operations they call (tests/golden/make_cnn_loss_golden.py); tests/test_oracle.py holds the restatements below to it at 1e-12.
 
 `bf16=True` mirrors the engine's rounding points: weights, and every stored activation tensor
 (conv outputs after activation, the block sum) rounded to bfloat16; the residual projection is accumulated

@@ -99,8 +99,8 @@ def test_five_adam_steps(OM, name, path):
         kk = k.split("/after5/")[1]
         record_margin(f"online_{name}_movement_vs_reference_rel", rel(sd[kk] - init[kk], GOLD[k] - init[kk]))
         # Adam's first steps are ~lr*sign(g): a bf16-sized difference in a near-zero gradient flips a whole step.  Measured against the
-        # reference's fp32 vectors: 0.054 / 0.091 / 0.130 over the three configurations (profiles/r05_test_margins.json); bar 0.2 (0.35 until round 5)
-        assert rel(sd[kk] - init[kk], GOLD[k] - init[kk]) <= 0.2, (kk, rel(sd[kk] - init[kk], GOLD[k] - init[kk]))
+        # reference's fp32 vectors: 0.054 / 0.091 / 0.130 over the three configurations (profiles/r05_test_margins.json, r06: the same); bar 0.17 (0.2 in round 5, 0.35 before)
+        assert rel(sd[kk] - init[kk], GOLD[k] - init[kk]) <= 0.17, (kk, rel(sd[kk] - init[kk], GOLD[k] - init[kk]))
 
 
 @pytest.mark.parametrize("flags", [0, 2])

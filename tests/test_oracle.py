@@ -242,3 +242,22 @@ def test_cnn_metric_restatements_against_a_loop():
     assert CO.categorical_accuracy(yt, yp) == acc and CO.categorical_accuracy(yt, yt) == 1.0
     tie = np.zeros((1, 1, 10))
     assert CO.categorical_accuracy(tie, yp[:1, :1] * 0 + np.arange(10)[::-1]) == 1.0      # first index on ties: 0 == argmax of a decreasing row
+
+
+def test_cnn_loss_functions_match_the_reference_function_bodies():
+    """oracle/cnn_oracle.py's `mae_adjusted`, `mse_adjusted` and `continuous_ranked_probability_score` against
+    tests/golden/cnn_loss_golden.npz - made by tests/golden/make_cnn_loss_golden.py, which executes the SOURCE of the reference's own three
+    functions (baseline_models/CNN/training/hpo_train.py:83-121, taken out of the file by ast) with `tf` / `K` bound to numpy namesakes:
+    terms, axes, slices and the 120/128, 8/128 weights are the reference's text.  float64, 1e-12."""
+    import os
+    sys_path = os.path.join(os.path.dirname(__file__), "golden")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_cnn_loss_golden", os.path.join(sys_path, "make_cnn_loss_golden.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)                                    # (only its seeded `inputs()` is used here: /root/reference is not read)
+    from oracle import cnn_oracle as CO
+    gold = np.load(os.path.join(sys_path, "cnn_loss_golden.npz"))
+    for key, (yt, yp) in gen.inputs().items():
+        assert abs(CO.mae_adjusted(yt, yp) - float(gold[f"{key}/mae_adjusted"])) <= 1e-12
+        assert abs(CO.mse_adjusted(yt, yp) - float(gold[f"{key}/mse_adjusted"])) <= 1e-12
+        assert abs(CO.continuous_ranked_probability_score(yt, yp) - float(gold[f"{key}/continuous_ranked_probability_score"])) <= 1e-12
