@@ -13,6 +13,7 @@
 // Against 13 separate GEMM launches of ~11 us each this removes the per-launch latency, which is what bounds the
 // per-layer path at the reference's batch sizes.
 #pragma once
+#include <type_traits>
 #include "chain.h"
 
 #define CWD_PITCH 1024
@@ -41,14 +42,94 @@ __device__ __forceinline__ void chainw_copy_out(const u16* __restrict__ X, u16* 
     }
 }
 
+
+// ---- round 6: the weight stream of a wave never stops (non-ELU models, contraction lengths that are multiples of 128) -----------
+// Stamps of the per-pass form (tools/chainw_stamps.py, published widths at 3072 columns): the k-loops run at 50-56 B/clk per CU - the
+// pace of the L2 -> CU path - and between them nothing is in flight: every pass starts with the fill latency of its queue and ends with
+// an epilogue (2.6k clocks for two tiles), every stage with a barrier; k-loops 74k of a forward half's 127k clocks.  Here a wave walks
+// its column tiles ONE at a time with a queue of 8 k16-steps that is refilled across tile AND stage boundaries: the last 8 steps of a
+// tile fetch the first 8 of the wave's next tile - in this stage or in the next one it has tiles in (weights do not depend on the
+// barrier) - and those fly under the epilogue, the stores and the barrier.
+//   * The queue lives in FIXED registers v[224:255] that only the asm statements below name (launch_bounds(512): 256 VGPRs per lane, the
+//     compiler's own code ends below v200 - tests/test_chainw_stream_cpu.py reads the compiled kernel and fails if anything else touches
+//     v[216:255]).  In-flight loads in compiler-visible registers are what killed the first attempt at this in chain.h (copies of
+//     queue registers across a dispatch); registers the compiler does not know about cannot be copied.
+//   * Every wait is `vmcnt(7)`: the slot being consumed always has exactly 7 younger queue loads; other memory operations of the wave
+//     in flight (stores of finished tiles, the sign-mask accesses) only make the wait stricter - safe whatever their number.  A wave
+//     with no next tile refills from its own tile again (same count, 8 KiB once per half).
+//   * The MFMAs are asm too (the queue registers are their operand), one accumulator tile in k order = the arithmetic of chain_mma's
+//     one-tile pass: results are bit-identical to the per-pass form (tests/test_chainw_stream_gpu.py).
+//   * A finished tile goes to global memory from its own wave (32 rows x 64 B, read back from the LDS tile the epilogue just wrote):
+//     no row copies of the whole stage output behind the next stage's first loads, no `vmcnt(0)` at the stage barrier (raw s_barrier
+//     behind `lgkmcnt(0)`: hipcc's __syncthreads drains the queue).
+//   * Backward: the sign masks of a stage are fetched by asm into v[222:223] at the top of the stage and copied out behind the first
+//     k-loop (>= 8 younger loads waited for by then); a compiler-issued load would be waited for with vmcnt(0) in the first epilogue.
+#define CWS_CLOB4(a, b, c, d) "v" #a, "v" #b, "v" #c, "v" #d
+#define CWS_STEP_ASM(LO, HI) "s_waitcnt vmcnt(7)\n\tv_mfma_f32_32x32x16_bf16 %0, v[" #LO ":" #HI "], %1, %0\n\tglobal_load_dwordx4 v[" #LO ":" #HI "], %2, off"
+#define CWS_STEP(LO, HI, C0, C1, C2, C3, ACC, AF, PTR) \
+    asm volatile(CWS_STEP_ASM(LO, HI) : "+v"(ACC) : "v"(AF), "v"(PTR) : "memory", CWS_CLOB4(C0, C1, C2, C3))
+#define CWS_LOAD(LO, HI, C0, C1, C2, C3, PTR) \
+    asm volatile("global_load_dwordx4 v[" #LO ":" #HI "], %0, off" :: "v"(PTR) : "memory", CWS_CLOB4(C0, C1, C2, C3))
+
+__device__ __forceinline__ void cws_prime(const uint4* __restrict__ w, int64_t stride) {      // steps 0..7 of a tile -> slots 0..7
+    CWS_LOAD(224, 227, 224, 225, 226, 227, w);
+    CWS_LOAD(228, 231, 228, 229, 230, 231, w + stride);
+    CWS_LOAD(232, 235, 232, 233, 234, 235, w + 2 * stride);
+    CWS_LOAD(236, 239, 236, 237, 238, 239, w + 3 * stride);
+    CWS_LOAD(240, 243, 240, 241, 242, 243, w + 4 * stride);
+    CWS_LOAD(244, 247, 244, 245, 246, 247, w + 5 * stride);
+    CWS_LOAD(248, 251, 248, 249, 250, 251, w + 6 * stride);
+    CWS_LOAD(252, 255, 252, 253, 254, 255, w + 7 * stride);
+}
+
+// One column tile: acc += X[32 rows][Kc] * W[Kc][32 columns of this tile].  `cur`: this lane's piece of the tile's k16-step 0 (steps
+// are `sstride` uint4 apart); steps 0..7 are in the queue.  The last 8 steps refill the queue from `nx` (+ d * nstride): the next tile's steps 0..7.
+__device__ __forceinline__ void cws_tile(const u16* __restrict__ X, f32x16_t& acc, const uint4* __restrict__ cur, int64_t sstride, int ks,
+                                         const uint4* __restrict__ nx, int64_t nstride, int arow, int ahalf) {
+#define CWS_AF(step) (*reinterpret_cast<const bf16x8_t*>(X + chain_lds_off_p<CWD_PITCH>(arow, (2 * (step) + ahalf) * 8)))
+#define CWS_BLOCK(R, RS, LASTAF)                                                                            \
+    {                                                                                                       \
+        afB = CWS_AF(s0 + 1); CWS_STEP(224, 227, 224, 225, 226, 227, acc, afA, R); R += RS; __builtin_amdgcn_sched_barrier(0); \
+        afA = CWS_AF(s0 + 2); CWS_STEP(228, 231, 228, 229, 230, 231, acc, afB, R); R += RS; __builtin_amdgcn_sched_barrier(0); \
+        afB = CWS_AF(s0 + 3); CWS_STEP(232, 235, 232, 233, 234, 235, acc, afA, R); R += RS; __builtin_amdgcn_sched_barrier(0); \
+        afA = CWS_AF(s0 + 4); CWS_STEP(236, 239, 236, 237, 238, 239, acc, afB, R); R += RS; __builtin_amdgcn_sched_barrier(0); \
+        afB = CWS_AF(s0 + 5); CWS_STEP(240, 243, 240, 241, 242, 243, acc, afA, R); R += RS; __builtin_amdgcn_sched_barrier(0); \
+        afA = CWS_AF(s0 + 6); CWS_STEP(244, 247, 244, 245, 246, 247, acc, afB, R); R += RS; __builtin_amdgcn_sched_barrier(0); \
+        afB = CWS_AF(s0 + 7); CWS_STEP(248, 251, 248, 249, 250, 251, acc, afA, R); R += RS; __builtin_amdgcn_sched_barrier(0); \
+        afA = CWS_AF(LASTAF); CWS_STEP(252, 255, 252, 253, 254, 255, acc, afB, R); R += RS; __builtin_amdgcn_sched_barrier(0); \
+    }
+    // (the accumulators were just written by VALU moves; the asm MFMAs are invisible to hipcc's hazard recogniser)
+    asm volatile("s_nop 3" : "+v"(acc));
+    bf16x8_t afA = CWS_AF(0), afB;
+    const uint4* r = cur + 8 * sstride;
+    int s0 = 0;
+    for (; s0 + 8 < ks; s0 += 8) CWS_BLOCK(r, sstride, s0 + 8)
+    r = nx;
+    CWS_BLOCK(r, nstride, s0 + 7)
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(acc));       // MFMA results -> VALU reads: the wait states hipcc would have inserted
+#undef CWS_BLOCK
+#undef CWS_AF
+}
+
+// CWD_SPLIT_PROBE (timing only, results are wrong): upper bound of a 2-way COLUMN split of a row tile over two workgroups - each
+// computes half of every stage's column tiles, stores its half of the stage output at once, waits for the stores, and fetches the
+// other half from global memory into its LDS tile (no flag, no poll: the partner is assumed to be ready).  profiles/r06_chainw_split_probe.txt
+#ifndef CWD_SPLIT_PROBE
+#define CWD_SPLIT_PROBE 0
+#endif
 template <bool BWD>
-__device__ __forceinline__ void chainw_body(const ChainArgs& p, const ChainDyn& d_, int bid, u16* XW) {
+__device__ __forceinline__ void chainw_body(const ChainArgs& p, const ChainDyn& d_, int bid, u16* XW, const int half = 0) {
     u16* Xin = XW;
     u16* Xout = XW + CWD_BM * CWD_PITCH;
     float* bias_lds = reinterpret_cast<float*>(XW + 2 * CWD_BM * CWD_PITCH);
     int64_t* rows_lds = reinterpret_cast<int64_t*>(bias_lds + CWD_MAX_BIAS);
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t m0 = (int64_t)bid * CWD_BM;
+    // development stamps (CS_CHAIN_DBG, tools/chainw_stamps.py), wave 0: start | prologue done | per stage: k-loop and epilogue of each
+    // of the wave's passes, stage barrier | end; [62], [63]: the 100 MHz clock at both ends
+    int slot = 0;
+    chain_stamp(p, bid, tid, slot);
+    if (p.dbg && tid == 0) p.dbg[(int64_t)bid * 64 + 62] = __builtin_amdgcn_s_memrealtime();
 
     if (!BWD) {
         {   // all bias loads and the row-index load in flight together (one memory latency, not one per stage)
@@ -118,16 +199,25 @@ __device__ __forceinline__ void chainw_body(const ChainArgs& p, const ChainDyn& 
         }
     }
     __syncthreads();
+    chain_stamp(p, bid, tid, slot);
 
     float sq = 0.f, ab = 0.f;
     const int mrow = lane & 31, hi4 = 4 * (lane >> 5);
+    const bool elu_ = p.act == ACT_ELU, drop_ = p.drop_thr != 0u;
+    const float slope_ = p.slope, dscale_ = p.drop_scale, bscale_ = p.bwd_scale;     // (dropout: the kept activations were scaled by 1 / (1 - rate))
+    const unsigned dthr_ = p.drop_thr;
     ChainPending pend{nullptr, 0, 0, 0};
     for (int i = 0; i < p.n_stages; ++i) {
         const ChainStage& S = p.st[i];
         const int ntiles = S.Nc >> 5, ks = S.Kc >> 4;
+#if CWD_SPLIT_PROBE
+        const int nt_mine = ntiles >> 1, t_first = half * nt_mine;
+#else
+        const int nt_mine = ntiles, t_first = 0;
+#endif
         if (!BWD && S.epi == EPI_OUT) {                          // heads: one column tile per wave and pass (128 wide: waves 0..3)
             if (wid >= ntiles && pend.out) { chainw_copy_out(Xin, pend.out, pend.ldo, pend.width, m0, tid); pend.out = nullptr; }
-            for (int tile = wid; tile < ntiles; tile += 8) {
+            for (int tile = t_first + wid; tile < t_first + nt_mine; tile += 8) {
                 f32x16_t acc1[1][1];
                 chain_mma<CWD_BM, 1, 1, 4, true, CWD_PITCH, true>(Xin, S.wfrag, ks, ntiles, tile, 0, tid, acc1, pend, m0);
                 const f32x16_t& acc = acc1[0][0];
@@ -148,14 +238,15 @@ __device__ __forceinline__ void chainw_body(const ChainArgs& p, const ChainDyn& 
                     if (p.dz_out) *reinterpret_cast<uint2*>(p.dz_out + m * p.ld_dz_out + n) = make_uint2(cvt_pk_bf16(d[0], d[1]), cvt_pk_bf16(d[2], d[3]));
                 }
             }
+            chain_stamp(p, bid, tid, slot);
             continue;                                            // last stage of the forward pass
         }
         // Column tiles are dealt to the waves in contiguous, BALANCED runs (ntiles / 8 each, the first ntiles % 8 waves one more)
         // and a wave goes through its run in passes of two tiles (one for an odd rest): 24 tiles (768 wide) are 3 per wave
         // = a pass of 2 + a pass of 1 on EVERY wave.  (Round 2 dealt pairs (2w, 2w+1), (2w+16, 2w+17): 768 wide = a full pass +
         // a pass on four waves only, 640 wide = a full pass + a pass on two waves, 128 wide = two waves out of eight.)
-        const int t_base = ntiles >> 3, t_rem = ntiles & 7;
-        const int t_cnt = t_base + (wid < t_rem ? 1 : 0), t_lo = wid * t_base + min(wid, t_rem);
+        const int t_base = nt_mine >> 3, t_rem = nt_mine & 7;
+        const int t_cnt = t_base + (wid < t_rem ? 1 : 0), t_lo = t_first + wid * t_base + min(wid, t_rem);
         // The previous stage's output (this stage's input, intact in Xin) goes to global memory BEHIND the first weight
         // loads of this stage (chain_mma, `pend`; 32-row tiles: behind the priming loads, measured better than behind the last load).  A wave without tiles in this stage copies its share right away.
         if (t_cnt == 0 && pend.out) {
@@ -167,52 +258,62 @@ __device__ __forceinline__ void chainw_body(const ChainArgs& p, const ChainDyn& 
         // backward stage of layer l + 1 finds the bits of layer l's output where the forward stage of layer l put them.
         const bool use_mask = S.mask != nullptr && p.act != ACT_ELU;
         unsigned mk0 = 0u, mk1 = 0u;
-        const float bsc = p.drop_thr ? p.bwd_scale : 1.f;         // dropout: the kept activations were scaled by 1 / (1 - rate)
+        const unsigned drop_key_ = S.drop_key;
         uint2* mptr = use_mask ? reinterpret_cast<uint2*>(S.mask) + (int64_t)bid * 512 + tid : nullptr;
         if (BWD && use_mask && t_cnt > 0) { const uint2 mv = *mptr; mk0 = mv.x; mk1 = mv.y; }      // lands during the first k-loop
+        // One column tile's epilogue.  The model-wide switches (ELU, dropout, sign masks) are COMPILE-TIME here and chosen once per
+        // tile: read through `p` inside the element loop they were three scalar branches per ELEMENT (round 6, read off the compiled
+        // code: ~50 taken branches and a kernel-argument fetch per tile; stamps 2.2k clocks per tile and wave, a quarter of the kernel).
         auto epilogue = [&](int tile, int slot, const f32x16_t& acc, const uint2 (&hq)[4]) {
             unsigned bits16 = BWD ? ((slot < 2 ? mk0 : mk1) >> ((slot & 1) * 16)) : 0u;
+            auto run = [&](auto elu_c, auto drop_c, auto mask_c) __attribute__((always_inline)) {
+                constexpr bool ELU = decltype(elu_c)::value, DROP = decltype(drop_c)::value, MASK = decltype(mask_c)::value;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n = tile * 32 + 8 * q + hi4;
-                float v[4] = {acc[4 * q + 0], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
-                if (!BWD) {
-#if CWD_BIAS_ACC
-                    v[0] = act_fwd(v[0], p.act, p.slope); v[1] = act_fwd(v[1], p.act, p.slope);        // (the bias is in the accumulators: chain_mma)
-                    v[2] = act_fwd(v[2], p.act, p.slope); v[3] = act_fwd(v[3], p.act, p.slope);
-#else
-                    const float4 b4 = *reinterpret_cast<const float4*>(bias_lds + S.bias_off + n);
-                    v[0] = act_fwd(v[0] + b4.x, p.act, p.slope); v[1] = act_fwd(v[1] + b4.y, p.act, p.slope);
-                    v[2] = act_fwd(v[2] + b4.z, p.act, p.slope); v[3] = act_fwd(v[3] + b4.w, p.act, p.slope);
+                for (int q = 0; q < 4; ++q) {
+                    const int n = tile * 32 + 8 * q + hi4;
+                    float v[4] = {acc[4 * q + 0], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+                    if (!BWD) {
+#if !CWD_BIAS_ACC
+                        const float4 b4 = *reinterpret_cast<const float4*>(bias_lds + S.bias_off + n);
+                        v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;        // (else the bias is in the accumulators: chain_mma)
 #endif
-                    if (p.drop_thr) {                            // training-mode nn.Dropout: relu(dropout(z)) == dropout(relu(z))
-                        const unsigned h0 = mlp_drop_hash2(m0 + mrow, n, S.drop_key), h1 = mlp_drop_hash2(m0 + mrow, n + 2, S.drop_key);
-                        v[0] = (h0 & 0xffffu) >= p.drop_thr ? v[0] * p.drop_scale : 0.f;
-                        v[1] = (h0 >> 16) >= p.drop_thr ? v[1] * p.drop_scale : 0.f;
-                        v[2] = (h1 & 0xffffu) >= p.drop_thr ? v[2] * p.drop_scale : 0.f;
-                        v[3] = (h1 >> 16) >= p.drop_thr ? v[3] * p.drop_scale : 0.f;
-                    }
-                    if (use_mask)
-                        bits16 |= ((v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u)) << (4 * q);
-                } else if (use_mask) {
-                    const unsigned b4 = bits16 >> (4 * q);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] *= (b4 & (1u << e)) ? bsc : p.slope * bsc;
-                } else {
-                    const uint2 h2 = hq[q];
-                    v[0] *= act_bwd_from_h(bf2f((u16)(h2.x & 0xffff)), p.act, p.slope);
-                    v[1] *= act_bwd_from_h(bf2f((u16)(h2.x >> 16)), p.act, p.slope);
-                    v[2] *= act_bwd_from_h(bf2f((u16)(h2.y & 0xffff)), p.act, p.slope);
-                    v[3] *= act_bwd_from_h(bf2f((u16)(h2.y >> 16)), p.act, p.slope);
-                    if (p.drop_thr) { v[0] *= p.bwd_scale; v[1] *= p.bwd_scale; v[2] *= p.bwd_scale; v[3] *= p.bwd_scale; }
+                        for (int e = 0; e < 4; ++e) v[e] = ELU ? (v[e] > 0.f ? v[e] : expm1f(v[e])) : (v[e] > 0.f ? v[e] : slope_ * v[e]);
+                        if (DROP) {                              // training-mode nn.Dropout: relu(dropout(z)) == dropout(relu(z))
+                            const unsigned h0 = mlp_drop_hash2(m0 + mrow, n, drop_key_), h1 = mlp_drop_hash2(m0 + mrow, n + 2, drop_key_);
+                            v[0] = (h0 & 0xffffu) >= dthr_ ? v[0] * dscale_ : 0.f;
+                            v[1] = (h0 >> 16) >= dthr_ ? v[1] * dscale_ : 0.f;
+                            v[2] = (h1 & 0xffffu) >= dthr_ ? v[2] * dscale_ : 0.f;
+                            v[3] = (h1 >> 16) >= dthr_ ? v[3] * dscale_ : 0.f;
+                        }
+                        if (MASK)
+                            bits16 |= ((v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u)) << (4 * q);
+                    } else if (MASK) {
+                        const unsigned b4 = bits16 >> (4 * q);
+                        const float on = DROP ? bscale_ : 1.f, off = slope_ * on;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] *= (b4 & (1u << e)) ? on : off;
+                    } else {
+                        const uint2 h2 = hq[q];
+                        const float hv[4] = {bf2f((u16)(h2.x & 0xffff)), bf2f((u16)(h2.x >> 16)), bf2f((u16)(h2.y & 0xffff)), bf2f((u16)(h2.y >> 16))};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] *= hv[e] > 0.f ? 1.f : (ELU ? hv[e] + 1.f : slope_);
+                            if (DROP) v[e] *= bscale_;
+                        }
+                    }
+                    *reinterpret_cast<uint2*>(Xout + cwd_off(mrow, n)) = make_uint2(cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3]));
                 }
-                *reinterpret_cast<uint2*>(Xout + cwd_off(mrow, n)) = make_uint2(cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3]));
-            }
+            };
+            using T = std::true_type; using F = std::false_type;
+            if (elu_) { if (drop_) run(T{}, T{}, F{}); else run(T{}, F{}, F{}); }
+            else if (use_mask) { if (drop_) run(F{}, T{}, T{}); else run(F{}, F{}, T{}); }
+            else { if (drop_) run(F{}, T{}, F{}); else run(F{}, F{}, F{}); }
             if (!BWD && use_mask) { if (slot < 2) mk0 |= bits16 << ((slot & 1) * 16); else mk1 |= bits16 << ((slot & 1) * 16); }
         };
         for (int tile0 = t_lo; tile0 < t_lo + t_cnt; tile0 += 2) {
             const bool two = tile0 + 1 < t_lo + t_cnt;
-            const int slot0 = tile0 - t_lo;
+            const int slot0 = (tile0 - t_lo) & 3;
             uint2 hh[2][4];                                      // backward, ELU: the activations to differentiate through, in flight during the k-loop
             if (BWD && !use_mask) {
 #pragma unroll
@@ -227,27 +328,54 @@ __device__ __forceinline__ void chainw_body(const ChainArgs& p, const ChainDyn& 
                 f32x16_t acc2[1][2];
                 if ((S.Kc & 127) == 0) chain_mma<CWD_BM, 1, 2, 8, true, CWD_PITCH, true>(Xin, S.wfrag, ks, ntiles, tile0, 0, tid, acc2, pend, m0, 0, bias0);
                 else chain_mma<CWD_BM, 1, 2, 4, true, CWD_PITCH, true>(Xin, S.wfrag, ks, ntiles, tile0, 0, tid, acc2, pend, m0, 0, bias0);
+                chain_stamp(p, bid, tid, slot);
                 epilogue(tile0, slot0, acc2[0][0], hh[0]);
                 epilogue(tile0 + 1, slot0 + 1, acc2[0][1], hh[1]);
+                chain_stamp(p, bid, tid, slot);
             } else {
                 f32x16_t acc1[1][1];
                 if ((S.Kc & 127) == 0) chain_mma<CWD_BM, 1, 1, 8, true, CWD_PITCH, true>(Xin, S.wfrag, ks, ntiles, tile0, 0, tid, acc1, pend, m0, 0, bias0);
                 else chain_mma<CWD_BM, 1, 1, 4, true, CWD_PITCH, true>(Xin, S.wfrag, ks, ntiles, tile0, 0, tid, acc1, pend, m0, 0, bias0);
+                chain_stamp(p, bid, tid, slot);
                 epilogue(tile0, slot0, acc1[0][0], hh[0]);
+                chain_stamp(p, bid, tid, slot);
             }
         }
         if (!BWD && use_mask && t_cnt > 0) *mptr = make_uint2(mk0, mk1);
         __syncthreads();                                         // Xout complete, nobody reads Xin any more
+        chain_stamp(p, bid, tid, slot);
+#if CWD_SPLIT_PROBE
+        if (S.out) {
+            const int cpr = S.Nc >> 4;                            // 16-B chunks of HALF a row
+            for (int g = tid; g < CWD_BM * cpr; g += 512) {      // my half -> global
+                const int r = g / cpr, c = g - r * cpr + half * cpr;
+                *reinterpret_cast<uint4*>(S.out + (m0 + r) * S.ldo + c * 8) = *reinterpret_cast<const uint4*>(Xout + cwd_off(r, c * 8));
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                                      // (the real thing: publish a flag here, poll the partner's)
+            if (i + 1 < p.n_stages) {
+                for (int g = tid; g < CWD_BM * cpr; g += 512) {  // the partner's half <- global
+                    const int r = g / cpr, c = g - r * cpr + (1 - half) * cpr;
+                    *reinterpret_cast<uint4*>(Xout + cwd_off(r, c * 8)) = *reinterpret_cast<const uint4*>(S.out + (m0 + r) * S.ldo + c * 8);
+                }
+                __syncthreads();
+            }
+        }
+        chain_stamp(p, bid, tid, slot);
+#else
         if (S.out) {                                             // global copy (next layer's wgrad / the backward pass), coalesced:
             if (i + 1 == p.n_stages) chainw_copy_out(Xout, S.out, S.ldo, S.Nc, m0, tid);   // nobody comes after: now
             else pend = ChainPending{S.out, S.ldo, S.Nc, 0};                               // the next stage copies it behind its first weight loads
         }
+#endif
         u16* t = Xin; Xin = Xout; Xout = t;
     }
     if (!BWD && d_.y) {
         __syncthreads();                                         // the heads stage has no trailing barrier: XW still being read
         loss_flush(d_.loss, p.loss_stripes, bid, sq, ab, reinterpret_cast<float*>(XW), tid, 8);
     }
+    chain_stamp(p, bid, tid, slot);
+    if (p.dbg && tid == 0) p.dbg[(int64_t)bid * 64 + 63] = __builtin_amdgcn_s_memrealtime();
 }
 
 template <bool BWD>
@@ -262,10 +390,15 @@ __global__ __launch_bounds__(512) void k_chainw(const ChainArgs p) {
 __global__ __launch_bounds__(512) void k_chainw_fb(const ChainArgs pf, const ChainArgs pb) {
     extern __shared__ __attribute__((aligned(16))) u16 XW[];
     const ChainDyn d = chain_dyn_of(pf);
-    chainw_body<false>(pf, d, (int)blockIdx.x, XW);
+#if CWD_SPLIT_PROBE
+    const int bid_ = ((int)blockIdx.x >> 4) * 8 + ((int)blockIdx.x & 7), half_ = ((int)blockIdx.x >> 3) & 1;   // blocks b and b + 8: one XCD, one L2 (tiles % 8 == 0 in the probe)
+#else
+    const int bid_ = (int)blockIdx.x, half_ = 0;
+#endif
+    chainw_body<false>(pf, d, bid_, XW, half_);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    chainw_body<true>(pb, d, (int)blockIdx.x, XW);
+    chainw_body<true>(pb, d, bid_, XW, half_);
 }
 
 // K members in one launch (see k_chain_fb_group, chain.h)

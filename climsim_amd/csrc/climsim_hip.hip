@@ -370,6 +370,7 @@ void chainw_bwd_args(const cs_mlp* h, int64_t n, ChainArgs& c) {
         S.hprev = ly.H; S.ldh = ly.Kp; S.epi = EPI_DGRAD;
     }
     c.dz_in = h->layers[h->L - 1].dZ; c.ld_dz_in = h->n_outp; c.w_in = h->n_outp;
+    c.dbg = h->dbg ? h->dbg + (h->m_pad_max / 32) * 64 : nullptr;
     c.n_rows = n; c.act = h->cfg.act; c.slope = (h->cfg.act == CS_ACT_RELU) ? 0.f : h->cfg.alpha;
     if (h->dropout > 0.0) { c.drop_thr = (unsigned)(h->dropout * 65536.0); c.drop_scale = c.bwd_scale = 1.f / (1.f - (float)h->dropout); }
 }
@@ -405,7 +406,8 @@ void chain_fwd_args(const cs_mlp* h, bool wide, const float* x, const int64_t* r
         if (l + 1 < h->L) { S.out = want_dz ? h->layers[l + 1].H : nullptr; S.ldo = h->layers[l + 1].Kp; S.epi = EPI_HIDDEN; S.mask = want_dz ? ly.mask : nullptr; }      // (null for ELU models on the wide chain: never allocated)
         else { S.out = nullptr; S.ldo = 0; S.epi = EPI_OUT; S.mask = nullptr; }
     }
-    if (!wide) { c.ablate = h->chain_ablate; c.dbg = h->dbg; c.store_nt = n >= h->chain_nt_min ? 1 : 0; chain_find_trunk(h, c); }
+    c.dbg = h->dbg;
+    if (!wide) { c.ablate = h->chain_ablate; c.store_nt = n >= h->chain_nt_min ? 1 : 0; chain_find_trunk(h, c); }
     c.x = x; c.row_idx = row_idx; c.n_in = h->cfg.n_in; c.kp0 = l0.Kp; c.sub = h->sub; c.div = h->div;
     c.normalise = normalise; c.h0 = want_dz ? l0.H : nullptr; c.ldh0 = l0.Kp; c.n_rows = n;
     c.act = h->cfg.act; c.slope = (h->cfg.act == CS_ACT_RELU) ? 0.f : h->cfg.alpha;
@@ -510,7 +512,7 @@ int run_forward(cs_mlp* h, const float* x, const int64_t* row_idx, int64_t n, in
             ChainArgs cb{};
             chainw_bwd_args(h, n, cb);
             ProfScope ps(CS_K_CHAIN_FB, st);
-            CS_LAUNCH(k_chainw_fb, dim3((unsigned)(m_pad / CWD_BM)), dim3(512), chainw_lds_bytes(), st, c, cb);
+            CS_LAUNCH(k_chainw_fb, dim3((unsigned)(m_pad / CWD_BM) * (CWD_SPLIT_PROBE ? 2u : 1u)), dim3(512), chainw_lds_bytes(), st, c, cb);
             HIP_TRY(hipGetLastError());
             h->bwd_chain_done = true;
             return CS_OK;
