@@ -111,14 +111,8 @@ __device__ __forceinline__ void cws_tile(const u16* __restrict__ X, f32x16_t& ac
 #undef CWS_AF
 }
 
-// CWD_SPLIT_PROBE (timing only, results are wrong): upper bound of a 2-way COLUMN split of a row tile over two workgroups - each
-// computes half of every stage's column tiles, stores its half of the stage output at once, waits for the stores, and fetches the
-// other half from global memory into its LDS tile (no flag, no poll: the partner is assumed to be ready).  profiles/r06_chainw_split_probe.txt
-#ifndef CWD_SPLIT_PROBE
-#define CWD_SPLIT_PROBE 0
-#endif
 template <bool BWD>
-__device__ __forceinline__ void chainw_body(const ChainArgs& p, const ChainDyn& d_, int bid, u16* XW, const int half = 0) {
+__device__ __forceinline__ void chainw_body(const ChainArgs& p, const ChainDyn& d_, int bid, u16* XW) {
     u16* Xin = XW;
     u16* Xout = XW + CWD_BM * CWD_PITCH;
     float* bias_lds = reinterpret_cast<float*>(XW + 2 * CWD_BM * CWD_PITCH);
@@ -130,6 +124,28 @@ __device__ __forceinline__ void chainw_body(const ChainArgs& p, const ChainDyn& 
     int slot = 0;
     chain_stamp(p, bid, tid, slot);
     if (p.dbg && tid == 0) p.dbg[(int64_t)bid * 64 + 62] = __builtin_amdgcn_s_memrealtime();
+
+    // Continuous weight stream (cws_tile): stages 0 .. n_stream - 1 (the heads stage of a forward pass keeps chain_mma).  This wave's
+    // column tiles of stage j: a contiguous, balanced run (see the stage loop); the first stage it has tiles in is primed HERE, in
+    // front of the prologue's own loads - the weights do not depend on them.
+    const bool stream = p.trunk_n > 0;
+    const int n_stream = stream ? (BWD ? p.n_stages : p.n_stages - 1) : 0;
+    auto wave_run = [&](int j, int& lo, int& cnt) {
+        const int nt = p.st[j].Nc >> 5, base = nt >> 3, rem = nt & 7;
+        cnt = base + (wid < rem ? 1 : 0); lo = wid * base + min(wid, rem);
+    };
+    auto next_tile = [&](int j0, const uint4*& w, int64_t& stride) {      // first tile of this wave in a stage >= j0 (false: none)
+        for (int j = j0; j < n_stream; ++j) {
+            int lo, cnt;
+            wave_run(j, lo, cnt);
+            if (cnt > 0) { stride = (int64_t)(p.st[j].Nc >> 5) * 64; w = reinterpret_cast<const uint4*>(p.st[j].wfrag) + lo * 64 + lane; return true; }
+        }
+        return false;
+    };
+    if (stream) {
+        const uint4* w0; int64_t st0;
+        if (next_tile(0, w0, st0)) cws_prime(w0, st0);
+    }
 
     if (!BWD) {
         {   // all bias loads and the row-index load in flight together (one memory latency, not one per stage)
@@ -210,14 +226,9 @@ __device__ __forceinline__ void chainw_body(const ChainArgs& p, const ChainDyn& 
     for (int i = 0; i < p.n_stages; ++i) {
         const ChainStage& S = p.st[i];
         const int ntiles = S.Nc >> 5, ks = S.Kc >> 4;
-#if CWD_SPLIT_PROBE
-        const int nt_mine = ntiles >> 1, t_first = half * nt_mine;
-#else
-        const int nt_mine = ntiles, t_first = 0;
-#endif
         if (!BWD && S.epi == EPI_OUT) {                          // heads: one column tile per wave and pass (128 wide: waves 0..3)
             if (wid >= ntiles && pend.out) { chainw_copy_out(Xin, pend.out, pend.ldo, pend.width, m0, tid); pend.out = nullptr; }
-            for (int tile = t_first + wid; tile < t_first + nt_mine; tile += 8) {
+            for (int tile = wid; tile < ntiles; tile += 8) {
                 f32x16_t acc1[1][1];
                 chain_mma<CWD_BM, 1, 1, 4, true, CWD_PITCH, true>(Xin, S.wfrag, ks, ntiles, tile, 0, tid, acc1, pend, m0);
                 const f32x16_t& acc = acc1[0][0];
@@ -245,8 +256,8 @@ __device__ __forceinline__ void chainw_body(const ChainArgs& p, const ChainDyn& 
         // and a wave goes through its run in passes of two tiles (one for an odd rest): 24 tiles (768 wide) are 3 per wave
         // = a pass of 2 + a pass of 1 on EVERY wave.  (Round 2 dealt pairs (2w, 2w+1), (2w+16, 2w+17): 768 wide = a full pass +
         // a pass on four waves only, 640 wide = a full pass + a pass on two waves, 128 wide = two waves out of eight.)
-        const int t_base = nt_mine >> 3, t_rem = nt_mine & 7;
-        const int t_cnt = t_base + (wid < t_rem ? 1 : 0), t_lo = t_first + wid * t_base + min(wid, t_rem);
+        const int t_base = ntiles >> 3, t_rem = ntiles & 7;
+        const int t_cnt = t_base + (wid < t_rem ? 1 : 0), t_lo = wid * t_base + min(wid, t_rem);
         // The previous stage's output (this stage's input, intact in Xin) goes to global memory BEHIND the first weight
         // loads of this stage (chain_mma, `pend`; 32-row tiles: behind the priming loads, measured better than behind the last load).  A wave without tiles in this stage copies its share right away.
         if (t_cnt == 0 && pend.out) {
@@ -260,7 +271,10 @@ __device__ __forceinline__ void chainw_body(const ChainArgs& p, const ChainDyn& 
         unsigned mk0 = 0u, mk1 = 0u;
         const unsigned drop_key_ = S.drop_key;
         uint2* mptr = use_mask ? reinterpret_cast<uint2*>(S.mask) + (int64_t)bid * 512 + tid : nullptr;
-        if (BWD && use_mask && t_cnt > 0) { const uint2 mv = *mptr; mk0 = mv.x; mk1 = mv.y; }      // lands during the first k-loop
+        if (BWD && use_mask && t_cnt > 0) {                                                        // lands during the first k-loop
+            if (stream) asm volatile("global_load_dwordx2 v[222:223], %0, off" :: "v"(mptr) : "memory", "v222", "v223");
+            else { const uint2 mv = *mptr; mk0 = mv.x; mk1 = mv.y; }
+        }
         // One column tile's epilogue.  The model-wide switches (ELU, dropout, sign masks) are COMPILE-TIME here and chosen once per
         // tile: read through `p` inside the element loop they were three scalar branches per ELEMENT (round 6, read off the compiled
         // code: ~50 taken branches and a kernel-argument fetch per tile; stamps 2.2k clocks per tile and wave, a quarter of the kernel).
@@ -311,6 +325,47 @@ __device__ __forceinline__ void chainw_body(const ChainArgs& p, const ChainDyn& 
             else { if (drop_) run(F{}, T{}, F{}); else run(F{}, F{}, F{}); }
             if (!BWD && use_mask) { if (slot < 2) mk0 |= bits16 << ((slot & 1) * 16); else mk1 |= bits16 << ((slot & 1) * 16); }
         };
+        if (stream) {
+            const int64_t sstride = (int64_t)ntiles * 64;
+            const uint4* wst = reinterpret_cast<const uint4*>(S.wfrag) + lane;
+            const int ahalf = lane >> 5;
+            for (int k = 0; k < t_cnt; ++k) {
+                const int tile = t_lo + k;
+                const uint4* cur = wst + tile * 64;
+                const uint4* nx = cur + 64; int64_t nstride = sstride;               // the wave's next tile: in this stage ...
+                if (k + 1 == t_cnt && !next_tile(i + 1, nx, nstride)) nx = cur;      // ... in a later one, or none (refill from this tile again: the count stays)
+                f32x16_t acc;
+                if (!BWD && CWD_BIAS_ACC) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 b4 = *reinterpret_cast<const float4*>(bias_lds + S.bias_off + tile * 32 + 8 * q + hi4);
+                        acc[4 * q] = b4.x; acc[4 * q + 1] = b4.y; acc[4 * q + 2] = b4.z; acc[4 * q + 3] = b4.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                }
+                cws_tile(Xin, acc, cur, sstride, ks, nx, nstride, mrow, ahalf);
+                if (BWD && use_mask && k == 0) asm volatile("v_mov_b32 %0, v222\n\tv_mov_b32 %1, v223" : "=v"(mk0), "=v"(mk1) :: "v222", "v223");
+                chain_stamp(p, bid, tid, slot);
+                uint2 hnone[4];
+                epilogue(tile, k, acc, hnone);
+                if (S.out) {                                      // this tile -> global memory: 32 rows x 64 B, two 16-byte pieces per lane
+#pragma unroll
+                    for (int h2 = 0; h2 < 2; ++h2) {
+                        const int r = (lane >> 2) + 16 * h2, c = tile * 4 + (lane & 3);
+                        *reinterpret_cast<uint4*>(S.out + (m0 + r) * S.ldo + c * 8) = *reinterpret_cast<const uint4*>(Xout + cwd_off(r, c * 8));
+                    }
+                }
+                chain_stamp(p, bid, tid, slot);
+            }
+            if (!BWD && use_mask && t_cnt > 0) *mptr = make_uint2(mk0, mk1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                         // (raw: __syncthreads would wait for the queue - vmcnt(0))
+            chain_stamp(p, bid, tid, slot);
+            u16* t = Xin; Xin = Xout; Xout = t;
+            continue;
+        }
         for (int tile0 = t_lo; tile0 < t_lo + t_cnt; tile0 += 2) {
             const bool two = tile0 + 1 < t_lo + t_cnt;
             const int slot0 = (tile0 - t_lo) & 3;
@@ -344,36 +399,17 @@ __device__ __forceinline__ void chainw_body(const ChainArgs& p, const ChainDyn& 
         if (!BWD && use_mask && t_cnt > 0) *mptr = make_uint2(mk0, mk1);
         __syncthreads();                                         // Xout complete, nobody reads Xin any more
         chain_stamp(p, bid, tid, slot);
-#if CWD_SPLIT_PROBE
-        if (S.out) {
-            const int cpr = S.Nc >> 4;                            // 16-B chunks of HALF a row
-            for (int g = tid; g < CWD_BM * cpr; g += 512) {      // my half -> global
-                const int r = g / cpr, c = g - r * cpr + half * cpr;
-                *reinterpret_cast<uint4*>(S.out + (m0 + r) * S.ldo + c * 8) = *reinterpret_cast<const uint4*>(Xout + cwd_off(r, c * 8));
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();                                      // (the real thing: publish a flag here, poll the partner's)
-            if (i + 1 < p.n_stages) {
-                for (int g = tid; g < CWD_BM * cpr; g += 512) {  // the partner's half <- global
-                    const int r = g / cpr, c = g - r * cpr + (1 - half) * cpr;
-                    *reinterpret_cast<uint4*>(Xout + cwd_off(r, c * 8)) = *reinterpret_cast<const uint4*>(S.out + (m0 + r) * S.ldo + c * 8);
-                }
-                __syncthreads();
-            }
-        }
-        chain_stamp(p, bid, tid, slot);
-#else
         if (S.out) {                                             // global copy (next layer's wgrad / the backward pass), coalesced:
             if (i + 1 == p.n_stages) chainw_copy_out(Xout, S.out, S.ldo, S.Nc, m0, tid);   // nobody comes after: now
             else pend = ChainPending{S.out, S.ldo, S.Nc, 0};                               // the next stage copies it behind its first weight loads
         }
-#endif
         u16* t = Xin; Xin = Xout; Xout = t;
     }
     if (!BWD && d_.y) {
         __syncthreads();                                         // the heads stage has no trailing barrier: XW still being read
         loss_flush(d_.loss, p.loss_stripes, bid, sq, ab, reinterpret_cast<float*>(XW), tid, 8);
     }
+    if (stream) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the refills nobody consumed
     chain_stamp(p, bid, tid, slot);
     if (p.dbg && tid == 0) p.dbg[(int64_t)bid * 64 + 63] = __builtin_amdgcn_s_memrealtime();
 }
@@ -390,15 +426,10 @@ __global__ __launch_bounds__(512) void k_chainw(const ChainArgs p) {
 __global__ __launch_bounds__(512) void k_chainw_fb(const ChainArgs pf, const ChainArgs pb) {
     extern __shared__ __attribute__((aligned(16))) u16 XW[];
     const ChainDyn d = chain_dyn_of(pf);
-#if CWD_SPLIT_PROBE
-    const int bid_ = ((int)blockIdx.x >> 4) * 8 + ((int)blockIdx.x & 7), half_ = ((int)blockIdx.x >> 3) & 1;   // blocks b and b + 8: one XCD, one L2 (tiles % 8 == 0 in the probe)
-#else
-    const int bid_ = (int)blockIdx.x, half_ = 0;
-#endif
-    chainw_body<false>(pf, d, bid_, XW, half_);
+    chainw_body<false>(pf, d, (int)blockIdx.x, XW);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    chainw_body<true>(pb, d, bid_, XW, half_);
+    chainw_body<true>(pb, d, (int)blockIdx.x, XW);
 }
 
 // K members in one launch (see k_chain_fb_group, chain.h)

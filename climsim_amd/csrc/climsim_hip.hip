@@ -140,6 +140,7 @@ struct cs_mlp {
     int n_cu = 0;                  // compute units of the device (hipDeviceProp_t::multiProcessorCount)
     bool use_chain = false;
     bool bwd_chain_done = false;   // run_forward launched k_chain_fb: run_backward goes straight to the weight gradients
+    bool chainw_stream = true; // wide chain: continuous weight stream (cws_tile, chainw.h); CS_CHAINW_STREAM=0 = the per-pass form
     bool use_chainw = false;   // wide-model chain (chainw.h): widths any multiple of 128 up to 1024, batches up to chainw_max_n
     int64_t chainw_max_n = (int64_t)1 << 40;   // no limit: with the forward+backward launch the wide chain beats one GEMM per layer at every
                                                // batch (published model: 16384 columns 0.402 vs 0.498 ms, 131072: 2.79 vs 3.56); CS_CHAINW_MAX_N lowers it
@@ -360,6 +361,14 @@ void chain_find_trunk(const cs_mlp* h, ChainArgs& c) {
 }
 
 // The same for the wide chain (k_chainw: act' from the global activation copies, any output width).
+// The continuous stream takes non-ELU models whose contraction lengths are multiples of 128 (8 k16-steps = one queue)
+static int chainw_stream_stages(const cs_mlp* h, const ChainArgs& c) {
+    if (!h->chainw_stream || h->cfg.act == CS_ACT_ELU) return 0;
+    for (int i = 0; i < c.n_stages; ++i)
+        if ((c.st[i].Kc & 127) || (c.st[i].Nc & 31)) return 0;
+    return c.n_stages;
+}
+
 void chainw_bwd_args(const cs_mlp* h, int64_t n, ChainArgs& c) {
     c.n_stages = h->L - 1;
     for (int l = h->L - 1, i = 0; l >= 1; --l, ++i) {
@@ -371,6 +380,7 @@ void chainw_bwd_args(const cs_mlp* h, int64_t n, ChainArgs& c) {
     }
     c.dz_in = h->layers[h->L - 1].dZ; c.ld_dz_in = h->n_outp; c.w_in = h->n_outp;
     c.dbg = h->dbg ? h->dbg + (h->m_pad_max / 32) * 64 : nullptr;
+    c.trunk_n = chainw_stream_stages(h, c);
     c.n_rows = n; c.act = h->cfg.act; c.slope = (h->cfg.act == CS_ACT_RELU) ? 0.f : h->cfg.alpha;
     if (h->dropout > 0.0) { c.drop_thr = (unsigned)(h->dropout * 65536.0); c.drop_scale = c.bwd_scale = 1.f / (1.f - (float)h->dropout); }
 }
@@ -407,6 +417,7 @@ void chain_fwd_args(const cs_mlp* h, bool wide, const float* x, const int64_t* r
         else { S.out = nullptr; S.ldo = 0; S.epi = EPI_OUT; S.mask = nullptr; }
     }
     c.dbg = h->dbg;
+    if (wide) c.trunk_n = chainw_stream_stages(h, c);
     if (!wide) { c.ablate = h->chain_ablate; c.store_nt = n >= h->chain_nt_min ? 1 : 0; chain_find_trunk(h, c); }
     c.x = x; c.row_idx = row_idx; c.n_in = h->cfg.n_in; c.kp0 = l0.Kp; c.sub = h->sub; c.div = h->div;
     c.normalise = normalise; c.h0 = want_dz ? l0.H : nullptr; c.ldh0 = l0.Kp; c.n_rows = n;
@@ -512,7 +523,7 @@ int run_forward(cs_mlp* h, const float* x, const int64_t* row_idx, int64_t n, in
             ChainArgs cb{};
             chainw_bwd_args(h, n, cb);
             ProfScope ps(CS_K_CHAIN_FB, st);
-            CS_LAUNCH(k_chainw_fb, dim3((unsigned)(m_pad / CWD_BM) * (CWD_SPLIT_PROBE ? 2u : 1u)), dim3(512), chainw_lds_bytes(), st, c, cb);
+            CS_LAUNCH(k_chainw_fb, dim3((unsigned)(m_pad / CWD_BM)), dim3(512), chainw_lds_bytes(), st, c, cb);
             HIP_TRY(hipGetLastError());
             h->bwd_chain_done = true;
             return CS_OK;
@@ -769,6 +780,7 @@ int cs_mlp_create(cs_mlp_t** out, const cs_mlp_cfg* cfg) {
     }
     if (h->use_chain) h->use_chainw = false;               // the tuned kernels take the 128/256/512 models
     if (const char* e = getenv("CS_CHAINW_MAX_N")) h->chainw_max_n = atoll(e);
+    if (const char* e = getenv("CS_CHAINW_STREAM")) h->chainw_stream = atoi(e) != 0;
     if (h->use_chainw) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chainw<false>), hipFuncAttributeMaxDynamicSharedMemorySize, chainw_lds_bytes()));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chainw<true>), hipFuncAttributeMaxDynamicSharedMemorySize, chainw_lds_bytes()));

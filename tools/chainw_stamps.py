@@ -1,5 +1,6 @@
 """Development: shader-clock stamps of the wide chain (k_chainw_fb), wave 0 of every workgroup: k-loop / epilogue of each pass, stage
-barriers.  `SPLIT=1` with a -DCWD_SPLIT_PROBE=1 build (CLIMSIM_HIP_LIB): half the column tiles per workgroup + the exchange stamp."""
+barriers.  Default = the continuous stream (one stamp pair per column tile of the wave); `CS_CHAINW_STREAM=0` = the per-pass form
+(one pair per pass of two tiles)."""
 import ctypes as C
 import os
 import sys
@@ -15,7 +16,7 @@ from climsim_amd.mlp import MLPEmulator  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 3072
 UNITS = tuple(int(u) for u in sys.argv[2].split(",")) if len(sys.argv) > 2 else (768, 640, 512, 640, 640)
-SPLIT = int(os.environ.get("SPLIT", "0"))
+STREAM = os.environ.get("CS_CHAINW_STREAM", "1") != "0"
 m = MLPEmulator(units=UNITS, activation="leakyrelu", optimizer="RAdam", max_batch=B, seed=0)
 x = (torch.rand((B, 124), device="cuda") - 0.5).contiguous()
 y = (torch.rand((B, 128), device="cuda") * 0.1).contiguous()
@@ -36,9 +37,9 @@ _lib.check(m.lib.cs_mlp_debug_stamps(m._h, buf.ctypes.data_as(C.c_void_p), 2 * h
 
 
 def passes(width):
-    nt = width // 32 // (2 if SPLIT else 1)
+    nt = width // 32
     t0 = nt // 8 + (1 if nt % 8 else 0)          # wave 0's tiles
-    return (t0 + 1) // 2
+    return t0 if STREAM else (t0 + 1) // 2
 
 
 widths = list(UNITS) + [128]
@@ -53,7 +54,7 @@ for name, base, ws in (("fwd", 0, fwd_w), ("bwd", half, bwd_w)):
     d = lambda a, b: float((st[:, b] - st[:, a]).mean())
     print(f"== {name}: {st.shape[0]} workgroups, {real.mean():.1f} us each (100 MHz clock); clocks, mean over workgroups")
     print(f"   prologue {d(0, 1):.0f}")
-    tot = {"k-loop": 0.0, "epilogue": 0.0, "barrier": 0.0, "exchange": 0.0}
+    tot = {"k-loop": 0.0, "epilogue": 0.0, "barrier": 0.0}
     for w in ws:
         np_ = passes(w)
         row = []
@@ -61,10 +62,7 @@ for name, base, ws in (("fwd", 0, fwd_w), ("bwd", half, bwd_w)):
             row.append((d(i, i + 1), d(i + 1, i + 2))); i += 2
             tot["k-loop"] += row[-1][0]; tot["epilogue"] += row[-1][1]
         bar = d(i, i + 1); i += 1; tot["barrier"] += bar
-        ex = 0.0
-        if SPLIT:
-            ex = d(i, i + 1); i += 1; tot["exchange"] += ex
-        print(f"   stage width {w:4d}: " + " ".join(f"[k-loop {a:.0f} epi {b:.0f}]" for a, b in row) + f" barrier {bar:.0f}" + (f" exchange {ex:.0f}" if SPLIT else ""))
+        print(f"   stage width {w:4d}: " + " ".join(f"[k-loop {a:.0f} epi {b:.0f}]" for a, b in row) + f" barrier {bar:.0f}")
     if name == "fwd":
         print(f"   heads {d(i, i + 1):.0f}"); i += 1
     print(f"   tail {d(i, i + 1):.0f}   total {d(0, i + 1):.0f}   sums " + " ".join(f"{k} {v:.0f}" for k, v in tot.items()))
