@@ -681,12 +681,19 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const ChainDyn& d
             float bv[CHAIN_MAX_STAGES / 2];
             int64_t rv = -1;
             if (tid < BM && m0 + tid < d_.n_rows) rv = d_.row_idx ? d_.row_idx[m0 + tid] : m0 + tid;
+            // Branch-free: every stage slot has a valid source (the host points the unused ones at the first bias, length 0), so the
+            // pointers and lengths are fetched in a few wide scalar loads and the vector loads go out back to back.  With a test of
+            // `bias_len[i]` guarding the fetch of `bias_src[i]` hipcc issued one scalar load per member, each waited for before the
+            // next (round 6 stamps of the wide chain: 4.3k clocks to ISSUE the loads).
+            const float* bp[CHAIN_MAX_STAGES / 2];
+            int bl[CHAIN_MAX_STAGES / 2], bo[CHAIN_MAX_STAGES / 2];
+#pragma unroll
+            for (int i = 0; i < CHAIN_MAX_STAGES / 2; ++i) { bp[i] = p.bias_src[i]; bl[i] = p.bias_len[i]; bo[i] = p.st[i].bias_off; }
+#pragma unroll
+            for (int i = 0; i < CHAIN_MAX_STAGES / 2; ++i) bv[i] = bp[i][tid < bl[i] ? tid : 0];
 #pragma unroll
             for (int i = 0; i < CHAIN_MAX_STAGES / 2; ++i)
-                bv[i] = (i < p.n_stages && tid < p.bias_len[i]) ? p.bias_src[i][tid] : 0.f;
-#pragma unroll
-            for (int i = 0; i < CHAIN_MAX_STAGES / 2; ++i)
-                if (i < p.n_stages && tid < p.bias_len[i]) bias_lds[p.st[i].bias_off + tid] = bv[i];
+                if (tid < bl[i]) bias_lds[bo[i] + tid] = bv[i];
             if (tid < BM) rows_lds[tid] = rv;
         }
         __syncthreads();
@@ -798,6 +805,7 @@ __device__ __forceinline__ int chain_warm_Q(int ngrid) { return min(32, max(1, n
 template <int BM, bool BWD, bool ELU>
 __global__ __launch_bounds__(512) void k_chain(const ChainArgs p) {
     extern __shared__ __attribute__((aligned(16))) u16 X[];      // [BM][CHAIN_PITCH]
+    kernarg_touch<(int)sizeof(ChainArgs)>();
     float* bias_lds = reinterpret_cast<float*>(X + BM * CHAIN_PITCH);
     int64_t* rows_lds = reinterpret_cast<int64_t*>(bias_lds + CHAIN_MAX_BIAS);
     const int Q = chain_warm_Q((int)gridDim.x);
@@ -813,6 +821,7 @@ __global__ __launch_bounds__(512) void k_chain(const ChainArgs p) {
 template <int BM, bool ELU>
 __global__ __launch_bounds__(512) void k_chain_fb(const ChainArgs pf, const ChainArgs pb) {
     extern __shared__ __attribute__((aligned(16))) u16 X[];
+    kernarg_touch<2 * (int)sizeof(ChainArgs)>();
     float* bias_lds = reinterpret_cast<float*>(X + BM * CHAIN_PITCH);
     int64_t* rows_lds = reinterpret_cast<int64_t*>(bias_lds + CHAIN_MAX_BIAS);
     const ChainDyn d = chain_dyn_of(pf);

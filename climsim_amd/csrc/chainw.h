@@ -146,25 +146,40 @@ __device__ __forceinline__ void chainw_body(const ChainArgs& p, const ChainDyn& 
         const uint4* w0; int64_t st0;
         if (next_tile(0, w0, st0)) cws_prime(w0, st0);
     }
+#ifdef CWD_FINE_STAMPS
+    if (!BWD) chain_stamp(p, bid, tid, slot);
+#endif
 
     if (!BWD) {
         {   // all bias loads and the row-index load in flight together (one memory latency, not one per stage)
             float bv[CHAIN_MAX_STAGES][2];
             int64_t rv = -1;
             if (tid < CWD_BM && m0 + tid < d_.n_rows) rv = d_.row_idx ? d_.row_idx[m0 + tid] : m0 + tid;
+            // (branch-free, as in chain.h: unused stage slots point at the first bias with length 0)
+            const float* bp[CHAIN_MAX_STAGES];
+            int bl[CHAIN_MAX_STAGES], bo[CHAIN_MAX_STAGES];
+#pragma unroll
+            for (int i = 0; i < CHAIN_MAX_STAGES; ++i) { bp[i] = p.bias_src[i]; bl[i] = p.bias_len[i]; bo[i] = p.st[i].bias_off; }
+#pragma unroll
+            for (int i = 0; i < CHAIN_MAX_STAGES; ++i)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) bv[i][u] = bp[i][tid + 512 * u < bl[i] ? tid + 512 * u : 0];
+#ifdef CWD_FINE_STAMPS
+            chain_stamp(p, bid, tid, slot);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            chain_stamp(p, bid, tid, slot);
+#endif
 #pragma unroll
             for (int i = 0; i < CHAIN_MAX_STAGES; ++i)
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
-                    bv[i][u] = (i < p.n_stages && tid + 512 * u < p.bias_len[i]) ? p.bias_src[i][tid + 512 * u] : 0.f;
-#pragma unroll
-            for (int i = 0; i < CHAIN_MAX_STAGES; ++i)
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-                    if (i < p.n_stages && tid + 512 * u < p.bias_len[i]) bias_lds[p.st[i].bias_off + tid + 512 * u] = bv[i][u];
+                    if (tid + 512 * u < bl[i]) bias_lds[bo[i] + tid + 512 * u] = bv[i][u];
             if (tid < CWD_BM) rows_lds[tid] = rv;
         }
         __syncthreads();
+#ifdef CWD_FINE_STAMPS
+        chain_stamp(p, bid, tid, slot);
+#endif
         const int groups = p.kp0 >> 2;                           // 4 features per item
         const int items = CWD_BM * groups;
         const bool vec = (p.n_in & 3) == 0;
@@ -189,6 +204,10 @@ __device__ __forceinline__ void chainw_body(const ChainArgs& p, const ChainDyn& 
                     }
                 }
             }
+#ifdef CWD_FINE_STAMPS
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            chain_stamp(p, bid, tid, slot);
+#endif
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int g = g0 + u * 512;
@@ -231,6 +250,9 @@ __device__ __forceinline__ void chainw_body(const ChainArgs& p, const ChainDyn& 
             for (int tile = wid; tile < ntiles; tile += 8) {
                 f32x16_t acc1[1][1];
                 chain_mma<CWD_BM, 1, 1, 4, true, CWD_PITCH, true>(Xin, S.wfrag, ks, ntiles, tile, 0, tid, acc1, pend, m0);
+#ifdef CWD_FINE_STAMPS
+                chain_stamp(p, bid, tid, slot);
+#endif
                 const f32x16_t& acc = acc1[0][0];
                 const int64_t m = m0 + mrow;
                 const bool row_ok = m < d_.n_rows;
@@ -425,6 +447,7 @@ __global__ __launch_bounds__(512) void k_chainw(const ChainArgs p) {
 // after every thread has waited for its own stores and the barrier, from this XCD's L2.
 __global__ __launch_bounds__(512) void k_chainw_fb(const ChainArgs pf, const ChainArgs pb) {
     extern __shared__ __attribute__((aligned(16))) u16 XW[];
+    kernarg_touch<2 * (int)sizeof(ChainArgs)>();
     const ChainDyn d = chain_dyn_of(pf);
     chainw_body<false>(pf, d, (int)blockIdx.x, XW);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -416,6 +416,8 @@ void chain_fwd_args(const cs_mlp* h, bool wide, const float* x, const int64_t* r
         if (l + 1 < h->L) { S.out = want_dz ? h->layers[l + 1].H : nullptr; S.ldo = h->layers[l + 1].Kp; S.epi = EPI_HIDDEN; S.mask = want_dz ? ly.mask : nullptr; }      // (null for ELU models on the wide chain: never allocated)
         else { S.out = nullptr; S.ldo = 0; S.epi = EPI_OUT; S.mask = nullptr; }
     }
+    // (the prologues fetch the biases of ALL stage slots without a branch: the unused ones read element 0 of the first and keep nothing)
+    for (int l = h->L; l < CHAIN_MAX_STAGES; ++l) { c.bias_src[l] = c.bias_src[0]; c.bias_len[l] = 0; }
     c.dbg = h->dbg;
     if (wide) c.trunk_n = chainw_stream_stages(h, c);
     if (!wide) { c.ablate = h->chain_ablate; c.store_nt = n >= h->chain_nt_min ? 1 : 0; chain_find_trunk(h, c); }

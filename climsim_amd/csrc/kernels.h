@@ -42,6 +42,27 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {   // 2 x f
     return r;
 }
 __device__ __forceinline__ uint2 pack4_hw(float a, float b, float c, float d) { return make_uint2(cvt_pk_bf16(a, b), cvt_pk_bf16(c, d)); }
+// Kernel arguments live in memory the command processor wrote for THIS launch: every 64-byte line of them is a miss the first time a
+// wave's scalar loads reach it (~1k clocks), and hipcc fetches struct members where the code uses them - behind one another where a
+// branch on one member guards the next (round 6 stamps of the wide chain's prologue: 4.3k clocks to ISSUE the sixteen bias loads of
+// eight stages, each behind its own fetch of `bias_src[i]` / `bias_len[i]`).  kernarg_touch<BYTES>() at the top of a kernel requests
+// every line of the first BYTES of the argument segment at once and waits for them together: one miss latency, then hits.
+// Same-box A/Bs (profiles/r06_prologue_ab.txt): tuned chain at 8192 columns 73.7 -> 72.7 us, k_wgrad3 31.1 -> 30.7 us; the optimiser kernel
+// reads its few arguments at once anyway and lost 0.1 us to the wait - not used there.
+#ifndef CS_KERNARG_TOUCH
+#define CS_KERNARG_TOUCH 1                // 0: A/B builds without the touch
+#endif
+template <int BYTES>
+__device__ __forceinline__ void kernarg_touch() {
+    if (!CS_KERNARG_TOUCH) return;
+    typedef const char __attribute__((address_space(4))) * kptr_t;
+    const kptr_t k = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+    unsigned t;
+#pragma unroll
+    for (int o = 0; o + 64 < BYTES; o += 64) asm volatile("s_load_dword %0, %1, %2" : "=s"(t) : "s"(k), "i"(o));
+    asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : "s"(k), "i"((BYTES - 1) / 64 * 64));
+}
+
 __device__ __forceinline__ float act_fwd(float z, int kind, float slope) {
     if (kind == ACT_ELU) return z > 0.f ? z : expm1f(z);
     return z > 0.f ? z : slope * z;

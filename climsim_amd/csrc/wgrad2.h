@@ -638,6 +638,7 @@ __device__ __forceinline__ void wgrad3_body(const WgradArgs& pa, const int work,
 template <int SLOTS, int R>
 __global__ __launch_bounds__(WG3_THREADS) void k_wgrad3(const WgradArgs pa) {
     extern __shared__ __attribute__((aligned(16))) u16 ring[];    // [stage][H|Z][R][128]
+    kernarg_touch<(int)sizeof(WgradArgs)>();                      // (the layer table is searched member by member: kernels.h)
     wgrad3_body<SLOTS, R>(pa, xcd_work_id(blockIdx.x, gridDim.x), ring);
 }
 

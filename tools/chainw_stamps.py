@@ -17,6 +17,7 @@ from climsim_amd.mlp import MLPEmulator  # noqa: E402
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 3072
 UNITS = tuple(int(u) for u in sys.argv[2].split(",")) if len(sys.argv) > 2 else (768, 640, 512, 640, 640)
 STREAM = os.environ.get("CS_CHAINW_STREAM", "1") != "0"
+FINE = os.environ.get("FINE", "0") == "1"          # a -DCWD_FINE_STAMPS build: prologue in three parts, heads in two
 m = MLPEmulator(units=UNITS, activation="leakyrelu", optimizer="RAdam", max_batch=B, seed=0)
 x = (torch.rand((B, 124), device="cuda") - 0.5).contiguous()
 y = (torch.rand((B, 128), device="cuda") * 0.1).contiguous()
@@ -53,7 +54,11 @@ for name, base, ws in (("fwd", 0, fwd_w), ("bwd", half, bwd_w)):
     i = 1
     d = lambda a, b: float((st[:, b] - st[:, a]).mean())
     print(f"== {name}: {st.shape[0]} workgroups, {real.mean():.1f} us each (100 MHz clock); clocks, mean over workgroups")
-    print(f"   prologue {d(0, 1):.0f}")
+    if FINE and name == "fwd":
+        print(f"   prologue: queue primed {d(0, 1):.0f} | bias + row-index loads issued {d(1, 2):.0f} | landed {d(2, 3):.0f} | LDS, barrier {d(3, 4):.0f} | inputs landed {d(4, 5):.0f} | normalise, LDS, barrier {d(5, 6):.0f}")
+        i = 6
+    else:
+        print(f"   prologue {d(0, 1):.0f}")
     tot = {"k-loop": 0.0, "epilogue": 0.0, "barrier": 0.0}
     for w in ws:
         np_ = passes(w)
@@ -63,7 +68,9 @@ for name, base, ws in (("fwd", 0, fwd_w), ("bwd", half, bwd_w)):
             tot["k-loop"] += row[-1][0]; tot["epilogue"] += row[-1][1]
         bar = d(i, i + 1); i += 1; tot["barrier"] += bar
         print(f"   stage width {w:4d}: " + " ".join(f"[k-loop {a:.0f} epi {b:.0f}]" for a, b in row) + f" barrier {bar:.0f}")
-    if name == "fwd":
+    if name == "fwd" and FINE:
+        print(f"   heads: k-loop {d(i, i + 1):.0f} | targets, loss, stores {d(i + 1, i + 2):.0f}"); i += 2
+    elif name == "fwd":
         print(f"   heads {d(i, i + 1):.0f}"); i += 1
     print(f"   tail {d(i, i + 1):.0f}   total {d(0, i + 1):.0f}   sums " + " ".join(f"{k} {v:.0f}" for k, v in tot.items()))
 m.close()
