@@ -82,6 +82,7 @@ template <int MODE>
 __global__ __launch_bounds__(CV2_THREADS) void k_conv2(const ConvProg P) {
     const ConvArgs& p0 = P.st[0];      // geometry (row tiles, channel tiles, seq, zero page) is that of every stage
     extern __shared__ __attribute__((aligned(16))) unsigned char cv2_ring[];
+    kernarg_touch<(int)sizeof(ConvProg)>();     // every stage reads its own ConvArgs: a first-touch miss per stage otherwise (kernels.h)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     // Waves 0-7 compute (64 x 112 each), waves 8-11 only request operand slabs: a workgroup's waves go to the SIMDs

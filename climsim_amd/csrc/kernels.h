@@ -57,10 +57,11 @@ __device__ __forceinline__ void kernarg_touch() {
     if (!CS_KERNARG_TOUCH) return;
     typedef const char __attribute__((address_space(4))) * kptr_t;
     const kptr_t k = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
-    unsigned t;
-#pragma unroll
-    for (int o = 0; o + 64 < BYTES; o += 64) asm volatile("s_load_dword %0, %1, %2" : "=s"(t) : "s"(k), "i"(o));
-    asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : "s"(k), "i"((BYTES - 1) / 64 * 64));
+    // ONE asm statement (loads + wait): the destination register belongs to the statement until the wait has passed.  Separate
+    // statements let hipcc reuse it between them - for a value a load still in flight then overwrote (k_conv2, round 6: memory fault).
+    unsigned t, off;
+    asm volatile("s_mov_b32 %1, 0\n1:\n\ts_load_dword %0, %2, %1\n\ts_add_u32 %1, %1, 64\n\ts_cmp_lt_u32 %1, %3\n\ts_cbranch_scc1 1b\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(t), "=&s"(off) : "s"(k), "i"(BYTES) : "scc", "memory");
 }
 
 __device__ __forceinline__ float act_fwd(float z, int kind, float slope) {
