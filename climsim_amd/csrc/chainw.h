@@ -62,6 +62,11 @@ __device__ __forceinline__ void chainw_copy_out(const u16* __restrict__ X, u16* 
 //   * A finished tile goes to global memory from its own wave (32 rows x 64 B, read back from the LDS tile the epilogue just wrote):
 //     no row copies of the whole stage output behind the next stage's first loads, no `vmcnt(0)` at the stage barrier (raw s_barrier
 //     behind `lgkmcnt(0)`: hipcc's __syncthreads drains the queue).
+//   * Measured and NOT kept (profiles/r06_chainw_prio.txt): a SIMD holds two of the workgroup's waves (w, w + 4) and serves the older
+//     first - waves 0-3 reach a stage's barrier ~4k clocks before waves 4-7 where all own the same number of tiles (16, 24 tiles), together
+//     where they own one more (20 tiles: 3 against 2).  Taking turns at `s_setprio` tile by tile evens the arrivals out (spread 4.4k
+//     -> 0.9k clocks) and the stage ends 0.7k earlier - the L2 -> CU path is busy either way - while the kernel as a whole got 1.5 us
+//     slower (95.4 -> 96.9 us).
 //   * Backward: the sign masks of a stage are fetched by asm into v[222:223] at the top of the stage and copied out behind the first
 //     k-loop (>= 8 younger loads waited for by then); a compiler-issued load would be waited for with vmcnt(0) in the first epilogue.
 #define CWS_CLOB4(a, b, c, d) "v" #a, "v" #b, "v" #c, "v" #d
@@ -122,6 +127,10 @@ __device__ __forceinline__ void chainw_body(const ChainArgs& p, const ChainDyn& 
     // development stamps (CS_CHAIN_DBG, tools/chainw_stamps.py), wave 0: start | prologue done | per stage: k-loop and epilogue of each
     // of the wave's passes, stage barrier | end; [62], [63]: the 100 MHz clock at both ends
     int slot = 0;
+#ifdef CWD_WAVE_STAMPS
+#define chain_stamp(p_, b_, t_, s_) ((void)0)
+    if (!BWD && p.dbg && tid == 0) p.dbg[(int64_t)bid * 64 + 54] = __builtin_amdgcn_s_memtime();
+#endif
     chain_stamp(p, bid, tid, slot);
     if (p.dbg && tid == 0) p.dbg[(int64_t)bid * 64 + 62] = __builtin_amdgcn_s_memrealtime();
 
@@ -382,8 +391,14 @@ __device__ __forceinline__ void chainw_body(const ChainArgs& p, const ChainDyn& 
                 chain_stamp(p, bid, tid, slot);
             }
             if (!BWD && use_mask && t_cnt > 0) *mptr = make_uint2(mk0, mk1);
+#ifdef CWD_WAVE_STAMPS                                            // development: when every wave reaches the stage barrier (forward half)
+            if (!BWD && p.dbg && lane == 0 && i < 6) p.dbg[(int64_t)bid * 64 + 8 * i + wid] = __builtin_amdgcn_s_memtime();
+#endif
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                         // (raw: __syncthreads would wait for the queue - vmcnt(0))
+#ifdef CWD_WAVE_STAMPS
+            if (!BWD && p.dbg && tid == 0 && i < 6) p.dbg[(int64_t)bid * 64 + 48 + i] = __builtin_amdgcn_s_memtime();
+#endif
             chain_stamp(p, bid, tid, slot);
             u16* t = Xin; Xin = Xout; Xout = t;
             continue;

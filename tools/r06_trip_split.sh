@@ -1,13 +1,14 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out
 V=$PWD/climsim_amd/variants
-F="amdgpu.ids\|Warning"
 {
+echo "## wave stamps, CWD_PRIO=3 (turns where the tiles divide evenly)"; CLIMSIM_HIP_LIB=$V/lib_wave.so timeout 300 python tools/chainw_wave_stamps.py 3072 2>&1 | grep -v "amdgpu.ids"
 for r in 1 2 3; do
-  echo "## rotation $r touch"; timeout 300 python tools/cnn_train_time.py 512 2>&1 | grep "ms/step\|rror\|fault"
-  echo "## rotation $r no touch"; CLIMSIM_HIP_LIB=$V/lib_cnn_notouch.so timeout 300 python tools/cnn_train_time.py 512 2>&1 | grep "ms/step"
+  for v in default p0; do
+    L=""; [ $v != default ] && L=$V/lib_$v.so
+    echo "## rotation $r $v"; CLIMSIM_HIP_LIB=$L timeout 300 python tools/pub_mlp_time.py 2>&1 | grep "0, 640) B 3072\|0, 640) B 8192\|chain_fb"
+  done
 done
-echo "## MLP"; timeout 300 python tools/step_time.py 8192 3072 2>&1 | grep -v "$F"; timeout 300 python tools/pub_mlp_time.py 2>&1 | grep "0, 640) B 3072"
-echo "## tests"; timeout 2400 python -m pytest tests/test_chainw_stream_gpu.py tests/test_hot_mlp_gpu.py tests/test_mlp_large_gpu.py tests/test_cnn_gpu.py -m gpu -q -x 2>&1 | grep -E "passed|failed|rror" | head
-} > gpurun_out/r06_cnn_touch_ab.txt 2>&1
-cat gpurun_out/r06_cnn_touch_ab.txt
+echo "## widths (default | p0)"; timeout 600 python tools/chainw_width_time.py 2>&1 | grep "chain_fb"; CLIMSIM_HIP_LIB=$V/lib_p0.so timeout 600 python tools/chainw_width_time.py 2>&1 | grep "chain_fb"
+} > gpurun_out/r06_chainw_prio3.txt 2>&1
+cat gpurun_out/r06_chainw_prio3.txt
