@@ -15,6 +15,8 @@
 #pragma once
 #include <type_traits>
 #include "chain.h"
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"        // "clobber list contains reserved registers" (the stream's queue, below): that is the point
 
 #define CWD_PITCH 1024
 #define CWD_BM 32
@@ -50,13 +52,18 @@ __device__ __forceinline__ void chainw_copy_out(const u16* __restrict__ X, u16* 
 // its column tiles ONE at a time with a queue of 8 k16-steps that is refilled across tile AND stage boundaries: the last 8 steps of a
 // tile fetch the first 8 of the wave's next tile - in this stage or in the next one it has tiles in (weights do not depend on the
 // barrier) - and those fly under the epilogue, the stores and the barrier.
-//   * The queue lives in FIXED registers v[224:255] that only the asm statements below name (launch_bounds(512): 256 VGPRs per lane, the
-//     compiler's own code ends below v200 - tests/test_chainw_stream_cpu.py reads the compiled kernel and fails if anything else touches
-//     v[216:255]).  In-flight loads in compiler-visible registers are what killed the first attempt at this in chain.h (copies of
-//     queue registers across a dispatch); registers the compiler does not know about cannot be copied.
+//   * The queue lives in FIXED registers v[224:255] (a second block v[192:223] for depth-16 builds) that only the asm statements below
+//     name, the sign-mask fetch in v[190:191]; the kernels carry `amdgpu_num_vgpr(190)`: hipcc's own code stays below v190 by
+//     construction (its peak is v154), and tests/test_chainw_audit_cpu.py disassembles the shipped code object and fails if anything else
+//     touches v[190:255].  In-flight loads in compiler-visible registers are what killed the first attempt at this in chain.h (copies
+//     of queue registers across a dispatch); registers the compiler does not know about cannot be copied.
 //   * Every wait is `vmcnt(7)`: the slot being consumed always has exactly 7 younger queue loads; other memory operations of the wave
-//     in flight (stores of finished tiles, the sign-mask accesses) only make the wait stricter - safe whatever their number.  A wave
-//     with no next tile refills from its own tile again (same count, 8 KiB once per half).
+//     in flight (stores of finished tiles, the sign-mask accesses) only make the wait stricter - safe whatever their number.  The
+//     FETCH side is a cursor (CwsCursor) that runs 8 steps ahead of the MFMAs through the wave's tiles in program order; past the last
+//     tile it walks that tile again (same count, 8 KiB once per half).
+//   * No memory operation hipcc knows of may be pending on any path into the k-loop (run_stage): it guards the data registers of its own
+//     stores with `vmcnt(0)` where it reuses them - inside the loop, draining the queue every block.  The streamed stages are their own
+//     instance of the stage code; their stores (tiles, sign masks, stamps, the prologue's input copy) are asm.
 //   * The MFMAs are asm too (the queue registers are their operand), one accumulator tile in k order = the arithmetic of chain_mma's
 //     one-tile pass: results are bit-identical to the per-pass form (tests/test_chainw_stream_gpu.py).
 //   * A finished tile goes to global memory from its own wave (32 rows x 64 B, read back from the LDS tile the epilogue just wrote):
@@ -67,18 +74,33 @@ __device__ __forceinline__ void chainw_copy_out(const u16* __restrict__ X, u16* 
 //     where they own one more (20 tiles: 3 against 2).  Taking turns at `s_setprio` tile by tile evens the arrivals out (spread 4.4k
 //     -> 0.9k clocks) and the stage ends 0.7k earlier - the L2 -> CU path is busy either way - while the kernel as a whole got 1.5 us
 //     slower (95.4 -> 96.9 us).
-//   * Backward: the sign masks of a stage are fetched by asm into v[222:223] at the top of the stage and copied out behind the first
+//   * Backward: the sign masks of a stage are fetched by asm into v[190:191] at the top of the stage and copied out behind the first
 //     k-loop (>= 8 younger loads waited for by then); a compiler-issued load would be waited for with vmcnt(0) in the first epilogue.
+#ifndef CWS_DEPTH
+#define CWS_DEPTH 8                       // k16-steps (KiB) of weights a wave keeps in flight: 8 (block B alone), or 16 (blocks A + B; A/B builds:
+                                          // measured SLOWER - published model 95.1 -> 99.4 us, k-loops 62.7k -> 69.1k clocks per half, profiles/r06_chainw_depth.txt)
+#endif
+#define CWS_VGPR_CAP 190                  // hipcc's own code stays below (amdgpu_num_vgpr on the kernels): v[190:191] masks, v[192:255] queue
 #define CWS_CLOB4(a, b, c, d) "v" #a, "v" #b, "v" #c, "v" #d
-#define CWS_STEP_ASM(LO, HI) "s_waitcnt vmcnt(7)\n\tv_mfma_f32_32x32x16_bf16 %0, v[" #LO ":" #HI "], %1, %0\n\tglobal_load_dwordx4 v[" #LO ":" #HI "], %2, off"
-#define CWS_STEP(LO, HI, C0, C1, C2, C3, ACC, AF, PTR) \
-    asm volatile(CWS_STEP_ASM(LO, HI) : "+v"(ACC) : "v"(AF), "v"(PTR) : "memory", CWS_CLOB4(C0, C1, C2, C3))
+#define CWS_STEP(LO, HI, C0, C1, C2, C3, ACC, AF, PTR)                                                                             \
+    asm volatile("s_waitcnt vmcnt(%3)\n\tv_mfma_f32_32x32x16_bf16 %0, v[" #LO ":" #HI "], %1, %0\n\tglobal_load_dwordx4 v[" #LO ":" #HI "], %2, off" \
+                 : "+v"(ACC) : "v"(AF), "v"(PTR), "i"(CWS_DEPTH - 1) : "memory", CWS_CLOB4(C0, C1, C2, C3))
 #define CWS_LOAD(LO, HI, C0, C1, C2, C3, PTR) \
     asm volatile("global_load_dwordx4 v[" #LO ":" #HI "], %0, off" :: "v"(PTR) : "memory", CWS_CLOB4(C0, C1, C2, C3))
 
-__device__ __forceinline__ void cws_prime(const uint4* __restrict__ w, int64_t stride) {      // steps 0..7 of a tile -> slots 0..7
-    CWS_LOAD(224, 227, 224, 225, 226, 227, w);
-    CWS_LOAD(228, 231, 228, 229, 230, 231, w + stride);
+__device__ __forceinline__ void cws_fetch_a(const uint4* __restrict__ w, int64_t stride) {
+    CWS_LOAD(192, 195, 192, 193, 194, 195, w + 0 * stride);
+    CWS_LOAD(196, 199, 196, 197, 198, 199, w + 1 * stride);
+    CWS_LOAD(200, 203, 200, 201, 202, 203, w + 2 * stride);
+    CWS_LOAD(204, 207, 204, 205, 206, 207, w + 3 * stride);
+    CWS_LOAD(208, 211, 208, 209, 210, 211, w + 4 * stride);
+    CWS_LOAD(212, 215, 212, 213, 214, 215, w + 5 * stride);
+    CWS_LOAD(216, 219, 216, 217, 218, 219, w + 6 * stride);
+    CWS_LOAD(220, 223, 220, 221, 222, 223, w + 7 * stride);
+}
+__device__ __forceinline__ void cws_fetch_b(const uint4* __restrict__ w, int64_t stride) {
+    CWS_LOAD(224, 227, 224, 225, 226, 227, w + 0 * stride);
+    CWS_LOAD(228, 231, 228, 229, 230, 231, w + 1 * stride);
     CWS_LOAD(232, 235, 232, 233, 234, 235, w + 2 * stride);
     CWS_LOAD(236, 239, 236, 237, 238, 239, w + 3 * stride);
     CWS_LOAD(240, 243, 240, 241, 242, 243, w + 4 * stride);
@@ -87,12 +109,19 @@ __device__ __forceinline__ void cws_prime(const uint4* __restrict__ w, int64_t s
     CWS_LOAD(252, 255, 252, 253, 254, 255, w + 7 * stride);
 }
 
-// One column tile: acc += X[32 rows][Kc] * W[Kc][32 columns of this tile].  `cur`: this lane's piece of the tile's k16-step 0 (steps
-// are `sstride` uint4 apart); steps 0..7 are in the queue.  The last 8 steps refill the queue from `nx` (+ d * nstride): the next tile's steps 0..7.
-__device__ __forceinline__ void cws_tile(const u16* __restrict__ X, f32x16_t& acc, const uint4* __restrict__ cur, int64_t sstride, int ks,
-                                         const uint4* __restrict__ nx, int64_t nstride, int arow, int ahalf) {
 #define CWS_AF(step) (*reinterpret_cast<const bf16x8_t*>(X + chain_lds_off_p<CWD_PITCH>(arow, (2 * (step) + ahalf) * 8)))
-#define CWS_BLOCK(R, RS, LASTAF)                                                                            \
+#define CWS_BLOCK_A(R, RS, LASTAF)                                                                          \
+    {                                                                                                       \
+        afB = CWS_AF(s0 + 1); CWS_STEP(192, 195, 192, 193, 194, 195, acc, afA, R); R += RS; __builtin_amdgcn_sched_barrier(0); \
+        afA = CWS_AF(s0 + 2); CWS_STEP(196, 199, 196, 197, 198, 199, acc, afB, R); R += RS; __builtin_amdgcn_sched_barrier(0); \
+        afB = CWS_AF(s0 + 3); CWS_STEP(200, 203, 200, 201, 202, 203, acc, afA, R); R += RS; __builtin_amdgcn_sched_barrier(0); \
+        afA = CWS_AF(s0 + 4); CWS_STEP(204, 207, 204, 205, 206, 207, acc, afB, R); R += RS; __builtin_amdgcn_sched_barrier(0); \
+        afB = CWS_AF(s0 + 5); CWS_STEP(208, 211, 208, 209, 210, 211, acc, afA, R); R += RS; __builtin_amdgcn_sched_barrier(0); \
+        afA = CWS_AF(s0 + 6); CWS_STEP(212, 215, 212, 213, 214, 215, acc, afB, R); R += RS; __builtin_amdgcn_sched_barrier(0); \
+        afB = CWS_AF(s0 + 7); CWS_STEP(216, 219, 216, 217, 218, 219, acc, afA, R); R += RS; __builtin_amdgcn_sched_barrier(0); \
+        afA = CWS_AF(LASTAF); CWS_STEP(220, 223, 220, 221, 222, 223, acc, afB, R); R += RS; __builtin_amdgcn_sched_barrier(0); \
+    }
+#define CWS_BLOCK_B(R, RS, LASTAF)                                                                          \
     {                                                                                                       \
         afB = CWS_AF(s0 + 1); CWS_STEP(224, 227, 224, 225, 226, 227, acc, afA, R); R += RS; __builtin_amdgcn_sched_barrier(0); \
         afA = CWS_AF(s0 + 2); CWS_STEP(228, 231, 228, 229, 230, 231, acc, afB, R); R += RS; __builtin_amdgcn_sched_barrier(0); \
@@ -103,17 +132,67 @@ __device__ __forceinline__ void cws_tile(const u16* __restrict__ X, f32x16_t& ac
         afB = CWS_AF(s0 + 7); CWS_STEP(248, 251, 248, 249, 250, 251, acc, afA, R); R += RS; __builtin_amdgcn_sched_barrier(0); \
         afA = CWS_AF(LASTAF); CWS_STEP(252, 255, 252, 253, 254, 255, acc, afB, R); R += RS; __builtin_amdgcn_sched_barrier(0); \
     }
+
+// stamp store of the streamed stages (asm: see run_stage)
+__device__ __forceinline__ void cws_stamp(const ChainArgs& p, int bid, int tid, int& slot) {
+    if (p.dbg && tid == 0 && slot < 64) {
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 1" :: "v"(p.dbg + (int64_t)bid * 64 + slot), "v"(t) : "memory");
+    }
+    ++slot;
+}
+
+// Fetch side of a wave's weight stream: where the NEXT 8 steps to request come from.  It runs CWS_DEPTH steps ahead of the MFMAs through
+// the wave's column tiles in program order - tile after tile of a stage, then the first tile of the next stage the wave has tiles in
+// (weights do not depend on the stage barrier) - and, past the last tile, over that tile again (the counts stay exact; 8-16 KiB per half).
+struct CwsCursor {
+    const uint4* ptr;          // this lane's piece of the next step to request
+    int64_t stride;            // uint4 per k16-step of the cursor's stage
+    int left;                  // steps of the cursor's tile not yet requested (a multiple of 8)
+    int stage, k, lo, cnt;     // tile k of the wave's run [lo, lo + cnt) in `stage`
+    int n_stream, wid, lane;
+    __device__ __forceinline__ void run_of(const ChainArgs& p, int j, int& lo_, int& cnt_) const {
+        const int nt = p.st[j].Nc >> 5, base = nt >> 3, rem = nt & 7;
+        cnt_ = base + (wid < rem ? 1 : 0); lo_ = wid * base + min(wid, rem);
+    }
+    __device__ __forceinline__ void begin_tile(const ChainArgs& p) {
+        stride = (int64_t)(p.st[stage].Nc >> 5) * 64;
+        ptr = reinterpret_cast<const uint4*>(p.st[stage].wfrag) + (lo + k) * 64 + lane;
+        left = p.st[stage].Kc >> 4;
+    }
+    __device__ __forceinline__ bool seek(const ChainArgs& p, int j0) {        // first stage >= j0 the wave has tiles in
+        for (int j = j0; j < n_stream; ++j) {
+            int lo_, cnt_;
+            run_of(p, j, lo_, cnt_);
+            if (cnt_ > 0) { stage = j; k = 0; lo = lo_; cnt = cnt_; begin_tile(p); return true; }
+        }
+        return false;
+    }
+    __device__ __forceinline__ void advance8(const ChainArgs& p) {
+        left -= 8;
+        if (left > 0) { ptr += 8 * stride; return; }
+        if (++k < cnt) { begin_tile(p); return; }
+        if (!seek(p, stage + 1)) { k = cnt - 1; begin_tile(p); }
+    }
+};
+
+// One column tile: acc += X[32 rows][16 ks] * W[16 ks][32 columns of this tile], steps 0..CWS_DEPTH-1 of it already requested (`phase`:
+// which block of 8 slots holds the next step; depth 8 uses block B alone).  Every step refills its slot from the cursor.
+__device__ __forceinline__ void cws_tile(const u16* __restrict__ X, f32x16_t& acc, int ks, CwsCursor& f, const ChainArgs& p, int& phase,
+                                         int arow, int ahalf) {
     // (the accumulators were just written by VALU moves; the asm MFMAs are invisible to hipcc's hazard recogniser)
     asm volatile("s_nop 3" : "+v"(acc));
     bf16x8_t afA = CWS_AF(0), afB;
-    const uint4* r = cur + 8 * sstride;
-    int s0 = 0;
-    for (; s0 + 8 < ks; s0 += 8) CWS_BLOCK(r, sstride, s0 + 8)
-    r = nx;
-    CWS_BLOCK(r, nstride, s0 + 7)
+    for (int s0 = 0; s0 < ks; s0 += 8) {
+        const uint4* r = f.ptr;
+        const int64_t rs = f.stride;
+        const int last = min(s0 + 8, ks - 1);
+        if (CWS_DEPTH == 8 || phase) CWS_BLOCK_B(r, rs, last)
+        else CWS_BLOCK_A(r, rs, last)
+        phase ^= 1;
+        f.advance8(p);
+    }
     asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(acc));       // MFMA results -> VALU reads: the wait states hipcc would have inserted
-#undef CWS_BLOCK
-#undef CWS_AF
 }
 
 template <bool BWD>
@@ -139,21 +218,11 @@ __device__ __forceinline__ void chainw_body(const ChainArgs& p, const ChainDyn& 
     // front of the prologue's own loads - the weights do not depend on them.
     const bool stream = p.trunk_n > 0;
     const int n_stream = stream ? (BWD ? p.n_stages : p.n_stages - 1) : 0;
-    auto wave_run = [&](int j, int& lo, int& cnt) {
-        const int nt = p.st[j].Nc >> 5, base = nt >> 3, rem = nt & 7;
-        cnt = base + (wid < rem ? 1 : 0); lo = wid * base + min(wid, rem);
-    };
-    auto next_tile = [&](int j0, const uint4*& w, int64_t& stride) {      // first tile of this wave in a stage >= j0 (false: none)
-        for (int j = j0; j < n_stream; ++j) {
-            int lo, cnt;
-            wave_run(j, lo, cnt);
-            if (cnt > 0) { stride = (int64_t)(p.st[j].Nc >> 5) * 64; w = reinterpret_cast<const uint4*>(p.st[j].wfrag) + lo * 64 + lane; return true; }
-        }
-        return false;
-    };
-    if (stream) {
-        const uint4* w0; int64_t st0;
-        if (next_tile(0, w0, st0)) cws_prime(w0, st0);
+    CwsCursor fetch{nullptr, 0, 0, 0, 0, 0, 0, n_stream, wid, lane};
+    int phase = 0;
+    if (stream && fetch.seek(p, 0)) {
+        if (CWS_DEPTH == 16) { cws_fetch_a(fetch.ptr, fetch.stride); fetch.advance8(p); }
+        cws_fetch_b(fetch.ptr, fetch.stride); fetch.advance8(p);
     }
 #ifdef CWD_FINE_STAMPS
     if (!BWD) chain_stamp(p, bid, tid, slot);
@@ -232,7 +301,9 @@ __device__ __forceinline__ void chainw_body(const ChainArgs& p, const ChainDyn& 
                 }
                 const uint2 pk = pack4(v[0], v[1], v[2], v[3]);
                 *reinterpret_cast<uint2*>(Xin + cwd_off(mlv[u], cv[u])) = pk;
-                if (p.h0) *reinterpret_cast<uint2*>(p.h0 + (m0 + mlv[u]) * p.ldh0 + cv[u]) = pk;
+                if (p.h0) {      // (asm: no store hipcc knows of may be pending where the stream starts - it would guard the data registers with vmcnt(0) inside the k-loop)
+                    asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 1" :: "v"(p.h0 + (m0 + mlv[u]) * p.ldh0 + cv[u]), "v"(pk) : "memory");
+                }
             }
         }
     } else {
@@ -251,10 +322,15 @@ __device__ __forceinline__ void chainw_body(const ChainArgs& p, const ChainDyn& 
     const float slope_ = p.slope, dscale_ = p.drop_scale, bscale_ = p.bwd_scale;     // (dropout: the kept activations were scaled by 1 / (1 - rate))
     const unsigned dthr_ = p.drop_thr;
     ChainPending pend{nullptr, 0, 0, 0};
-    for (int i = 0; i < p.n_stages; ++i) {
+    // One stage.  TWO instances - the streamed stages and the per-pass ones (heads; ELU models; odd contraction lengths) - in two loops:
+    // a compiler-issued store anywhere on a path into the stream's k-loop makes hipcc guard its data registers with a `vmcnt(0)` where
+    // they are reused, i.e. INSIDE the k-loop, every block (round 6: the row copy of the per-pass form, never executed by a streamed
+    // stage, drained the queue of the forward half every 16 steps).  The streamed instance contains no memory operation hipcc knows of.
+    auto run_stage = [&](const int i, auto streamed_c) __attribute__((always_inline)) {
+        constexpr bool STREAMED = decltype(streamed_c)::value;
         const ChainStage& S = p.st[i];
         const int ntiles = S.Nc >> 5, ks = S.Kc >> 4;
-        if (!BWD && S.epi == EPI_OUT) {                          // heads: one column tile per wave and pass (128 wide: waves 0..3)
+        if (!STREAMED && !BWD && S.epi == EPI_OUT) {             // heads: one column tile per wave and pass (128 wide: waves 0..3)
             if (wid >= ntiles && pend.out) { chainw_copy_out(Xin, pend.out, pend.ldo, pend.width, m0, tid); pend.out = nullptr; }
             for (int tile = wid; tile < ntiles; tile += 8) {
                 f32x16_t acc1[1][1];
@@ -281,7 +357,7 @@ __device__ __forceinline__ void chainw_body(const ChainArgs& p, const ChainDyn& 
                 }
             }
             chain_stamp(p, bid, tid, slot);
-            continue;                                            // last stage of the forward pass
+            return;                                              // last stage of the forward pass
         }
         // Column tiles are dealt to the waves in contiguous, BALANCED runs (ntiles / 8 each, the first ntiles % 8 waves one more)
         // and a wave goes through its run in passes of two tiles (one for an odd rest): 24 tiles (768 wide) are 3 per wave
@@ -291,7 +367,7 @@ __device__ __forceinline__ void chainw_body(const ChainArgs& p, const ChainDyn& 
         const int t_cnt = t_base + (wid < t_rem ? 1 : 0), t_lo = wid * t_base + min(wid, t_rem);
         // The previous stage's output (this stage's input, intact in Xin) goes to global memory BEHIND the first weight
         // loads of this stage (chain_mma, `pend`; 32-row tiles: behind the priming loads, measured better than behind the last load).  A wave without tiles in this stage copies its share right away.
-        if (t_cnt == 0 && pend.out) {
+        if (!STREAMED && t_cnt == 0 && pend.out) {
             chainw_copy_out(Xin, pend.out, pend.ldo, pend.width, m0, tid);
             pend.out = nullptr;
         }
@@ -303,7 +379,7 @@ __device__ __forceinline__ void chainw_body(const ChainArgs& p, const ChainDyn& 
         const unsigned drop_key_ = S.drop_key;
         uint2* mptr = use_mask ? reinterpret_cast<uint2*>(S.mask) + (int64_t)bid * 512 + tid : nullptr;
         if (BWD && use_mask && t_cnt > 0) {                                                        // lands during the first k-loop
-            if (stream) asm volatile("global_load_dwordx2 v[222:223], %0, off" :: "v"(mptr) : "memory", "v222", "v223");
+            if (STREAMED) asm volatile("global_load_dwordx2 v[190:191], %0, off" :: "v"(mptr) : "memory", "v190", "v191");
             else { const uint2 mv = *mptr; mk0 = mv.x; mk1 = mv.y; }
         }
         // One column tile's epilogue.  The model-wide switches (ELU, dropout, sign masks) are COMPILE-TIME here and chosen once per
@@ -356,15 +432,10 @@ __device__ __forceinline__ void chainw_body(const ChainArgs& p, const ChainDyn& 
             else { if (drop_) run(F{}, T{}, F{}); else run(F{}, F{}, F{}); }
             if (!BWD && use_mask) { if (slot < 2) mk0 |= bits16 << ((slot & 1) * 16); else mk1 |= bits16 << ((slot & 1) * 16); }
         };
-        if (stream) {
-            const int64_t sstride = (int64_t)ntiles * 64;
-            const uint4* wst = reinterpret_cast<const uint4*>(S.wfrag) + lane;
+        if constexpr (STREAMED) {
             const int ahalf = lane >> 5;
             for (int k = 0; k < t_cnt; ++k) {
                 const int tile = t_lo + k;
-                const uint4* cur = wst + tile * 64;
-                const uint4* nx = cur + 64; int64_t nstride = sstride;               // the wave's next tile: in this stage ...
-                if (k + 1 == t_cnt && !next_tile(i + 1, nx, nstride)) nx = cur;      // ... in a later one, or none (refill from this tile again: the count stays)
                 f32x16_t acc;
                 if (!BWD && CWD_BIAS_ACC) {
 #pragma unroll
@@ -376,21 +447,28 @@ __device__ __forceinline__ void chainw_body(const ChainArgs& p, const ChainDyn& 
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
                 }
-                cws_tile(Xin, acc, cur, sstride, ks, nx, nstride, mrow, ahalf);
-                if (BWD && use_mask && k == 0) asm volatile("v_mov_b32 %0, v222\n\tv_mov_b32 %1, v223" : "=v"(mk0), "=v"(mk1) :: "v222", "v223");
-                chain_stamp(p, bid, tid, slot);
+                cws_tile(Xin, acc, ks, fetch, p, phase, mrow, ahalf);
+                if (BWD && use_mask && k == 0) asm volatile("v_mov_b32 %0, v190\n\tv_mov_b32 %1, v191" : "=v"(mk0), "=v"(mk1) :: "v190", "v191");
+                cws_stamp(p, bid, tid, slot);
                 uint2 hnone[4];
                 epilogue(tile, k, acc, hnone);
                 if (S.out) {                                      // this tile -> global memory: 32 rows x 64 B, two 16-byte pieces per lane
 #pragma unroll
                     for (int h2 = 0; h2 < 2; ++h2) {
                         const int r = (lane >> 2) + 16 * h2, c = tile * 4 + (lane & 3);
-                        *reinterpret_cast<uint4*>(S.out + (m0 + r) * S.ldo + c * 8) = *reinterpret_cast<const uint4*>(Xout + cwd_off(r, c * 8));
+                        // (asm: a store hipcc knows about makes it protect the data registers with `vmcnt(0)` where it reuses them - inside the
+                        //  next k-loop, draining the queue every block; s_nop: nothing pads an asm store whose data the next instruction may rewrite)
+                        const uint4 v = *reinterpret_cast<const uint4*>(Xout + cwd_off(r, c * 8));
+                        const u32x4_t vv = {v.x, v.y, v.z, v.w};
+                        asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(S.out + (m0 + r) * S.ldo + c * 8), "v"(vv) : "memory");
                     }
                 }
-                chain_stamp(p, bid, tid, slot);
+                cws_stamp(p, bid, tid, slot);
             }
-            if (!BWD && use_mask && t_cnt > 0) *mptr = make_uint2(mk0, mk1);
+            if (!BWD && use_mask && t_cnt > 0) {
+                const uint2 mv = make_uint2(mk0, mk1);
+                asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 1" :: "v"(mptr), "v"(mv) : "memory");
+            }
 #ifdef CWD_WAVE_STAMPS                                            // development: when every wave reaches the stage barrier (forward half)
             if (!BWD && p.dbg && lane == 0 && i < 6) p.dbg[(int64_t)bid * 64 + 8 * i + wid] = __builtin_amdgcn_s_memtime();
 #endif
@@ -399,10 +477,10 @@ __device__ __forceinline__ void chainw_body(const ChainArgs& p, const ChainDyn& 
 #ifdef CWD_WAVE_STAMPS
             if (!BWD && p.dbg && tid == 0 && i < 6) p.dbg[(int64_t)bid * 64 + 48 + i] = __builtin_amdgcn_s_memtime();
 #endif
-            chain_stamp(p, bid, tid, slot);
+            cws_stamp(p, bid, tid, slot);
             u16* t = Xin; Xin = Xout; Xout = t;
-            continue;
-        }
+            return;
+        } else {
         for (int tile0 = t_lo; tile0 < t_lo + t_cnt; tile0 += 2) {
             const bool two = tile0 + 1 < t_lo + t_cnt;
             const int slot0 = (tile0 - t_lo) & 3;
@@ -441,7 +519,10 @@ __device__ __forceinline__ void chainw_body(const ChainArgs& p, const ChainDyn& 
             else pend = ChainPending{S.out, S.ldo, S.Nc, 0};                               // the next stage copies it behind its first weight loads
         }
         u16* t = Xin; Xin = Xout; Xout = t;
-    }
+        }
+    };
+    for (int i = 0; i < n_stream; ++i) run_stage(i, std::true_type{});
+    for (int i = n_stream; i < p.n_stages; ++i) run_stage(i, std::false_type{});
     if (!BWD && d_.y) {
         __syncthreads();                                         // the heads stage has no trailing barrier: XW still being read
         loss_flush(d_.loss, p.loss_stripes, bid, sq, ab, reinterpret_cast<float*>(XW), tid, 8);
@@ -452,7 +533,7 @@ __device__ __forceinline__ void chainw_body(const ChainArgs& p, const ChainDyn& 
 }
 
 template <bool BWD>
-__global__ __launch_bounds__(512) void k_chainw(const ChainArgs p) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(CWS_VGPR_CAP))) void k_chainw(const ChainArgs p) {
     extern __shared__ __attribute__((aligned(16))) u16 XW[];
     chainw_body<BWD>(p, chain_dyn_of(p), (int)blockIdx.x, XW);
 }
@@ -460,7 +541,7 @@ __global__ __launch_bounds__(512) void k_chainw(const ChainArgs p) {
 // Forward and backward pass of a training step in one launch (as k_chain_fb, chain.h): rows are independent, so the
 // workgroup that produced dz of the heads and the activation copies of its 32 rows is the one that reads them back -
 // after every thread has waited for its own stores and the barrier, from this XCD's L2.
-__global__ __launch_bounds__(512) void k_chainw_fb(const ChainArgs pf, const ChainArgs pb) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(CWS_VGPR_CAP))) void k_chainw_fb(const ChainArgs pf, const ChainArgs pb) {
     extern __shared__ __attribute__((aligned(16))) u16 XW[];
     kernarg_touch<2 * (int)sizeof(ChainArgs)>();
     const ChainDyn d = chain_dyn_of(pf);
@@ -471,7 +552,7 @@ __global__ __launch_bounds__(512) void k_chainw_fb(const ChainArgs pf, const Cha
 }
 
 // K members in one launch (see k_chain_fb_group, chain.h)
-__global__ __launch_bounds__(512) void k_chainw_fb_group(const ChainPair* __restrict__ members, const GroupTable tab, const ChainDynTable dyn) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(CWS_VGPR_CAP))) void k_chainw_fb_group(const ChainPair* __restrict__ members, const GroupTable tab, const ChainDynTable dyn) {
     extern __shared__ __attribute__((aligned(16))) u16 XW[];
     const int w = xcd_work_id((int)blockIdx.x, (int)gridDim.x);       // a contiguous run of work ids per XCD (k_chain_fb_group)
     const int m = group_member(tab, w);
@@ -485,9 +566,10 @@ __global__ __launch_bounds__(512) void k_chainw_fb_group(const ChainPair* __rest
 }
 
 // forward pass only of K members in one launch (see k_chain_group, chain.h)
-__global__ __launch_bounds__(512) void k_chainw_group(const ChainArgs* __restrict__ members, const GroupTable tab, const ChainDynTable dyn) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(CWS_VGPR_CAP))) void k_chainw_group(const ChainArgs* __restrict__ members, const GroupTable tab, const ChainDynTable dyn) {
     extern __shared__ __attribute__((aligned(16))) u16 XW[];
     const int w = xcd_work_id((int)blockIdx.x, (int)gridDim.x);
     const int m = group_member(tab, w);
     chainw_body<false>(members[tab.idx[m]], dyn.d[m], w - tab.begin[m], XW);
 }
+#pragma clang diagnostic pop

@@ -780,6 +780,7 @@ int cs_mlp_create(cs_mlp_t** out, const cs_mlp_cfg* cfg) {
         if (boff > CHAIN_MAX_BIAS) h->use_chain = false;       // LDS bias block of the tuned chain / of the wide chain
         if (boff > CWD_MAX_BIAS) h->use_chainw = false;
     }
+    if (getenv("CS_FORCE_CHAINW") && atoi(getenv("CS_FORCE_CHAINW"))) h->use_chain = false;   // development: the wide chain on a model the tuned kernels would take
     if (h->use_chain) h->use_chainw = false;               // the tuned kernels take the 128/256/512 models
     if (const char* e = getenv("CS_CHAINW_MAX_N")) h->chainw_max_n = atoll(e);
     if (const char* e = getenv("CS_CHAINW_STREAM")) h->chainw_stream = atoi(e) != 0;

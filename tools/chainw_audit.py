@@ -1,5 +1,5 @@
 """Audit of the wide chain's kernels AS SHIPPED (CPU only: the gfx950 code object inside climsim_amd/libclimsim_hip.so, disassembled
-with llvm-objdump): the weight queue of the continuous stream lives in v[224:255] and the sign-mask fetch in v[222:223] - registers
+with llvm-objdump): the weight queue of the continuous stream lives in v[192:255] and the sign-mask fetch in v[190:191] - registers
 only the asm statements of chainw.h name.  Prints, per kernel, the highest VGPR any OTHER instruction touches and the lines that
 break the reservation (none expected).  `python tools/chainw_audit.py [listing.s]`; exit status 1 on a break."""
 import os
@@ -9,12 +9,13 @@ import subprocess
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RESERVED_FROM = 216
+RESERVED_FROM = 190
+Q = r"(19[2-9]|2[0-5]\d)"
 ALLOWED = (
-    re.compile(r"^\s*global_load_dwordx4 v\[(2[2-5]\d):(2[2-5]\d)\], v\[\d+:\d+\], off$"),
-    re.compile(r"^\s*global_load_dwordx2 v\[222:223\], v\[\d+:\d+\], off$"),
-    re.compile(r"^\s*v_mfma_f32_32x32x16_bf16 v\[\d+:\d+\], v\[(2[2-5]\d):(2[2-5]\d)\], v\[\d+:\d+\], v\[\d+:\d+\]$"),
-    re.compile(r"^\s*v_mov_b32(_e32)? v\d+, v22[23]$"),
+    re.compile(r"^\s*global_load_dwordx4 v\[" + Q + r":" + Q + r"\], v\[\d+:\d+\], off$"),
+    re.compile(r"^\s*global_load_dwordx2 v\[190:191\], v\[\d+:\d+\], off$"),
+    re.compile(r"^\s*v_mfma_f32_32x32x16_bf16 v\[\d+:\d+\], v\[" + Q + r":" + Q + r"\], v\[\d+:\d+\], v\[\d+:\d+\]$"),
+    re.compile(r"^\s*v_mov_b32(_e32)? v\d+, v19[01]$"),
 )
 VREG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
 
