@@ -91,6 +91,18 @@ __device__ __forceinline__ int chain_lds_off_p(int row, int col) {   // element 
 __device__ __forceinline__ int chain_lds_off(int row, int col) { return chain_lds_off_p<CHAIN_PITCH>(row, col); }
 __device__ __forceinline__ unsigned bf_pos(unsigned h16) { return (unsigned)((h16 & 0xffffu) - 1u) < 0x7fffu; }   // bf16 > 0
 
+// Stores of the chain kernels are issued from asm: a store hipcc knows about makes it guard the store's DATA registers with a
+// `vmcnt(0)` wherever it reuses them - round 6 found such drains in front of a stage's priming loads (waiting for the previous stage's
+// sign-mask store to be acknowledged) and, in the wide chain, inside the k-loop.  (s_nop: nothing pads an asm store whose data the
+// next instruction may rewrite - cdna_hip_programming.md 5.7.)
+__device__ __forceinline__ void st_asm16(void* dst, const uint4& v, bool nt = false) {
+    const u32x4_t vv = {v.x, v.y, v.z, v.w};
+    if (nt) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(dst), "v"(vv) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(vv) : "memory");
+}
+__device__ __forceinline__ void st_asm8(void* dst, const uint2& v) { asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory"); }
+__device__ __forceinline__ void st_asm4(void* dst, unsigned v) { asm volatile("global_store_dword %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory"); }
+
 // Stage output rows LDS -> global, fully coalesced (one wave-instruction = 1 KiB of one row).  The MFMA
 // result layout gives every lane 4 columns of ONE row, so storing from registers touches 32 rows per
 // instruction with 16-byte pieces - 8x the write requests for the same bytes.
@@ -106,8 +118,7 @@ __device__ __forceinline__ void chain_copy_out(const u16* __restrict__ X, u16* _
     for (int g = tid; g < total; g += 512) {
         const int r = g >> cpr_shift, c = g & ((1 << cpr_shift) - 1);
         const uint4 v = *reinterpret_cast<const uint4*>(X + r * CHAIN_PITCH + ((c ^ (r & 15)) << 3));
-        if (nt) __builtin_nontemporal_store((u32x4_t){v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4_t*>(out + (m0 + r) * ldo + c * 8));
-        else *reinterpret_cast<uint4*>(out + (m0 + r) * ldo + c * 8) = v;
+        st_asm16(out + (m0 + r) * ldo + c * 8, v, nt);
     }
 }
 
@@ -364,8 +375,13 @@ __device__ __forceinline__ void chain_heads(const float* __restrict__ bias_lds, 
     }
 }
 
+// (the store is asm: a store hipcc knows about makes it guard the data registers with a `vmcnt(0)` wherever it reuses them - round 6 found
+//  one in the middle of a stage's priming loads, and one inside the wide chain's k-loop: chainw.h)
 __device__ __forceinline__ void chain_stamp(const ChainArgs& p, int bid, int tid, int& slot) {
-    if (p.dbg && tid == 0 && slot < 64) p.dbg[(int64_t)bid * 64 + slot] = __builtin_amdgcn_s_memtime();
+    if (p.dbg && tid == 0 && slot < 64) {
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 1" :: "v"(p.dbg + (int64_t)bid * 64 + slot), "v"(t) : "memory");
+    }
     ++slot;
 }
 
@@ -456,7 +472,7 @@ __device__ __forceinline__ void chain_stage(u16* X, const float* bias_lds, const
             // (the stage's sign words belong to the threads that ran the epilogue: waves 0-3 of a `dup` stage, forward and backward)
             // a 32-row tile has 32 elements per thread: only word 0 carries bits, and only that word is stored
             // (12.6 -> 3.1 MB of mask traffic per pass at 8192 columns); 64 / 128-row tiles store all four
-            if (BMROWS == 32) reinterpret_cast<unsigned*>(S.mask)[(int64_t)bid * 512 + tid] = msk[0];
+            if (BMROWS == 32) st_asm4(reinterpret_cast<unsigned*>(S.mask) + (int64_t)bid * 512 + tid, msk[0]);
             else *mptr = msk;
         }
     }
@@ -657,6 +673,11 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const ChainDyn& d
     // (CS_CHAIN_ABLATE & 512, round-6 experiment: the prologue warms - and waits for - the first two stages only; the others' lines are
     //  requested behind stage 0, to arrive under its epilogue instead of standing in front of the first MFMA)
     const int warm_first = (!BWD && (p.ablate & 512)) ? min(2, p.n_stages) : p.n_stages;
+    // (Round 6, measured and not kept - profiles/r06_warm_ab.txt: hipcc compiles `sink ^= w[...]` into load, wait, xor per line, and only
+    //  the first lines / 512 workgroups of an XCD own any line of a stage - at 8192 columns 8 of 32 carry four dependent latencies in their
+    //  prologue, 24 none.  Touches as LDS-DMA loads nobody waits for, their 512-line chunks dealt round-robin over the XCD's workgroups:
+    //  the prologues even out (per-workgroup spread 8.0k -> 2.4k clocks) and get LONGER on average (8.7k -> 10.9k: every workgroup's first
+    //  weight wait now stands behind a touch of its own), the kernel 72.4 -> 75.3 us.  The uneven form ships.)
     auto warm_range = [&](int s_lo, int s_hi) {
         const int Q = wQ, q = wq;
         for (int i = s_lo; i < s_hi; ++i) {
@@ -736,7 +757,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const ChainDyn& d
                 }
                 const uint2 pk = pack4(v[0], v[1], v[2], v[3]);
                 *reinterpret_cast<uint2*>(X + chain_lds_off(mlv[u], cv[u])) = pk;
-                if (p.h0) *reinterpret_cast<uint2*>(p.h0 + (m0 + mlv[u]) * p.ldh0 + cv[u]) = pk;
+                if (p.h0) st_asm8(p.h0 + (m0 + mlv[u]) * p.ldh0 + cv[u], pk);
             }
         }
     } else if (!p.fused) {

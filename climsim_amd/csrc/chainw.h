@@ -133,15 +133,6 @@ __device__ __forceinline__ void cws_fetch_b(const uint4* __restrict__ w, int64_t
         afA = CWS_AF(LASTAF); CWS_STEP(252, 255, 252, 253, 254, 255, acc, afB, R); R += RS; __builtin_amdgcn_sched_barrier(0); \
     }
 
-// stamp store of the streamed stages (asm: see run_stage)
-__device__ __forceinline__ void cws_stamp(const ChainArgs& p, int bid, int tid, int& slot) {
-    if (p.dbg && tid == 0 && slot < 64) {
-        const unsigned long long t = __builtin_amdgcn_s_memtime();
-        asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 1" :: "v"(p.dbg + (int64_t)bid * 64 + slot), "v"(t) : "memory");
-    }
-    ++slot;
-}
-
 // Fetch side of a wave's weight stream: where the NEXT 8 steps to request come from.  It runs CWS_DEPTH steps ahead of the MFMAs through
 // the wave's column tiles in program order - tile after tile of a stage, then the first tile of the next stage the wave has tiles in
 // (weights do not depend on the stage barrier) - and, past the last tile, over that tile again (the counts stay exact; 8-16 KiB per half).
@@ -449,7 +440,7 @@ __device__ __forceinline__ void chainw_body(const ChainArgs& p, const ChainDyn& 
                 }
                 cws_tile(Xin, acc, ks, fetch, p, phase, mrow, ahalf);
                 if (BWD && use_mask && k == 0) asm volatile("v_mov_b32 %0, v190\n\tv_mov_b32 %1, v191" : "=v"(mk0), "=v"(mk1) :: "v190", "v191");
-                cws_stamp(p, bid, tid, slot);
+                chain_stamp(p, bid, tid, slot);
                 uint2 hnone[4];
                 epilogue(tile, k, acc, hnone);
                 if (S.out) {                                      // this tile -> global memory: 32 rows x 64 B, two 16-byte pieces per lane
@@ -463,7 +454,7 @@ __device__ __forceinline__ void chainw_body(const ChainArgs& p, const ChainDyn& 
                         asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(S.out + (m0 + r) * S.ldo + c * 8), "v"(vv) : "memory");
                     }
                 }
-                cws_stamp(p, bid, tid, slot);
+                chain_stamp(p, bid, tid, slot);
             }
             if (!BWD && use_mask && t_cnt > 0) {
                 const uint2 mv = make_uint2(mk0, mk1);
@@ -477,7 +468,7 @@ __device__ __forceinline__ void chainw_body(const ChainArgs& p, const ChainDyn& 
 #ifdef CWD_WAVE_STAMPS
             if (!BWD && p.dbg && tid == 0 && i < 6) p.dbg[(int64_t)bid * 64 + 48 + i] = __builtin_amdgcn_s_memtime();
 #endif
-            cws_stamp(p, bid, tid, slot);
+            chain_stamp(p, bid, tid, slot);
             u16* t = Xin; Xin = Xout; Xout = t;
             return;
         } else {
