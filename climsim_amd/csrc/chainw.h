@@ -325,14 +325,23 @@ __device__ __forceinline__ void chainw_body(const ChainArgs& p, const ChainDyn& 
             if (wid >= ntiles && pend.out) { chainw_copy_out(Xin, pend.out, pend.ldo, pend.width, m0, tid); pend.out = nullptr; }
             for (int tile = wid; tile < ntiles; tile += 8) {
                 f32x16_t acc1[1][1];
+                const int64_t m = m0 + mrow;
+                const bool row_ok = m < d_.n_rows;
+                const int64_t yrow = row_ok ? rows_lds[mrow] : 0;
+                // the target rows are requested in FRONT of the k-loop (round 6: fetched in the epilogue they stood there with their whole
+                // memory latency - 6.2k clocks of heads epilogue against a 2.7k k-loop); older than the queue's loads, they land under them
+                float4 tg[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = tile * 32 + 8 * q + hi4;
+                    tg[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (d_.y && row_ok && n < p.n_real) tg[q] = *reinterpret_cast<const float4*>(d_.y + yrow * p.n_real + n);
+                }
                 chain_mma<CWD_BM, 1, 1, 4, true, CWD_PITCH, true>(Xin, S.wfrag, ks, ntiles, tile, 0, tid, acc1, pend, m0);
 #ifdef CWD_FINE_STAMPS
                 chain_stamp(p, bid, tid, slot);
 #endif
                 const f32x16_t& acc = acc1[0][0];
-                const int64_t m = m0 + mrow;
-                const bool row_ok = m < d_.n_rows;
-                const int64_t yrow = row_ok ? rows_lds[mrow] : 0;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int n = tile * 32 + 8 * q + hi4;
@@ -340,8 +349,7 @@ __device__ __forceinline__ void chainw_body(const ChainArgs& p, const ChainDyn& 
                     const float4 b4 = *reinterpret_cast<const float4*>(bias_lds + S.bias_off + n);
                     float v[4] = {acc[4 * q + 0] + b4.x, acc[4 * q + 1] + b4.y, acc[4 * q + 2] + b4.z, acc[4 * q + 3] + b4.w};
                     float d[4];
-                    float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (d_.y && valid) t4 = *reinterpret_cast<const float4*>(d_.y + yrow * p.n_real + n);
+                    const float4 t4 = tg[q];
                     head4(v, d, n >= p.n_lin, p.keep, n, d_.y && valid, t4, p.loss_kind, sq, ab);
                     if (valid && d_.yhat) *reinterpret_cast<float4*>(d_.yhat + m * p.n_real + n) = make_float4(v[0], v[1], v[2], v[3]);
                     if (p.dz_out) *reinterpret_cast<uint2*>(p.dz_out + m * p.ld_dz_out + n) = make_uint2(cvt_pk_bf16(d[0], d[1]), cvt_pk_bf16(d[2], d[3]));
