@@ -63,6 +63,14 @@ struct Cw3Args {
 // slab stays in the ring while it is computed on (the dZ fragments are streamed from it three column groups ahead of the MFMAs
 // instead of all 28 registers' worth being fetched a slab ahead: 16 VGPRs less, which is what ends the spills of conv_wgrad2.h at
 // 168 VGPRs), so the loaders run SLOTS - 2 slabs ahead of the one in use: 3 (as conv_wgrad2.h) and 2.
+// Float atomic on a pointer KNOWN to be global memory.  `atomicAdd(float*)` on a pointer that came out of a descriptor in memory is a
+// FLAT atomic: it counts in lgkmcnt as well as vmcnt, so every LDS read of the flush behind it waits for the atomic's address to be
+// resolved (round 6, read off the compiled flush: 160 flat_atomic_add_f32 per wave and entry, each followed by staging reads).
+__device__ __forceinline__ void cw3_atomic_add(float* p, float v) {
+    typedef float __attribute__((address_space(1))) * gptr;
+    (void)__builtin_amdgcn_global_atomic_fadd_f32((gptr)p, v);
+}
+
 template <int W> struct Cw3Geo {
     static constexpr int SLOTS = W == 6 ? 5 : 4;
     static constexpr unsigned XB = W == 6 ? 8192u : 16384u;          // bytes of the X tile's region = offset of the dZ tile
@@ -321,10 +329,10 @@ __device__ __forceinline__ void cw3_compute(const Cw3Args& pa, const Cw3Tile* __
                     for (int rr = 0; rr < 8 && cch[i] + 8 * hh + rr < T.cin; ++rr) {
                         float* dst = row + (int64_t)(8 * hh + rr) * T.cout;
                         const float v0 = stg[rr * 112 + lane];
-                        if (lane < nmax) atomicAdd(dst + lane, v0);
+                        if (lane < nmax) cw3_atomic_add(dst + lane, v0);
                         if (lane < 48) {
                             const float v1 = stg[rr * 112 + 64 + lane];
-                            if (64 + lane < nmax) atomicAdd(dst + 64 + lane, v1);
+                            if (64 + lane < nmax) cw3_atomic_add(dst + 64 + lane, v1);
                         }
                     }
                 }
@@ -332,7 +340,7 @@ __device__ __forceinline__ void cw3_compute(const Cw3Args& pa, const Cw3Tile* __
 #pragma unroll
                 for (int j = 0; j < 7; ++j) {
                     const int n = T.n0 + wn * 112 + j * 16 + (lane & 15);
-                    if (n < T.cout) atomicAdd(T.db + n, acc[i][j][0]);
+                    if (n < T.cout) cw3_atomic_add(T.db + n, acc[i][j][0]);
                 }
             }
         }
