@@ -76,6 +76,9 @@ __device__ __forceinline__ void chainw_copy_out(const u16* __restrict__ X, u16* 
 //     slower (95.4 -> 96.9 us).
 //   * Backward: the sign masks of a stage are fetched by asm into v[190:191] at the top of the stage and copied out behind the first
 //     k-loop (>= 8 younger loads waited for by then); a compiler-issued load would be waited for with vmcnt(0) in the first epilogue.
+#ifndef CWD_LEAN_EPI
+#define CWD_LEAN_EPI 1                    // 0: the general epilogue forms only (A/B builds)
+#endif
 #ifndef CWS_DEPTH
 #define CWS_DEPTH 8                       // k16-steps (KiB) of weights a wave keeps in flight: 8 (block B alone), or 16 (blocks A + B; A/B builds:
                                           // measured SLOWER - published model 95.1 -> 99.4 us, k-loops 62.7k -> 69.1k clocks per half, profiles/r06_chainw_depth.txt)
@@ -309,7 +312,7 @@ __device__ __forceinline__ void chainw_body(const ChainArgs& p, const ChainDyn& 
 
     float sq = 0.f, ab = 0.f;
     const int mrow = lane & 31, hi4 = 4 * (lane >> 5);
-    const bool elu_ = p.act == ACT_ELU, drop_ = p.drop_thr != 0u;
+    const bool elu_ = p.act == ACT_ELU, drop_ = p.drop_thr != 0u, lean_ = p.slope >= 0.f && p.slope <= 1.f && CWD_LEAN_EPI;
     const float slope_ = p.slope, dscale_ = p.drop_scale, bscale_ = p.bwd_scale;     // (dropout: the kept activations were scaled by 1 / (1 - rate))
     const unsigned dthr_ = p.drop_thr;
     ChainPending pend{nullptr, 0, 0, 0};
@@ -386,8 +389,14 @@ __device__ __forceinline__ void chainw_body(const ChainArgs& p, const ChainDyn& 
         // code: ~50 taken branches and a kernel-argument fetch per tile; stamps 2.2k clocks per tile and wave, a quarter of the kernel).
         auto epilogue = [&](int tile, int slot, const f32x16_t& acc, const uint2 (&hq)[4]) {
             unsigned bits16 = BWD ? ((slot < 2 ? mk0 : mk1) >> ((slot & 1) * 16)) : 0u;
-            auto run = [&](auto elu_c, auto drop_c, auto mask_c) __attribute__((always_inline)) {
+            // LEAN (0 <= slope <= 1, no ELU): the activation as max(z, slope z) with the products formed in pairs (v_pk_mul_f32), the sign bits
+            // by compare + add-with-carry (two instructions per element) - the same values as the general form (identical for every finite z; the
+            // tests hold it against the per-pass form, which shares this code, and against the oracles): 5.75 -> 3.5 VALU instructions per forward
+            // element, forward epilogues 23.6k -> 19.5k clocks per half (profiles/r06_chainw_stream.txt).
+            auto run = [&](auto elu_c, auto drop_c, auto mask_c, auto lean_c) __attribute__((always_inline)) {
                 constexpr bool ELU = decltype(elu_c)::value, DROP = decltype(drop_c)::value, MASK = decltype(mask_c)::value;
+                constexpr bool LEAN = decltype(lean_c)::value && !ELU;
+                typedef float f32x2_t __attribute__((ext_vector_type(2)));
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int n = tile * 32 + 8 * q + hi4;
@@ -397,8 +406,14 @@ __device__ __forceinline__ void chainw_body(const ChainArgs& p, const ChainDyn& 
                         const float4 b4 = *reinterpret_cast<const float4*>(bias_lds + S.bias_off + n);
                         v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;        // (else the bias is in the accumulators: chain_mma)
 #endif
+                        if (LEAN) {
+                            f32x2_t s01 = {v[0], v[1]}, s23 = {v[2], v[3]};
+                            s01 *= slope_; s23 *= slope_;
+                            v[0] = fmaxf(v[0], s01[0]); v[1] = fmaxf(v[1], s01[1]); v[2] = fmaxf(v[2], s23[0]); v[3] = fmaxf(v[3], s23[1]);
+                        } else {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = ELU ? (v[e] > 0.f ? v[e] : expm1f(v[e])) : (v[e] > 0.f ? v[e] : slope_ * v[e]);
+                            for (int e = 0; e < 4; ++e) v[e] = ELU ? (v[e] > 0.f ? v[e] : expm1f(v[e])) : (v[e] > 0.f ? v[e] : slope_ * v[e]);
+                        }
                         if (DROP) {                              // training-mode nn.Dropout: relu(dropout(z)) == dropout(relu(z))
                             const unsigned h0 = mlp_drop_hash2(m0 + mrow, n, drop_key_), h1 = mlp_drop_hash2(m0 + mrow, n + 2, drop_key_);
                             v[0] = (h0 & 0xffffu) >= dthr_ ? v[0] * dscale_ : 0.f;
@@ -406,11 +421,17 @@ __device__ __forceinline__ void chainw_body(const ChainArgs& p, const ChainDyn& 
                             v[2] = (h1 & 0xffffu) >= dthr_ ? v[2] * dscale_ : 0.f;
                             v[3] = (h1 >> 16) >= dthr_ ? v[3] * dscale_ : 0.f;
                         }
-                        if (MASK)
+                        if (MASK && LEAN) {                      // b = 2 b + (v > 0), from the last element down: element e lands at bit e
+                            unsigned b = 0u;
+#pragma unroll
+                            for (int e = 3; e >= 0; --e)
+                                asm("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(b) : "v"(v[e]) : "vcc");
+                            bits16 |= b << (4 * q);
+                        } else if (MASK)
                             bits16 |= ((v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u)) << (4 * q);
                     } else if (MASK) {
                         const unsigned b4 = bits16 >> (4 * q);
-                        const float on = DROP ? bscale_ : 1.f, off = slope_ * on;
+                        const float on = DROP ? bscale_ : 1.f, off = slope_ * on;       // (a bit-field select between dz and slope dz measured slower: 17.8k -> 19.9k clocks of backward epilogue)
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] *= (b4 & (1u << e)) ? on : off;
                     } else {
@@ -426,9 +447,12 @@ __device__ __forceinline__ void chainw_body(const ChainArgs& p, const ChainDyn& 
                 }
             };
             using T = std::true_type; using F = std::false_type;
-            if (elu_) { if (drop_) run(T{}, T{}, F{}); else run(T{}, F{}, F{}); }
-            else if (use_mask) { if (drop_) run(F{}, T{}, T{}); else run(F{}, F{}, T{}); }
-            else { if (drop_) run(F{}, T{}, F{}); else run(F{}, F{}, F{}); }
+            if (elu_) { if (drop_) run(T{}, T{}, F{}, F{}); else run(T{}, F{}, F{}, F{}); }
+            else if (lean_) {
+                if (use_mask) { if (drop_) run(F{}, T{}, T{}, T{}); else run(F{}, F{}, T{}, T{}); }
+                else { if (drop_) run(F{}, T{}, F{}, T{}); else run(F{}, F{}, F{}, T{}); }
+            } else if (use_mask) { if (drop_) run(F{}, T{}, T{}, F{}); else run(F{}, F{}, T{}, F{}); }
+            else { if (drop_) run(F{}, T{}, F{}, F{}); else run(F{}, F{}, F{}, F{}); }
             if (!BWD && use_mask) { if (slot < 2) mk0 |= bits16 << ((slot & 1) * 16); else mk1 |= bits16 << ((slot & 1) * 16); }
         };
         if constexpr (STREAMED) {
