@@ -328,7 +328,12 @@ __device__ __forceinline__ void chain_epilogue(u16* __restrict__ X, const float*
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], slope * v[e]);
                     }
-                    const unsigned bits = (v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u);
+                    // sign bits by compare + add-with-carry (b = 2 b + (v > 0), from the last element down): two instructions per element
+                    // where compare / select / or took 2.75 (chainw.h, round 6)
+                    unsigned bits = 0u;
+#pragma unroll
+                    for (int e = 3; e >= 0; --e)
+                        asm("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"(v[e]) : "vcc");
                     mk[t >> 1] |= bits << sh;
                 } else if (ELU) {    // ELU backward needs h itself (generic, slower path)
                     const uint2 h2 = *reinterpret_cast<const uint2*>(S.hprev + (m0 + mlb + a * 32) * S.ldh + c * 8 + hi4);
