@@ -392,7 +392,8 @@ __device__ __forceinline__ void chainw_body(const ChainArgs& p, const ChainDyn& 
             // LEAN (0 <= slope <= 1, no ELU): the activation as max(z, slope z) with the products formed in pairs (v_pk_mul_f32), the sign bits
             // by compare + add-with-carry (two instructions per element) - the same values as the general form (identical for every finite z; the
             // tests hold it against the per-pass form, which shares this code, and against the oracles): 5.75 -> 3.5 VALU instructions per forward
-            // element, forward epilogues 23.6k -> 19.5k clocks per half (profiles/r06_chainw_stream.txt).
+            // element, forward epilogues 23.6k -> 19.5k clocks per half; the backward select as v_bfe_i32 + v_bfi_b32 from asm (as C++ hipcc turns it
+            // back into and / compare / select, slower than before): 17.9k -> 16.2k (profiles/r06_chainw_stream.txt).
             auto run = [&](auto elu_c, auto drop_c, auto mask_c, auto lean_c) __attribute__((always_inline)) {
                 constexpr bool ELU = decltype(elu_c)::value, DROP = decltype(drop_c)::value, MASK = decltype(mask_c)::value;
                 constexpr bool LEAN = decltype(lean_c)::value && !ELU;
@@ -431,9 +432,21 @@ __device__ __forceinline__ void chainw_body(const ChainArgs& p, const ChainDyn& 
                             bits16 |= ((v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u)) << (4 * q);
                     } else if (MASK) {
                         const unsigned b4 = bits16 >> (4 * q);
-                        const float on = DROP ? bscale_ : 1.f, off = slope_ * on;       // (a bit-field select between dz and slope dz measured slower: 17.8k -> 19.9k clocks of backward epilogue)
+                        if (LEAN && !DROP) {                     // bit-field select between dz and slope dz (asm: chain.h's backward epilogue)
+                            f32x2_t s01 = {v[0], v[1]}, s23 = {v[2], v[3]};
+                            s01 *= slope_; s23 *= slope_;
+                            const float sv[4] = {s01[0], s01[1], s23[0], s23[1]};
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] *= (b4 & (1u << e)) ? on : off;
+                            for (int e = 0; e < 4; ++e) {
+                                unsigned m;
+                                asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(b4), "n"(e));
+                                asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(v[e]) : "v"(m), "v"(v[e]), "v"(sv[e]));
+                            }
+                        } else {
+                            const float on = DROP ? bscale_ : 1.f, off = slope_ * on;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] *= (b4 & (1u << e)) ? on : off;
+                        }
                     } else {
                         const uint2 h2 = hq[q];
                         const float hv[4] = {bf2f((u16)(h2.x & 0xffff)), bf2f((u16)(h2.x >> 16)), bf2f((u16)(h2.y & 0xffff)), bf2f((u16)(h2.y >> 16))};
