@@ -325,8 +325,14 @@ __device__ __forceinline__ void chain_epilogue(u16* __restrict__ X, const float*
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : __expf(v[e]) - 1.f;   // abs err 6e-8, below bf16 resolution
                     } else {
+                        // max(z, slope z): products in pairs, the maximum as ONE v_max_f32 from asm (fmaxf costs a canonicalising
+                        // max(z, z) in front of every maximum under IEEE mode: three instructions per element, round 6)
+                        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+                        f32x2_t s01 = {v[0], v[1]}, s23 = {v[2], v[3]};
+                        s01 *= slope; s23 *= slope;
+                        const float sv[4] = {s01[0], s01[1], s23[0], s23[1]};
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], slope * v[e]);
+                        for (int e = 0; e < 4; ++e) asm("v_max_f32 %0, %1, %2" : "=v"(v[e]) : "v"(v[e]), "v"(sv[e]));
                     }
                     // sign bits by compare + add-with-carry (b = 2 b + (v > 0), from the last element down): two instructions per element
                     // where compare / select / or took 2.75 (chainw.h, round 6)

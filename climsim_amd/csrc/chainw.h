@@ -410,7 +410,9 @@ __device__ __forceinline__ void chainw_body(const ChainArgs& p, const ChainDyn& 
                         if (LEAN) {
                             f32x2_t s01 = {v[0], v[1]}, s23 = {v[2], v[3]};
                             s01 *= slope_; s23 *= slope_;
-                            v[0] = fmaxf(v[0], s01[0]); v[1] = fmaxf(v[1], s01[1]); v[2] = fmaxf(v[2], s23[0]); v[3] = fmaxf(v[3], s23[1]);
+                            const float sv[4] = {s01[0], s01[1], s23[0], s23[1]};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) asm("v_max_f32 %0, %1, %2" : "=v"(v[e]) : "v"(v[e]), "v"(sv[e]));      // (fmaxf: + a canonicalising max(z, z) each)
                         } else {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = ELU ? (v[e] > 0.f ? v[e] : expm1f(v[e])) : (v[e] > 0.f ? v[e] : slope_ * v[e]);
