@@ -388,9 +388,20 @@ __global__ __launch_bounds__(CV2_THREADS) void k_conv2(const ConvProg P) {
             auto masked = [&](int i, int j) __attribute__((always_inline)) {
                 const int t = (i * 7 + j) * 4;
                 const unsigned b4 = mwb[t >> 5] >> (t & 31);
+                // (round 6, as the layer chains' backward epilogue: products in pairs, the select as a sign-extended mask bit ANDed in -
+                //  2.5 instructions per element where and / compare / multiply / select took 4; asm, or hipcc rebuilds the select)
+                typedef float f32x2_t __attribute__((ext_vector_type(2)));
+                f32x2_t s01 = {acc[i][j][0], acc[i][j][1]}, s23 = {acc[i][j][2], acc[i][j][3]};
+                s01 *= mscale_f; s23 *= mscale_f;
+                const float sv[4] = {s01[0], s01[1], s23[0], s23[1]};
                 f32x4_t r;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) r[e] = (b4 & (1u << e)) ? acc[i][j][e] * mscale_f : 0.f;
+                for (int e = 0; e < 4; ++e) {
+                    unsigned m, o;
+                    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(b4), "n"(e));
+                    asm("v_and_b32 %0, %1, %2" : "=v"(o) : "v"(m), "v"(sv[e]));
+                    r[e] = __builtin_bit_cast(float, o);
+                }
                 return r;
             };
             CV2_STORE_TILE_X(p.out2, p.ldo2, masked)
@@ -425,7 +436,7 @@ __global__ __launch_bounds__(CV2_THREADS) void k_conv2(const ConvProg P) {
             const int64_t m = mw + mi;
             float v[4] = {acc[i][j][0] + b4.x, acc[i][j][1] + b4.y, acc[i][j][2] + b4.z, acc[i][j][3] + b4.w};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], act_floor);      // ReLU | identity, branch-free
+            for (int e = 0; e < 4; ++e) asm("v_max_f32 %0, %1, %2" : "=v"(v[e]) : "v"(v[e]), "v"(act_floor));      // ReLU | identity, branch-free (fmaxf: + a canonicalising max(z, z))
             if (MODE == CONV_TRAIN_FWD && dthr_) {
                 const unsigned h0 = drop_hash2(m, n, dkey_), h1 = drop_hash2(m, n + 2, dkey_);
                 v[0] = (h0 & 0xffffu) >= dthr_ ? v[0] * dscale_f : 0.f;
@@ -437,7 +448,10 @@ __global__ __launch_bounds__(CV2_THREADS) void k_conv2(const ConvProg P) {
             for (int e = 0; e < 4; ++e) acc[i][j][e] = v[e];
             if (MODE == CONV_TRAIN_FWD) {
                 const int t = (i * 7 + j) * 4;
-                const unsigned b4m = (v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u);
+                unsigned b4m = 0u;                      // b = 2 b + (v > 0), from the last element down (compare + add-with-carry: chain.h)
+#pragma unroll
+                for (int e = 3; e >= 0; --e)
+                    asm("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(b4m) : "v"(v[e]) : "vcc");
                 mwb[t >> 5] |= b4m << (t & 31);
             }
             return acc[i][j];
