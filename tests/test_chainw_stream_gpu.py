@@ -28,6 +28,8 @@ CASES = [
     ((768, 640, 512, 640, 640), "relu", "Adam", 1000),            # ragged last row tile
     ((640, 128, 1024), "leakyrelu", "Adam", 2048),                # a stage with tiles on four waves only; four tiles per wave
     ((896, 384), "relu", "AdamTorch", 4100),
+    ((256,) * 10, "relu", "Adam", 777),                           # twelve layers: the fetch cursor across many stages, two waves without tiles in every one
+    ((1024, 128, 128, 1024), "leakyrelu", "Adam", 96),            # consecutive 128-wide stages (waves 4-7 skip two stages in a row), three row tiles
 ]
 
 
